@@ -1,0 +1,165 @@
+/*
+ * margin_rphmm.h -- C-ABI of libmargin_rphmm.so: the MI355X (gfx950) engine for margin's
+ * read-partitioning HMM (stRPHmm) forward/backward hot path.
+ *
+ * This is the drop-in boundary.  Every entry point is extern "C", takes
+ * plain pointers and sizes, returns an int status (MRP_OK == 0) and never aborts the process.
+ * The reference interface each entry point stands in for is cited as <file>:<line> relative to
+ * the upstream tree (UCSC-nanopore-cgl/margin @ v1).  INTEGRATION.md shows the adaptor a margin
+ * maintainer adds to impl/hmm.c to route stRPHmm_forwardBackward through mrp_fb_run().
+ *
+ * Vocabulary follows the reference: a *chunk* owns a reference (sites x alleles) and the uint8
+ * profile bytes of its reads; an *hmm job* is one stRPHmm flattened to arrays: columns, cells
+ * (64-bit read bipartitions), merge columns (maskFrom/maskTo) and merge cells.
+ *
+ * Threading: a context is bound to one device and one HIP stream and is NOT shared between
+ * threads; create one context per host thread (reference: phase.c:276 OpenMP chunk loop).
+ */
+#ifndef MARGIN_RPHMM_H_
+#define MARGIN_RPHMM_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- status codes -------------------------------------------------------------------------- */
+#define MRP_OK 0
+#define MRP_ERR_ARG 1        /* malformed job (reference: st_errAbort paths, hmm.c:293-319,542-555) */
+#define MRP_ERR_NO_DEVICE 2  /* no usable gfx950 device: the product path fails loudly, no CPU fallback */
+#define MRP_ERR_HIP 3        /* a HIP runtime call failed; see mrp_last_error() */
+#define MRP_ERR_NOMEM 4
+#define MRP_ERR_UNSUPPORTED 5 /* e.g. more than MRP_MAX_ALLELES alleles at a site in ancestor mode */
+#define MRP_ERR_LOOKUP 6     /* a cell's masked partition has no merge cell (mergeColumn.c:63-79 returned NULL) */
+
+/* ---- limits (inc/margin.h:135,142) --------------------------------------------------------- */
+#define MRP_ALLELE_LOG_PROB_BITS 8
+#define MRP_MAX_READ_PARTITIONING_DEPTH 64
+#define MRP_MAX_ALLELES 16
+
+/* ---- flags: the two stRPHmmParameters fields read by the sweep (hmm.c:819, emissions.c:236) - */
+#define MRP_FLAG_MAX_NOT_SUM 1u             /* maxNotSumTransitions: logAddP = max (hmm.c:15-20) */
+#define MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB 2u /* includeAncestorSubProb (emissions.c:205-218) */
+
+typedef struct mrp_context mrp_context;
+typedef struct mrp_chunk mrp_chunk;
+typedef struct mrp_batch mrp_batch;
+
+/* Human-readable text for the last failure on the calling thread. */
+const char *mrp_last_error(void);
+/* "margin_rphmm <version> gfx950" */
+const char *mrp_version(void);
+/* Number of visible HIP devices (0 if none / runtime unavailable). */
+int mrp_device_count(void);
+
+/* Context: device + stream + reusable device workspace.  (No reference counterpart: the CPU
+ * path allocates scratch per column, hmm.c:836,872.) */
+int mrp_context_create(int device, mrp_context **out);
+void mrp_context_destroy(mrp_context *ctx);
+int mrp_context_synchronize(mrp_context *ctx);
+
+/*
+ * Chunk = stReference + all stProfileSeq bytes of one genome chunk, uploaded once.
+ *   n_sites, allele_number[n_sites]                 stSite.alleleNumber   (inc/margin.h:164-171)
+ *   substitution_log_probs: concatenated A_s*A_s uint16 tables, site-major ([from*A+to],
+ *       emissions.c:13-19); NULL = all zero
+ *   allele_prior_log_probs: concatenated A_s uint16; NULL = all zero
+ *   profile_pool[pool_bytes]: the profileProbs arrays of every read, back to back
+ *       (profileSeq.c:13-29; bubbleGraph.c:2423-2435 for the byte encoding)
+ * stSite.alleleOffset is the prefix sum of allele_number and is derived internally.
+ */
+int mrp_chunk_create(mrp_context *ctx, int64_t n_sites, const uint32_t *allele_number,
+                     const uint16_t *substitution_log_probs, const uint16_t *allele_prior_log_probs,
+                     const uint8_t *profile_pool, int64_t pool_bytes, mrp_chunk **out);
+void mrp_chunk_destroy(mrp_chunk *chunk);
+
+/*
+ * One flattened stRPHmm (inc/margin.h:340-353,393-402,421-425,439-445,463-467).
+ * All arrays are host memory owned by the caller; cells are in LIST ORDER (column->head ...
+ * ->nCell) and the outputs are written back in the same order.
+ */
+typedef struct mrp_hmm_job {
+    const mrp_chunk *chunk;
+    int32_t n_columns;            /* stRPHmm.columnNumber (>= 1) */
+    uint32_t flags;               /* MRP_FLAG_* */
+    const int32_t *col_ref_start; /* [K] stRPColumn.refStart (site index) */
+    const int32_t *col_length;    /* [K] stRPColumn.length   (sites, > 0) */
+    const int32_t *col_depth;     /* [K] stRPColumn.depth    (0..64; 0 = gap column, hmm.c:337-345) */
+    const int64_t *col_cell_off;  /* [K+1] prefix sum of cells per column */
+    const int64_t *col_read_off;  /* [K+1] prefix sum of depth */
+    const int64_t *read_byte_off; /* [sum depth] offset into profile_pool of column->seqs[i] (hmm.c:121-122) */
+    const uint64_t *partition;    /* [sum C] stRPCell.partition */
+    const uint64_t *mask_from;    /* [K-1] stRPMergeColumn.maskFrom */
+    const uint64_t *mask_to;      /* [K-1] stRPMergeColumn.maskTo */
+    const int64_t *mcol_cell_off; /* [K]   prefix sum of merge cells per merge column (K-1 entries + 1) */
+    const uint64_t *merge_from;   /* [sum M] stRPMergeCell.fromPartition */
+    const uint64_t *merge_to;     /* [sum M] stRPMergeCell.toPartition */
+    /* Optional pre-resolved transitions: index (within the adjacent merge column) of the merge
+     * cell each cell feeds (mergeColumn.c:63) / is fed by (mergeColumn.c:72).  NULL = resolved by
+     * the library from partition & mask against merge_from / merge_to.  First column's cell_prev
+     * and last column's cell_next entries are ignored. */
+    const uint32_t *cell_next;    /* [sum C] or NULL */
+    const uint32_t *cell_prev;    /* [sum C] or NULL */
+    /* Outputs = post-conditions of stRPHmm_forwardBackward (hmm.c:931-942) */
+    double *cell_forward;         /* [sum C] stRPCell.forwardLogProb */
+    double *cell_backward;        /* [sum C] stRPCell.backwardLogProb (excludes own emission, hmm.c:881-892) */
+    double *merge_forward;        /* [sum M] stRPMergeCell.forwardLogProb */
+    double *merge_backward;       /* [sum M] stRPMergeCell.backwardLogProb */
+    double *col_total;            /* [K] stRPColumn.totalLogProb */
+    double *hmm_forward;          /* [1] stRPHmm.forwardLogProb */
+    double *hmm_backward;         /* [1] stRPHmm.backwardLogProb */
+} mrp_hmm_job;
+
+/*
+ * stRPHmm_forwardBackward for n_jobs independent HMMs in one device batch ("run_many").
+ * Replaces: impl/hmm.c:931 (callers coordination.c:312, bubbleGraph.c:2749, hmm.c:1332).
+ * Upload -> bit-plane kernel -> forward/backward kernel -> download, synchronous on return.
+ */
+int mrp_fb_run(mrp_context *ctx, int64_t n_jobs, const mrp_hmm_job *jobs);
+
+/*
+ * Device-resident batches: the same sweep split into its stages so that many HMMs (all
+ * components of a merge level, both strands, many chunks) stay in HBM and launches can be
+ * timed on their own.  mrp_fb_run == create + add* + upload + launch + download + destroy.
+ */
+int mrp_batch_create(mrp_context *ctx, mrp_batch **out);
+int mrp_batch_add(mrp_batch *batch, const mrp_hmm_job *job); /* copies the job's inputs */
+int mrp_batch_upload(mrp_batch *batch);                      /* H2D + transition resolve */
+int mrp_batch_launch(mrp_batch *batch);                      /* async on the context stream */
+int mrp_batch_download(mrp_batch *batch);                    /* D2H + scatter into job outputs; syncs */
+void mrp_batch_destroy(mrp_batch *batch);
+
+/* Launch statistics of the most recent mrp_batch_launch on this batch. */
+typedef struct mrp_launch_stats {
+    double planes_ms;   /* bit-plane kernel, HIP-event time on the context stream */
+    double sweep_ms;    /* forward/backward kernel(s), HIP-event time */
+    int64_t n_hmms, n_columns, n_cells, n_merge_cells;
+    int64_t profile_bytes;      /* sum_k depth_k * alleles_k */
+    int64_t algorithmic_bytes;  /* sum_k 24*C_k + 32*M_k + depth_k*alleles_k + 8 */
+    int64_t popcount_ops;       /* sum_k C_k * L_k * 2 * A * 8 popcount64 of the CPU formulation */
+    int64_t units;              /* not known to the library; 0 */
+} mrp_launch_stats;
+/* Waits for the launch to finish, then fills stats. */
+int mrp_batch_stats(mrp_batch *batch, mrp_launch_stats *out);
+
+/*
+ * Emission-only entry points, the unit-tested secondary seam (inc/margin.h:217-233).
+ * mrp_count_bit_vectors replaces calculateCountBitVectors (emissions.c:91-123): for one column
+ * (depth reads, n_alleles consecutive allele slots, seqs given as offsets into the chunk's
+ * profile pool) returns planes[n_alleles*8] computed on the device.
+ * mrp_emissions replaces emissionLogProbability (emissions.c:221-240) for n_cells partitions of
+ * one column; out[i] = -(double)cost, exactly as the reference returns it.
+ */
+int mrp_count_bit_vectors(mrp_context *ctx, const mrp_chunk *chunk, int32_t first_site,
+                          int32_t n_sites, int32_t depth, const int64_t *read_byte_off,
+                          uint64_t *planes_out);
+int mrp_emissions(mrp_context *ctx, const mrp_chunk *chunk, int32_t first_site, int32_t n_sites,
+                  int32_t depth, const int64_t *read_byte_off, uint32_t flags, int64_t n_cells,
+                  const uint64_t *partitions, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MARGIN_RPHMM_H_ */
