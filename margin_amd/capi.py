@@ -1,0 +1,251 @@
+"""Thin ctypes binding of libmargin_rphmm.so (the C-ABI in include/margin_rphmm.h).
+
+This is plumbing for the tests and the benchmark: every call goes through the C-ABI exactly as a
+C caller (margin's impl/hmm.c adaptor) would.  There is no Python or CPU
+implementation of the sweep behind it -- if the library or a device is missing, calls raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libmargin_rphmm.so")
+
+MRP_OK = 0
+MRP_ERR_ARG, MRP_ERR_NO_DEVICE, MRP_ERR_HIP, MRP_ERR_NOMEM, MRP_ERR_UNSUPPORTED, MRP_ERR_LOOKUP = 1, 2, 3, 4, 5, 6
+FLAG_MAX_NOT_SUM = 1
+FLAG_INCLUDE_ANCESTOR_SUB_PROB = 2
+
+#: every symbol include/margin_rphmm.h declares (checked by the CPU test-suite)
+EXPORTED_SYMBOLS = [
+    "mrp_last_error", "mrp_version", "mrp_device_count", "mrp_context_create", "mrp_context_destroy",
+    "mrp_context_synchronize", "mrp_chunk_create", "mrp_chunk_destroy", "mrp_fb_run", "mrp_batch_create",
+    "mrp_batch_add", "mrp_batch_upload", "mrp_batch_launch", "mrp_batch_download", "mrp_batch_destroy",
+    "mrp_batch_stats", "mrp_count_bit_vectors", "mrp_emissions",
+]
+
+
+class MrpError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"mrp error {code}: {msg}")
+        self.code = code
+
+
+class HmmJob(C.Structure):
+    _fields_ = [("chunk", C.c_void_p), ("n_columns", C.c_int32), ("flags", C.c_uint32),
+                ("col_ref_start", C.c_void_p), ("col_length", C.c_void_p), ("col_depth", C.c_void_p),
+                ("col_cell_off", C.c_void_p), ("col_read_off", C.c_void_p), ("read_byte_off", C.c_void_p),
+                ("partition", C.c_void_p), ("mask_from", C.c_void_p), ("mask_to", C.c_void_p),
+                ("mcol_cell_off", C.c_void_p), ("merge_from", C.c_void_p), ("merge_to", C.c_void_p),
+                ("cell_next", C.c_void_p), ("cell_prev", C.c_void_p),
+                ("cell_forward", C.c_void_p), ("cell_backward", C.c_void_p), ("merge_forward", C.c_void_p),
+                ("merge_backward", C.c_void_p), ("col_total", C.c_void_p), ("hmm_forward", C.c_void_p),
+                ("hmm_backward", C.c_void_p)]
+
+
+class LaunchStats(C.Structure):
+    _fields_ = [("planes_ms", C.c_double), ("sweep_ms", C.c_double), ("n_hmms", C.c_int64),
+                ("n_columns", C.c_int64), ("n_cells", C.c_int64), ("n_merge_cells", C.c_int64),
+                ("profile_bytes", C.c_int64), ("algorithmic_bytes", C.c_int64), ("popcount_ops", C.c_int64),
+                ("units", C.c_int64)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen the in-tree library; raises if it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FileNotFoundError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = C.CDLL(LIB_PATH)
+    vp, i64, i32, u32 = C.c_void_p, C.c_int64, C.c_int32, C.c_uint32
+    P = C.POINTER
+    L.mrp_last_error.restype = C.c_char_p
+    L.mrp_version.restype = C.c_char_p
+    L.mrp_device_count.restype = C.c_int
+    L.mrp_context_create.argtypes = [C.c_int, P(vp)]
+    L.mrp_context_destroy.argtypes = [vp]
+    L.mrp_context_destroy.restype = None
+    L.mrp_context_synchronize.argtypes = [vp]
+    L.mrp_chunk_create.argtypes = [vp, i64, vp, vp, vp, vp, i64, P(vp)]
+    L.mrp_chunk_destroy.argtypes = [vp]
+    L.mrp_chunk_destroy.restype = None
+    L.mrp_fb_run.argtypes = [vp, i64, P(HmmJob)]
+    L.mrp_batch_create.argtypes = [vp, P(vp)]
+    L.mrp_batch_add.argtypes = [vp, P(HmmJob)]
+    L.mrp_batch_upload.argtypes = [vp]
+    L.mrp_batch_launch.argtypes = [vp]
+    L.mrp_batch_download.argtypes = [vp]
+    L.mrp_batch_destroy.argtypes = [vp]
+    L.mrp_batch_destroy.restype = None
+    L.mrp_batch_stats.argtypes = [vp, P(LaunchStats)]
+    L.mrp_count_bit_vectors.argtypes = [vp, vp, i32, i32, i32, vp, vp]
+    L.mrp_emissions.argtypes = [vp, vp, i32, i32, i32, vp, u32, i64, vp, vp]
+    _lib = L
+    return L
+
+
+def _check(rc: int):
+    if rc != MRP_OK:
+        raise MrpError(rc, load().mrp_last_error().decode())
+
+
+class Context:
+    def __init__(self, device: int = 0):
+        L = load()
+        h = C.c_void_p()
+        _check(L.mrp_context_create(device, C.byref(h)))
+        self.h = h
+
+    def synchronize(self):
+        _check(load().mrp_context_synchronize(self.h))
+
+    def close(self):
+        if self.h:
+            load().mrp_context_destroy(self.h)
+            self.h = None
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+
+class DeviceChunk:
+    """mrp_chunk for a margin_amd.synth.Chunk (or raw arrays)."""
+
+    def __init__(self, ctx: Context, allele_number, sub, prior, pool):
+        L = load()
+        self.ctx = ctx
+        an = np.ascontiguousarray(allele_number, dtype=np.uint32)
+        sub = None if sub is None else np.ascontiguousarray(sub, dtype=np.uint16)
+        prior = None if prior is None else np.ascontiguousarray(prior, dtype=np.uint16)
+        pool = np.ascontiguousarray(pool, dtype=np.uint8)
+        h = C.c_void_p()
+        _check(L.mrp_chunk_create(ctx.h, an.shape[0], an.ctypes.data,
+                                  None if sub is None else sub.ctypes.data,
+                                  None if prior is None else prior.ctypes.data,
+                                  pool.ctypes.data if pool.size else None, pool.size, C.byref(h)))
+        self.h = h
+
+    @classmethod
+    def from_chunk(cls, ctx: Context, chunk):
+        return cls(ctx, chunk.allele_number, chunk.sub, chunk.prior, chunk.pool)
+
+    def close(self):
+        if self.h:
+            load().mrp_chunk_destroy(self.h)
+            self.h = None
+
+
+_IN = [("col_ref_start", np.int32), ("col_length", np.int32), ("col_depth", np.int32), ("col_cell_off", np.int64),
+       ("col_read_off", np.int64), ("read_byte_off", np.int64), ("partition", np.uint64), ("mask_from", np.uint64),
+       ("mask_to", np.uint64), ("mcol_cell_off", np.int64), ("merge_from", np.uint64), ("merge_to", np.uint64)]
+
+
+class Job:
+    """Owns the numpy arrays behind one mrp_hmm_job and its outputs."""
+
+    def __init__(self, dchunk: DeviceChunk, flat: Dict[str, np.ndarray], flags: int, use_indices: bool = True):
+        K = int(flat["n_columns"])
+        self.K = K
+        self.arr = {}
+        for name, dt in _IN:
+            a = np.ascontiguousarray(flat[name], dtype=dt)
+            if a.size == 0:
+                a = np.zeros(1, dtype=dt)
+            self.arr[name] = a
+        nC = int(flat["col_cell_off"][K])
+        nM = int(flat["mcol_cell_off"][K - 1]) if K > 1 else 0
+        self.n_cells, self.n_merge = nC, nM
+        if use_indices and "cell_next" in flat:
+            self.arr["cell_next"] = np.ascontiguousarray(flat["cell_next"], dtype=np.uint32)
+            self.arr["cell_prev"] = np.ascontiguousarray(flat["cell_prev"], dtype=np.uint32)
+        self.out = dict(cell_forward=np.full(nC, np.nan), cell_backward=np.full(nC, np.nan),
+                        merge_forward=np.full(max(nM, 1), np.nan), merge_backward=np.full(max(nM, 1), np.nan),
+                        col_total=np.full(K, np.nan), hmm_forward=np.full(1, np.nan), hmm_backward=np.full(1, np.nan))
+        j = HmmJob()
+        j.chunk = dchunk.h
+        j.n_columns = K
+        j.flags = flags
+        for name, _ in _IN:
+            setattr(j, name, self.arr[name].ctypes.data)
+        j.cell_next = self.arr["cell_next"].ctypes.data if "cell_next" in self.arr else None
+        j.cell_prev = self.arr["cell_prev"].ctypes.data if "cell_prev" in self.arr else None
+        for name, a in self.out.items():
+            setattr(j, name, a.ctypes.data)
+        self.c = j
+
+    def results(self) -> Dict[str, np.ndarray]:
+        r = dict(self.out)
+        r["merge_forward"] = r["merge_forward"][:self.n_merge]
+        r["merge_backward"] = r["merge_backward"][:self.n_merge]
+        return r
+
+
+def fb_run(ctx: Context, jobs: Sequence[Job]):
+    """mrp_fb_run over the given jobs (one device batch)."""
+    arr = (HmmJob * max(len(jobs), 1))()
+    for i, j in enumerate(jobs):
+        arr[i] = j.c
+    _check(load().mrp_fb_run(ctx.h, len(jobs), arr))
+
+
+class Batch:
+    def __init__(self, ctx: Context):
+        h = C.c_void_p()
+        _check(load().mrp_batch_create(ctx.h, C.byref(h)))
+        self.h = h
+        self.jobs: List[Job] = []
+
+    def add(self, job: Job, keep: bool = True):
+        _check(load().mrp_batch_add(self.h, C.byref(job.c)))
+        if keep:
+            self.jobs.append(job)
+
+    def upload(self):
+        _check(load().mrp_batch_upload(self.h))
+
+    def launch(self):
+        _check(load().mrp_batch_launch(self.h))
+
+    def download(self):
+        _check(load().mrp_batch_download(self.h))
+
+    def stats(self) -> LaunchStats:
+        s = LaunchStats()
+        _check(load().mrp_batch_stats(self.h, C.byref(s)))
+        return s
+
+    def close(self):
+        if self.h:
+            load().mrp_batch_destroy(self.h)
+            self.h = None
+
+
+def count_bit_vectors(ctx: Context, dchunk: DeviceChunk, first_site: int, n_sites: int, read_byte_off,
+                      n_slots: int) -> np.ndarray:
+    off = np.ascontiguousarray(read_byte_off, dtype=np.int64)
+    out = np.zeros(max(n_slots, 1) * 8, dtype=np.uint64)
+    _check(load().mrp_count_bit_vectors(ctx.h, dchunk.h, first_site, n_sites, off.shape[0],
+                                        off.ctypes.data if off.size else None, out.ctypes.data))
+    return out[:n_slots * 8]
+
+
+def emissions(ctx: Context, dchunk: DeviceChunk, first_site: int, n_sites: int, read_byte_off, flags: int,
+              partitions) -> np.ndarray:
+    off = np.ascontiguousarray(read_byte_off, dtype=np.int64)
+    part = np.ascontiguousarray(partitions, dtype=np.uint64)
+    out = np.zeros(max(part.shape[0], 1), dtype=np.float64)
+    _check(load().mrp_emissions(ctx.h, dchunk.h, first_site, n_sites, off.shape[0],
+                                off.ctypes.data if off.size else None, flags, part.shape[0], part.ctypes.data,
+                                out.ctypes.data))
+    return out[:part.shape[0]]

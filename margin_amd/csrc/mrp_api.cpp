@@ -1,0 +1,694 @@
+/*
+ * mrp_api.cpp -- host side of the C-ABI declared in include/margin_rphmm.h.
+ *
+ * Validates and concatenates flattened stRPHmm jobs into batch-wide arrays (mrp_device.h),
+ * moves them to HBM, launches the plane and sweep kernels on the context's stream and scatters
+ * the post-conditions of stRPHmm_forwardBackward (hmm.c:931-942) back into the caller's arrays.
+ * There is no CPU implementation of the sweep in this library: without a HIP device every entry
+ * point that computes returns MRP_ERR_NO_DEVICE.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "../../include/margin_rphmm.h"
+#include "mrp_device.h"
+#include "mrp_kernels.h"
+
+namespace {
+
+thread_local char g_err[512] = "";
+
+int fail(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (expr);                                                                         \
+        if (e_ != hipSuccess) return fail(MRP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+template <typename T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t n = 0;
+    ~DevBuf() { release(); }
+    void release() {
+        if (p) (void) hipFree(p);
+        p = nullptr;
+        n = 0;
+    }
+    hipError_t alloc(size_t count) {
+        release();
+        n = count;
+        return hipMalloc((void **) &p, std::max<size_t>(count, 1) * sizeof(T) + 16);
+    }
+    hipError_t upload(const std::vector<T> &h, hipStream_t s) {
+        hipError_t e = alloc(h.size());
+        if (e != hipSuccess || h.empty()) return e;
+        return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    }
+};
+
+}  // namespace
+
+struct mrp_context {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+};
+
+struct mrp_chunk {
+    mrp_context *ctx = nullptr;
+    int64_t n_sites = 0, pool_bytes = 0;
+    std::vector<uint32_t> allele_number, allele_offset, sub_offset;
+    uint32_t max_sub = 0, max_prior = 0;
+    DevBuf<uint32_t> d_allele_number, d_allele_offset, d_sub_offset;
+    DevBuf<uint16_t> d_sub, d_prior;
+    DevBuf<uint8_t> d_pool;
+    DevChunk dev{};
+};
+
+struct JobOut {
+    double *cell_f, *cell_b, *merge_f, *merge_b, *col_total, *hmm_f, *hmm_b;
+    int64_t cell0, n_cells, mcell0, n_merge, col0, n_cols;
+};
+
+struct mrp_batch {
+    mrp_context *ctx = nullptr;
+    std::vector<const mrp_chunk *> chunks;
+    std::vector<DevHmm> hmms;
+    std::vector<DevCol> cols;
+    std::vector<int64_t> read_byte_off;
+    std::vector<uint64_t> partition;
+    std::vector<uint32_t> cell_next, cell_prev;
+    std::vector<JobOut> outs;
+    int64_t n_merge = 0, n_slots = 0;
+    mrp_launch_stats stats{};
+    /* launch plan */
+    std::vector<int32_t> order_wide, order_narrow, order_f64;
+    int max_merge_wide = 1, max_merge_narrow = 1;
+    /* device */
+    bool uploaded = false, launched = false;
+    DevBuf<DevHmm> d_hmms;
+    DevBuf<DevCol> d_cols;
+    DevBuf<DevChunk> d_chunks;
+    DevBuf<int64_t> d_read_byte_off;
+    DevBuf<uint64_t> d_partition, d_planes;
+    DevBuf<uint32_t> d_next, d_prev, d_slot_total, d_cost;
+    DevBuf<double> d_f, d_b, d_mf, d_mb, d_total, d_hmm_fb;
+    DevBuf<int32_t> d_order_wide, d_order_narrow, d_order_f64;
+    MrpBatchDev dev{};
+};
+
+extern "C" {
+
+const char *mrp_last_error(void) { return g_err; }
+const char *mrp_version(void) { return "margin_rphmm 0.1.0 gfx950"; }
+
+int mrp_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int mrp_context_create(int device, mrp_context **out) {
+    if (!out) return fail(MRP_ERR_ARG, "mrp_context_create: out is NULL");
+    *out = nullptr;
+    int n = mrp_device_count();
+    if (n <= 0) return fail(MRP_ERR_NO_DEVICE, "no HIP device visible: the stRPHmm sweep has no CPU fallback");
+    if (device < 0 || device >= n) return fail(MRP_ERR_ARG, "device %d out of range (0..%d)", device, n - 1);
+    HIP_TRY(hipSetDevice(device));
+    mrp_context *ctx = new (std::nothrow) mrp_context();
+    if (!ctx) return fail(MRP_ERR_NOMEM, "out of host memory");
+    ctx->device = device;
+    hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+    for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
+    if (e != hipSuccess) {
+        mrp_context_destroy(ctx);
+        return fail(MRP_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
+    }
+    *out = ctx;
+    return MRP_OK;
+}
+
+void mrp_context_destroy(mrp_context *ctx) {
+    if (!ctx) return;
+    (void) hipSetDevice(ctx->device);
+    for (auto &e : ctx->ev)
+        if (e) (void) hipEventDestroy(e);
+    if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+int mrp_context_synchronize(mrp_context *ctx) {
+    if (!ctx) return fail(MRP_ERR_ARG, "context is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MRP_OK;
+}
+
+int mrp_chunk_create(mrp_context *ctx, int64_t n_sites, const uint32_t *allele_number,
+                     const uint16_t *substitution_log_probs, const uint16_t *allele_prior_log_probs,
+                     const uint8_t *profile_pool, int64_t pool_bytes, mrp_chunk **out) {
+    if (!ctx || !out || n_sites < 0 || pool_bytes < 0 || (n_sites > 0 && !allele_number) ||
+        (pool_bytes > 0 && !profile_pool))
+        return fail(MRP_ERR_ARG, "mrp_chunk_create: bad arguments");
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    mrp_chunk *ch = new (std::nothrow) mrp_chunk();
+    if (!ch) return fail(MRP_ERR_NOMEM, "out of host memory");
+    ch->ctx = ctx;
+    ch->n_sites = n_sites;
+    ch->pool_bytes = pool_bytes;
+    ch->allele_number.assign(allele_number, allele_number + n_sites);
+    ch->allele_offset.resize(n_sites + 1);
+    ch->sub_offset.resize(n_sites + 1);
+    uint64_t off = 0, soff = 0;
+    for (int64_t i = 0; i < n_sites; i++) {
+        ch->allele_offset[i] = (uint32_t) off;
+        ch->sub_offset[i] = (uint32_t) soff;
+        uint64_t A = allele_number[i];
+        if (A == 0 || A > 65535) {
+            delete ch;
+            return fail(MRP_ERR_ARG, "site %lld has %llu alleles", (long long) i, (unsigned long long) A);
+        }
+        off += A;
+        soff += A * A;
+        if (off > 0xFFFFFFFFull || soff > 0xFFFFFFFFull) {
+            delete ch;
+            return fail(MRP_ERR_ARG, "allele tables exceed 32-bit offsets");
+        }
+    }
+    ch->allele_offset[n_sites] = (uint32_t) off;
+    ch->sub_offset[n_sites] = (uint32_t) soff;
+    std::vector<uint16_t> sub(soff, 0), prior(off, 0);
+    if (substitution_log_probs) sub.assign(substitution_log_probs, substitution_log_probs + soff);
+    if (allele_prior_log_probs) prior.assign(allele_prior_log_probs, allele_prior_log_probs + off);
+    for (uint16_t v : sub) ch->max_sub = std::max<uint32_t>(ch->max_sub, v);
+    for (uint16_t v : prior) ch->max_prior = std::max<uint32_t>(ch->max_prior, v);
+    hipStream_t s = ctx->stream;
+    hipError_t e = ch->d_allele_number.upload(ch->allele_number, s);
+    if (e == hipSuccess) e = ch->d_allele_offset.upload(ch->allele_offset, s);
+    if (e == hipSuccess) e = ch->d_sub_offset.upload(ch->sub_offset, s);
+    if (e == hipSuccess) e = ch->d_sub.upload(sub, s);
+    if (e == hipSuccess) e = ch->d_prior.upload(prior, s);
+    if (e == hipSuccess) e = ch->d_pool.alloc((size_t) pool_bytes);
+    if (e == hipSuccess && pool_bytes > 0)
+        e = hipMemcpyAsync(ch->d_pool.p, profile_pool, (size_t) pool_bytes, hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e != hipSuccess) {
+        delete ch;
+        return fail(MRP_ERR_HIP, "chunk upload failed: %s", hipGetErrorString(e));
+    }
+    ch->dev.allele_number = ch->d_allele_number.p;
+    ch->dev.allele_offset = ch->d_allele_offset.p;
+    ch->dev.sub_offset = ch->d_sub_offset.p;
+    ch->dev.sub = ch->d_sub.p;
+    ch->dev.prior = ch->d_prior.p;
+    ch->dev.pool = ch->d_pool.p;
+    *out = ch;
+    return MRP_OK;
+}
+
+void mrp_chunk_destroy(mrp_chunk *chunk) {
+    if (!chunk) return;
+    (void) hipSetDevice(chunk->ctx->device);
+    delete chunk;
+}
+
+int mrp_batch_create(mrp_context *ctx, mrp_batch **out) {
+    if (!ctx || !out) return fail(MRP_ERR_ARG, "mrp_batch_create: bad arguments");
+    mrp_batch *b = new (std::nothrow) mrp_batch();
+    if (!b) return fail(MRP_ERR_NOMEM, "out of host memory");
+    b->ctx = ctx;
+    *out = b;
+    return MRP_OK;
+}
+
+void mrp_batch_destroy(mrp_batch *batch) {
+    if (!batch) return;
+    (void) hipSetDevice(batch->ctx->device);
+    (void) hipStreamSynchronize(batch->ctx->stream);
+    delete batch;
+}
+
+/* resolve cell -> merge cell indices from keys: stHash_search of mergeColumn.c:63-79 */
+static int resolve_column(const uint64_t *part, int64_t n_cells, uint64_t mask, const uint64_t *keys,
+                          int64_t n_keys, uint32_t *out) {
+    size_t cap = 16;
+    while (cap < (size_t) n_keys * 2) cap *= 2;
+    std::vector<uint64_t> hk(cap);
+    std::vector<uint32_t> hv(cap, 0xFFFFFFFFu);
+    auto mix = [](uint64_t x) {
+        x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+        return x;
+    };
+    for (int64_t i = 0; i < n_keys; i++) {
+        size_t s = mix(keys[i]) & (cap - 1);
+        while (hv[s] != 0xFFFFFFFFu) {
+            if (hk[s] == keys[i]) return MRP_ERR_ARG; /* duplicate key: mergeColumn.c:104-107 asserts */
+            s = (s + 1) & (cap - 1);
+        }
+        hk[s] = keys[i];
+        hv[s] = (uint32_t) i;
+    }
+    for (int64_t c = 0; c < n_cells; c++) {
+        const uint64_t key = part[c] & mask;
+        size_t s = mix(key) & (cap - 1);
+        uint32_t found = 0xFFFFFFFFu;
+        while (hv[s] != 0xFFFFFFFFu) {
+            if (hk[s] == key) { found = hv[s]; break; }
+            s = (s + 1) & (cap - 1);
+        }
+        if (found == 0xFFFFFFFFu) return MRP_ERR_LOOKUP;
+        out[c] = found;
+    }
+    return MRP_OK;
+}
+
+int mrp_batch_add(mrp_batch *b, const mrp_hmm_job *job) {
+    if (!b || !job) return fail(MRP_ERR_ARG, "mrp_batch_add: NULL argument");
+    if (b->uploaded) return fail(MRP_ERR_ARG, "mrp_batch_add: batch already uploaded");
+    const int K = job->n_columns;
+    if (K < 1) return fail(MRP_ERR_ARG, "hmm has %d columns", K);
+    if (!job->chunk || !job->col_ref_start || !job->col_length || !job->col_depth || !job->col_cell_off ||
+        !job->col_read_off || !job->partition)
+        return fail(MRP_ERR_ARG, "hmm job is missing required arrays");
+    if (K > 1 && (!job->mcol_cell_off || ((!job->cell_next || !job->cell_prev) &&
+                                          (!job->mask_from || !job->mask_to || !job->merge_from || !job->merge_to))))
+        return fail(MRP_ERR_ARG, "hmm job is missing its merge column arrays");
+    if (!job->cell_forward || !job->cell_backward || !job->col_total || !job->hmm_forward || !job->hmm_backward ||
+        (K > 1 && (!job->merge_forward || !job->merge_backward)))
+        return fail(MRP_ERR_ARG, "hmm job is missing output arrays");
+    const mrp_chunk *ch = job->chunk;
+    if (ch->ctx != b->ctx) return fail(MRP_ERR_ARG, "chunk belongs to a different context");
+    const bool ancestor = (job->flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
+
+    int chunk_index = -1;
+    for (size_t i = 0; i < b->chunks.size(); i++)
+        if (b->chunks[i] == ch) chunk_index = (int) i;
+    if (chunk_index < 0) {
+        chunk_index = (int) b->chunks.size();
+        b->chunks.push_back(ch);
+    }
+
+    /* validate before touching the batch */
+    if (job->col_cell_off[0] != 0 || job->col_read_off[0] != 0 || (K > 1 && job->mcol_cell_off[0] != 0))
+        return fail(MRP_ERR_ARG, "prefix-sum arrays must start at 0");
+    for (int k = 0; k < K; k++) {
+        const int64_t nc = job->col_cell_off[k + 1] - job->col_cell_off[k];
+        const int64_t nd = job->col_read_off[k + 1] - job->col_read_off[k];
+        if (nc < 1 || nc > 0x7FFFFFFF) return fail(MRP_ERR_ARG, "column %d has %lld cells", k, (long long) nc);
+        if (job->col_depth[k] < 0 || job->col_depth[k] > MRP_MAX_READ_PARTITIONING_DEPTH || nd != job->col_depth[k])
+            return fail(MRP_ERR_ARG, "column %d: depth %d inconsistent", k, job->col_depth[k]);
+        if (job->col_length[k] < 1 || job->col_ref_start[k] < 0 ||
+            (int64_t) job->col_ref_start[k] + job->col_length[k] > ch->n_sites)
+            return fail(MRP_ERR_ARG, "column %d: site interval [%d,+%d) outside the reference", k,
+                        job->col_ref_start[k], job->col_length[k]);
+        if (nd > 0 && !job->read_byte_off) return fail(MRP_ERR_ARG, "read_byte_off is NULL");
+        const uint32_t slots = ch->allele_offset[job->col_ref_start[k] + job->col_length[k]] -
+                               ch->allele_offset[job->col_ref_start[k]];
+        for (int64_t i = 0; i < nd; i++) {
+            const int64_t o = job->read_byte_off[job->col_read_off[k] + i];
+            if (o < 0 || o + (int64_t) slots > ch->pool_bytes)
+                return fail(MRP_ERR_ARG, "column %d read %lld: profile bytes outside the pool", k, (long long) i);
+        }
+        if (ancestor) {
+            for (int s = 0; s < job->col_length[k]; s++)
+                if (ch->allele_number[job->col_ref_start[k] + s] > MRP_MAX_ALLELES)
+                    return fail(MRP_ERR_UNSUPPORTED, "site %d has more than %d alleles (ancestor mode)",
+                                job->col_ref_start[k] + s, MRP_MAX_ALLELES);
+        }
+        if (k + 1 < K) {
+            const int64_t nm = job->mcol_cell_off[k + 1] - job->mcol_cell_off[k];
+            if (nm < 1 || nm > 0x7FFFFFFF) return fail(MRP_ERR_ARG, "merge column %d has %lld cells", k, (long long) nm);
+        }
+    }
+
+    const int64_t n_cells = job->col_cell_off[K];
+    const int64_t n_merge = K > 1 ? job->mcol_cell_off[K - 1] : 0;
+    const int64_t cell0 = (int64_t) b->partition.size();
+    const int64_t mcell0 = b->n_merge;
+    const int64_t col0 = (int64_t) b->cols.size();
+    const int64_t read0 = (int64_t) b->read_byte_off.size();
+
+    std::vector<uint32_t> nxt((size_t) n_cells, 0), prv((size_t) n_cells, 0);
+    for (int k = 0; k < K; k++) {
+        const int64_t c0 = job->col_cell_off[k], nc = job->col_cell_off[k + 1] - c0;
+        if (k + 1 < K) {
+            const int64_t m0 = job->mcol_cell_off[k], nm = job->mcol_cell_off[k + 1] - m0;
+            if (job->cell_next) {
+                for (int64_t c = 0; c < nc; c++) {
+                    if (job->cell_next[c0 + c] >= (uint64_t) nm) return fail(MRP_ERR_ARG, "cell_next out of range");
+                    nxt[c0 + c] = job->cell_next[c0 + c];
+                }
+            } else {
+                int rc = resolve_column(job->partition + c0, nc, job->mask_from[k], job->merge_from + m0, nm, &nxt[c0]);
+                if (rc != MRP_OK) return fail(rc, "column %d: a cell has no next merge cell (mergeColumn.c:63)", k);
+            }
+        }
+        if (k > 0) {
+            const int64_t m0 = job->mcol_cell_off[k - 1], nm = job->mcol_cell_off[k] - m0;
+            if (job->cell_prev) {
+                for (int64_t c = 0; c < nc; c++) {
+                    if (job->cell_prev[c0 + c] >= (uint64_t) nm) return fail(MRP_ERR_ARG, "cell_prev out of range");
+                    prv[c0 + c] = job->cell_prev[c0 + c];
+                }
+            } else {
+                int rc = resolve_column(job->partition + c0, nc, job->mask_to[k - 1], job->merge_to + m0, nm, &prv[c0]);
+                if (rc != MRP_OK) return fail(rc, "column %d: a cell has no previous merge cell (mergeColumn.c:72)", k);
+            }
+        }
+    }
+
+    DevHmm h{};
+    h.col0 = col0;
+    h.n_cols = K;
+    h.flags = job->flags;
+    h.max_merge = 1;
+    h.max_cells = 1;
+    h.cost_bound = 0;
+    for (int k = 0; k < K; k++) {
+        DevCol c{};
+        c.cell_off = cell0 + job->col_cell_off[k];
+        c.n_cells = (int32_t) (job->col_cell_off[k + 1] - job->col_cell_off[k]);
+        c.mcell_off = k + 1 < K ? mcell0 + job->mcol_cell_off[k] : 0;
+        c.n_merge = k + 1 < K ? (int32_t) (job->mcol_cell_off[k + 1] - job->mcol_cell_off[k]) : 0;
+        c.slot_off = b->n_slots;
+        c.read_off = read0 + job->col_read_off[k];
+        c.site_start = job->col_ref_start[k];
+        c.n_sites = job->col_length[k];
+        c.depth = job->col_depth[k];
+        c.n_slots = (int32_t) (ch->allele_offset[c.site_start + c.n_sites] - ch->allele_offset[c.site_start]);
+        c.chunk = chunk_index;
+        b->n_slots += c.n_slots;
+        b->cols.push_back(c);
+        h.max_merge = std::max(h.max_merge, c.n_merge);
+        h.max_cells = std::max(h.max_cells, c.n_cells);
+        int64_t per_site = 255ll * c.depth;
+        if (ancestor) per_site += 2ll * ch->max_sub + ch->max_prior;
+        h.cost_bound += per_site * c.n_sites;
+        /* statistics: SURVEY.md 8(d) algorithmic bytes and the CPU formulation's popcount count */
+        b->stats.profile_bytes += (int64_t) c.depth * c.n_slots;
+        b->stats.algorithmic_bytes += 24ll * c.n_cells + 32ll * c.n_merge + (int64_t) c.depth * c.n_slots + 8;
+        b->stats.popcount_ops += (int64_t) c.n_cells * 2 * c.n_slots * 8;
+    }
+    b->hmms.push_back(h);
+    b->partition.insert(b->partition.end(), job->partition, job->partition + n_cells);
+    b->cell_next.insert(b->cell_next.end(), nxt.begin(), nxt.end());
+    b->cell_prev.insert(b->cell_prev.end(), prv.begin(), prv.end());
+    if (job->col_read_off[K] > 0)
+        b->read_byte_off.insert(b->read_byte_off.end(), job->read_byte_off, job->read_byte_off + job->col_read_off[K]);
+    b->n_merge += n_merge;
+    JobOut o{job->cell_forward, job->cell_backward, job->merge_forward, job->merge_backward, job->col_total,
+             job->hmm_forward, job->hmm_backward, cell0, n_cells, mcell0, n_merge, col0, K};
+    b->outs.push_back(o);
+    b->stats.n_hmms += 1;
+    b->stats.n_columns += K;
+    b->stats.n_cells += n_cells;
+    b->stats.n_merge_cells += n_merge;
+    return MRP_OK;
+}
+
+int mrp_batch_upload(mrp_batch *b) {
+    if (!b) return fail(MRP_ERR_ARG, "batch is NULL");
+    if (b->uploaded) return MRP_OK;
+    mrp_context *ctx = b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+
+    /* launch plan: int32/LDS path for max-plus HMMs that fit, fp64 path otherwise */
+    std::vector<std::pair<int64_t, int32_t>> wide, narrow, generic;
+    for (size_t i = 0; i < b->hmms.size(); i++) {
+        const DevHmm &h = b->hmms[i];
+        const int64_t work = b->outs[i].n_cells;
+        const bool max_mode = (h.flags & MRP_FLAG_MAX_NOT_SUM) != 0;
+        const size_t lds = (size_t) (2 * (int64_t) h.max_merge + 4) * sizeof(int32_t);
+        if (max_mode && h.cost_bound < (1ll << 30) && lds <= (size_t) MRP_LDS_BUDGET) {
+            if (h.max_cells > 128) wide.push_back({-work, (int32_t) i});
+            else narrow.push_back({-work, (int32_t) i});
+        } else {
+            generic.push_back({-work, (int32_t) i});
+        }
+    }
+    auto plan = [&](std::vector<std::pair<int64_t, int32_t>> &v, std::vector<int32_t> &order, int *max_merge) {
+        std::sort(v.begin(), v.end()); /* largest first */
+        order.clear();
+        int mm = 1;
+        for (auto &p : v) {
+            order.push_back(p.second);
+            mm = std::max(mm, b->hmms[p.second].max_merge);
+        }
+        if (max_merge) *max_merge = mm;
+    };
+    plan(wide, b->order_wide, &b->max_merge_wide);
+    plan(narrow, b->order_narrow, &b->max_merge_narrow);
+    plan(generic, b->order_f64, nullptr);
+
+    std::vector<DevChunk> chunks;
+    for (auto *c : b->chunks) chunks.push_back(c->dev);
+
+    HIP_TRY(b->d_hmms.upload(b->hmms, s));
+    HIP_TRY(b->d_cols.upload(b->cols, s));
+    HIP_TRY(b->d_chunks.upload(chunks, s));
+    HIP_TRY(b->d_read_byte_off.upload(b->read_byte_off, s));
+    HIP_TRY(b->d_partition.upload(b->partition, s));
+    HIP_TRY(b->d_next.upload(b->cell_next, s));
+    HIP_TRY(b->d_prev.upload(b->cell_prev, s));
+    HIP_TRY(b->d_order_wide.upload(b->order_wide, s));
+    HIP_TRY(b->d_order_narrow.upload(b->order_narrow, s));
+    HIP_TRY(b->d_order_f64.upload(b->order_f64, s));
+    const size_t nC = b->partition.size();
+    HIP_TRY(b->d_planes.alloc((size_t) b->n_slots * 8));
+    HIP_TRY(b->d_slot_total.alloc((size_t) b->n_slots));
+    HIP_TRY(b->d_cost.alloc(nC));
+    HIP_TRY(b->d_f.alloc(nC));
+    HIP_TRY(b->d_b.alloc(nC));
+    HIP_TRY(b->d_mf.alloc((size_t) b->n_merge));
+    HIP_TRY(b->d_mb.alloc((size_t) b->n_merge));
+    HIP_TRY(b->d_total.alloc(b->cols.size()));
+    HIP_TRY(b->d_hmm_fb.alloc(2 * b->hmms.size()));
+    HIP_TRY(hipStreamSynchronize(s));
+
+    MrpBatchDev &d = b->dev;
+    d.hmms = b->d_hmms.p;
+    d.cols = b->d_cols.p;
+    d.chunks = b->d_chunks.p;
+    d.read_byte_off = b->d_read_byte_off.p;
+    d.partition = b->d_partition.p;
+    d.cell_next = b->d_next.p;
+    d.cell_prev = b->d_prev.p;
+    d.planes = b->d_planes.p;
+    d.slot_total = b->d_slot_total.p;
+    d.cell_cost = b->d_cost.p;
+    d.cell_f = b->d_f.p;
+    d.cell_b = b->d_b.p;
+    d.merge_f = b->d_mf.p;
+    d.merge_b = b->d_mb.p;
+    d.col_total = b->d_total.p;
+    d.hmm_fb = b->d_hmm_fb.p;
+    d.n_hmms = (int64_t) b->hmms.size();
+    d.n_cols = (int64_t) b->cols.size();
+    d.n_cells = (int64_t) nC;
+    d.n_merge = b->n_merge;
+    d.n_slots = b->n_slots;
+    /* host copies of the bulky inputs are no longer needed */
+    std::vector<uint64_t>().swap(b->partition);
+    std::vector<uint32_t>().swap(b->cell_next);
+    std::vector<uint32_t>().swap(b->cell_prev);
+    std::vector<int64_t>().swap(b->read_byte_off);
+    b->uploaded = true;
+    return MRP_OK;
+}
+
+int mrp_batch_launch(mrp_batch *b) {
+    if (!b) return fail(MRP_ERR_ARG, "batch is NULL");
+    if (!b->uploaded) {
+        int rc = mrp_batch_upload(b);
+        if (rc != MRP_OK) return rc;
+    }
+    mrp_context *ctx = b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const MrpBatchDev &d = b->dev;
+    HIP_TRY(hipEventRecord(ctx->ev[0], s));
+    HIP_TRY(mrp_launch_planes(d, s));
+    HIP_TRY(hipEventRecord(ctx->ev[1], s));
+    if (!b->order_f64.empty()) {
+        /* stRPHmm_initialiseProbs (hmm.c:752-789) for the accumulate-in-place fp64 path */
+        const double neg = -__builtin_inf();
+        HIP_TRY(mrp_launch_fill_f64(b->d_mf.p, d.n_merge, neg, s));
+        HIP_TRY(mrp_launch_fill_f64(b->d_mb.p, d.n_merge, neg, s));
+        HIP_TRY(mrp_launch_fill_f64(b->d_total.p, d.n_cols, neg, s));
+        HIP_TRY(mrp_launch_fill_f64(b->d_hmm_fb.p, 2 * d.n_hmms, neg, s));
+    }
+    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_wide.p, (int64_t) b->order_wide.size(), 1024, b->max_merge_wide, s));
+    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), 128, b->max_merge_narrow, s));
+    HIP_TRY(mrp_launch_sweep_f64(d, b->d_order_f64.p, (int64_t) b->order_f64.size(), 256, s));
+    HIP_TRY(hipEventRecord(ctx->ev[2], s));
+    b->launched = true;
+    return MRP_OK;
+}
+
+int mrp_batch_stats(mrp_batch *b, mrp_launch_stats *out) {
+    if (!b || !out) return fail(MRP_ERR_ARG, "mrp_batch_stats: NULL argument");
+    *out = b->stats;
+    if (b->launched) {
+        mrp_context *ctx = b->ctx;
+        HIP_TRY(hipSetDevice(ctx->device));
+        HIP_TRY(hipEventSynchronize(ctx->ev[2]));
+        float a = 0, c = 0;
+        HIP_TRY(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&c, ctx->ev[1], ctx->ev[2]));
+        out->planes_ms = a;
+        out->sweep_ms = c;
+    }
+    return MRP_OK;
+}
+
+int mrp_batch_download(mrp_batch *b) {
+    if (!b) return fail(MRP_ERR_ARG, "batch is NULL");
+    if (!b->launched) return fail(MRP_ERR_ARG, "mrp_batch_download before mrp_batch_launch");
+    mrp_context *ctx = b->ctx;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    const MrpBatchDev &d = b->dev;
+    std::vector<double> f((size_t) d.n_cells), bb((size_t) d.n_cells), mf((size_t) d.n_merge), mb((size_t) d.n_merge),
+        tot((size_t) d.n_cols), fb((size_t) (2 * d.n_hmms));
+    auto pull = [&](std::vector<double> &h, const double *p) -> hipError_t {
+        if (h.empty()) return hipSuccess;
+        return hipMemcpyAsync(h.data(), p, h.size() * sizeof(double), hipMemcpyDeviceToHost, s);
+    };
+    HIP_TRY(pull(f, d.cell_f));
+    HIP_TRY(pull(bb, d.cell_b));
+    HIP_TRY(pull(mf, d.merge_f));
+    HIP_TRY(pull(mb, d.merge_b));
+    HIP_TRY(pull(tot, d.col_total));
+    HIP_TRY(pull(fb, d.hmm_fb));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t i = 0; i < b->outs.size(); i++) {
+        const JobOut &o = b->outs[i];
+        memcpy(o.cell_f, f.data() + o.cell0, sizeof(double) * (size_t) o.n_cells);
+        memcpy(o.cell_b, bb.data() + o.cell0, sizeof(double) * (size_t) o.n_cells);
+        if (o.n_merge > 0) {
+            memcpy(o.merge_f, mf.data() + o.mcell0, sizeof(double) * (size_t) o.n_merge);
+            memcpy(o.merge_b, mb.data() + o.mcell0, sizeof(double) * (size_t) o.n_merge);
+        }
+        memcpy(o.col_total, tot.data() + o.col0, sizeof(double) * (size_t) o.n_cols);
+        *o.hmm_f = fb[2 * i];
+        *o.hmm_b = fb[2 * i + 1];
+    }
+    return MRP_OK;
+}
+
+int mrp_fb_run(mrp_context *ctx, int64_t n_jobs, const mrp_hmm_job *jobs) {
+    if (!ctx || n_jobs < 0 || (n_jobs > 0 && !jobs)) return fail(MRP_ERR_ARG, "mrp_fb_run: bad arguments");
+    if (n_jobs == 0) return MRP_OK;
+    mrp_batch *b = nullptr;
+    int rc = mrp_batch_create(ctx, &b);
+    for (int64_t i = 0; rc == MRP_OK && i < n_jobs; i++) rc = mrp_batch_add(b, &jobs[i]);
+    if (rc == MRP_OK) rc = mrp_batch_upload(b);
+    if (rc == MRP_OK) rc = mrp_batch_launch(b);
+    if (rc == MRP_OK) rc = mrp_batch_download(b);
+    mrp_batch_destroy(b);
+    return rc;
+}
+
+/* ---- emission-only seam -------------------------------------------------------------------- */
+static int one_column(mrp_context *ctx, const mrp_chunk *chunk, int32_t first_site, int32_t n_sites, int32_t depth,
+                      const int64_t *read_byte_off, DevCol *col) {
+    if (!ctx || !chunk || chunk->ctx != ctx) return fail(MRP_ERR_ARG, "bad context/chunk");
+    if (depth < 0 || depth > MRP_MAX_READ_PARTITIONING_DEPTH || n_sites < 0 || first_site < 0 ||
+        (int64_t) first_site + n_sites > chunk->n_sites || (depth > 0 && !read_byte_off))
+        return fail(MRP_ERR_ARG, "bad column description");
+    memset(col, 0, sizeof(*col));
+    col->n_cells = 0;
+    col->site_start = first_site;
+    col->n_sites = n_sites;
+    col->depth = depth;
+    col->n_slots = (int32_t) (chunk->allele_offset[first_site + n_sites] - chunk->allele_offset[first_site]);
+    for (int i = 0; i < depth; i++)
+        if (read_byte_off[i] < 0 || read_byte_off[i] + col->n_slots > chunk->pool_bytes)
+            return fail(MRP_ERR_ARG, "read %d: profile bytes outside the pool", i);
+    return MRP_OK;
+}
+
+static int run_planes(mrp_context *ctx, const mrp_chunk *chunk, const DevCol &col, const int64_t *read_byte_off,
+                      DevBuf<DevCol> &d_col, DevBuf<DevChunk> &d_chunk, DevBuf<int64_t> &d_off,
+                      DevBuf<uint64_t> &d_planes, DevBuf<uint32_t> &d_tot) {
+    hipStream_t s = ctx->stream;
+    std::vector<DevCol> hc(1, col);
+    std::vector<DevChunk> hch(1, chunk->dev);
+    std::vector<int64_t> ho(read_byte_off, read_byte_off + col.depth);
+    HIP_TRY(d_col.upload(hc, s));
+    HIP_TRY(d_chunk.upload(hch, s));
+    HIP_TRY(d_off.upload(ho, s));
+    HIP_TRY(d_planes.alloc((size_t) col.n_slots * 8));
+    HIP_TRY(d_tot.alloc((size_t) col.n_slots));
+    MrpBatchDev d{};
+    d.cols = d_col.p;
+    d.chunks = d_chunk.p;
+    d.read_byte_off = d_off.p;
+    d.planes = d_planes.p;
+    d.slot_total = d_tot.p;
+    d.n_cols = 1;
+    HIP_TRY(mrp_launch_planes(d, s));
+    return MRP_OK;
+}
+
+int mrp_count_bit_vectors(mrp_context *ctx, const mrp_chunk *chunk, int32_t first_site, int32_t n_sites, int32_t depth,
+                          const int64_t *read_byte_off, uint64_t *planes_out) {
+    DevCol col;
+    int rc = one_column(ctx, chunk, first_site, n_sites, depth, read_byte_off, &col);
+    if (rc != MRP_OK) return rc;
+    if (col.n_slots == 0) return MRP_OK;
+    if (!planes_out) return fail(MRP_ERR_ARG, "planes_out is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf<DevCol> d_col; DevBuf<DevChunk> d_chunk; DevBuf<int64_t> d_off; DevBuf<uint64_t> d_planes; DevBuf<uint32_t> d_tot;
+    rc = run_planes(ctx, chunk, col, read_byte_off, d_col, d_chunk, d_off, d_planes, d_tot);
+    if (rc != MRP_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(planes_out, d_planes.p, sizeof(uint64_t) * 8 * (size_t) col.n_slots, hipMemcpyDeviceToHost,
+                           ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MRP_OK;
+}
+
+int mrp_emissions(mrp_context *ctx, const mrp_chunk *chunk, int32_t first_site, int32_t n_sites, int32_t depth,
+                  const int64_t *read_byte_off, uint32_t flags, int64_t n_cells, const uint64_t *partitions,
+                  double *out) {
+    DevCol col;
+    int rc = one_column(ctx, chunk, first_site, n_sites, depth, read_byte_off, &col);
+    if (rc != MRP_OK) return rc;
+    if (n_cells < 0 || (n_cells > 0 && (!partitions || !out))) return fail(MRP_ERR_ARG, "bad cell arrays");
+    if (n_cells == 0) return MRP_OK;
+    if (flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB)
+        for (int s = 0; s < n_sites; s++)
+            if (chunk->allele_number[first_site + s] > MRP_MAX_ALLELES)
+                return fail(MRP_ERR_UNSUPPORTED, "site %d has more than %d alleles (ancestor mode)", first_site + s,
+                            MRP_MAX_ALLELES);
+    HIP_TRY(hipSetDevice(ctx->device));
+    DevBuf<DevCol> d_col; DevBuf<DevChunk> d_chunk; DevBuf<int64_t> d_off; DevBuf<uint64_t> d_planes; DevBuf<uint32_t> d_tot;
+    rc = run_planes(ctx, chunk, col, read_byte_off, d_col, d_chunk, d_off, d_planes, d_tot);
+    if (rc != MRP_OK) return rc;
+    DevBuf<uint64_t> d_part; DevBuf<double> d_out;
+    std::vector<uint64_t> hp(partitions, partitions + n_cells);
+    HIP_TRY(d_part.upload(hp, ctx->stream));
+    HIP_TRY(d_out.alloc((size_t) n_cells));
+    HIP_TRY(mrp_launch_emissions(d_col.p, d_chunk.p, d_planes.p, d_tot.p, flags, n_cells, d_part.p, d_out.p, ctx->stream));
+    HIP_TRY(hipMemcpyAsync(out, d_out.p, sizeof(double) * (size_t) n_cells, hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(hipStreamSynchronize(ctx->stream));
+    return MRP_OK;
+}
+
+}  /* extern "C" */

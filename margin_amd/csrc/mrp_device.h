@@ -1,0 +1,54 @@
+/*
+ * mrp_device.h -- structures shared by the host side of libmargin_rphmm.so and its gfx950 kernels.
+ *
+ * HBM layout of a batch (DESIGN.md "Data layout in HBM"): every array is the concatenation over
+ * all HMMs of the batch, so a launch touches a handful of large, contiguous allocations:
+ *
+ *   per cell   (sum C) : partition u64 | next u32 | prev u32 | f f64 | b f64 | e u32 (scratch)
+ *   per merge  (sum M) : mf f64 | mb f64
+ *   per column (sum K) : DevCol (64 B, read through the scalar cache) | total f64
+ *   per allele slot    : 8 bit planes u64 (emissions.c:91-123) | column-wide byte sum u32
+ *   per hmm            : DevHmm | forward f64, backward f64
+ */
+#ifndef MRP_DEVICE_H_
+#define MRP_DEVICE_H_
+
+#include <stdint.h>
+
+struct DevChunk {
+    const uint32_t *allele_number; /* [n_sites] */
+    const uint32_t *allele_offset; /* [n_sites+1] */
+    const uint32_t *sub_offset;    /* [n_sites+1] prefix sum of A^2 */
+    const uint16_t *sub;           /* substitutionLogProbs */
+    const uint16_t *prior;         /* allelePriorLogProbs, indexed by allele_offset */
+    const uint8_t *pool;           /* profile bytes */
+};
+
+struct DevCol {
+    int64_t cell_off;   /* first cell of the column in the batch cell arrays */
+    int64_t mcell_off;  /* first merge cell of the merge column that FOLLOWS this column */
+    int64_t slot_off;   /* first allele slot of the column in the plane arrays */
+    int64_t read_off;   /* first entry of the column in read_byte_off */
+    int32_t n_cells;
+    int32_t n_merge;    /* merge cells of the following merge column; 0 for the last column */
+    int32_t site_start;
+    int32_t n_sites;
+    int32_t depth;
+    int32_t n_slots;    /* alleles summed over the column's sites */
+    int32_t chunk;
+    int32_t pad;
+};
+
+struct DevHmm {
+    int64_t col0;       /* first column in the batch column arrays */
+    int32_t n_cols;
+    uint32_t flags;
+    int32_t max_merge;  /* largest merge column of this hmm */
+    int32_t max_cells;  /* largest column */
+    int64_t cost_bound; /* upper bound of |forward| over the whole hmm (selects the int32 path) */
+};
+
+/* sentinel for log(0) in the integer (max-plus) kernels */
+#define MRP_NEG_I32 ((int32_t) 0x80000000)
+
+#endif

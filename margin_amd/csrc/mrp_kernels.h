@@ -1,0 +1,47 @@
+/* mrp_kernels.h -- launch wrappers of the gfx950 kernels (definitions in mrp_kernels.hip). */
+#ifndef MRP_KERNELS_H_
+#define MRP_KERNELS_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mrp_device.h"
+
+struct MrpBatchDev {
+    /* inputs */
+    const DevHmm *hmms;
+    const DevCol *cols;
+    const DevChunk *chunks;
+    const int64_t *read_byte_off;
+    const uint64_t *partition;
+    const uint32_t *cell_next;
+    const uint32_t *cell_prev;
+    /* scratch */
+    uint64_t *planes;
+    uint32_t *slot_total;
+    uint32_t *cell_cost;
+    /* outputs */
+    double *cell_f;
+    double *cell_b;
+    double *merge_f;
+    double *merge_b;
+    double *col_total;
+    double *hmm_fb; /* [2 * n_hmms] forward, backward */
+    int64_t n_hmms, n_cols, n_cells, n_merge, n_slots;
+};
+
+/* usable dynamic LDS per workgroup for the sweep kernels, bytes */
+#define MRP_LDS_BUDGET (160 * 1024 - 1024)
+
+hipError_t mrp_launch_planes(const MrpBatchDev &d, hipStream_t stream);
+/* order[0..n) = indices into d.hmms handled by this launch, one workgroup each */
+hipError_t mrp_launch_sweep_i32(const MrpBatchDev &d, const int32_t *order_dev, int64_t n, int block_threads,
+                                int max_merge, hipStream_t stream);
+hipError_t mrp_launch_sweep_f64(const MrpBatchDev &d, const int32_t *order_dev, int64_t n, int block_threads,
+                                hipStream_t stream);
+hipError_t mrp_launch_fill_f64(double *p, int64_t n, double v, hipStream_t stream);
+hipError_t mrp_launch_emissions(const DevCol *col_dev, const DevChunk *chunks, const uint64_t *planes,
+                                const uint32_t *slot_total, uint32_t flags, int64_t n_cells,
+                                const uint64_t *partitions, double *out, hipStream_t stream);
+
+#endif

@@ -1,0 +1,137 @@
+"""GPU parity: the HIP sweep, called through the C-ABI, against the CPU oracle on the same inputs."""
+import numpy as np
+import pytest
+
+from margin_amd import capi, synth
+from tests.helpers import assert_job_equal, posteriors, run_jobs_on_gpu
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def small_ont(orc):
+    chunk = synth.make_ont_chunk(seed=3, region_bp=100_000, n_sites=200, coverage=30)
+    oc = orc.OracleChunk(chunk)
+    res = oc.phase(synth.shipped_phase_params(), capture_jobs=True)
+    yield chunk, res
+    oc.close()
+
+
+def test_max_mode_every_merge_level_bit_exact(gpu_ctx, small_ont):
+    """Every forward/backward sweep the phasing driver issues (coordination.c:312 at every merge
+    level, bubbleGraph.c:2749 final sweep with the ancestor model) is bit-identical."""
+    chunk, res = small_ont
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    flats = res["jobs"]
+    assert len(flats) > 10 and max(int(np.diff(f["col_cell_off"]).max()) for f in flats) >= 5000
+    out = run_jobs_on_gpu(gpu_ctx, dchunk, flats, use_indices=True)
+    for f, r in zip(flats, out):
+        assert_job_equal(f, r, exact=True)
+    dchunk.close()
+
+
+def test_library_resolves_transitions_from_keys(gpu_ctx, small_ont):
+    """cell_next/cell_prev == NULL: the library performs mergeColumn.c:63-79 itself."""
+    chunk, res = small_ont
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    flats = res["jobs"][-6:]
+    out = run_jobs_on_gpu(gpu_ctx, dchunk, flats, use_indices=False)
+    for f, r in zip(flats, out):
+        assert_job_equal(f, r, exact=True)
+    dchunk.close()
+
+
+def test_max_mode_through_fp64_kernel(gpu_ctx, small_ont):
+    """The generic fp64 kernel in max mode must agree bit for bit as well (flag path: not MAX -> no;
+    here: force it by dropping to sum kernel selection via a huge cost bound is not possible, so
+    exercise it with sum mode below and max mode on unit-test chunks with many alleles)."""
+    chunk = synth.make_unit_test_chunk(seed=5, ref_length=120, coverage=12, min_read=10, max_read=40, error_rate=0.05)
+    from oracle import orc
+    oc = orc.OracleChunk(chunk)
+    params = synth.unit_test_params(max_partitions=50, max_not_sum=1)
+    res = oc.phase(params, capture_jobs=True)
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    out = run_jobs_on_gpu(gpu_ctx, dchunk, res["jobs"])
+    for f, r in zip(res["jobs"], out):
+        assert_job_equal(f, r, exact=True)
+    dchunk.close()
+    oc.close()
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_sum_mode_within_tolerance(gpu_ctx, orc, seed):
+    """log-sum-exp mode (tests/stRPHmmTest.c:761,807,830 run it): values within 1e-9 absolute and
+    posteriors within the 1e-5 the north star states."""
+    chunk = synth.make_unit_test_chunk(seed=seed, ref_length=150, coverage=15, min_read=10, max_read=60, error_rate=0.05)
+    oc = orc.OracleChunk(chunk)
+    res = oc.phase(synth.unit_test_params(max_partitions=50, max_not_sum=0), capture_jobs=True)
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    out = run_jobs_on_gpu(gpu_ctx, dchunk, res["jobs"])
+    for f, r in zip(res["jobs"], out):
+        assert_job_equal(f, r, exact=False, atol=1e-9)
+        p_ref = posteriors(f, f["cell_forward"], f["cell_backward"], f["col_total"])
+        p_gpu = posteriors(f, r["cell_forward"], r["cell_backward"], r["col_total"])
+        assert np.abs(p_ref - p_gpu).max() <= 1e-5
+    dchunk.close()
+    oc.close()
+
+
+def test_bit_count_vectors_and_emissions_kat(gpu_ctx):
+    """tests/stRPHmmTest.c:882-928 on the device: planes and getLogProbOfAllele-based emission
+    equal the naive per-read sums, for depth 0..63."""
+    rng = np.random.default_rng(2024)
+    for depth in list(range(0, 64, 3)) + [63, 64]:
+        n_sites = int(rng.integers(1, 10))
+        A = rng.integers(1, 10, size=n_sites).astype(np.uint32)
+        off = np.concatenate([[0], np.cumsum(A)]).astype(np.int64)
+        total = int(off[-1])
+        rows = rng.integers(0, 256, size=(max(depth, 1), total)).astype(np.uint8)
+        pool = rows.reshape(-1)
+        ctx = gpu_ctx
+        dchunk = capi.DeviceChunk(ctx, A, None, None, pool)
+        byte_off = (np.arange(depth) * total).astype(np.int64)
+        planes = capi.count_bit_vectors(ctx, dchunk, 0, n_sites, byte_off, total).reshape(total, 8)
+        expect = np.zeros((total, 8), dtype=np.uint64)
+        for i in range(depth):
+            for b in range(8):
+                expect[:, b] |= ((rows[i].astype(np.uint64) >> np.uint64(b)) & np.uint64(1)) << np.uint64(i)
+        assert (planes == expect).all()
+        mask = (1 << depth) - 1
+        parts = np.array([int(rng.integers(0, 2**63)) & mask for _ in range(37)] + [0, mask], dtype=np.uint64)
+        got = capi.emissions(ctx, dchunk, 0, n_sites, byte_off, 0, parts)
+        for p, g in zip(parts, got):
+            sel = np.array([(int(p) >> i) & 1 for i in range(depth)], dtype=bool)
+            h1 = rows[:depth][sel].astype(np.int64).sum(axis=0) if depth else np.zeros(total, np.int64)
+            h2 = rows[:depth][~sel].astype(np.int64).sum(axis=0) if depth else np.zeros(total, np.int64)
+            cost = sum(int(h1[off[s]:off[s + 1]].min()) + int(h2[off[s]:off[s + 1]].min()) for s in range(n_sites))
+            assert g == -float(cost)
+        dchunk.close()
+
+
+def test_malformed_jobs_are_rejected(gpu_ctx, small_ont):
+    """Error convention: status codes, never an abort."""
+    chunk, res = small_ont
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    flat = dict(res["jobs"][-1])
+    # corrupt the merge cell that cell 0 of column 1 is fed by: its key no longer exists
+    k = 1
+    c0 = int(flat["col_cell_off"][k])
+    mask_to = int(flat["mask_to"][k - 1])
+    key = int(flat["partition"][c0]) & mask_to
+    m0, m1 = int(flat["mcol_cell_off"][k - 1]), int(flat["mcol_cell_off"][k])
+    idx = m0 + [int(x) for x in flat["merge_to"][m0:m1]].index(key)
+    outside = (~mask_to) & ((1 << 64) - 1)
+    assert outside != 0
+    bad = dict(flat)
+    bad["merge_to"] = flat["merge_to"].copy()
+    bad["merge_to"][idx] = np.uint64(key | (outside & -outside))
+    with pytest.raises(capi.MrpError) as e:
+        capi.fb_run(gpu_ctx, [capi.Job(dchunk, bad, int(flat["flags"]), use_indices=False)])
+    assert e.value.code == capi.MRP_ERR_LOOKUP
+    bad2 = dict(flat)
+    bad2["col_depth"] = flat["col_depth"].copy()
+    bad2["col_depth"][0] = 65
+    with pytest.raises(capi.MrpError) as e:
+        capi.fb_run(gpu_ctx, [capi.Job(dchunk, bad2, int(flat["flags"]))])
+    assert e.value.code == capi.MRP_ERR_ARG
+    dchunk.close()
