@@ -115,7 +115,7 @@ typedef struct mrp_hmm_job {
 /*
  * stRPHmm_forwardBackward for n_jobs independent HMMs in one device batch ("run_many").
  * Replaces: impl/hmm.c:931 (callers coordination.c:312, bubbleGraph.c:2749, hmm.c:1332).
- * Upload -> bit-plane kernel -> forward/backward kernel -> download, synchronous on return.
+ * Upload -> bit-plane kernel -> emission kernel -> recursion kernel -> download, synchronous on return.
  */
 int mrp_fb_run(mrp_context *ctx, int64_t n_jobs, const mrp_hmm_job *jobs);
 
@@ -134,7 +134,8 @@ void mrp_batch_destroy(mrp_batch *batch);
 /* Launch statistics of the most recent mrp_batch_launch on this batch. */
 typedef struct mrp_launch_stats {
     double planes_ms;   /* bit-plane kernel, HIP-event time on the context stream */
-    double sweep_ms;    /* forward/backward kernel(s), HIP-event time */
+    double emission_ms; /* emission kernel (all cells of the batch), HIP-event time */
+    double sweep_ms;    /* forward/backward recursion kernel(s), HIP-event time */
     int64_t n_hmms, n_columns, n_cells, n_merge_cells;
     int64_t profile_bytes;      /* sum_k depth_k * alleles_k */
     int64_t algorithmic_bytes;  /* sum_k 24*C_k + 32*M_k + depth_k*alleles_k + 8 */

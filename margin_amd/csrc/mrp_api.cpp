@@ -65,7 +65,7 @@ struct DevBuf {
 struct mrp_context {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
 };
 
 struct mrp_chunk {
@@ -92,6 +92,7 @@ struct mrp_batch {
     std::vector<int64_t> read_byte_off;
     std::vector<uint64_t> partition;
     std::vector<uint32_t> cell_next, cell_prev;
+    std::vector<int2> tiles;
     std::vector<JobOut> outs;
     int64_t n_merge = 0, n_slots = 0;
     mrp_launch_stats stats{};
@@ -108,6 +109,7 @@ struct mrp_batch {
     DevBuf<uint32_t> d_next, d_prev, d_slot_total, d_cost;
     DevBuf<double> d_f, d_b, d_mf, d_mb, d_total, d_hmm_fb;
     DevBuf<int32_t> d_order_wide, d_order_narrow, d_order_f64;
+    DevBuf<int2> d_tiles;
     MrpBatchDev dev{};
 };
 
@@ -133,7 +135,7 @@ int mrp_context_create(int device, mrp_context **out) {
     if (!ctx) return fail(MRP_ERR_NOMEM, "out of host memory");
     ctx->device = device;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
-    for (int i = 0; i < 3 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
+    for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
     if (e != hipSuccess) {
         mrp_context_destroy(ctx);
         return fail(MRP_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
@@ -392,7 +394,9 @@ int mrp_batch_add(mrp_batch *b, const mrp_hmm_job *job) {
         c.depth = job->col_depth[k];
         c.n_slots = (int32_t) (ch->allele_offset[c.site_start + c.n_sites] - ch->allele_offset[c.site_start]);
         c.chunk = chunk_index;
+        c.flags = job->flags;
         b->n_slots += c.n_slots;
+        for (int t0 = 0; t0 < c.n_cells; t0 += MRP_EMIT_TILE) b->tiles.push_back(make_int2((int) b->cols.size(), t0));
         b->cols.push_back(c);
         h.max_merge = std::max(h.max_merge, c.n_merge);
         h.max_cells = std::max(h.max_cells, c.n_cells);
@@ -436,7 +440,7 @@ int mrp_batch_upload(mrp_batch *b) {
         const bool max_mode = (h.flags & MRP_FLAG_MAX_NOT_SUM) != 0;
         const size_t lds = (size_t) (2 * (int64_t) h.max_merge + 4) * sizeof(int32_t);
         if (max_mode && h.cost_bound < (1ll << 30) && lds <= (size_t) MRP_LDS_BUDGET) {
-            if (h.max_cells > 128) wide.push_back({-work, (int32_t) i});
+            if (h.max_cells > 256) wide.push_back({-work, (int32_t) i});
             else narrow.push_back({-work, (int32_t) i});
         } else {
             generic.push_back({-work, (int32_t) i});
@@ -469,6 +473,7 @@ int mrp_batch_upload(mrp_batch *b) {
     HIP_TRY(b->d_order_wide.upload(b->order_wide, s));
     HIP_TRY(b->d_order_narrow.upload(b->order_narrow, s));
     HIP_TRY(b->d_order_f64.upload(b->order_f64, s));
+    HIP_TRY(b->d_tiles.upload(b->tiles, s));
     const size_t nC = b->partition.size();
     HIP_TRY(b->d_planes.alloc((size_t) b->n_slots * 8));
     HIP_TRY(b->d_slot_total.alloc((size_t) b->n_slots));
@@ -525,6 +530,8 @@ int mrp_batch_launch(mrp_batch *b) {
     HIP_TRY(hipEventRecord(ctx->ev[0], s));
     HIP_TRY(mrp_launch_planes(d, s));
     HIP_TRY(hipEventRecord(ctx->ev[1], s));
+    HIP_TRY(mrp_launch_emission(d, b->d_tiles.p, (int64_t) b->tiles.size(), s));
+    HIP_TRY(hipEventRecord(ctx->ev[3], s));
     if (!b->order_f64.empty()) {
         /* stRPHmm_initialiseProbs (hmm.c:752-789) for the accumulate-in-place fp64 path */
         const double neg = -__builtin_inf();
@@ -534,7 +541,7 @@ int mrp_batch_launch(mrp_batch *b) {
         HIP_TRY(mrp_launch_fill_f64(b->d_hmm_fb.p, 2 * d.n_hmms, neg, s));
     }
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_wide.p, (int64_t) b->order_wide.size(), 1024, b->max_merge_wide, s));
-    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), 128, b->max_merge_narrow, s));
+    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), 64, b->max_merge_narrow, s));
     HIP_TRY(mrp_launch_sweep_f64(d, b->d_order_f64.p, (int64_t) b->order_f64.size(), 256, s));
     HIP_TRY(hipEventRecord(ctx->ev[2], s));
     b->launched = true;
@@ -548,10 +555,12 @@ int mrp_batch_stats(mrp_batch *b, mrp_launch_stats *out) {
         mrp_context *ctx = b->ctx;
         HIP_TRY(hipSetDevice(ctx->device));
         HIP_TRY(hipEventSynchronize(ctx->ev[2]));
-        float a = 0, c = 0;
+        float a = 0, e = 0, c = 0;
         HIP_TRY(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
-        HIP_TRY(hipEventElapsedTime(&c, ctx->ev[1], ctx->ev[2]));
+        HIP_TRY(hipEventElapsedTime(&e, ctx->ev[1], ctx->ev[3]));
+        HIP_TRY(hipEventElapsedTime(&c, ctx->ev[3], ctx->ev[2]));
         out->planes_ms = a;
+        out->emission_ms = e;
         out->sweep_ms = c;
     }
     return MRP_OK;

@@ -36,7 +36,7 @@ struct DevCol {
     int32_t depth;
     int32_t n_slots;    /* alleles summed over the column's sites */
     int32_t chunk;
-    int32_t pad;
+    uint32_t flags;     /* MRP_FLAG_* of the owning hmm */
 };
 
 struct DevHmm {

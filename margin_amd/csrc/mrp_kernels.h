@@ -34,6 +34,9 @@ struct MrpBatchDev {
 #define MRP_LDS_BUDGET (160 * 1024 - 1024)
 
 hipError_t mrp_launch_planes(const MrpBatchDev &d, hipStream_t stream);
+/* tiles[i] = {column index in d.cols, first cell of the tile}; MRP_EMIT_TILE cells per tile */
+#define MRP_EMIT_TILE 256
+hipError_t mrp_launch_emission(const MrpBatchDev &d, const int2 *tiles_dev, int64_t n_tiles, hipStream_t stream);
 /* order[0..n) = indices into d.hmms handled by this launch, one workgroup each */
 hipError_t mrp_launch_sweep_i32(const MrpBatchDev &d, const int32_t *order_dev, int64_t n, int block_threads,
                                 int max_merge, hipStream_t stream);

@@ -3,11 +3,14 @@
  *
  *  mrp_planes_kernel      calculateCountBitVectors (emissions.c:91-123): one wave per column,
  *                         lane = read, the 64-bit plane word is the wave ballot itself.
- *  mrp_sweep_i32_kernel   stRPHmm_forwardBackward (hmm.c:931-942) in max-plus mode
+ *  mrp_emission_kernel    emissionLogProbability (emissions.c:221-240) for every cell of the batch:
+ *                         independent of the recursion, so it runs chip-wide; one wave per tile of
+ *                         a column, popcount bit-plane sums with the planes in scalar registers.
+ *  mrp_sweep_i32_kernel   the recursion of stRPHmm_forwardBackward (hmm.c:931-942) in max-plus mode
  *                         (maxNotSumTransitions, every shipped config): one persistent workgroup
  *                         walks the columns of one HMM; merge-cell arrays live in LDS as int32 and
- *                         are combined with ds_max; emissions are popcount bit-plane sums with the
- *                         planes held in scalar registers.
+ *                         are combined with ds_max; the next column's cells are fetched while the
+ *                         current one is processed.
  *  mrp_sweep_f64_kernel   the same recursion in fp64 for log-sum-exp mode (hmm.c:19,
  *                         stMath_logAddExact) and for HMMs too large for the int32/LDS path.
  *
@@ -186,8 +189,76 @@ static __device__ uint32_t column_cost_ancestor(const DevCol &c, const DevChunk 
 }
 
 /* ------------------------------------------------------------------------------------------ */
-/* max-plus sweep, int32 merge arrays in LDS                                                   */
+/* emission kernel: every cell of every column of every HMM of the batch, fully parallel       */
 /* ------------------------------------------------------------------------------------------ */
+/* One wave per tile of up to 64*EMIT_CPT consecutive cells of ONE column, so the column's bit
+ * planes are wave-uniform (scalar loads) and the partition loads are coalesced. */
+#define EMIT_CPT 4
+#define EMIT_TILE (WAVE * EMIT_CPT)
+__global__ void __launch_bounds__(256) mrp_emission_kernel(MrpBatchDev d, const int2 *__restrict__ tiles,
+                                                           int64_t n_tiles) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t tile = (int64_t) blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
+    if (tile >= n_tiles) return;
+    const int col_index = K_PTR(int32_t, tiles)[2 * tile];
+    const int start = K_PTR(int32_t, tiles)[2 * tile + 1];
+    const DevCol c = k_load(d.cols + col_index);
+    const DevChunk ch = k_load(d.chunks + c.chunk);
+    K_AS(uint64_t) planes = K_PTR(uint64_t, d.planes);
+    K_AS(uint32_t) slot_total = K_PTR(uint32_t, d.slot_total);
+    uint64_t P[EMIT_CPT];
+    uint32_t cost[EMIT_CPT];
+#pragma unroll
+    for (int j = 0; j < EMIT_CPT; j++) {
+        const int idx = start + j * WAVE + lane;
+        P[j] = idx < c.n_cells ? d.partition[c.cell_off + idx] : 0ull;
+    }
+    if (c.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) {
+#pragma unroll
+        for (int j = 0; j < EMIT_CPT; j++) cost[j] = column_cost_ancestor(c, ch, planes, slot_total, P[j]);
+    } else if (c.depth <= 32) {
+        column_cost_plain<EMIT_CPT, true>(c, K_PTR(uint32_t, ch.allele_number), planes, slot_total, P, cost);
+    } else {
+        column_cost_plain<EMIT_CPT, false>(c, K_PTR(uint32_t, ch.allele_number), planes, slot_total, P, cost);
+    }
+#pragma unroll
+    for (int j = 0; j < EMIT_CPT; j++) {
+        const int idx = start + j * WAVE + lane;
+        if (idx < c.n_cells) d.cell_cost[c.cell_off + idx] = cost[j];
+    }
+}
+
+hipError_t mrp_launch_emission(const MrpBatchDev &d, const int2 *tiles_dev, int64_t n_tiles, hipStream_t stream) {
+    if (n_tiles == 0) return hipSuccess;
+    const int waves = 4;
+    hipLaunchKernelGGL(mrp_emission_kernel, dim3((unsigned) ((n_tiles + waves - 1) / waves)), dim3(waves * WAVE), 0,
+                       stream, d, tiles_dev, n_tiles);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* max-plus recursion, int32 merge arrays in LDS                                               */
+/* ------------------------------------------------------------------------------------------ */
+/* per-thread registers for one column's share of cells: emission cost, next / previous merge index */
+template <int CPT>
+struct CellRegs {
+    uint32_t cost[CPT], nxt[CPT], prv[CPT];
+};
+template <int CPT>
+static __device__ __forceinline__ void load_cells(CellRegs<CPT> &r, const MrpBatchDev &d, int64_t cell_off,
+                                                  int n_cells, int tid, int T) {
+#pragma unroll
+    for (int j = 0; j < CPT; j++) {
+        const int idx = j * T + tid;
+        if (idx < n_cells) {
+            const int64_t g = cell_off + idx;
+            r.cost[j] = d.cell_cost[g];
+            r.nxt[j] = d.cell_next[g];
+            r.prv[j] = d.cell_prev[g];
+        }
+    }
+}
+
 template <int CPT>
 __global__ void __launch_bounds__(1024)
 mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_merge) {
@@ -200,51 +271,43 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
     const int64_t hmm_index = K_PTR(int32_t, order)[blockIdx.x];
     const DevHmm h = k_load(d.hmms + hmm_index);
     const DevCol *cols = d.cols + h.col0;
-    K_AS(uint64_t) planes = K_PTR(uint64_t, d.planes);
-    K_AS(uint32_t) slot_total = K_PTR(uint32_t, d.slot_total);
     const int K = h.n_cols;
-    const bool ancestor = (h.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
 
     for (int i = tid; i < 2 * max_merge; i += T) lds[i] = MRP_NEG_I32;
     if (tid < 4) red[tid] = MRP_NEG_I32;
-    __syncthreads();
 
     /* ---------------- forward (hmm.c:827-879) ---------------- */
+    DevCol c = k_load(cols);
+    CellRegs<CPT> ra, rb;
+    load_cells<CPT>(ra, d, c.cell_off, c.n_cells, tid, T);
+    __syncthreads();
     for (int k = 0; k < K; k++) {
-        const DevCol c = k_load(cols + k);
-        const DevChunk ch = k_load(d.chunks + c.chunk);
         const bool first = (k == 0), last = (k == K - 1);
-        const bool narrow = c.depth <= 32;
+        /* the next column's descriptor and cells do not depend on the recursion: fetch them now */
+        DevCol cn = c;
+        if (!last) {
+            cn = k_load(cols + k + 1);
+            load_cells<CPT>(rb, d, cn.cell_off, cn.n_cells, tid, T);
+        }
         int32_t local_max = MRP_NEG_I32;
-        for (int base = 0; base < c.n_cells; base += T * CPT) {
-            uint64_t P[CPT];
-            uint32_t cost[CPT];
 #pragma unroll
-            for (int j = 0; j < CPT; j++) {
-                const int idx = base + j * T + tid;
-                P[j] = idx < c.n_cells ? d.partition[c.cell_off + idx] : 0ull;
+        for (int j = 0; j < CPT; j++) {
+            const int idx = j * T + tid;
+            if (idx < c.n_cells) {
+                const int32_t fp = first ? 0 : cur[ra.prv[j]];
+                const int32_t fv = add_i32(fp, -(int32_t) ra.cost[j]);    /* forwardCellCalc1, hmm.c:791-812 */
+                d.cell_f[c.cell_off + idx] = i32_to_log(fv);
+                if (!last) atomicMax(&nxt[ra.nxt[j]], fv);                /* forwardCellCalc2, hmm.c:814-825 */
+                else local_max = max(local_max, fv);
             }
-            if (ancestor) {
-#pragma unroll
-                for (int j = 0; j < CPT; j++) cost[j] = column_cost_ancestor(c, ch, planes, slot_total, P[j]);
-            } else if (narrow) {
-                column_cost_plain<CPT, true>(c, K_PTR(uint32_t, ch.allele_number), planes, slot_total, P, cost);
-            } else {
-                column_cost_plain<CPT, false>(c, K_PTR(uint32_t, ch.allele_number), planes, slot_total, P, cost);
-            }
-#pragma unroll
-            for (int j = 0; j < CPT; j++) {
-                const int idx = base + j * T + tid;
-                if (idx < c.n_cells) {
-                    const int64_t g = c.cell_off + idx;
-                    const int32_t fp = first ? 0 : cur[d.cell_prev[g]];
-                    const int32_t fv = add_i32(fp, -(int32_t) cost[j]);   /* forwardCellCalc1, hmm.c:791-812 */
-                    d.cell_f[g] = i32_to_log(fv);
-                    d.cell_cost[g] = cost[j];
-                    if (!last) atomicMax(&nxt[d.cell_next[g]], fv);        /* forwardCellCalc2, hmm.c:814-825 */
-                    else local_max = max(local_max, fv);
-                }
-            }
+        }
+        for (int idx = CPT * T + tid; idx < c.n_cells; idx += T) {        /* columns wider than CPT*T */
+            const int64_t g = c.cell_off + idx;
+            const int32_t fp = first ? 0 : cur[d.cell_prev[g]];
+            const int32_t fv = add_i32(fp, -(int32_t) d.cell_cost[g]);
+            d.cell_f[g] = i32_to_log(fv);
+            if (!last) atomicMax(&nxt[d.cell_next[g]], fv);
+            else local_max = max(local_max, fv);
         }
         if (last) {
             local_max = wave_max_i32(local_max);
@@ -253,28 +316,49 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
         __syncthreads();
         if (!last) {
             for (int m = tid; m < c.n_merge; m += T) d.merge_f[c.mcell_off + m] = i32_to_log(nxt[m]);
-            const int n_clear = (k + 2 < K) ? K_PTR(DevCol, cols)[k + 1].n_merge : 0;
+            const int n_clear = (k + 2 < K) ? cn.n_merge : 0;
             for (int m = tid; m < n_clear; m += T) cur[m] = MRP_NEG_I32;
         }
         __syncthreads();
         int32_t *t = cur; cur = nxt; nxt = t;
+        c = cn;
+        ra = rb;
     }
     const int32_t hmm_forward = red[0];
 
     /* ---------------- backward (hmm.c:910-929) ---------------- */
-    /* cur = mb of the merge column after column k (read), nxt = mb of the one before (accumulated) */
-    {
-        const int n_clear = K >= 2 ? K_PTR(DevCol, cols)[K - 2].n_merge : 0;
-        for (int m = tid; m < n_clear; m += T) nxt[m] = MRP_NEG_I32;
+    /* c is the last column.  cur = mb of the merge column after column k (read), nxt = mb of the
+     * merge column before it (accumulated). */
+    DevCol pc = c;
+    if (K >= 2) {
+        pc = k_load(cols + K - 2);
+        for (int m = tid; m < pc.n_merge; m += T) nxt[m] = MRP_NEG_I32;
     }
+    load_cells<CPT>(ra, d, c.cell_off, c.n_cells, tid, T);
     __syncthreads();
     for (int k = K - 1; k >= 0; k--) {
-        const DevCol c = k_load(cols + k);
         const bool first = (k == 0), last = (k == K - 1);
+        /* pc = column k-1 (already loaded); fetch its cells and the descriptor of column k-2 */
+        DevCol ppc = pc;
+        if (!first) {
+            load_cells<CPT>(rb, d, pc.cell_off, pc.n_cells, tid, T);
+            if (k >= 2) ppc = k_load(cols + k - 2);
+        }
         int32_t local_max = MRP_NEG_I32;
-        for (int idx = tid; idx < c.n_cells; idx += T) {
+#pragma unroll
+        for (int j = 0; j < CPT; j++) {
+            const int idx = j * T + tid;
+            if (idx < c.n_cells) {
+                const int32_t bv = last ? 0 : cur[ra.nxt[j]];             /* backwardCellCalc, hmm.c:881-908 */
+                d.cell_b[c.cell_off + idx] = i32_to_log(bv);
+                const int32_t p = add_i32(bv, -(int32_t) ra.cost[j]);
+                if (!first) atomicMax(&nxt[ra.prv[j]], p);
+                else local_max = max(local_max, p);
+            }
+        }
+        for (int idx = CPT * T + tid; idx < c.n_cells; idx += T) {
             const int64_t g = c.cell_off + idx;
-            const int32_t bv = last ? 0 : cur[d.cell_next[g]];             /* backwardCellCalc, hmm.c:881-908 */
+            const int32_t bv = last ? 0 : cur[d.cell_next[g]];
             d.cell_b[g] = i32_to_log(bv);
             const int32_t p = add_i32(bv, -(int32_t) d.cell_cost[g]);
             if (!first) atomicMax(&nxt[d.cell_prev[g]], p);
@@ -286,7 +370,6 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
         }
         __syncthreads();
         if (!first) {
-            const DevCol pc = k_load(cols + k - 1);
             int32_t tot = MRP_NEG_I32;
             for (int m = tid; m < pc.n_merge; m += T) {
                 const int32_t mbv = nxt[m];
@@ -296,7 +379,7 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
             }
             tot = wave_max_i32(tot);
             if ((tid & (WAVE - 1)) == 0) atomicMax(&red[2], tot);
-            const int n_clear = (k >= 2) ? K_PTR(DevCol, cols)[k - 2].n_merge : 0;
+            const int n_clear = (k >= 2) ? ppc.n_merge : 0;
             for (int m = tid; m < n_clear; m += T) cur[m] = MRP_NEG_I32;
         }
         __syncthreads();
@@ -305,6 +388,9 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
             red[2] = MRP_NEG_I32;
         }
         int32_t *t = cur; cur = nxt; nxt = t;
+        c = pc;
+        pc = ppc;
+        ra = rb;
     }
     if (tid == 0) {
         d.col_total[h.col0 + K - 1] = i32_to_log(hmm_forward);
@@ -318,18 +404,10 @@ hipError_t mrp_launch_sweep_i32(const MrpBatchDev &d, const int32_t *order_dev, 
     if (n == 0) return hipSuccess;
     if (max_merge < 1) max_merge = 1;
     const size_t lds = (size_t) (2 * max_merge + 4) * sizeof(int32_t);
-    hipError_t e;
-    if (block_threads >= 512) {
-        auto k = mrp_sweep_i32_kernel<4>;
-        e = hipFuncSetAttribute((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned) n), dim3(block_threads), lds, stream, d, order_dev, max_merge);
-    } else {
-        auto k = mrp_sweep_i32_kernel<1>;
-        e = hipFuncSetAttribute((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-        if (e != hipSuccess) return e;
-        hipLaunchKernelGGL(k, dim3((unsigned) n), dim3(block_threads), lds, stream, d, order_dev, max_merge);
-    }
+    auto k = mrp_sweep_i32_kernel<4>;
+    hipError_t e = hipFuncSetAttribute((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k, dim3((unsigned) n), dim3(block_threads), lds, stream, d, order_dev, max_merge);
     return hipGetLastError();
 }
 
@@ -376,10 +454,7 @@ __global__ void __launch_bounds__(1024) mrp_sweep_f64_kernel(MrpBatchDev d, cons
     const int64_t hmm_index = K_PTR(int32_t, order)[blockIdx.x];
     const DevHmm h = k_load(d.hmms + hmm_index);
     const DevCol *cols = d.cols + h.col0;
-    K_AS(uint64_t) planes = K_PTR(uint64_t, d.planes);
-    K_AS(uint32_t) slot_total = K_PTR(uint32_t, d.slot_total);
     const int K = h.n_cols;
-    const bool ancestor = (h.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
     const bool max_not_sum = (h.flags & MRP_FLAG_MAX_NOT_SUM) != 0;
     const double NEG = -__builtin_inf();
     double *hmm_f = d.hmm_fb + 2 * hmm_index, *hmm_b = hmm_f + 1;
@@ -387,21 +462,15 @@ __global__ void __launch_bounds__(1024) mrp_sweep_f64_kernel(MrpBatchDev d, cons
 
     for (int k = 0; k < K; k++) {
         const DevCol c = k_load(cols + k);
-        const DevChunk ch = k_load(d.chunks + c.chunk);
         const bool first = (k == 0), last = (k == K - 1);
         const DevCol pc = k_load(cols + (first ? k : k - 1));
         double local = NEG;
         for (int idx = tid; idx < c.n_cells; idx += T) {
             const int64_t g = c.cell_off + idx;
-            const uint64_t P[1] = {d.partition[g]};
-            uint32_t cost[1];
-            if (ancestor) cost[0] = column_cost_ancestor(c, ch, planes, slot_total, P[0]);
-            else column_cost_plain<1, false>(c, K_PTR(uint32_t, ch.allele_number), planes, slot_total, P, cost);
-            const double e = -((double) cost[0]);                            /* emissions.c:239 */
+            const double e = -((double) d.cell_cost[g]);                         /* emissions.c:239 */
             double fv = first ? 0.0 : load_agent(&d.merge_f[pc.mcell_off + d.cell_prev[g]]);
             fv += e;
             d.cell_f[g] = fv;
-            d.cell_cost[g] = cost[0];
             if (!last) atomic_log_add_p(&d.merge_f[c.mcell_off + d.cell_next[g]], fv, max_not_sum);
             else local = log_add_p(local, fv, max_not_sum);
         }
