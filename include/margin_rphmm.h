@@ -78,7 +78,8 @@ void mrp_chunk_destroy(mrp_chunk *chunk);
 /*
  * One flattened stRPHmm (inc/margin.h:340-353,393-402,421-425,439-445,463-467).
  * All arrays are host memory owned by the caller; cells are in LIST ORDER (column->head ...
- * ->nCell) and the outputs are written back in the same order.
+ * ->nCell) and the outputs are written back in the same order.  A job whose seven output
+ * pointers are all NULL is device-only: it is swept, its results stay in HBM.
  */
 typedef struct mrp_hmm_job {
     const mrp_chunk *chunk;
@@ -159,6 +160,80 @@ int mrp_count_bit_vectors(mrp_context *ctx, const mrp_chunk *chunk, int32_t firs
 int mrp_emissions(mrp_context *ctx, const mrp_chunk *chunk, int32_t first_site, int32_t n_sites,
                   int32_t depth, const int64_t *read_byte_off, uint32_t flags, int64_t n_cells,
                   const uint64_t *partitions, double *out);
+
+/* ============================================================================================
+ * Host pipeline around the sweep (SURVEY.md section 8a last row / 8f): the structural stRPHmm
+ * operations that DEFINE the inputs of every sweep, written against flat arrays instead of
+ * linked lists + hash tables so that an hmm is, byte for byte, a device-ready mrp_hmm_job.
+ * Same names, argument meaning and error behaviour as the reference functions they mirror;
+ * every stRPHmm_forwardBackward inside them runs on the device through mrp_fb_run.
+ * ============================================================================================ */
+
+/* The stRPHmmParameters fields read by impl/hmm.c, coordination.c, genomeFragment.c
+ * (inc/margin.h:239-322; shipped values: params/base_params.json "phase"). */
+typedef struct mrp_params {
+    int32_t max_not_sum_transitions;
+    int32_t include_inverted_partitions;
+    int32_t include_ancestor_sub_prob;
+    int32_t reserved;
+    int64_t min_partitions_in_a_column;
+    int64_t max_partitions_in_a_column;
+    double min_posterior_probability_for_partition;
+    int64_t max_coverage_depth;
+    int64_t min_read_coverage_to_support_phasing_between_heterozygous_sites;
+    int64_t rounds_of_iterative_refinement;
+} mrp_params;
+
+/* One stProfileSeq (inc/margin.h:191-203): its bytes live in the chunk's profile pool. */
+typedef struct mrp_read {
+    const char *name;      /* readId; orders hmms that share start and length (hmm.c:82-87) */
+    int32_t ref_start;     /* first site */
+    int32_t length;        /* number of sites (> 0) */
+    int32_t forward_strand; /* BamChunkRead.forwardStrand (bubbleGraph.c:2709) */
+    int32_t reserved;
+    int64_t pool_offset;   /* offset of profileProbs in the chunk's pool */
+} mrp_read;
+
+typedef struct mrp_hmm mrp_hmm; /* a flat stRPHmm */
+
+/* getRPHmms (coordination.c:490-516) over reads[read_index[0..n)): tiling paths, hierarchical
+ * merge (fuse -> align -> cross product -> forward/backward on the device -> prune).  Returns a
+ * malloc'd array of hmms ordered and non-overlapping in reference coordinates.  If record is not
+ * NULL every sweep issued is also appended to that batch (mrp_batch_add) for later replay. */
+int mrp_get_rp_hmms(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *reads, const int32_t *read_index,
+                    int64_t n, const mrp_params *params, mrp_batch *record, mrp_hmm ***hmms_out, int64_t *n_out);
+void mrp_hmm_destroy(mrp_hmm *hmm);
+void mrp_free(void *p);
+/* Expose an hmm's arrays as an mrp_hmm_job (inputs and the outputs of its last sweep; pointers
+ * stay owned by the hmm).  col_reads_out (optional) receives the per-column read ids. */
+int mrp_hmm_view(const mrp_hmm *hmm, mrp_hmm_job *view, const int32_t **col_reads_out, int32_t *ref_start,
+                 int32_t *ref_length);
+/* stRPHmm_forwardBackward (hmm.c:931) on a flat hmm; flags from params. */
+int mrp_hmm_forward_backward(mrp_context *ctx, const mrp_chunk *chunk, mrp_hmm *hmm, const mrp_params *params,
+                             mrp_batch *record);
+/* stRPHmm_prune (hmm.c:1160) */
+int mrp_hmm_prune(mrp_hmm *hmm, const mrp_params *params);
+/* stRPHmm_forwardTraceBack (hmm.c:165-219): cell index (within its column) per column. */
+int mrp_hmm_forward_trace_back(const mrp_hmm *hmm, int32_t *cell_index_per_column);
+
+/* stGenomeFragment (inc/margin.h:482-520) + read partition, as plain arrays. */
+typedef struct mrp_phase_result {
+    int32_t ref_start, length;
+    uint64_t *genotype_string, *haplotype_string1, *haplotype_string2, *ancestor_string;
+    uint64_t *reads_supporting_haplotype1, *reads_supporting_haplotype2;
+    float *genotype_probs, *haplotype_probs1, *haplotype_probs2;
+    int32_t *reads1, *reads2; /* indices into the reads array */
+    int64_t n_reads1, n_reads2;
+    double hmm_forward, hmm_backward; /* of the final sweep */
+    int64_t n_sweeps;                 /* forward/backward sweeps issued */
+} mrp_phase_result;
+
+/* bubbleGraph_phaseBubbleGraph (bubbleGraph.c:2673-2801) from profile sequences: coverage
+ * filter, strand split, getRPHmms per strand (ancestor model off), join, final sweep (ancestor
+ * model on), trace back, genome fragment, iterative refinement, re-adding filtered reads. */
+int mrp_phase_reads(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *reads, int64_t n_reads,
+                    const mrp_params *params, mrp_batch *record, mrp_phase_result **out);
+void mrp_phase_result_destroy(mrp_phase_result *r);
 
 #ifdef __cplusplus
 }

@@ -25,7 +25,9 @@ EXPORTED_SYMBOLS = [
     "mrp_last_error", "mrp_version", "mrp_device_count", "mrp_context_create", "mrp_context_destroy",
     "mrp_context_synchronize", "mrp_chunk_create", "mrp_chunk_destroy", "mrp_fb_run", "mrp_batch_create",
     "mrp_batch_add", "mrp_batch_upload", "mrp_batch_launch", "mrp_batch_download", "mrp_batch_destroy",
-    "mrp_batch_stats", "mrp_count_bit_vectors", "mrp_emissions",
+    "mrp_batch_stats", "mrp_count_bit_vectors", "mrp_emissions", "mrp_get_rp_hmms", "mrp_hmm_destroy", "mrp_free",
+    "mrp_hmm_view", "mrp_hmm_forward_backward", "mrp_hmm_prune", "mrp_hmm_forward_trace_back", "mrp_phase_reads",
+    "mrp_phase_result_destroy",
 ]
 
 
@@ -52,6 +54,50 @@ class LaunchStats(C.Structure):
                 ("n_columns", C.c_int64), ("n_cells", C.c_int64), ("n_merge_cells", C.c_int64),
                 ("profile_bytes", C.c_int64), ("algorithmic_bytes", C.c_int64), ("popcount_ops", C.c_int64),
                 ("units", C.c_int64)]
+
+
+class Params(C.Structure):
+    """mrp_params (mirror of the stRPHmmParameters fields the L1 code reads)."""
+    _fields_ = [("max_not_sum_transitions", C.c_int32), ("include_inverted_partitions", C.c_int32),
+                ("include_ancestor_sub_prob", C.c_int32), ("reserved", C.c_int32),
+                ("min_partitions_in_a_column", C.c_int64), ("max_partitions_in_a_column", C.c_int64),
+                ("min_posterior_probability_for_partition", C.c_double), ("max_coverage_depth", C.c_int64),
+                ("min_read_coverage_to_support_phasing_between_heterozygous_sites", C.c_int64),
+                ("rounds_of_iterative_refinement", C.c_int64)]
+
+    @classmethod
+    def from_reference_names(cls, d: dict) -> "Params":
+        """Build from a dict keyed by the reference's parameter names (params/base_params.json)."""
+        p = cls()
+        p.max_not_sum_transitions = int(d["maxNotSumTransitions"])
+        p.include_inverted_partitions = int(d["includeInvertedPartitions"])
+        p.include_ancestor_sub_prob = int(d.get("includeAncestorSubProb", 1))
+        p.min_partitions_in_a_column = int(d["minPartitionsInAColumn"])
+        p.max_partitions_in_a_column = int(d["maxPartitionsInAColumn"])
+        p.min_posterior_probability_for_partition = float(d["minPosteriorProbabilityForPartition"])
+        p.max_coverage_depth = int(d["maxCoverageDepth"])
+        p.min_read_coverage_to_support_phasing_between_heterozygous_sites = int(
+            d.get("minReadCoverageToSupportPhasingBetweenHeterozygousSites", 0))
+        p.rounds_of_iterative_refinement = int(d.get("roundsOfIterativeRefinement", 0))
+        return p
+
+
+class ReadRec(C.Structure):
+    _fields_ = [("name", C.c_char_p), ("ref_start", C.c_int32), ("length", C.c_int32),
+                ("forward_strand", C.c_int32), ("reserved", C.c_int32), ("pool_offset", C.c_int64)]
+
+
+class PhaseResult(C.Structure):
+    _fields_ = [("ref_start", C.c_int32), ("length", C.c_int32),
+                ("genotype_string", C.POINTER(C.c_uint64)), ("haplotype_string1", C.POINTER(C.c_uint64)),
+                ("haplotype_string2", C.POINTER(C.c_uint64)), ("ancestor_string", C.POINTER(C.c_uint64)),
+                ("reads_supporting_haplotype1", C.POINTER(C.c_uint64)),
+                ("reads_supporting_haplotype2", C.POINTER(C.c_uint64)),
+                ("genotype_probs", C.POINTER(C.c_float)), ("haplotype_probs1", C.POINTER(C.c_float)),
+                ("haplotype_probs2", C.POINTER(C.c_float)),
+                ("reads1", C.POINTER(C.c_int32)), ("reads2", C.POINTER(C.c_int32)),
+                ("n_reads1", C.c_int64), ("n_reads2", C.c_int64),
+                ("hmm_forward", C.c_double), ("hmm_backward", C.c_double), ("n_sweeps", C.c_int64)]
 
 
 _lib = None
@@ -88,6 +134,18 @@ def load():
     L.mrp_batch_stats.argtypes = [vp, P(LaunchStats)]
     L.mrp_count_bit_vectors.argtypes = [vp, vp, i32, i32, i32, vp, vp]
     L.mrp_emissions.argtypes = [vp, vp, i32, i32, i32, vp, u32, i64, vp, vp]
+    L.mrp_get_rp_hmms.argtypes = [vp, vp, P(ReadRec), vp, i64, P(Params), vp, P(P(vp)), P(i64)]
+    L.mrp_hmm_destroy.argtypes = [vp]
+    L.mrp_hmm_destroy.restype = None
+    L.mrp_free.argtypes = [vp]
+    L.mrp_free.restype = None
+    L.mrp_hmm_view.argtypes = [vp, P(HmmJob), P(vp), P(i32), P(i32)]
+    L.mrp_hmm_forward_backward.argtypes = [vp, vp, vp, P(Params), vp]
+    L.mrp_hmm_prune.argtypes = [vp, P(Params)]
+    L.mrp_hmm_forward_trace_back.argtypes = [vp, vp]
+    L.mrp_phase_reads.argtypes = [vp, vp, P(ReadRec), i64, P(Params), vp, P(P(PhaseResult))]
+    L.mrp_phase_result_destroy.argtypes = [P(PhaseResult)]
+    L.mrp_phase_result_destroy.restype = None
     _lib = L
     return L
 
@@ -249,3 +307,104 @@ def emissions(ctx: Context, dchunk: DeviceChunk, first_site: int, n_sites: int, 
                                 off.ctypes.data if off.size else None, flags, part.shape[0], part.ctypes.data,
                                 out.ctypes.data))
     return out[:part.shape[0]]
+
+
+# ---- host pipeline (rphmm_host.c) -----------------------------------------------------------
+
+def read_records(chunk):
+    """mrp_read[] for a margin_amd.synth.Chunk; returns (ctypes array, keep-alive list)."""
+    n = len(chunk.reads)
+    arr = (ReadRec * max(n, 1))()
+    names = [r.name.encode() for r in chunk.reads]
+    for i, r in enumerate(chunk.reads):
+        arr[i].name = names[i]
+        arr[i].ref_start = r.ref_start
+        arr[i].length = r.length
+        arr[i].forward_strand = r.strand
+        arr[i].pool_offset = r.pool_off
+    return arr, names
+
+
+def _as_np(ptr, n, dtype):
+    if n == 0:
+        return np.zeros(0, dtype=dtype)
+    return np.ctypeslib.as_array(C.cast(ptr, C.POINTER(np.ctypeslib.as_ctypes_type(dtype))), shape=(n,)).copy()
+
+
+def hmm_to_flat(hmm_handle) -> Dict[str, np.ndarray]:
+    """Copy a flat mrp_hmm into the same dict layout oracle.orc.flatten produces."""
+    L = load()
+    v = HmmJob()
+    cr = C.c_void_p()
+    rs, rl = C.c_int32(), C.c_int32()
+    _check(L.mrp_hmm_view(hmm_handle, C.byref(v), C.byref(cr), C.byref(rs), C.byref(rl)))
+    K = int(v.n_columns)
+    cell_off = _as_np(v.col_cell_off, K + 1, np.int64)
+    read_off = _as_np(v.col_read_off, K + 1, np.int64)
+    mcol = _as_np(v.mcol_cell_off, K, np.int64)
+    nC, nD, nM = int(cell_off[K]), int(read_off[K]), int(mcol[K - 1]) if K > 1 else 0
+    d = dict(n_columns=K, ref_start=rs.value, ref_length=rl.value,
+             col_ref_start=_as_np(v.col_ref_start, K, np.int32), col_length=_as_np(v.col_length, K, np.int32),
+             col_depth=_as_np(v.col_depth, K, np.int32), col_cell_off=cell_off, col_read_off=read_off,
+             read_byte_off=_as_np(v.read_byte_off, nD, np.int64), read_ids=_as_np(cr, nD, np.int32).astype(np.int64),
+             partition=_as_np(v.partition, nC, np.uint64), mask_from=_as_np(v.mask_from, K - 1, np.uint64),
+             mask_to=_as_np(v.mask_to, K - 1, np.uint64), mcol_cell_off=mcol,
+             merge_from=_as_np(v.merge_from, nM, np.uint64), merge_to=_as_np(v.merge_to, nM, np.uint64),
+             cell_next=_as_np(v.cell_next, nC, np.uint32), cell_prev=_as_np(v.cell_prev, nC, np.uint32))
+    if v.cell_forward:
+        d.update(cell_forward=_as_np(v.cell_forward, nC, np.float64), cell_backward=_as_np(v.cell_backward, nC, np.float64),
+                 merge_forward=_as_np(v.merge_forward, nM, np.float64), merge_backward=_as_np(v.merge_backward, nM, np.float64),
+                 col_total=_as_np(v.col_total, K, np.float64),
+                 hmm_forward=float(C.cast(v.hmm_forward, C.POINTER(C.c_double))[0]),
+                 hmm_backward=float(C.cast(v.hmm_backward, C.POINTER(C.c_double))[0]))
+    return d
+
+
+def get_rp_hmms(ctx: Context, dchunk: DeviceChunk, chunk, params: Params, read_index=None, record: Optional[Batch] = None):
+    """mrp_get_rp_hmms; returns list of opaque hmm handles (destroy with hmm_destroy)."""
+    L = load()
+    recs, _keep = read_records(chunk)
+    idx = np.arange(len(chunk.reads), dtype=np.int32) if read_index is None else np.ascontiguousarray(read_index, dtype=np.int32)
+    out = C.POINTER(C.c_void_p)()
+    n_out = C.c_int64(0)
+    _check(L.mrp_get_rp_hmms(ctx.h, dchunk.h, recs, idx.ctypes.data if idx.size else None, idx.shape[0],
+                             C.byref(params), record.h if record else None, C.byref(out), C.byref(n_out)))
+    hmms = [C.c_void_p(out[i]) for i in range(n_out.value)]
+    L.mrp_free(out)
+    return hmms
+
+
+def hmm_destroy(h):
+    load().mrp_hmm_destroy(h)
+
+
+def hmm_forward_backward(ctx: Context, dchunk: DeviceChunk, h, params: Params):
+    _check(load().mrp_hmm_forward_backward(ctx.h, dchunk.h, h, C.byref(params), None))
+
+
+def hmm_forward_trace_back(h, n_columns: int) -> np.ndarray:
+    path = np.zeros(n_columns, dtype=np.int32)
+    _check(load().mrp_hmm_forward_trace_back(h, path.ctypes.data))
+    return path
+
+
+def phase_reads(ctx: Context, dchunk: DeviceChunk, chunk, params: Params, record: Optional[Batch] = None) -> dict:
+    """mrp_phase_reads (bubbleGraph.c:2673 driver) -> dict with the same keys as the oracle's."""
+    L = load()
+    recs, _keep = read_records(chunk)
+    res = C.POINTER(PhaseResult)()
+    _check(L.mrp_phase_reads(ctx.h, dchunk.h, recs, len(chunk.reads), C.byref(params), record.h if record else None,
+                             C.byref(res)))
+    g = res.contents
+    n = int(g.length)
+    out = dict(ref_start=int(g.ref_start), length=n,
+               reads1=[int(g.reads1[i]) for i in range(g.n_reads1)], reads2=[int(g.reads2[i]) for i in range(g.n_reads2)],
+               hap1=_as_np(g.haplotype_string1, n, np.uint64), hap2=_as_np(g.haplotype_string2, n, np.uint64),
+               genotype=_as_np(g.genotype_string, n, np.uint64), ancestor=_as_np(g.ancestor_string, n, np.uint64),
+               genotype_probs=_as_np(g.genotype_probs, n, np.float32), hap_probs1=_as_np(g.haplotype_probs1, n, np.float32),
+               hap_probs2=_as_np(g.haplotype_probs2, n, np.float32),
+               support1=_as_np(g.reads_supporting_haplotype1, n, np.uint64),
+               support2=_as_np(g.reads_supporting_haplotype2, n, np.uint64),
+               hmm_forward=float(g.hmm_forward), hmm_backward=float(g.hmm_backward), n_sweeps=int(g.n_sweeps))
+    L.mrp_phase_result_destroy(res)
+    return out

@@ -19,6 +19,7 @@
 #include "../../include/margin_rphmm.h"
 #include "mrp_device.h"
 #include "mrp_kernels.h"
+#include "rphmm_host.h"
 
 namespace {
 
@@ -72,6 +73,8 @@ struct mrp_chunk {
     mrp_context *ctx = nullptr;
     int64_t n_sites = 0, pool_bytes = 0;
     std::vector<uint32_t> allele_number, allele_offset, sub_offset;
+    std::vector<uint16_t> sub, prior; /* host copies for the structural code (rphmm_host.c) */
+    std::vector<uint8_t> pool;
     uint32_t max_sub = 0, max_prior = 0;
     DevBuf<uint32_t> d_allele_number, d_allele_offset, d_sub_offset;
     DevBuf<uint16_t> d_sub, d_prior;
@@ -114,6 +117,25 @@ struct mrp_batch {
 };
 
 extern "C" {
+
+void mrp_chunk_host_view(const mrp_chunk *chunk, mrp_chunk_host *out) {
+    out->n_sites = chunk->n_sites;
+    out->allele_number = chunk->allele_number.data();
+    out->allele_offset = chunk->allele_offset.data();
+    out->sub_offset = chunk->sub_offset.data();
+    out->sub = chunk->sub.data();
+    out->prior = chunk->prior.data();
+    out->pool = chunk->pool.data();
+    out->pool_bytes = chunk->pool_bytes;
+}
+mrp_context *mrp_chunk_context(const mrp_chunk *chunk) { return chunk->ctx; }
+int mrp_set_error(int code, const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
 
 const char *mrp_last_error(void) { return g_err; }
 const char *mrp_version(void) { return "margin_rphmm 0.1.0 gfx950"; }
@@ -194,7 +216,10 @@ int mrp_chunk_create(mrp_context *ctx, int64_t n_sites, const uint32_t *allele_n
     }
     ch->allele_offset[n_sites] = (uint32_t) off;
     ch->sub_offset[n_sites] = (uint32_t) soff;
-    std::vector<uint16_t> sub(soff, 0), prior(off, 0);
+    std::vector<uint16_t> &sub = ch->sub, &prior = ch->prior;
+    sub.assign(soff, 0);
+    prior.assign(off, 0);
+    if (pool_bytes > 0) ch->pool.assign(profile_pool, profile_pool + pool_bytes);
     if (substitution_log_probs) sub.assign(substitution_log_probs, substitution_log_probs + soff);
     if (allele_prior_log_probs) prior.assign(allele_prior_log_probs, allele_prior_log_probs + off);
     for (uint16_t v : sub) ch->max_sub = std::max<uint32_t>(ch->max_sub, v);
@@ -290,8 +315,10 @@ int mrp_batch_add(mrp_batch *b, const mrp_hmm_job *job) {
     if (K > 1 && (!job->mcol_cell_off || ((!job->cell_next || !job->cell_prev) &&
                                           (!job->mask_from || !job->mask_to || !job->merge_from || !job->merge_to))))
         return fail(MRP_ERR_ARG, "hmm job is missing its merge column arrays");
-    if (!job->cell_forward || !job->cell_backward || !job->col_total || !job->hmm_forward || !job->hmm_backward ||
-        (K > 1 && (!job->merge_forward || !job->merge_backward)))
+    const bool device_only = !job->cell_forward && !job->cell_backward && !job->col_total && !job->hmm_forward &&
+                             !job->hmm_backward && !job->merge_forward && !job->merge_backward;
+    if (!device_only && (!job->cell_forward || !job->cell_backward || !job->col_total || !job->hmm_forward ||
+                         !job->hmm_backward || (K > 1 && (!job->merge_forward || !job->merge_backward))))
         return fail(MRP_ERR_ARG, "hmm job is missing output arrays");
     const mrp_chunk *ch = job->chunk;
     if (ch->ctx != b->ctx) return fail(MRP_ERR_ARG, "chunk belongs to a different context");
@@ -588,6 +615,7 @@ int mrp_batch_download(mrp_batch *b) {
     HIP_TRY(hipStreamSynchronize(s));
     for (size_t i = 0; i < b->outs.size(); i++) {
         const JobOut &o = b->outs[i];
+        if (!o.cell_f) continue; /* device-only job */
         memcpy(o.cell_f, f.data() + o.cell0, sizeof(double) * (size_t) o.n_cells);
         memcpy(o.cell_b, bb.data() + o.cell0, sizeof(double) * (size_t) o.n_cells);
         if (o.n_merge > 0) {

@@ -1,0 +1,1165 @@
+/*
+ * rphmm_host.c -- host pipeline of libmargin_rphmm.so, in C as the reference's host code is.
+ *
+ * The structural stRPHmm operations of impl/hmm.c, column.c, mergeColumn.c, coordination.c,
+ * genomeFragment.c and the phasing driver bubbleGraph.c:2673-2801, re-designed around ONE flat
+ * structure-of-arrays hmm (struct mrp_hmm) whose arrays are exactly the arrays of mrp_hmm_job:
+ * cells are rows of (partition, next, prev), merge cells rows of (from, to), transitions are
+ * indices instead of hash lookups.  Nothing is flattened before a sweep; the device batch is a
+ * memcpy of these arrays.  Every forward/backward sweep runs on the GPU via mrp_fb_run /
+ * mrp_batch_*; there is no CPU sweep in this file.
+ *
+ * Order conventions (DESIGN.md "Order semantics"): cell order is the reference's list order;
+ * merge cells keep creation order; stList_sort2 is taken to be stable; stHash/stSet iteration
+ * (address dependent in the reference) is creation order.
+ */
+#define _GNU_SOURCE
+#include "rphmm_host.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------------------------------ */
+/* helpers                                                                                     */
+/* ------------------------------------------------------------------------------------------ */
+static void *xmalloc(size_t n) { /* like st_malloc: out of memory is fatal */
+    void *p = malloc(n ? n : 1);
+    if (!p) { fprintf(stderr, "margin_rphmm: out of host memory\n"); abort(); }
+    return p;
+}
+static void *xcalloc(size_t n, size_t s) {
+    void *p = calloc(n ? n : 1, s ? s : 1);
+    if (!p) { fprintf(stderr, "margin_rphmm: out of host memory\n"); abort(); }
+    return p;
+}
+static void *xrealloc(void *q, size_t n) {
+    void *p = realloc(q, n ? n : 1);
+    if (!p) { fprintf(stderr, "margin_rphmm: out of host memory\n"); abort(); }
+    return p;
+}
+void mrp_free(void *p) { free(p); }
+
+#define VEC(T) struct { T *a; int64_t n, cap; }
+#define VEC_PUSH(v, x)                                                                        \
+    do {                                                                                      \
+        if ((v).n == (v).cap) {                                                               \
+            (v).cap = (v).cap ? (v).cap * 2 : 16;                                             \
+            (v).a = xrealloc((v).a, sizeof(*(v).a) * (size_t) (v).cap);                       \
+        }                                                                                     \
+        (v).a[(v).n++] = (x);                                                                 \
+    } while (0)
+#define VEC_RESERVE(v, extra)                                                                 \
+    do {                                                                                      \
+        if ((v).n + (int64_t) (extra) > (v).cap) {                                            \
+            while ((v).n + (int64_t) (extra) > (v).cap) (v).cap = (v).cap ? (v).cap * 2 : 16; \
+            (v).a = xrealloc((v).a, sizeof(*(v).a) * (size_t) (v).cap);                       \
+        }                                                                                     \
+    } while (0)
+
+static inline uint64_t mix64(uint64_t x) {
+    x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33;
+    return x;
+}
+/* uint64 -> uint32 open-addressing map (stands in for the stHash of mergeColumn.c:27-31) */
+typedef struct { uint64_t *k; uint32_t *v; uint64_t mask; } u64map;
+#define U64MAP_EMPTY 0xFFFFFFFFu
+static void u64map_init(u64map *m, int64_t expect) {
+    uint64_t cap = 16;
+    while (cap < (uint64_t) expect * 2) cap *= 2;
+    m->mask = cap - 1;
+    m->k = xmalloc(sizeof(uint64_t) * cap);
+    m->v = xmalloc(sizeof(uint32_t) * cap);
+    memset(m->v, 0xFF, sizeof(uint32_t) * cap);
+}
+static void u64map_free(u64map *m) { free(m->k); free(m->v); m->k = NULL; m->v = NULL; }
+static inline uint32_t u64map_get(const u64map *m, uint64_t key) {
+    uint64_t i = mix64(key) & m->mask;
+    while (m->v[i] != U64MAP_EMPTY) {
+        if (m->k[i] == key) return m->v[i];
+        i = (i + 1) & m->mask;
+    }
+    return U64MAP_EMPTY;
+}
+static inline void u64map_put(u64map *m, uint64_t key, uint32_t val) { /* caller sized the map */
+    uint64_t i = mix64(key) & m->mask;
+    while (m->v[i] != U64MAP_EMPTY) {
+        if (m->k[i] == key) { m->v[i] = val; return; }
+        i = (i + 1) & m->mask;
+    }
+    m->k[i] = key; m->v[i] = val;
+}
+
+/* partitions.c */
+static inline uint64_t accept_mask(int64_t depth) { /* :13-19 */
+    return depth < 64 ? ~(0xFFFFFFFFFFFFFFFFULL << depth) : 0xFFFFFFFFFFFFFFFFULL;
+}
+static inline uint64_t merge_bits(uint64_t p1, uint64_t p2, int64_t d1) { /* :21-28 */
+    return d1 < 64 ? ((p2 << d1) | p1) : p1;
+}
+static inline uint64_t invert_partition(uint64_t p, int64_t depth) { return accept_mask(depth) & ~p; } /* :37-42 */
+
+/* ------------------------------------------------------------------------------------------ */
+/* the flat hmm                                                                                */
+/* ------------------------------------------------------------------------------------------ */
+struct mrp_hmm {
+    int32_t ref_start, ref_length; /* stRPHmm.refStart / refLength */
+    int32_t max_depth;
+    VEC(int32_t) reads;            /* stRPHmm.profileSeqs (read indices) */
+    /* columns */
+    VEC(int32_t) col_start, col_len, col_depth;
+    VEC(int64_t) cell_off, read_off;   /* K+1 */
+    VEC(int32_t) col_reads;            /* per column, bit order */
+    VEC(int64_t) read_byte_off;        /* per column per read: offset of column->seqs[i] in the pool */
+    /* cells */
+    VEC(uint64_t) part;
+    VEC(uint32_t) next, prev;
+    /* merge columns */
+    VEC(uint64_t) mask_from, mask_to;  /* K-1 */
+    VEC(int64_t) mcell_off;            /* K (first entry 0) */
+    VEC(uint64_t) mfrom, mto;
+    /* results of the last sweep */
+    double *f, *b, *mf, *mb, *total;
+    double fwd, bwd;
+    int has_results;
+};
+
+static int64_t hmm_K(const mrp_hmm *h) { return h->col_start.n; }
+
+static mrp_hmm *hmm_new(void) {
+    mrp_hmm *h = xcalloc(1, sizeof(*h));
+    VEC_PUSH(h->cell_off, 0);
+    VEC_PUSH(h->read_off, 0);
+    VEC_PUSH(h->mcell_off, 0);
+    return h;
+}
+static void hmm_free_results(mrp_hmm *h) {
+    free(h->f); free(h->b); free(h->mf); free(h->mb); free(h->total);
+    h->f = h->b = h->mf = h->mb = h->total = NULL;
+    h->has_results = 0;
+}
+void mrp_hmm_destroy(mrp_hmm *h) {
+    if (!h) return;
+    free(h->reads.a); free(h->col_start.a); free(h->col_len.a); free(h->col_depth.a); free(h->cell_off.a);
+    free(h->read_off.a); free(h->col_reads.a); free(h->read_byte_off.a); free(h->part.a); free(h->next.a);
+    free(h->prev.a); free(h->mask_from.a); free(h->mask_to.a); free(h->mcell_off.a); free(h->mfrom.a); free(h->mto.a);
+    hmm_free_results(h);
+    free(h);
+}
+
+/* per-job view of the reads + chunk the structural code works against */
+typedef struct {
+    const mrp_chunk *chunk;
+    mrp_chunk_host ch;
+    const mrp_read *reads;
+    int64_t n_reads;
+    mrp_context *ctx;
+    mrp_batch *record;
+    int64_t n_sweeps;
+    uint32_t max_alleles;
+} world;
+
+static int64_t read_byte_offset(const world *w, int32_t read, int32_t site) { /* profileSeq.c:41-47 */
+    const mrp_read *r = &w->reads[read];
+    return r->pool_offset + (int64_t) (w->ch.allele_offset[site] - w->ch.allele_offset[r->ref_start]);
+}
+
+/* begin a column; cells are appended afterwards */
+static void hmm_begin_column(mrp_hmm *h, const world *w, int32_t start, int32_t len, int32_t depth,
+                             const int32_t *col_reads) {
+    VEC_PUSH(h->col_start, start);
+    VEC_PUSH(h->col_len, len);
+    VEC_PUSH(h->col_depth, depth);
+    for (int32_t i = 0; i < depth; i++) {
+        VEC_PUSH(h->col_reads, col_reads[i]);
+        VEC_PUSH(h->read_byte_off, read_byte_offset(w, col_reads[i], start));
+    }
+    if (depth > h->max_depth) h->max_depth = depth;
+}
+static void hmm_end_column(mrp_hmm *h) {
+    VEC_PUSH(h->cell_off, h->part.n);
+    VEC_PUSH(h->read_off, h->col_reads.n);
+}
+static inline void hmm_add_cell(mrp_hmm *h, uint64_t p, uint32_t prev) {
+    VEC_PUSH(h->part, p);
+    VEC_PUSH(h->prev, prev);
+    VEC_PUSH(h->next, 0u);
+}
+static void hmm_begin_merge(mrp_hmm *h, uint64_t mask_from, uint64_t mask_to) {
+    VEC_PUSH(h->mask_from, mask_from);
+    VEC_PUSH(h->mask_to, mask_to);
+}
+static void hmm_end_merge(mrp_hmm *h) { VEC_PUSH(h->mcell_off, h->mfrom.n); }
+
+/* stRPHmm_construct hmm.c:97-133: one column, cells {1, 0} */
+static mrp_hmm *hmm_from_read(const world *w, int32_t read) {
+    mrp_hmm *h = hmm_new();
+    const mrp_read *r = &w->reads[read];
+    h->ref_start = r->ref_start;
+    h->ref_length = r->length;
+    VEC_PUSH(h->reads, read);
+    hmm_begin_column(h, w, r->ref_start, r->length, 1, &read);
+    hmm_add_cell(h, 1, 0);
+    hmm_add_cell(h, 0, 0);
+    hmm_end_column(h);
+    return h;
+}
+
+/* stRPHmm_cmpFn hmm.c:67-95 (single reference per chunk; pointer tie-break -> creation order) */
+static int hmm_cmp(const world *w, const mrp_hmm *a, const mrp_hmm *b) {
+    if (a->ref_start != b->ref_start) return a->ref_start > b->ref_start ? 1 : -1;
+    if (a->ref_length != b->ref_length) return b->ref_length > a->ref_length ? 1 : -1;
+    if (a->reads.n > 0 && b->reads.n > 0) {
+        int i = strcmp(w->reads[a->reads.a[0]].name, w->reads[b->reads.a[0]].name);
+        if (i != 0) return i;
+    }
+    return a > b ? 1 : (a < b ? -1 : 0);
+}
+static int hmm_overlap(const mrp_hmm *a, const mrp_hmm *b) { /* hmm.c:1165-1190 */
+    if (a->ref_start > b->ref_start) return hmm_overlap(b, a);
+    return a->ref_start + a->ref_length > b->ref_start;
+}
+
+typedef VEC(mrp_hmm *) hmm_vec;
+
+static const world *g_sort_world; /* qsort context; the pipeline is single-threaded per call */
+static __thread const world *t_sort_world;
+static int hmm_cmp_qsort(const void *a, const void *b) {
+    (void) g_sort_world;
+    return hmm_cmp(t_sort_world, *(mrp_hmm *const *) a, *(mrp_hmm *const *) b);
+}
+static void sort_hmms(const world *w, mrp_hmm **a, int64_t n) {
+    t_sort_world = w;
+    qsort(a, (size_t) n, sizeof(*a), hmm_cmp_qsort);
+}
+
+/* getTilingPaths coordination.c:186-222 (+ :19-55): consumes the array */
+typedef VEC(hmm_vec *) path_vec;
+static path_vec tiling_paths_from(const world *w, mrp_hmm **hmms, int64_t n) {
+    sort_hmms(w, hmms, n);
+    uint8_t *used = xcalloc((size_t) n, 1);
+    path_vec paths = {0};
+    int64_t remaining = n, first = 0;
+    while (remaining > 0) {
+        hmm_vec *tp = xcalloc(1, sizeof(*tp));
+        VEC_PUSH(paths, tp);
+        while (used[first]) first++;
+        int64_t cur = first;
+        VEC_PUSH(*tp, hmms[cur]); used[cur] = 1; remaining--;
+        while (1) {
+            const mrp_hmm *h1 = hmms[cur];
+            int64_t nxt = -1;
+            for (int64_t j = cur + 1; j < n; j++) {
+                if (used[j]) continue;
+                if (h1->ref_start + h1->ref_length <= hmms[j]->ref_start) { nxt = j; break; }
+            }
+            if (nxt < 0) break;
+            VEC_PUSH(*tp, hmms[nxt]); used[nxt] = 1; remaining--;
+            cur = nxt;
+        }
+    }
+    free(used);
+    return paths;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* fuse + align + cross product in one pass                                                    */
+/* ------------------------------------------------------------------------------------------ */
+/* A piece is a column of a source hmm (or a gap) restricted to a site interval; a connector is
+ * the merge column that leads out of it.  stRPHmm_fuse (hmm.c:283-372) contributes ZERO
+ * connectors and gap pieces, stRPHmm_alignColumns (hmm.c:374-507) the prefix/suffix gaps and,
+ * through stRPColumn_split (column.c:70-130), the IDENT connectors. */
+typedef enum { CONN_NONE = 0, CONN_REAL, CONN_ZERO, CONN_IDENT } conn_kind;
+typedef struct {
+    const mrp_hmm *h; /* NULL = gap column (depth 0, one cell, partition 0) */
+    int32_t k;        /* column in h */
+    int32_t start, len;
+    conn_kind out;    /* connector to the next piece */
+} piece;
+typedef VEC(piece) piece_vec;
+
+static void pieces_of_path(const hmm_vec *tp, int32_t S, int32_t E, piece_vec *out) {
+    int32_t pos = S;
+    for (int64_t i = 0; i < tp->n; i++) {
+        const mrp_hmm *h = tp->a[i];
+        if (h->ref_start > pos) { /* gap (hmm.c:335-359, :396-424) */
+            piece g = {NULL, 0, pos, h->ref_start - pos, CONN_ZERO};
+            VEC_PUSH(*out, g);
+        }
+        const int64_t K = hmm_K(h);
+        for (int64_t k = 0; k < K; k++) {
+            piece p = {h, (int32_t) k, h->col_start.a[k], h->col_len.a[k], k + 1 < K ? CONN_REAL : CONN_ZERO};
+            VEC_PUSH(*out, p);
+        }
+        pos = h->ref_start + h->ref_length;
+    }
+    if (pos < E) { /* suffix gap (hmm.c:435-462) */
+        piece g = {NULL, 0, pos, E - pos, CONN_ZERO};
+        VEC_PUSH(*out, g);
+    }
+    out->a[out->n - 1].out = CONN_NONE;
+}
+/* cut both piece lists at the union of their boundaries (hmm.c:476-504) */
+static void align_pieces(const piece_vec *a, const piece_vec *b, piece_vec *oa, piece_vec *ob) {
+    int64_t i = 0, j = 0;
+    piece pa = a->a[0], pb = b->a[0];
+    while (1) {
+        const int32_t len = pa.len < pb.len ? pa.len : pb.len;
+        piece ca = pa, cb = pb;
+        ca.len = len; cb.len = len;
+        if (pa.len > len) ca.out = CONN_IDENT;
+        if (pb.len > len) cb.out = CONN_IDENT;
+        VEC_PUSH(*oa, ca);
+        VEC_PUSH(*ob, cb);
+        if (pa.len > len) { pa.start += len; pa.len -= len; } else { i++; if (i < a->n) pa = a->a[i]; }
+        if (pb.len > len) { pb.start += len; pb.len -= len; } else { j++; if (j < b->n) pb = b->a[j]; }
+        if (i >= a->n || j >= b->n) break;
+    }
+}
+
+static const uint64_t ZERO_PART[1] = {0};
+static inline int64_t piece_cells(const piece *p) { return p->h ? p->h->cell_off.a[p->k + 1] - p->h->cell_off.a[p->k] : 1; }
+static inline const uint64_t *piece_parts(const piece *p) { return p->h ? p->h->part.a + p->h->cell_off.a[p->k] : ZERO_PART; }
+static inline int32_t piece_depth(const piece *p) { return p->h ? p->h->col_depth.a[p->k] : 0; }
+static inline const int32_t *piece_reads(const piece *p) { return p->h ? p->h->col_reads.a + p->h->read_off.a[p->k] : NULL; }
+
+/* connector accessors */
+typedef struct {
+    uint64_t mask_from, mask_to;
+    int64_t M;
+    const uint64_t *from, *to;
+} conn_view;
+static void conn_of(const piece *p, conn_view *c) {
+    switch (p->out) {
+        case CONN_REAL: {
+            const mrp_hmm *h = p->h;
+            c->mask_from = h->mask_from.a[p->k]; c->mask_to = h->mask_to.a[p->k];
+            c->M = h->mcell_off.a[p->k + 1] - h->mcell_off.a[p->k];
+            c->from = h->mfrom.a + h->mcell_off.a[p->k]; c->to = h->mto.a + h->mcell_off.a[p->k];
+            break;
+        }
+        case CONN_IDENT: { /* column.c:86-101 */
+            c->mask_from = c->mask_to = accept_mask(piece_depth(p));
+            c->M = piece_cells(p);
+            c->from = c->to = piece_parts(p);
+            break;
+        }
+        default: /* ZERO: hmm.c:324-331 */
+            c->mask_from = c->mask_to = 0; c->M = 1; c->from = c->to = ZERO_PART;
+    }
+}
+
+/* stRPHmm_createCrossProductOfTwoAlignedHmm hmm.c:534-750 over two aligned piece lists */
+static mrp_hmm *cross_product(const world *w, const piece_vec *A, const piece_vec *B, const hmm_vec *tpA,
+                              const hmm_vec *tpB, const mrp_params *params, int32_t S, int32_t E) {
+    mrp_hmm *h = hmm_new();
+    h->ref_start = S; h->ref_length = E - S;
+    for (int64_t i = 0; i < tpA->n; i++) for (int64_t r = 0; r < tpA->a[i]->reads.n; r++) VEC_PUSH(h->reads, tpA->a[i]->reads.a[r]);
+    for (int64_t i = 0; i < tpB->n; i++) for (int64_t r = 0; r < tpB->a[i]->reads.n; r++) VEC_PUSH(h->reads, tpB->a[i]->reads.a[r]);
+    const int inv = params->include_inverted_partitions != 0;
+    const int64_t n = A->n;
+    u64map prev_to = {0}; /* toPartition -> merge index of the merge column before the current column */
+    int have_prev = 0;
+    uint64_t prev_mask_to = 0;
+    int32_t colreads[MRP_MAX_READ_PARTITIONING_DEPTH];
+    for (int64_t s = 0; s < n; s++) {
+        const piece *pa = &A->a[s], *pb = &B->a[s];
+        const int32_t d1 = piece_depth(pa), d2 = piece_depth(pb), depth = d1 + d2;
+        if (depth > MRP_MAX_READ_PARTITIONING_DEPTH) {
+            mrp_hmm_destroy(h); u64map_free(&prev_to);
+            mrp_set_error(MRP_ERR_ARG, "cross product column depth %d exceeds %d", depth, MRP_MAX_READ_PARTITIONING_DEPTH);
+            return NULL;
+        }
+        if (d1) memcpy(colreads, piece_reads(pa), sizeof(int32_t) * (size_t) d1);
+        if (d2) memcpy(colreads + d1, piece_reads(pb), sizeof(int32_t) * (size_t) d2);
+        hmm_begin_column(h, w, pa->start, pa->len, depth, colreads);
+        const int64_t C1 = piece_cells(pa), C2 = piece_cells(pb);
+        const uint64_t *P1 = piece_parts(pa), *P2 = piece_parts(pb);
+        const int64_t cell0 = h->part.n;
+        VEC_RESERVE(h->part, 2 * C1 * C2); VEC_RESERVE(h->prev, 2 * C1 * C2); VEC_RESERVE(h->next, 2 * C1 * C2);
+        if (inv) { /* hmm.c:627-655 */
+            u64map seen; u64map_init(&seen, 2 * C1 * C2);
+            for (int64_t c1 = 0; c1 < C1; c1++)
+                for (int64_t c2 = 0; c2 < C2; c2++) {
+                    const uint64_t p = merge_bits(P1[c1], P2[c2], d1);
+                    if (u64map_get(&seen, p) == U64MAP_EMPTY) {
+                        u64map_put(&seen, p, 1);
+                        hmm_add_cell(h, p, 0);
+                        if (depth > 0) {
+                            const uint64_t ip = invert_partition(p, depth);
+                            u64map_put(&seen, ip, 1);
+                            hmm_add_cell(h, ip, 0);
+                        }
+                    }
+                }
+            u64map_free(&seen);
+        } else { /* hmm.c:657-668 */
+            for (int64_t c1 = 0; c1 < C1; c1++)
+                for (int64_t c2 = 0; c2 < C2; c2++) hmm_add_cell(h, merge_bits(P1[c1], P2[c2], d1), 0);
+        }
+        hmm_end_column(h);
+        const int64_t nC = h->part.n - cell0;
+        /* link to the previous merge column (mergeColumn.c:72-79) */
+        if (have_prev) {
+            for (int64_t c = 0; c < nC; c++) {
+                const uint32_t m = u64map_get(&prev_to, h->part.a[cell0 + c] & prev_mask_to);
+                if (m == U64MAP_EMPTY) {
+                    mrp_hmm_destroy(h); u64map_free(&prev_to);
+                    mrp_set_error(MRP_ERR_LOOKUP, "cross product: cell without previous merge cell");
+                    return NULL;
+                }
+                h->prev.a[cell0 + c] = m;
+            }
+            u64map_free(&prev_to);
+            have_prev = 0;
+        }
+        if (s + 1 == n) break;
+        /* merge column hmm.c:686-740 */
+        conn_view ca, cb;
+        conn_of(pa, &ca); conn_of(pb, &cb);
+        const int32_t d1n = piece_depth(&A->a[s + 1]), d2n = piece_depth(&B->a[s + 1]);
+        const uint64_t from_mask = merge_bits(ca.mask_from, cb.mask_from, d1);
+        const uint64_t to_mask = merge_bits(ca.mask_to, cb.mask_to, d1n);
+        hmm_begin_merge(h, from_mask, to_mask);
+        const int64_t m0 = h->mfrom.n;
+        u64map from_map; u64map_init(&from_map, 2 * ca.M * cb.M);
+        u64map_init(&prev_to, 2 * ca.M * cb.M);
+        for (int64_t i = 0; i < ca.M; i++)
+            for (int64_t j = 0; j < cb.M; j++) {
+                const uint64_t from = merge_bits(ca.from[i], cb.from[j], d1);
+                const uint64_t to = merge_bits(ca.to[i], cb.to[j], d1n);
+                if (inv) {
+                    if (u64map_get(&from_map, from) == U64MAP_EMPTY) {
+                        u64map_put(&from_map, from, (uint32_t) (h->mfrom.n - m0));
+                        u64map_put(&prev_to, to, (uint32_t) (h->mfrom.n - m0));
+                        VEC_PUSH(h->mfrom, from); VEC_PUSH(h->mto, to);
+                        if (__builtin_popcountll(from_mask) > 0) {
+                            const uint64_t ifrom = from_mask & invert_partition(from, d1 + d2);
+                            const uint64_t ito = to_mask & invert_partition(to, d1n + d2n);
+                            u64map_put(&from_map, ifrom, (uint32_t) (h->mfrom.n - m0));
+                            u64map_put(&prev_to, ito, (uint32_t) (h->mfrom.n - m0));
+                            VEC_PUSH(h->mfrom, ifrom); VEC_PUSH(h->mto, ito);
+                        }
+                    }
+                } else {
+                    u64map_put(&from_map, from, (uint32_t) (h->mfrom.n - m0));
+                    u64map_put(&prev_to, to, (uint32_t) (h->mfrom.n - m0));
+                    VEC_PUSH(h->mfrom, from); VEC_PUSH(h->mto, to);
+                }
+            }
+        hmm_end_merge(h);
+        /* link this column's cells to it (mergeColumn.c:63-70) */
+        for (int64_t c = 0; c < nC; c++) {
+            const uint32_t m = u64map_get(&from_map, h->part.a[cell0 + c] & from_mask);
+            if (m == U64MAP_EMPTY) {
+                mrp_hmm_destroy(h); u64map_free(&from_map); u64map_free(&prev_to);
+                mrp_set_error(MRP_ERR_LOOKUP, "cross product: cell without next merge cell");
+                return NULL;
+            }
+            h->next.a[cell0 + c] = m;
+        }
+        u64map_free(&from_map);
+        have_prev = 1;
+        prev_mask_to = to_mask;
+    }
+    return h;
+}
+
+/* fuseTilingPath coordination.c:244-261 without a partner: concatenate hmms with ZERO connectors
+ * and gap columns (hmm.c:283-372). */
+static mrp_hmm *fuse_path(const world *w, const hmm_vec *tp) {
+    if (tp->n == 1) return tp->a[0];
+    mrp_hmm *h = hmm_new();
+    h->ref_start = tp->a[0]->ref_start;
+    h->ref_length = tp->a[tp->n - 1]->ref_start + tp->a[tp->n - 1]->ref_length - h->ref_start;
+    piece_vec ps = {0};
+    pieces_of_path(tp, h->ref_start, h->ref_start + h->ref_length, &ps);
+    for (int64_t i = 0; i < tp->n; i++) for (int64_t r = 0; r < tp->a[i]->reads.n; r++) VEC_PUSH(h->reads, tp->a[i]->reads.a[r]);
+    for (int64_t s = 0; s < ps.n; s++) {
+        const piece *p = &ps.a[s];
+        hmm_begin_column(h, w, p->start, p->len, piece_depth(p), piece_reads(p));
+        const int64_t C = piece_cells(p);
+        const uint64_t *P = piece_parts(p);
+        const int real_prev = s > 0 && ps.a[s - 1].out == CONN_REAL;
+        const int real_next = p->out == CONN_REAL;
+        for (int64_t c = 0; c < C; c++) {
+            hmm_add_cell(h, P[c], real_prev ? p->h->prev.a[p->h->cell_off.a[p->k] + c] : 0);
+            h->next.a[h->next.n - 1] = real_next ? p->h->next.a[p->h->cell_off.a[p->k] + c] : 0;
+        }
+        hmm_end_column(h);
+        if (p->out == CONN_NONE) break;
+        conn_view cv; conn_of(p, &cv);
+        hmm_begin_merge(h, cv.mask_from, cv.mask_to);
+        for (int64_t m = 0; m < cv.M; m++) { VEC_PUSH(h->mfrom, cv.from[m]); VEC_PUSH(h->mto, cv.to[m]); }
+        hmm_end_merge(h);
+    }
+    free(ps.a);
+    for (int64_t i = 0; i < tp->n; i++) mrp_hmm_destroy(tp->a[i]);
+    return h;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* sweeps on the device                                                                        */
+/* ------------------------------------------------------------------------------------------ */
+static uint32_t sweep_flags(const mrp_params *p) {
+    return (p->max_not_sum_transitions ? MRP_FLAG_MAX_NOT_SUM : 0u) |
+           (p->include_ancestor_sub_prob ? MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB : 0u);
+}
+static void hmm_alloc_results(mrp_hmm *h) {
+    hmm_free_results(h);
+    const int64_t K = hmm_K(h);
+    h->f = xmalloc(sizeof(double) * (size_t) h->part.n);
+    h->b = xmalloc(sizeof(double) * (size_t) h->part.n);
+    h->mf = xmalloc(sizeof(double) * (size_t) (h->mfrom.n + 1));
+    h->mb = xmalloc(sizeof(double) * (size_t) (h->mfrom.n + 1));
+    h->total = xmalloc(sizeof(double) * (size_t) K);
+    h->has_results = 1;
+}
+static void hmm_job(const world *w, mrp_hmm *h, uint32_t flags, mrp_hmm_job *j, int with_outputs) {
+    memset(j, 0, sizeof(*j));
+    j->chunk = w->chunk;
+    j->n_columns = (int32_t) hmm_K(h);
+    j->flags = flags;
+    j->col_ref_start = h->col_start.a; j->col_length = h->col_len.a; j->col_depth = h->col_depth.a;
+    j->col_cell_off = h->cell_off.a; j->col_read_off = h->read_off.a; j->read_byte_off = h->read_byte_off.a;
+    j->partition = h->part.a; j->mask_from = h->mask_from.a; j->mask_to = h->mask_to.a;
+    j->mcol_cell_off = h->mcell_off.a; j->merge_from = h->mfrom.a; j->merge_to = h->mto.a;
+    j->cell_next = h->next.a; j->cell_prev = h->prev.a;
+    if (with_outputs) {
+        j->cell_forward = h->f; j->cell_backward = h->b; j->merge_forward = h->mf; j->merge_backward = h->mb;
+        j->col_total = h->total; j->hmm_forward = &h->fwd; j->hmm_backward = &h->bwd;
+    }
+}
+/* stRPHmm_forwardBackward for a set of independent hmms: one device batch */
+static int sweep_many(world *w, mrp_hmm **hmms, int64_t n, const mrp_params *params) {
+    if (n == 0) return MRP_OK;
+    const uint32_t flags = sweep_flags(params);
+    mrp_hmm_job *jobs = xcalloc((size_t) n, sizeof(*jobs));
+    for (int64_t i = 0; i < n; i++) {
+        hmm_alloc_results(hmms[i]);
+        hmm_job(w, hmms[i], flags, &jobs[i], 1);
+    }
+    int rc = mrp_fb_run(w->ctx, n, jobs);
+    if (rc == MRP_OK && w->record) {
+        for (int64_t i = 0; rc == MRP_OK && i < n; i++) {
+            mrp_hmm_job dj;
+            hmm_job(w, hmms[i], flags, &dj, 0);
+            rc = mrp_batch_add(w->record, &dj);
+        }
+    }
+    w->n_sweeps += n;
+    free(jobs);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* prune (hmm.c:944-1163)                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { int64_t idx; double key; } keyed;
+static void keyed_sort_desc(keyed *a, int64_t n, keyed *tmp) { /* stable, descending */
+    for (int64_t wdt = 1; wdt < n; wdt *= 2) {
+        for (int64_t lo = 0; lo < n; lo += 2 * wdt) {
+            const int64_t mid = lo + wdt < n ? lo + wdt : n, hi = lo + 2 * wdt < n ? lo + 2 * wdt : n;
+            int64_t i = lo, j = mid, o = lo;
+            while (i < mid && j < hi) { if (a[j].key > a[i].key) tmp[o++] = a[j++]; else tmp[o++] = a[i++]; }
+            while (i < mid) tmp[o++] = a[i++];
+            while (j < hi) tmp[o++] = a[j++];
+        }
+        memcpy(a, tmp, sizeof(keyed) * (size_t) n);
+    }
+}
+static int posterior(double f, double b, double total, double limit, double *out) { /* column.c:177-193, mergeColumn.c:129-146 */
+    const double p = exp(f + b - total);
+    if (p > limit || p < 0.0) return mrp_set_error(MRP_ERR_ARG, "ERROR: invalid prob %f", p);
+    *out = p > 1.0 ? 1.0 : p;
+    return MRP_OK;
+}
+
+int mrp_hmm_prune(mrp_hmm *h, const mrp_params *P) {
+    if (!h || !P) return mrp_set_error(MRP_ERR_ARG, "mrp_hmm_prune: NULL argument");
+    if (!h->has_results) return mrp_set_error(MRP_ERR_ARG, "mrp_hmm_prune before a forward/backward sweep");
+    const int64_t K = hmm_K(h);
+    int64_t max_c = 1, max_m = 1;
+    for (int64_t k = 0; k < K; k++) {
+        const int64_t c = h->cell_off.a[k + 1] - h->cell_off.a[k];
+        if (c > max_c) max_c = c;
+        if (k + 1 < K) { const int64_t m = h->mcell_off.a[k + 1] - h->mcell_off.a[k]; if (m > max_m) max_m = m; }
+    }
+    /* kept cells per column (old cell indices, new order) and kept-flag per merge cell */
+    int64_t *keep_off = xmalloc(sizeof(int64_t) * (size_t) (K + 1));
+    int64_t *keep_idx = xmalloc(sizeof(int64_t) * (size_t) (h->part.n + 1));
+    uint8_t *keep_m = xcalloc((size_t) (h->mfrom.n + 1), 1);
+    keyed *ka = xmalloc(sizeof(keyed) * (size_t) (max_c > max_m ? max_c : max_m));
+    keyed *kt = xmalloc(sizeof(keyed) * (size_t) (max_c > max_m ? max_c : max_m));
+    uint8_t *chosen = xmalloc((size_t) max_m);
+    int rc = MRP_OK;
+    /* stRPHmm_pruneForwards hmm.c:1049-1109 */
+    keep_off[0] = 0;
+    for (int64_t k = 0; k < K && rc == MRP_OK; k++) {
+        const int64_t c0 = h->cell_off.a[k], nc = h->cell_off.a[k + 1] - c0;
+        int64_t n = 0;
+        for (int64_t c = 0; c < nc; c++) { /* getLinkedCells :1021-1047 */
+            if (k > 0 && !keep_m[h->mcell_off.a[k - 1] + h->prev.a[c0 + c]]) continue;
+            ka[n].idx = c;
+            rc = posterior(h->f[c0 + c], h->b[c0 + c], h->total[k], 1.1, &ka[n].key);
+            if (rc != MRP_OK) break;
+            n++;
+        }
+        if (rc != MRP_OK) break;
+        keyed_sort_desc(ka, n, kt);
+        while (n > P->min_partitions_in_a_column &&
+               (n > P->max_partitions_in_a_column || ka[n - 1].key < P->min_posterior_probability_for_partition))
+            n--;
+        for (int64_t i = 0; i < n; i++) keep_idx[keep_off[k] + i] = ka[i].idx;
+        keep_off[k + 1] = keep_off[k] + n;
+        if (k + 1 == K) break;
+        /* getLinkedMergeCells :989-1004, sort + shrink :1088-1101 */
+        const int64_t m0 = h->mcell_off.a[k], nm = h->mcell_off.a[k + 1] - m0;
+        memset(chosen, 0, (size_t) nm);
+        int64_t mn = 0;
+        for (int64_t i = 0; i < n; i++) {
+            const uint32_t m = h->next.a[c0 + keep_idx[keep_off[k] + i]];
+            if (!chosen[m]) {
+                chosen[m] = 1;
+                ka[mn].idx = m;
+                rc = posterior(h->mf[m0 + m], h->mb[m0 + m], h->total[k + 1], 1.001, &ka[mn].key);
+                if (rc != MRP_OK) break;
+                mn++;
+            }
+        }
+        if (rc != MRP_OK) break;
+        keyed_sort_desc(ka, mn, kt);
+        while (mn > P->min_partitions_in_a_column &&
+               (mn > P->max_partitions_in_a_column || ka[mn - 1].key < P->min_posterior_probability_for_partition))
+            mn--;
+        for (int64_t i = 0; i < mn; i++) keep_m[m0 + ka[i].idx] = 1;
+    }
+    /* stRPHmm_pruneBackwards hmm.c:1111-1158 */
+    for (int64_t k = K - 1; k >= 0 && rc == MRP_OK; k--) {
+        const int64_t c0 = h->cell_off.a[k];
+        int64_t n = 0;
+        for (int64_t i = keep_off[k]; i < keep_off[k + 1]; i++) {
+            const int64_t c = keep_idx[i];
+            if (k + 1 < K && !keep_m[h->mcell_off.a[k] + h->next.a[c0 + c]]) continue;
+            keep_idx[keep_off[k] + n++] = c; /* order kept: the re-sort of an already sorted list is a no-op */
+        }
+        /* entries past the new length are marked unused */
+        for (int64_t i = keep_off[k] + n; i < keep_off[k + 1]; i++) keep_idx[i] = -1;
+        if (k == 0) break;
+        const int64_t m0 = h->mcell_off.a[k - 1], nm = h->mcell_off.a[k] - m0;
+        memset(chosen, 0, (size_t) nm);
+        for (int64_t i = 0; i < n; i++) chosen[h->prev.a[c0 + keep_idx[keep_off[k] + i]]] = 1;
+        for (int64_t m = 0; m < nm; m++) keep_m[m0 + m] = keep_m[m0 + m] && chosen[m];
+    }
+    if (rc == MRP_OK) {
+        /* rebuild compactly: merge cells keep their relative order (filterMergeCells :964-987),
+         * cells are relinked in sorted order (relinkCells :1006-1019) */
+        uint32_t *remap = xmalloc(sizeof(uint32_t) * (size_t) (h->mfrom.n + 1));
+        int64_t nm_new = 0;
+        int64_t *new_moff = xmalloc(sizeof(int64_t) * (size_t) K);
+        new_moff[0] = 0;
+        for (int64_t k = 0; k + 1 < K; k++) {
+            const int64_t m0 = h->mcell_off.a[k], nm = h->mcell_off.a[k + 1] - m0;
+            uint32_t local = 0;
+            for (int64_t m = 0; m < nm; m++) {
+                if (keep_m[m0 + m]) {
+                    remap[m0 + m] = local++;
+                    h->mfrom.a[nm_new] = h->mfrom.a[m0 + m];
+                    h->mto.a[nm_new] = h->mto.a[m0 + m];
+                    h->mf[nm_new] = h->mf[m0 + m];
+                    h->mb[nm_new] = h->mb[m0 + m];
+                    nm_new++;
+                } else remap[m0 + m] = U64MAP_EMPTY;
+            }
+            new_moff[k + 1] = nm_new;
+        }
+        const int64_t nC_old = h->part.n;
+        uint64_t *np = xmalloc(sizeof(uint64_t) * (size_t) (nC_old + 1));
+        uint32_t *nn = xmalloc(sizeof(uint32_t) * (size_t) (nC_old + 1)), *npv = xmalloc(sizeof(uint32_t) * (size_t) (nC_old + 1));
+        double *nf = xmalloc(sizeof(double) * (size_t) (nC_old + 1)), *nb = xmalloc(sizeof(double) * (size_t) (nC_old + 1));
+        int64_t o = 0;
+        int64_t *new_coff = xmalloc(sizeof(int64_t) * (size_t) (K + 1));
+        new_coff[0] = 0;
+        for (int64_t k = 0; k < K; k++) {
+            const int64_t c0 = h->cell_off.a[k];
+            for (int64_t i = keep_off[k]; i < keep_off[k + 1]; i++) {
+                const int64_t c = keep_idx[i];
+                if (c < 0) break;
+                np[o] = h->part.a[c0 + c];
+                nn[o] = k + 1 < K ? remap[h->mcell_off.a[k] + h->next.a[c0 + c]] : 0;
+                npv[o] = k > 0 ? remap[h->mcell_off.a[k - 1] + h->prev.a[c0 + c]] : 0;
+                nf[o] = h->f[c0 + c]; nb[o] = h->b[c0 + c];
+                o++;
+            }
+            new_coff[k + 1] = o;
+        }
+        memcpy(h->part.a, np, sizeof(uint64_t) * (size_t) o);
+        memcpy(h->next.a, nn, sizeof(uint32_t) * (size_t) o);
+        memcpy(h->prev.a, npv, sizeof(uint32_t) * (size_t) o);
+        memcpy(h->f, nf, sizeof(double) * (size_t) o);
+        memcpy(h->b, nb, sizeof(double) * (size_t) o);
+        h->part.n = h->next.n = h->prev.n = o;
+        h->mfrom.n = h->mto.n = nm_new;
+        memcpy(h->cell_off.a, new_coff, sizeof(int64_t) * (size_t) (K + 1));
+        memcpy(h->mcell_off.a, new_moff, sizeof(int64_t) * (size_t) K);
+        free(remap); free(new_moff); free(np); free(nn); free(npv); free(nf); free(nb); free(new_coff);
+    }
+    free(keep_off); free(keep_idx); free(keep_m); free(ka); free(kt); free(chosen);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* coordination.c                                                                              */
+/* ------------------------------------------------------------------------------------------ */
+typedef struct { hmm_vec members; } component;
+typedef VEC(component *) comp_vec;
+
+/* getOverlappingComponents coordination.c:69-184; components in creation order */
+static comp_vec overlapping_components(const world *w, const hmm_vec *tp1, const hmm_vec *tp2) {
+    comp_vec comps = {0};
+    /* component index per hmm of tp1 / tp2 */
+    int64_t *c1 = xmalloc(sizeof(int64_t) * (size_t) (tp1->n + 1)), *c2 = xmalloc(sizeof(int64_t) * (size_t) (tp2->n + 1));
+    for (int64_t i = 0; i < tp1->n; i++) c1[i] = -1;
+    for (int64_t i = 0; i < tp2->n; i++) c2[i] = -1;
+#define NEW_COMP(hmm, slot) do { component *c_ = xcalloc(1, sizeof(component)); VEC_PUSH(c_->members, (hmm)); \
+                                 (slot) = comps.n; VEC_PUSH(comps, c_); } while (0)
+    int64_t j = 0;
+    for (int64_t i = 0; i < tp1->n; i++) {
+        mrp_hmm *h1 = tp1->a[i];
+        int64_t comp = -1, k = 0;
+        while (j + k < tp2->n) {
+            mrp_hmm *h2 = tp2->a[j + k];
+            if (hmm_overlap(h1, h2)) {
+                k++;
+                if (comp < 0) {
+                    comp = c2[j + k - 1];
+                    if (comp < 0) { NEW_COMP(h2, c2[j + k - 1]); comp = c2[j + k - 1]; }
+                    VEC_PUSH(comps.a[comp]->members, h1);
+                    c1[i] = comp;
+                } else {
+                    VEC_PUSH(comps.a[comp]->members, h2);
+                    c2[j + k - 1] = comp;
+                }
+            } else {
+                if (hmm_cmp(w, h1, h2) < 0) {
+                    if (comp < 0) { NEW_COMP(h1, c1[i]); comp = c1[i]; }
+                    break;
+                } else {
+                    if (c2[j + k] < 0) NEW_COMP(h2, c2[j + k]);
+                    j++;
+                }
+            }
+        }
+        if (comp < 0) NEW_COMP(h1, c1[i]);
+    }
+    while (j < tp2->n) {
+        if (c2[j] < 0) NEW_COMP(tp2->a[j], c2[j]);
+        j++;
+    }
+#undef NEW_COMP
+    free(c1); free(c2);
+    return comps;
+}
+
+/* mergeTwoTilingPaths coordination.c:263-339.  All cross products of the call are swept in one
+ * device batch (the components are independent), then pruned. */
+static int merge_two_tiling_paths(world *w, hmm_vec *tp1, hmm_vec *tp2, const mrp_params *params, hmm_vec **out) {
+    comp_vec comps = overlapping_components(w, tp1, tp2);
+    free(tp1->a); free(tp1); free(tp2->a); free(tp2);
+    hmm_vec *res = xcalloc(1, sizeof(*res));
+    hmm_vec crossed = {0};
+    int rc = MRP_OK;
+    for (int64_t i = 0; i < comps.n; i++) {
+        component *comp = comps.a[i];
+        if (rc == MRP_OK) {
+            path_vec sub = tiling_paths_from(w, comp->members.a, comp->members.n);
+            if (sub.n == 2) {
+                hmm_vec *a = sub.a[0], *b = sub.a[1];
+                int32_t S = a->a[0]->ref_start < b->a[0]->ref_start ? a->a[0]->ref_start : b->a[0]->ref_start;
+                int32_t Ea = a->a[a->n - 1]->ref_start + a->a[a->n - 1]->ref_length;
+                int32_t Eb = b->a[b->n - 1]->ref_start + b->a[b->n - 1]->ref_length;
+                int32_t E = Ea > Eb ? Ea : Eb;
+                piece_vec pa = {0}, pb = {0}, qa = {0}, qb = {0};
+                pieces_of_path(a, S, E, &pa);
+                pieces_of_path(b, S, E, &pb);
+                align_pieces(&pa, &pb, &qa, &qb);
+                mrp_hmm *x = cross_product(w, &qa, &qb, a, b, params, S, E);
+                free(pa.a); free(pb.a); free(qa.a); free(qb.a);
+                for (int64_t t = 0; t < a->n; t++) mrp_hmm_destroy(a->a[t]);
+                for (int64_t t = 0; t < b->n; t++) mrp_hmm_destroy(b->a[t]);
+                if (x) { VEC_PUSH(crossed, x); VEC_PUSH(*res, x); } else rc = MRP_ERR_ARG;
+            } else if (sub.n == 1 && sub.a[0]->n == 1) {
+                VEC_PUSH(*res, sub.a[0]->a[0]);
+            } else {
+                rc = mrp_set_error(MRP_ERR_ARG, "overlap component with %lld tiling paths", (long long) sub.n);
+            }
+            for (int64_t t = 0; t < sub.n; t++) { free(sub.a[t]->a); free(sub.a[t]); }
+            free(sub.a);
+        }
+        free(comp->members.a); free(comp);
+    }
+    free(comps.a);
+    if (rc == MRP_OK) rc = sweep_many(w, crossed.a, crossed.n, params);       /* coordination.c:312 */
+    for (int64_t i = 0; rc == MRP_OK && i < crossed.n; i++) rc = mrp_hmm_prune(crossed.a[i], params); /* :313 */
+    free(crossed.a);
+    if (rc == MRP_OK) sort_hmms(w, res->a, res->n);                           /* :336 */
+    *out = res;
+    return rc;
+}
+
+static void free_path(hmm_vec *tp, int destroy_hmms) {
+    if (!tp) return;
+    if (destroy_hmms) for (int64_t i = 0; i < tp->n; i++) mrp_hmm_destroy(tp->a[i]);
+    free(tp->a); free(tp);
+}
+
+/* mergeTilingPaths coordination.c:341-409 */
+static int merge_tiling_paths(world *w, hmm_vec **paths, int64_t n, const mrp_params *params, hmm_vec **out) {
+    if (n == 0) { *out = xcalloc(1, sizeof(hmm_vec)); return MRP_OK; }
+    if (n == 1) { *out = paths[0]; return MRP_OK; }
+    hmm_vec *tp1 = NULL, *tp2 = NULL;
+    int rc = MRP_OK;
+    if (n > 2) {
+        rc = merge_tiling_paths(w, paths, n / 2, params, &tp1);
+        if (rc == MRP_OK) rc = merge_tiling_paths(w, paths + n / 2, n - n / 2, params, &tp2);
+        else for (int64_t i = n / 2; i < n; i++) free_path(paths[i], 1);
+        if (rc != MRP_OK) { free_path(tp1, 1); free_path(tp2, 1); *out = NULL; return rc; }
+    } else {
+        tp1 = paths[0]; tp2 = paths[1];
+    }
+    return merge_two_tiling_paths(w, tp1, tp2, params, out);
+}
+
+static path_vec tiling_paths2(const world *w, const int32_t *read_index, int64_t n) { /* coordination.c:224-242 */
+    mrp_hmm **hmms = xmalloc(sizeof(*hmms) * (size_t) (n + 1));
+    for (int64_t i = 0; i < n; i++) hmms[i] = hmm_from_read(w, read_index[i]);
+    path_vec paths = tiling_paths_from(w, hmms, n);
+    free(hmms);
+    return paths;
+}
+
+static int get_rp_hmms(world *w, const int32_t *read_index, int64_t n, const mrp_params *params, hmm_vec **out) {
+    path_vec paths = tiling_paths2(w, read_index, n); /* coordination.c:498 */
+    if (paths.n > MRP_MAX_READ_PARTITIONING_DEPTH || paths.n > params->max_coverage_depth) { /* :500-504 */
+        for (int64_t i = 0; i < paths.n; i++) free_path(paths.a[i], 1);
+        const int64_t np = paths.n;
+        free(paths.a);
+        *out = NULL;
+        return mrp_set_error(MRP_ERR_ARG,
+                             "Coverage depth: read depth of %lld exceeds hard maximum of %d with configured maximum of %lld",
+                             (long long) np, MRP_MAX_READ_PARTITIONING_DEPTH, (long long) params->max_coverage_depth);
+    }
+    int rc = merge_tiling_paths(w, paths.a, paths.n, params, out);
+    free(paths.a);
+    return rc;
+}
+
+static int check_reads(const world *w, const mrp_read *reads, int64_t n) {
+    for (int64_t i = 0; i < n; i++) {
+        const mrp_read *r = &reads[i];
+        if (!r->name || r->length < 1 || r->ref_start < 0 || (int64_t) r->ref_start + r->length > w->ch.n_sites)
+            return mrp_set_error(MRP_ERR_ARG, "read %lld: bad interval [%d,+%d)", (long long) i, r->ref_start, r->length);
+        const int64_t nb = w->ch.allele_offset[r->ref_start + r->length] - w->ch.allele_offset[r->ref_start];
+        if (r->pool_offset < 0 || r->pool_offset + nb > w->ch.pool_bytes)
+            return mrp_set_error(MRP_ERR_ARG, "read %lld: profile bytes outside the pool", (long long) i);
+    }
+    return MRP_OK;
+}
+static int world_init(world *w, mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *reads, int64_t n_reads,
+                      mrp_batch *record) {
+    if (!ctx || !chunk || (n_reads > 0 && !reads)) return mrp_set_error(MRP_ERR_ARG, "NULL argument");
+    if (mrp_chunk_context(chunk) != ctx) return mrp_set_error(MRP_ERR_ARG, "chunk belongs to a different context");
+    memset(w, 0, sizeof(*w));
+    w->chunk = chunk; w->reads = reads; w->n_reads = n_reads; w->ctx = ctx; w->record = record;
+    mrp_chunk_host_view(chunk, &w->ch);
+    w->max_alleles = 1;
+    for (int64_t i = 0; i < w->ch.n_sites; i++) if (w->ch.allele_number[i] > w->max_alleles) w->max_alleles = w->ch.allele_number[i];
+    return check_reads(w, reads, n_reads);
+}
+
+int mrp_get_rp_hmms(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *reads, const int32_t *read_index,
+                    int64_t n, const mrp_params *params, mrp_batch *record, mrp_hmm ***hmms_out, int64_t *n_out) {
+    if (!params || !hmms_out || !n_out || n < 0 || (n > 0 && !read_index)) return mrp_set_error(MRP_ERR_ARG, "mrp_get_rp_hmms: bad arguments");
+    int64_t max_idx = -1;
+    for (int64_t i = 0; i < n; i++) { if (read_index[i] < 0) return mrp_set_error(MRP_ERR_ARG, "negative read index"); if (read_index[i] > max_idx) max_idx = read_index[i]; }
+    world w;
+    int rc = world_init(&w, ctx, chunk, reads, max_idx + 1, record);
+    if (rc != MRP_OK) return rc;
+    hmm_vec *tp = NULL;
+    rc = get_rp_hmms(&w, read_index, n, params, &tp);
+    if (rc != MRP_OK) { free_path(tp, 1); return rc; }
+    *n_out = tp->n;
+    *hmms_out = tp->a ? tp->a : xmalloc(sizeof(mrp_hmm *));
+    free(tp);
+    return MRP_OK;
+}
+
+int mrp_hmm_view(const mrp_hmm *hmm, mrp_hmm_job *view, const int32_t **col_reads_out, int32_t *ref_start,
+                 int32_t *ref_length) {
+    if (!hmm || !view) return mrp_set_error(MRP_ERR_ARG, "mrp_hmm_view: NULL argument");
+    world w; memset(&w, 0, sizeof(w));
+    hmm_job(&w, (mrp_hmm *) hmm, 0, view, hmm->has_results);
+    if (col_reads_out) *col_reads_out = hmm->col_reads.a;
+    if (ref_start) *ref_start = hmm->ref_start;
+    if (ref_length) *ref_length = hmm->ref_length;
+    return MRP_OK;
+}
+
+int mrp_hmm_forward_backward(mrp_context *ctx, const mrp_chunk *chunk, mrp_hmm *hmm, const mrp_params *params,
+                             mrp_batch *record) {
+    if (!hmm || !params) return mrp_set_error(MRP_ERR_ARG, "mrp_hmm_forward_backward: NULL argument");
+    world w;
+    int rc = world_init(&w, ctx, chunk, NULL, 0, record);
+    if (rc != MRP_OK) return rc;
+    return sweep_many(&w, &hmm, 1, params);
+}
+
+/* stRPHmm_forwardTraceBack hmm.c:165-219 */
+int mrp_hmm_forward_trace_back(const mrp_hmm *h, int32_t *path) {
+    if (!h || !path) return mrp_set_error(MRP_ERR_ARG, "mrp_hmm_forward_trace_back: NULL argument");
+    if (!h->has_results) return mrp_set_error(MRP_ERR_ARG, "trace back before a forward/backward sweep");
+    const int64_t K = hmm_K(h);
+    int64_t c0 = h->cell_off.a[K - 1], nc = h->cell_off.a[K] - c0;
+    int64_t best = 0;
+    double max_prob = h->f[c0];
+    for (int64_t c = 1; c < nc; c++) if (h->f[c0 + c] > max_prob) { max_prob = h->f[c0 + c]; best = c; }
+    path[K - 1] = (int32_t) best;
+    for (int64_t k = K - 1; k > 0; k--) {
+        const uint32_t m = h->prev.a[h->cell_off.a[k] + path[k]];
+        c0 = h->cell_off.a[k - 1]; nc = h->cell_off.a[k] - c0;
+        best = -1; max_prob = -INFINITY;
+        for (int64_t c = 0; c < nc; c++)
+            if (h->next.a[c0 + c] == m && h->f[c0 + c] > max_prob) { max_prob = h->f[c0 + c]; best = c; }
+        if (best < 0) return mrp_set_error(MRP_ERR_LOOKUP, "trace back: no cell feeds the chosen merge cell in column %lld", (long long) (k - 1));
+        path[k - 1] = (int32_t) best;
+    }
+    return MRP_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* genome fragment (emissions.c:246-343, genomeFragment.c)                                     */
+/* ------------------------------------------------------------------------------------------ */
+static mrp_phase_result *result_new(int32_t ref_start, int32_t length, int64_t n_reads) {
+    mrp_phase_result *r = xcalloc(1, sizeof(*r));
+    r->ref_start = ref_start; r->length = length;
+    const size_t n = (size_t) length;
+    r->genotype_string = xcalloc(n, sizeof(uint64_t)); r->haplotype_string1 = xcalloc(n, sizeof(uint64_t));
+    r->haplotype_string2 = xcalloc(n, sizeof(uint64_t)); r->ancestor_string = xcalloc(n, sizeof(uint64_t));
+    r->reads_supporting_haplotype1 = xcalloc(n, sizeof(uint64_t)); r->reads_supporting_haplotype2 = xcalloc(n, sizeof(uint64_t));
+    r->genotype_probs = xcalloc(n, sizeof(float)); r->haplotype_probs1 = xcalloc(n, sizeof(float));
+    r->haplotype_probs2 = xcalloc(n, sizeof(float));
+    r->reads1 = xcalloc((size_t) n_reads + 1, sizeof(int32_t)); r->reads2 = xcalloc((size_t) n_reads + 1, sizeof(int32_t));
+    return r;
+}
+void mrp_phase_result_destroy(mrp_phase_result *r) {
+    if (!r) return;
+    free(r->genotype_string); free(r->haplotype_string1); free(r->haplotype_string2); free(r->ancestor_string);
+    free(r->reads_supporting_haplotype1); free(r->reads_supporting_haplotype2); free(r->genotype_probs);
+    free(r->haplotype_probs1); free(r->haplotype_probs2); free(r->reads1); free(r->reads2);
+    free(r);
+}
+/* fillInPredictedGenome emissions.c:323-343 for column k with the given partition.  The allele
+ * costs are the same integers getLogProbOfAllele returns (sum of the bytes of the reads in the
+ * partition), summed directly. */
+static void fill_in_predicted_genome(const world *w, mrp_phase_result *g, const mrp_hmm *h, int64_t k, uint64_t partition) {
+    const int32_t depth = h->col_depth.a[k];
+    const int64_t *off = h->read_byte_off.a + h->read_off.a[k];
+    const int32_t start = h->col_start.a[k];
+    const uint32_t first_allele = w->ch.allele_offset[start];
+    uint64_t *h1 = xmalloc(sizeof(uint64_t) * 4 * (size_t) w->max_alleles), *h2 = h1 + w->max_alleles, *a1 = h2 + w->max_alleles,
+             *a2 = a1 + w->max_alleles;
+    for (int32_t s = 0; s < h->col_len.a[k]; s++) {
+        const int32_t site = start + s;
+        const uint32_t A = w->ch.allele_number[site], so = w->ch.allele_offset[site] - first_allele;
+        const uint16_t *sub = w->ch.sub + w->ch.sub_offset[site], *prior = w->ch.prior + w->ch.allele_offset[site];
+        for (uint32_t a = 0; a < A; a++) {
+            uint64_t x = 0, y = 0;
+            for (int32_t i = 0; i < depth; i++) {
+                const uint64_t v = w->ch.pool[off[i] + so + a];
+                if ((partition >> i) & 1) x += v; else y += v;
+            }
+            h1[a] = x; h2[a] = y;
+        }
+        for (uint32_t i = 0; i < A; i++) { /* ancestorHapProbabilities emissions.c:156-172 */
+            uint64_t x = h1[0] + sub[i * A], y = h2[0] + sub[i * A];
+            for (uint32_t q = 1; q < A; q++) {
+                if (h1[q] + sub[i * A + q] < x) x = h1[q] + sub[i * A + q];
+                if (h2[q] + sub[i * A + q] < y) y = h2[q] + sub[i * A + q];
+            }
+            a1[i] = x; a2[i] = y;
+        }
+        uint64_t best = a1[0] + a2[0] + prior[0], anc = 0; /* :283-292 */
+        for (uint32_t i = 1; i < A; i++) {
+            const uint64_t j = a1[i] + a2[i] + prior[i];
+            if (j < best) { best = j; anc = i; }
+        }
+        uint64_t hap1 = 0, hap2 = 0, m1 = h1[0] + sub[anc * A], m2 = h2[0] + sub[anc * A]; /* getMLAllele :246-261 */
+        for (uint32_t i = 1; i < A; i++) {
+            if (h1[i] + sub[anc * A + i] < m1) { m1 = h1[i] + sub[anc * A + i]; hap1 = i; }
+            if (h2[i] + sub[anc * A + i] < m2) { m2 = h2[i] + sub[anc * A + i]; hap2 = i; }
+        }
+        const int64_t q = site - g->ref_start;
+        g->ancestor_string[q] = anc;
+        g->haplotype_string1[q] = hap1;
+        g->haplotype_string2[q] = hap2;
+        g->genotype_string[q] = hap1 < hap2 ? hap1 * A + hap2 : hap2 * A + hap1;
+        g->genotype_probs[q] = -((float) best);
+        g->haplotype_probs1[q] = -(float) h1[hap1];
+        g->haplotype_probs2[q] = -(float) h2[hap2];
+        g->reads_supporting_haplotype1[q] = (uint64_t) __builtin_popcountll(partition);
+        g->reads_supporting_haplotype2[q] = (uint64_t) depth - (uint64_t) __builtin_popcountll(partition);
+    }
+    free(h1);
+}
+/* getLogProbOfReadGivenHaplotype genomeFragment.c:71-89 */
+static double read_log_prob(const world *w, const uint64_t *hap, int32_t start, int32_t length, int32_t read) {
+    const mrp_read *r = &w->reads[read];
+    double total = 0.0;
+    const uint32_t first = w->ch.allele_offset[r->ref_start];
+    for (int32_t i = 0; i < r->length; i++) {
+        const int64_t j = (int64_t) i + r->ref_start - start;
+        if (j >= 0 && j < length) {
+            const uint64_t allele = hap[j];
+            total -= w->ch.pool[r->pool_offset + (w->ch.allele_offset[i + r->ref_start] - first) + allele];
+        }
+    }
+    return total / 30.0; /* PROFILE_PROB_SCALAR inc/margin.h:189 */
+}
+
+/* stGenomeFragment_construct genomeFragment.c:40-69 (+ hmm.c:221-248) then
+ * stGenomeFragment_refineGenomeFragment genomeFragment.c:165-232 */
+static void genome_fragment(const world *w, mrp_phase_result *g, const mrp_hmm *h, const int32_t *path,
+                            int64_t max_iterations) {
+    const int64_t K = hmm_K(h);
+    /* side[read]: 0 = unseen, 1 = reads1, 2 = reads2; first sighting along the path wins per set
+     * (a read can be put in both sets by inconsistent columns; set semantics as in the reference) */
+    uint8_t *in1 = xcalloc((size_t) w->n_reads + 1, 1), *in2 = xcalloc((size_t) w->n_reads + 1, 1);
+    uint64_t *p = xmalloc(sizeof(uint64_t) * (size_t) K);
+    for (int64_t k = 0; k < K; k++) {
+        p[k] = h->part.a[h->cell_off.a[k] + path[k]];
+        const int32_t *cr = h->col_reads.a + h->read_off.a[k];
+        for (int32_t i = 0; i < h->col_depth.a[k]; i++) {
+            if ((p[k] >> i) & 1) { if (!in1[cr[i]]) { in1[cr[i]] = 1; g->reads1[g->n_reads1++] = cr[i]; } }
+            else { if (!in2[cr[i]]) { in2[cr[i]] = 1; g->reads2[g->n_reads2++] = cr[i]; } }
+        }
+        fill_in_predicted_genome(w, g, h, k, p[k]);
+    }
+    int64_t iteration = 0;
+    uint8_t *m12 = xcalloc((size_t) w->n_reads + 1, 1), *m21 = xcalloc((size_t) w->n_reads + 1, 1);
+    int32_t *n1 = xmalloc(sizeof(int32_t) * (size_t) (w->n_reads + 1)), *n2 = xmalloc(sizeof(int32_t) * (size_t) (w->n_reads + 1));
+    while (iteration++ < max_iterations) {
+        int64_t c12 = 0, c21 = 0;
+        memset(m12, 0, (size_t) w->n_reads + 1); memset(m21, 0, (size_t) w->n_reads + 1);
+        for (int64_t i = 0; i < g->n_reads1; i++) { /* :126-151 */
+            const int32_t r = g->reads1[i];
+            if (read_log_prob(w, g->haplotype_string1, g->ref_start, g->length, r) <
+                read_log_prob(w, g->haplotype_string2, g->ref_start, g->length, r)) { m12[r] = 1; c12++; }
+        }
+        for (int64_t i = 0; i < g->n_reads2; i++) {
+            const int32_t r = g->reads2[i];
+            if (read_log_prob(w, g->haplotype_string2, g->ref_start, g->length, r) <
+                read_log_prob(w, g->haplotype_string1, g->ref_start, g->length, r)) { m21[r] = 1; c21++; }
+        }
+        if (c12 + c21 == 0) break;
+        int64_t a = 0, b = 0;
+        for (int64_t i = 0; i < g->n_reads1; i++) if (!m12[g->reads1[i]]) n1[a++] = g->reads1[i];
+        for (int64_t i = 0; i < g->n_reads2; i++) if (!m21[g->reads2[i]]) n2[b++] = g->reads2[i];
+        for (int64_t i = 0; i < g->n_reads2; i++) if (m21[g->reads2[i]]) n1[a++] = g->reads2[i];
+        for (int64_t i = 0; i < g->n_reads1; i++) if (m12[g->reads1[i]]) n2[b++] = g->reads1[i];
+        memcpy(g->reads1, n1, sizeof(int32_t) * (size_t) a); memcpy(g->reads2, n2, sizeof(int32_t) * (size_t) b);
+        g->n_reads1 = a; g->n_reads2 = b;
+        for (int64_t k = 0; k < K; k++) { /* :211-226 */
+            const int32_t *cr = h->col_reads.a + h->read_off.a[k];
+            for (int32_t i = 0; i < h->col_depth.a[k]; i++) if (m12[cr[i]]) p[k] ^= (uint64_t) 1 << i;
+            for (int32_t i = 0; i < h->col_depth.a[k]; i++) if (m21[cr[i]]) p[k] ^= (uint64_t) 1 << i;
+            fill_in_predicted_genome(w, g, h, k, p[k]);
+        }
+    }
+    free(in1); free(in2); free(p); free(m12); free(m21); free(n1); free(n2);
+}
+
+/* filterReadsByCoverageDepth coordination.c:443-488 */
+static void filter_reads_by_coverage_depth(const world *w, const mrp_params *params, int32_t *filtered, int64_t *nf,
+                                           int32_t *discarded, int64_t *nd) {
+    int32_t *all = xmalloc(sizeof(int32_t) * (size_t) (w->n_reads + 1));
+    for (int64_t i = 0; i < w->n_reads; i++) all[i] = (int32_t) i;
+    path_vec paths = tiling_paths2(w, all, w->n_reads);
+    free(all);
+    keyed *a = xmalloc(sizeof(keyed) * (size_t) (paths.n + 1)), *t = xmalloc(sizeof(keyed) * (size_t) (paths.n + 1));
+    for (int64_t i = 0; i < paths.n; i++) {
+        int64_t total = 0;
+        for (int64_t j = 0; j < paths.a[i]->n; j++) total += w->reads[paths.a[i]->a[j]->reads.a[0]].length;
+        a[i].idx = i; a[i].key = (double) total;
+    }
+    keyed_sort_desc(a, paths.n, t);
+    int64_t np = paths.n;
+    *nf = 0; *nd = 0;
+    while (np > params->max_coverage_depth) {
+        hmm_vec *tp = paths.a[a[--np].idx];
+        for (int64_t j = tp->n - 1; j >= 0; j--) discarded[(*nd)++] = tp->a[j]->reads.a[0];
+    }
+    while (np > 0) {
+        hmm_vec *tp = paths.a[a[--np].idx];
+        for (int64_t j = tp->n - 1; j >= 0; j--) filtered[(*nf)++] = tp->a[j]->reads.a[0];
+    }
+    for (int64_t i = 0; i < paths.n; i++) free_path(paths.a[i], 1);
+    free(paths.a); free(a); free(t);
+}
+
+/* bubbleGraph_phaseBubbleGraph bubbleGraph.c:2673-2801 */
+int mrp_phase_reads(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *reads, int64_t n_reads,
+                    const mrp_params *params, mrp_batch *record, mrp_phase_result **out) {
+    if (!params || !out || n_reads < 0) return mrp_set_error(MRP_ERR_ARG, "mrp_phase_reads: bad arguments");
+    *out = NULL;
+    world w;
+    int rc = world_init(&w, ctx, chunk, reads, n_reads, record);
+    if (rc != MRP_OK) return rc;
+    if (n_reads == 0) { *out = result_new(0, 0, 0); return MRP_OK; } /* :2719-2728 */
+    int32_t *filtered = xmalloc(sizeof(int32_t) * (size_t) n_reads), *discarded = xmalloc(sizeof(int32_t) * (size_t) n_reads);
+    int64_t nf, nd;
+    filter_reads_by_coverage_depth(&w, params, filtered, &nf, discarded, &nd); /* :2699 */
+    uint8_t *is_disc = xcalloc((size_t) n_reads, 1);
+    for (int64_t i = 0; i < nd; i++) is_disc[discarded[i]] = 1;
+    int32_t *fwd = xmalloc(sizeof(int32_t) * (size_t) n_reads), *rev = xmalloc(sizeof(int32_t) * (size_t) n_reads);
+    int64_t nfwd = 0, nrev = 0;
+    for (int64_t i = 0; i < n_reads; i++) { /* :2705-2716 */
+        if (is_disc[i]) continue;
+        if (reads[i].forward_strand) fwd[nfwd++] = (int32_t) i; else rev[nrev++] = (int32_t) i;
+    }
+    mrp_params pc = *params;
+    pc.include_ancestor_sub_prob = 0; /* :2733 */
+    hmm_vec *tpF = NULL, *tpR = NULL, *joined = NULL;
+    mrp_hmm *hmm = NULL;
+    int32_t *path = NULL;
+    rc = get_rp_hmms(&w, fwd, nfwd, &pc, &tpF);                  /* :2736 */
+    if (rc == MRP_OK) rc = get_rp_hmms(&w, rev, nrev, &pc, &tpR); /* :2740 */
+    if (rc == MRP_OK) { rc = merge_two_tiling_paths(&w, tpF, tpR, &pc, &joined); tpF = tpR = NULL; } /* :2745 */
+    if (rc == MRP_OK && joined->n > 0) {
+        hmm = fuse_path(&w, joined);
+        free(joined->a); free(joined); joined = NULL;
+        pc.include_ancestor_sub_prob = 1; /* :2748 */
+        rc = sweep_many(&w, &hmm, 1, &pc); /* :2749 */
+        if (rc == MRP_OK) {
+            path = xmalloc(sizeof(int32_t) * (size_t) hmm_K(hmm));
+            rc = mrp_hmm_forward_trace_back(hmm, path); /* :2755 */
+        }
+        if (rc == MRP_OK) {
+            mrp_phase_result *g = result_new(hmm->ref_start, hmm->ref_length, n_reads);
+            genome_fragment(&w, g, hmm, path, params->rounds_of_iterative_refinement); /* :2761-2764 */
+            for (int64_t i = 0; i < nd; i++) { /* :2772-2779 */
+                const double x = read_log_prob(&w, g->haplotype_string1, g->ref_start, g->length, discarded[i]);
+                const double y = read_log_prob(&w, g->haplotype_string2, g->ref_start, g->length, discarded[i]);
+                if (x < y) g->reads2[g->n_reads2++] = discarded[i]; else g->reads1[g->n_reads1++] = discarded[i];
+            }
+            g->hmm_forward = hmm->fwd; g->hmm_backward = hmm->bwd; g->n_sweeps = w.n_sweeps;
+            *out = g;
+        }
+    } else if (rc == MRP_OK) {
+        *out = result_new(0, 0, n_reads);
+    }
+    free_path(tpF, 1); free_path(tpR, 1); free_path(joined, 1);
+    mrp_hmm_destroy(hmm);
+    free(path); free(filtered); free(discarded); free(is_disc); free(fwd); free(rev);
+    return rc;
+}
