@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Benchmark of the stRPHmm forward/backward hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): synthetic 1 Mb chunks, 2 000 biallelic het
+sites, 30x ONT-like reads, shipped ONT haplotag parameters (max-plus mode, 100 partitions per
+column).  One *step* = every forward/backward sweep needed to phase a batch of such chunks (all
+overlap components of every tiling-path merge level + the final sweep of each chunk), with the
+flattened HMMs already resident in HBM: bit-plane kernel -> emission kernel -> recursion kernel.
+A single 2 000-column HMM is a strictly sequential chain, so the chip is filled by keeping the
+sweeps of many independent chunks in flight (the reference's own parallel axis, phase.c:276).
+
+The job set is produced by the product's host pipeline (margin_amd/csrc/rphmm_host.c) running the
+real merge recursion with device sweeps; it is recorded into one device batch and replayed in the
+timed region.  The oracle is used only by the cpu_baseline leg.
+
+Prints ONE JSON line on rank 0 (see the contract in the task description).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import threading
+import time
+from concurrent.futures import ThreadPoolExecutor
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--chunks", type=int, default=int(os.environ.get("MRP_BENCH_CHUNKS", "96")),
+                    help="synthetic 1 Mb chunks resident per GPU")
+    ap.add_argument("--sites", type=int, default=2000)
+    ap.add_argument("--coverage", type=float, default=30.0)
+    ap.add_argument("--threads", type=int, default=int(os.environ.get("MRP_BENCH_THREADS", "0")))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    return ap.parse_args()
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    n_gpus = args.gpus
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    elif torch.cuda.is_available():
+        torch.cuda.set_device(local_rank)
+
+    import numpy as np
+    from margin_amd import capi, synth
+
+    params_dict = synth.shipped_phase_params()
+    params = capi.Params.from_reference_names(params_dict)
+    n_chunks = args.chunks
+    cpu_share = max(1, (os.cpu_count() or 8) // max(1, world if world > 1 else 1))
+    n_threads = args.threads or min(16, cpu_share, n_chunks)
+
+    main_ctx = capi.Context(local_rank)
+    big = capi.Batch(main_ctx)
+    keep = []           # device chunks must outlive the batch
+    units_lock = threading.Lock()
+    totals = dict(units=0, sweeps=0, reads=0)
+    tls = threading.local()
+
+    def build_one(i):
+        if not hasattr(tls, "ctx"):
+            tls.ctx = capi.Context(local_rank)  # one context (stream) per host thread
+        seed = 1000 * rank + i + 1
+        chunk = synth.make_ont_chunk(seed=seed, region_bp=args.sites * 500, n_sites=args.sites,
+                                     coverage=args.coverage)
+        dchunk = capi.DeviceChunk.from_chunk(tls.ctx, chunk)
+        res = capi.phase_reads(tls.ctx, dchunk, chunk, params, record=big)
+        with units_lock:
+            keep.append(dchunk)
+            totals["units"] += chunk.units
+            totals["sweeps"] += res["n_sweeps"]
+            totals["reads"] += len(chunk.reads)
+        return chunk if i == 0 else None
+
+    t0 = time.time()
+    with ThreadPoolExecutor(max_workers=n_threads) as ex:
+        first = list(ex.map(build_one, range(n_chunks)))[0]
+    t_build = time.time() - t0
+    big.upload()
+    main_ctx.synchronize()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        big.launch()
+    main_ctx.synchronize()
+    barrier()
+    planes_ms, emission_ms, sweep_ms = [], [], []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        big.launch()
+        s = big.stats()  # waits for this launch (HIP events on the library's stream)
+        planes_ms.append(s.planes_ms)
+        emission_ms.append(s.emission_ms)
+        sweep_ms.append(s.sweep_ms)
+    main_ctx.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        u = torch.tensor([float(totals["units"])], dtype=torch.float64, device="cuda")
+        dist.all_reduce(u, op=dist.ReduceOp.SUM)
+        units_all = float(u.item())
+    else:
+        units_all = float(totals["units"])
+
+    st = big.stats()
+    value = units_all * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+    sweep_avg = float(np.mean(sweep_ms))
+    emis_avg = float(np.mean(emission_ms))
+    planes_avg = float(np.mean(planes_ms))
+    alg = float(st.algorithmic_bytes)
+    # dominant kernel = recursion sweep; SURVEY.md 8(d): B = sum_k 24*C_k + 32*M_k + D_k*Al_k + 8
+    achieved = alg / (sweep_avg * 1e-3) / 1e9
+    roofline = dict(bound="hbm", kernel="mrp_sweep_i32_kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=achieved / HBM_PEAK_GBS, traffic=None,
+                    algorithmic_bytes_per_launch=alg, kernel_ms=sweep_avg,
+                    whole_step=dict(achieved=alg / (ms_per_step * 1e-3) / 1e9,
+                                    frac=alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                    planes_ms=planes_avg, emission_ms=emis_avg, sweep_ms=sweep_avg),
+                    popcount64_per_s=float(st.popcount_ops) / (ms_per_step * 1e-3))
+
+    out = dict(metric="het-sites x reads phased/sec (stRPHmm forward/backward sweeps, 30x ONT synthetic)",
+               value=value, unit="het-site-reads/s", n_gpus=n_gpus, steps=args.steps, warmup=args.warmup,
+               ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int32",
+               data="synthetic",
+               config=dict(workload=f"configs[1]: synthetic 1 Mb chunk, {args.sites} het sites, {args.coverage:g}x ONT reads, "
+                                    f"shipped ONT haplotag params; {n_chunks} chunks resident per GPU, all merge-level + final sweeps",
+                           chunks_per_gpu=n_chunks, hmms_per_gpu=int(st.n_hmms), columns_per_gpu=int(st.n_columns),
+                           cells_per_gpu=int(st.n_cells), merge_cells_per_gpu=int(st.n_merge_cells),
+                           units_per_gpu=int(totals["units"]), sweeps_per_gpu=int(totals["sweeps"]),
+                           parallelism=f"{world} process(es), one per GPU, chunks sharded, no collectives",
+                           host_build_s=t_build, host_threads=n_threads),
+               roofline=roofline)
+
+    if rank == 0 and not args.no_cpu_baseline and n_gpus == 1:
+        # CPU baseline: the oracle (C restatement of the reference's linked-list/hash implementation,
+        # -O3 -mpopcnt) timing only its stRPHmm_forwardBackward calls on ONE chunk of the same workload.
+        from oracle import orc
+        oc = orc.OracleChunk(first)
+        r = oc.phase(params_dict)
+        oc.close()
+        out["cpu_baseline"] = dict(value=first.units / r["fb_seconds"], unit="het-site-reads/s", cores=1, kind="port",
+                                   sample=f"1 of {n_chunks} chunks: all {r['fb_calls']} sweeps of one 1 Mb chunk "
+                                          f"({first.units} units, {r['fb_seconds']:.2f} s in forward/backward)")
+    if rank == 0:
+        print(json.dumps(out))
+    big.close()
+    for d in keep:
+        d.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

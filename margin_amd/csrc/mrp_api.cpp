@@ -13,6 +13,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -89,6 +90,7 @@ struct JobOut {
 
 struct mrp_batch {
     mrp_context *ctx = nullptr;
+    std::mutex mu; /* mrp_batch_add may be called from several host threads (recording) */
     std::vector<const mrp_chunk *> chunks;
     std::vector<DevHmm> hmms;
     std::vector<DevCol> cols;
@@ -321,7 +323,8 @@ int mrp_batch_add(mrp_batch *b, const mrp_hmm_job *job) {
                          !job->hmm_backward || (K > 1 && (!job->merge_forward || !job->merge_backward))))
         return fail(MRP_ERR_ARG, "hmm job is missing output arrays");
     const mrp_chunk *ch = job->chunk;
-    if (ch->ctx != b->ctx) return fail(MRP_ERR_ARG, "chunk belongs to a different context");
+    if (ch->ctx->device != b->ctx->device) return fail(MRP_ERR_ARG, "chunk lives on a different device");
+    std::lock_guard<std::mutex> lock(b->mu);
     const bool ancestor = (job->flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
 
     int chunk_index = -1;
