@@ -64,7 +64,7 @@ def main():
         torch.cuda.set_device(local_rank)
 
     import numpy as np
-    from margin_amd import capi, synth
+    from margin_amd import capi, sharding, synth
 
     params_dict = synth.shipped_phase_params()
     params = capi.Params.from_reference_names(params_dict)
@@ -79,10 +79,12 @@ def main():
     totals = dict(units=0, sweeps=0, reads=0)
     tls = threading.local()
 
+    seeds = sharding.chunk_seeds(rank, n_chunks)
+
     def build_one(i):
         if not hasattr(tls, "ctx"):
             tls.ctx = capi.Context(local_rank)  # one context (stream) per host thread
-        seed = 1000 * rank + i + 1
+        seed = seeds[i]
         chunk = synth.make_ont_chunk(seed=seed, region_bp=args.sites * 500, n_sites=args.sites,
                                      coverage=args.coverage)
         dchunk = capi.DeviceChunk.from_chunk(tls.ctx, chunk)
@@ -121,15 +123,8 @@ def main():
     main_ctx.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-        u = torch.tensor([float(totals["units"])], dtype=torch.float64, device="cuda")
-        dist.all_reduce(u, op=dist.ReduceOp.SUM)
-        units_all = float(u.item())
-    else:
-        units_all = float(totals["units"])
+    elapsed, units_all = sharding.reduce_elapsed_and_units(dist, elapsed, float(totals["units"]),
+                                                           device="cuda" if dist is not None else None)
 
     st = big.stats()
     value = units_all * args.steps / elapsed

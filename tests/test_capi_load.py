@@ -1,0 +1,61 @@
+"""CPU checks of the drop-in boundary: the C-ABI library loads, exports every symbol the header
+declares, and refuses to compute without a device (no CPU fallback)."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+from margin_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "margin_rphmm.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mrp_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_header_symbols_are_exported():
+    lib = capi.load()
+    declared = _declared_symbols()
+    assert len(declared) >= 25
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert set(capi.EXPORTED_SYMBOLS) <= set(declared)
+
+
+def test_no_torch_types_and_c_linkage():
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", capi.LIB_PATH], capture_output=True, text=True).stdout
+    exported = [l.split()[-1] for l in out.splitlines() if " T " in l]
+    for s in _declared_symbols():
+        assert s in exported            # unmangled: extern "C"
+    assert not [s for s in exported if "torch" in s.lower() or "at::" in s]
+
+
+def test_fails_loudly_without_a_device():
+    lib = capi.load()
+    if lib.mrp_device_count() > 0:
+        pytest.skip("a GPU is visible here")
+    h = C.c_void_p()
+    rc = lib.mrp_context_create(0, C.byref(h))
+    assert rc == capi.MRP_ERR_NO_DEVICE
+    assert b"no CPU fallback" in lib.mrp_last_error()
+    with pytest.raises(capi.MrpError):
+        capi.Context(0)
+
+
+def test_product_package_does_not_touch_the_oracle():
+    """The shipped path may not import, link or execute anything under oracle/."""
+    pkg = os.path.join(ROOT, "margin_amd")
+    for dirpath, _dirs, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".c", ".cpp", ".h", ".hip", "Makefile")):
+                text = open(os.path.join(dirpath, f), errors="ignore").read()
+                for pat in (r"^\s*(from|import)\s+oracle", r"liborc", r"\borc_[a-z]", r"rphmm_oracle", r"oracle/"):
+                    assert not re.search(pat, text, flags=re.M), (pat, os.path.join(dirpath, f))
+    import subprocess
+    out = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
+    assert "liborc" not in out
