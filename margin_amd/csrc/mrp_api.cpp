@@ -67,7 +67,9 @@ struct DevBuf {
 struct mrp_context {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux[2] = {nullptr, nullptr}; /* size classes of the recursion kernel run side by side */
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
 };
 
 struct mrp_chunk {
@@ -96,14 +98,17 @@ struct mrp_batch {
     std::vector<DevCol> cols;
     std::vector<int64_t> read_byte_off;
     std::vector<uint64_t> partition;
-    std::vector<uint32_t> cell_next, cell_prev;
-    std::vector<int2> tiles;
+    std::vector<SweepCol> scols;
+    std::vector<uint32_t> cell_next, cell_prev, cell_np;
+    std::vector<EmitTile> tiles;
+    int64_t n_fast_tiles = 0;
+    bool need_wide = false;
     std::vector<JobOut> outs;
     int64_t n_merge = 0, n_slots = 0;
     mrp_launch_stats stats{};
     /* launch plan */
-    std::vector<int32_t> order_wide, order_narrow, order_f64;
-    int max_merge_wide = 1, max_merge_narrow = 1;
+    std::vector<int32_t> order_wide, order_mid, order_narrow, order_f64;
+    int max_merge_wide = 1, max_merge_mid = 1, max_merge_narrow = 1;
     /* device */
     bool uploaded = false, launched = false;
     DevBuf<DevHmm> d_hmms;
@@ -111,10 +116,11 @@ struct mrp_batch {
     DevBuf<DevChunk> d_chunks;
     DevBuf<int64_t> d_read_byte_off;
     DevBuf<uint64_t> d_partition, d_planes;
-    DevBuf<uint32_t> d_next, d_prev, d_slot_total, d_cost;
+    DevBuf<SweepCol> d_scols;
+    DevBuf<uint32_t> d_next, d_prev, d_np, d_slot_total, d_cost;
     DevBuf<double> d_f, d_b, d_mf, d_mb, d_total, d_hmm_fb;
-    DevBuf<int32_t> d_order_wide, d_order_narrow, d_order_f64;
-    DevBuf<int2> d_tiles;
+    DevBuf<int32_t> d_order_wide, d_order_mid, d_order_narrow, d_order_f64;
+    DevBuf<EmitTile> d_tiles;
     MrpBatchDev dev{};
 };
 
@@ -160,6 +166,9 @@ int mrp_context_create(int device, mrp_context **out) {
     ctx->device = device;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->join[i], hipEventDisableTiming);
     if (e != hipSuccess) {
         mrp_context_destroy(ctx);
         return fail(MRP_ERR_HIP, "context setup failed: %s", hipGetErrorString(e));
@@ -173,6 +182,11 @@ void mrp_context_destroy(mrp_context *ctx) {
     (void) hipSetDevice(ctx->device);
     for (auto &e : ctx->ev)
         if (e) (void) hipEventDestroy(e);
+    if (ctx->fork) (void) hipEventDestroy(ctx->fork);
+    for (auto &e : ctx->join)
+        if (e) (void) hipEventDestroy(e);
+    for (auto &st : ctx->aux)
+        if (st) (void) hipStreamDestroy(st);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -426,7 +440,27 @@ int mrp_batch_add(mrp_batch *b, const mrp_hmm_job *job) {
         c.chunk = chunk_index;
         c.flags = job->flags;
         b->n_slots += c.n_slots;
-        for (int t0 = 0; t0 < c.n_cells; t0 += MRP_EMIT_TILE) b->tiles.push_back(make_int2((int) b->cols.size(), t0));
+        int32_t uniform = (int32_t) ch->allele_number[c.site_start];
+        for (int s2 = 1; s2 < c.n_sites; s2++)
+            if ((int32_t) ch->allele_number[c.site_start + s2] != uniform) uniform = 0;
+        for (int t0 = 0; t0 < c.n_cells; t0 += MRP_EMIT_TILE) {
+            EmitTile t{};
+            t.cell_off = c.cell_off + t0;
+            t.slot_off = c.slot_off;
+            t.n = std::min<int32_t>(MRP_EMIT_TILE, c.n_cells - t0);
+            t.col = (int32_t) b->cols.size();
+            t.n_sites = c.n_sites;
+            t.uniform_alleles = uniform;
+            t.depth = c.depth;
+            t.flags = job->flags;
+            b->tiles.push_back(t);
+        }
+        SweepCol sc{};
+        sc.cell_off = c.cell_off;
+        sc.mcell_off = c.mcell_off;
+        sc.n_cells = c.n_cells;
+        sc.n_merge = c.n_merge;
+        b->scols.push_back(sc);
         b->cols.push_back(c);
         h.max_merge = std::max(h.max_merge, c.n_merge);
         h.max_cells = std::max(h.max_cells, c.n_cells);
@@ -438,10 +472,19 @@ int mrp_batch_add(mrp_batch *b, const mrp_hmm_job *job) {
         b->stats.algorithmic_bytes += 24ll * c.n_cells + 32ll * c.n_merge + (int64_t) c.depth * c.n_slots + 8;
         b->stats.popcount_ops += (int64_t) c.n_cells * 2 * c.n_slots * 8;
     }
+    h.n_cells = n_cells;
+    h.n_merge = n_merge;
+    h.wide_idx = h.max_merge > 65535 ? 1 : 0;
+    if (h.wide_idx) b->need_wide = true;
     b->hmms.push_back(h);
     b->partition.insert(b->partition.end(), job->partition, job->partition + n_cells);
     b->cell_next.insert(b->cell_next.end(), nxt.begin(), nxt.end());
     b->cell_prev.insert(b->cell_prev.end(), prv.begin(), prv.end());
+    {
+        const size_t base = b->cell_np.size();
+        b->cell_np.resize(base + (size_t) n_cells);
+        for (int64_t c = 0; c < n_cells; c++) b->cell_np[base + c] = (nxt[c] & 0xFFFFu) | (prv[c] << 16);
+    }
     if (job->col_read_off[K] > 0)
         b->read_byte_off.insert(b->read_byte_off.end(), job->read_byte_off, job->read_byte_off + job->col_read_off[K]);
     b->n_merge += n_merge;
@@ -462,16 +505,19 @@ int mrp_batch_upload(mrp_batch *b) {
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
 
-    /* launch plan: int32/LDS path for max-plus HMMs that fit, fp64 path otherwise */
-    std::vector<std::pair<int64_t, int32_t>> wide, narrow, generic;
+    /* launch plan: int32/LDS path for max-plus HMMs that fit, fp64 path otherwise.  The int32 path is
+     * split into size classes (LDS per workgroup = 2 * largest merge column * 4 B) that are launched
+     * on separate streams so that small hmms do not inherit the residency of the largest one. */
+    std::vector<std::pair<int64_t, int32_t>> wide, mid, narrow, generic;
     for (size_t i = 0; i < b->hmms.size(); i++) {
         const DevHmm &h = b->hmms[i];
         const int64_t work = b->outs[i].n_cells;
         const bool max_mode = (h.flags & MRP_FLAG_MAX_NOT_SUM) != 0;
-        const size_t lds = (size_t) (2 * (int64_t) h.max_merge + 4) * sizeof(int32_t);
-        if (max_mode && h.cost_bound < (1ll << 30) && lds <= (size_t) MRP_LDS_BUDGET) {
-            if (h.max_cells > 256) wide.push_back({-work, (int32_t) i});
-            else narrow.push_back({-work, (int32_t) i});
+        const size_t lds = (size_t) (2 * (int64_t) h.max_merge + 4) * sizeof(int32_t) + 256 * 8;
+        if (max_mode && !h.wide_idx && b->outs[i].n_cells < (1ll << 30) && h.cost_bound < (1ll << 30) && lds <= (size_t) MRP_LDS_BUDGET) {
+            if (h.max_cells <= 256) narrow.push_back({-work, (int32_t) i});
+            else if (h.max_merge <= 4096) mid.push_back({-work, (int32_t) i});
+            else wide.push_back({-work, (int32_t) i});
         } else {
             generic.push_back({-work, (int32_t) i});
         }
@@ -487,6 +533,7 @@ int mrp_batch_upload(mrp_batch *b) {
         if (max_merge) *max_merge = mm;
     };
     plan(wide, b->order_wide, &b->max_merge_wide);
+    plan(mid, b->order_mid, &b->max_merge_mid);
     plan(narrow, b->order_narrow, &b->max_merge_narrow);
     plan(generic, b->order_f64, nullptr);
 
@@ -498,11 +545,21 @@ int mrp_batch_upload(mrp_batch *b) {
     HIP_TRY(b->d_chunks.upload(chunks, s));
     HIP_TRY(b->d_read_byte_off.upload(b->read_byte_off, s));
     HIP_TRY(b->d_partition.upload(b->partition, s));
-    HIP_TRY(b->d_next.upload(b->cell_next, s));
-    HIP_TRY(b->d_prev.upload(b->cell_prev, s));
+    HIP_TRY(b->d_scols.upload(b->scols, s));
+    HIP_TRY(b->d_np.upload(b->cell_np, s));
+    if (b->need_wide) {
+        HIP_TRY(b->d_next.upload(b->cell_next, s));
+        HIP_TRY(b->d_prev.upload(b->cell_prev, s));
+    }
     HIP_TRY(b->d_order_wide.upload(b->order_wide, s));
+    HIP_TRY(b->d_order_mid.upload(b->order_mid, s));
     HIP_TRY(b->d_order_narrow.upload(b->order_narrow, s));
     HIP_TRY(b->d_order_f64.upload(b->order_f64, s));
+    {   /* fast tiles first */
+        auto is_fast = [](const EmitTile &t) { return t.uniform_alleles != 0 && !(t.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB); };
+        auto mid_it = std::stable_partition(b->tiles.begin(), b->tiles.end(), is_fast);
+        b->n_fast_tiles = mid_it - b->tiles.begin();
+    }
     HIP_TRY(b->d_tiles.upload(b->tiles, s));
     const size_t nC = b->partition.size();
     HIP_TRY(b->d_planes.alloc((size_t) b->n_slots * 8));
@@ -522,6 +579,8 @@ int mrp_batch_upload(mrp_batch *b) {
     d.chunks = b->d_chunks.p;
     d.read_byte_off = b->d_read_byte_off.p;
     d.partition = b->d_partition.p;
+    d.scols = b->d_scols.p;
+    d.cell_np = b->d_np.p;
     d.cell_next = b->d_next.p;
     d.cell_prev = b->d_prev.p;
     d.planes = b->d_planes.p;
@@ -542,6 +601,7 @@ int mrp_batch_upload(mrp_batch *b) {
     std::vector<uint64_t>().swap(b->partition);
     std::vector<uint32_t>().swap(b->cell_next);
     std::vector<uint32_t>().swap(b->cell_prev);
+    std::vector<uint32_t>().swap(b->cell_np);
     std::vector<int64_t>().swap(b->read_byte_off);
     b->uploaded = true;
     return MRP_OK;
@@ -560,7 +620,7 @@ int mrp_batch_launch(mrp_batch *b) {
     HIP_TRY(hipEventRecord(ctx->ev[0], s));
     HIP_TRY(mrp_launch_planes(d, s));
     HIP_TRY(hipEventRecord(ctx->ev[1], s));
-    HIP_TRY(mrp_launch_emission(d, b->d_tiles.p, (int64_t) b->tiles.size(), s));
+    HIP_TRY(mrp_launch_emission(d, b->d_tiles.p, b->n_fast_tiles, (int64_t) b->tiles.size() - b->n_fast_tiles, s));
     HIP_TRY(hipEventRecord(ctx->ev[3], s));
     if (!b->order_f64.empty()) {
         /* stRPHmm_initialiseProbs (hmm.c:752-789) for the accumulate-in-place fp64 path */
@@ -570,9 +630,18 @@ int mrp_batch_launch(mrp_batch *b) {
         HIP_TRY(mrp_launch_fill_f64(b->d_total.p, d.n_cols, neg, s));
         HIP_TRY(mrp_launch_fill_f64(b->d_hmm_fb.p, 2 * d.n_hmms, neg, s));
     }
+    /* size classes side by side: wide on the main stream, mid and narrow on the auxiliary streams */
+    HIP_TRY(hipEventRecord(ctx->fork, s));
+    HIP_TRY(hipStreamWaitEvent(ctx->aux[0], ctx->fork, 0));
+    HIP_TRY(hipStreamWaitEvent(ctx->aux[1], ctx->fork, 0));
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_wide.p, (int64_t) b->order_wide.size(), 1024, b->max_merge_wide, s));
-    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), 64, b->max_merge_narrow, s));
+    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_mid.p, (int64_t) b->order_mid.size(), 512, b->max_merge_mid, ctx->aux[0]));
+    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), 64, b->max_merge_narrow, ctx->aux[1]));
     HIP_TRY(mrp_launch_sweep_f64(d, b->d_order_f64.p, (int64_t) b->order_f64.size(), 256, s));
+    HIP_TRY(hipEventRecord(ctx->join[0], ctx->aux[0]));
+    HIP_TRY(hipEventRecord(ctx->join[1], ctx->aux[1]));
+    HIP_TRY(hipStreamWaitEvent(s, ctx->join[0], 0));
+    HIP_TRY(hipStreamWaitEvent(s, ctx->join[1], 0));
     HIP_TRY(hipEventRecord(ctx->ev[2], s));
     b->launched = true;
     return MRP_OK;

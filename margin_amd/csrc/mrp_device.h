@@ -39,12 +39,38 @@ struct DevCol {
     uint32_t flags;     /* MRP_FLAG_* of the owning hmm */
 };
 
+/* what the recursion kernels need of a column (read through the scalar cache) */
+struct SweepCol {
+    int64_t cell_off;
+    int64_t mcell_off;
+    int32_t n_cells;
+    int32_t n_merge;
+    int32_t pad[2];
+};
+
+/* one unit of work of the emission kernel: up to MRP_EMIT_TILE consecutive cells of one column */
+struct EmitTile {
+    int64_t cell_off;        /* first cell of the tile in the batch cell arrays */
+    int64_t slot_off;        /* first allele slot of the column */
+    int32_t n;               /* cells in the tile */
+    int32_t col;             /* column index in the batch (general path) */
+    int32_t n_sites;
+    int32_t uniform_alleles; /* allele count shared by every site of the column, 0 if they differ */
+    int32_t depth;
+    uint32_t flags;
+    int32_t pad[2];
+};
+
 struct DevHmm {
     int64_t col0;       /* first column in the batch column arrays */
     int32_t n_cols;
     uint32_t flags;
     int32_t max_merge;  /* largest merge column of this hmm */
     int32_t max_cells;  /* largest column */
+    int32_t wide_idx;   /* transitions do not fit 16 bits: kernels read cell_next/cell_prev */
+    int32_t pad;
+    int64_t n_cells;    /* cells / merge cells of this hmm (contiguous in the batch arrays) */
+    int64_t n_merge;
     int64_t cost_bound; /* upper bound of |forward| over the whole hmm (selects the int32 path) */
 };
 

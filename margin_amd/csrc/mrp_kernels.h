@@ -11,10 +11,12 @@ struct MrpBatchDev {
     /* inputs */
     const DevHmm *hmms;
     const DevCol *cols;
+    const SweepCol *scols;
     const DevChunk *chunks;
     const int64_t *read_byte_off;
     const uint64_t *partition;
-    const uint32_t *cell_next;
+    const uint32_t *cell_np;   /* next | prev << 16 */
+    const uint32_t *cell_next; /* only when some hmm has > 65535 merge cells in a column */
     const uint32_t *cell_prev;
     /* scratch */
     uint64_t *planes;
@@ -34,9 +36,11 @@ struct MrpBatchDev {
 #define MRP_LDS_BUDGET (160 * 1024 - 1024)
 
 hipError_t mrp_launch_planes(const MrpBatchDev &d, hipStream_t stream);
-/* tiles[i] = {column index in d.cols, first cell of the tile}; MRP_EMIT_TILE cells per tile */
-#define MRP_EMIT_TILE 256
-hipError_t mrp_launch_emission(const MrpBatchDev &d, const int2 *tiles_dev, int64_t n_tiles, hipStream_t stream);
+/* MRP_EMIT_TILE cells per tile */
+#define MRP_EMIT_TILE 512
+/* tiles_dev[0..n_fast) take the uniform-allele fast path, the next n_general the general path */
+hipError_t mrp_launch_emission(const MrpBatchDev &d, const EmitTile *tiles_dev, int64_t n_fast, int64_t n_general,
+                               hipStream_t stream);
 /* order[0..n) = indices into d.hmms handled by this launch, one workgroup each */
 hipError_t mrp_launch_sweep_i32(const MrpBatchDev &d, const int32_t *order_dev, int64_t n, int block_threads,
                                 int max_merge, hipStream_t stream);

@@ -49,11 +49,13 @@ static __device__ __forceinline__ T k_load(const T *p) {
 static __device__ __forceinline__ double i32_to_log(int32_t v) {
     return v == MRP_NEG_I32 ? -__builtin_inf() : (double) v;
 }
-static __device__ __forceinline__ int32_t log_to_i32(double v) {
-    return v == -__builtin_inf() ? MRP_NEG_I32 : (int32_t) v;
-}
 static __device__ __forceinline__ int32_t add_i32(int32_t a, int32_t b) {
     return a == MRP_NEG_I32 ? MRP_NEG_I32 : a + b;
+}
+/* Workgroup barrier that orders LDS traffic only.  __syncthreads() also emits s_waitcnt vmcnt(0),
+ * which would drain the prefetched global loads (and wait for every store) at each column. */
+static __device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 static __device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
 #pragma unroll
@@ -191,211 +193,325 @@ static __device__ uint32_t column_cost_ancestor(const DevCol &c, const DevChunk 
 /* ------------------------------------------------------------------------------------------ */
 /* emission kernel: every cell of every column of every HMM of the batch, fully parallel       */
 /* ------------------------------------------------------------------------------------------ */
-/* One wave per tile of up to 64*EMIT_CPT consecutive cells of ONE column, so the column's bit
- * planes are wave-uniform (scalar loads) and the partition loads are coalesced. */
+/* cost of CPT partitions over one column whose sites all have A alleles, no ancestor model */
+template <int CPT, bool NARROW>
+static __device__ __forceinline__ void column_cost_uniform(int64_t slot, int n_sites, int A, K_AS(uint64_t) planes,
+                                                           K_AS(uint32_t) slot_total, const uint64_t *P,
+                                                           uint32_t *cost) {
+#pragma unroll
+    for (int j = 0; j < CPT; j++) cost[j] = 0;
+    for (int s = 0; s < n_sites; s++) {
+        uint32_t m1[CPT], m2[CPT];
+#pragma unroll
+        for (int j = 0; j < CPT; j++) { m1[j] = 0xFFFFFFFFu; m2[j] = 0xFFFFFFFFu; }
+        for (int a = 0; a < A; a++) {
+            K_AS(uint64_t) pl = planes + (slot + a) * 8;
+            uint64_t w[8];
+#pragma unroll
+            for (int b = 0; b < 8; b++) w[b] = pl[b];
+            const uint32_t t = slot_total[slot + a];
+#pragma unroll
+            for (int j = 0; j < CPT; j++) {
+                const uint32_t lp = allele_cost<NARROW>(w, P[j]);
+                m1[j] = min(m1[j], lp);
+                m2[j] = min(m2[j], t - lp);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < CPT; j++) cost[j] += m1[j] + m2[j];
+        slot += A;
+    }
+}
+
+/* One wave per tile of up to MRP_EMIT_TILE consecutive cells of ONE column: the column's bit
+ * planes are wave-uniform (scalar loads, SGPR operands of v_and) and the partition loads are
+ * coalesced.  The tile descriptor carries everything the common case needs (one dependent load
+ * level: descriptor -> {planes, partitions}); all partitions of the tile are requested up front. */
 #define EMIT_CPT 4
-#define EMIT_TILE (WAVE * EMIT_CPT)
-__global__ void __launch_bounds__(256) mrp_emission_kernel(MrpBatchDev d, const int2 *__restrict__ tiles,
+#define EMIT_ROUNDS (MRP_EMIT_TILE / (WAVE * EMIT_CPT))
+__global__ void __launch_bounds__(256) mrp_emission_kernel(MrpBatchDev d, const EmitTile *__restrict__ tiles,
                                                            int64_t n_tiles) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int64_t tile = (int64_t) blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
     if (tile >= n_tiles) return;
-    const int col_index = K_PTR(int32_t, tiles)[2 * tile];
-    const int start = K_PTR(int32_t, tiles)[2 * tile + 1];
-    const DevCol c = k_load(d.cols + col_index);
-    const DevChunk ch = k_load(d.chunks + c.chunk);
+    const EmitTile t = k_load(tiles + tile);
     K_AS(uint64_t) planes = K_PTR(uint64_t, d.planes);
     K_AS(uint32_t) slot_total = K_PTR(uint32_t, d.slot_total);
-    uint64_t P[EMIT_CPT];
-    uint32_t cost[EMIT_CPT];
+    uint64_t P[EMIT_ROUNDS * EMIT_CPT];
 #pragma unroll
-    for (int j = 0; j < EMIT_CPT; j++) {
-        const int idx = start + j * WAVE + lane;
-        P[j] = idx < c.n_cells ? d.partition[c.cell_off + idx] : 0ull;
-    }
-    if (c.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) {
-#pragma unroll
-        for (int j = 0; j < EMIT_CPT; j++) cost[j] = column_cost_ancestor(c, ch, planes, slot_total, P[j]);
-    } else if (c.depth <= 32) {
-        column_cost_plain<EMIT_CPT, true>(c, K_PTR(uint32_t, ch.allele_number), planes, slot_total, P, cost);
-    } else {
-        column_cost_plain<EMIT_CPT, false>(c, K_PTR(uint32_t, ch.allele_number), planes, slot_total, P, cost);
+    for (int j = 0; j < EMIT_ROUNDS * EMIT_CPT; j++) {
+        const int idx = j * WAVE + lane;
+        P[j] = idx < t.n ? d.partition[t.cell_off + idx] : 0ull;
     }
 #pragma unroll
-    for (int j = 0; j < EMIT_CPT; j++) {
-        const int idx = start + j * WAVE + lane;
-        if (idx < c.n_cells) d.cell_cost[c.cell_off + idx] = cost[j];
+    for (int r = 0; r < EMIT_ROUNDS; r++) {
+        if (r * WAVE * EMIT_CPT < t.n) {
+            uint32_t cost[EMIT_CPT];
+            if (t.depth <= 32)
+                column_cost_uniform<EMIT_CPT, true>(t.slot_off, t.n_sites, t.uniform_alleles, planes, slot_total,
+                                                    &P[r * EMIT_CPT], cost);
+            else
+                column_cost_uniform<EMIT_CPT, false>(t.slot_off, t.n_sites, t.uniform_alleles, planes, slot_total,
+                                                     &P[r * EMIT_CPT], cost);
+#pragma unroll
+            for (int j = 0; j < EMIT_CPT; j++) {
+                const int idx = (r * EMIT_CPT + j) * WAVE + lane;
+                if (idx < t.n) d.cell_cost[t.cell_off + idx] = cost[j];
+            }
+        }
     }
 }
 
-hipError_t mrp_launch_emission(const MrpBatchDev &d, const int2 *tiles_dev, int64_t n_tiles, hipStream_t stream) {
-    if (n_tiles == 0) return hipSuccess;
+/* tiles whose column mixes allele counts or uses the ancestor substitution model (final sweeps) */
+__global__ void __launch_bounds__(256) mrp_emission_general_kernel(MrpBatchDev d, const EmitTile *__restrict__ tiles,
+                                                                   int64_t n_tiles) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t tile = (int64_t) blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
+    if (tile >= n_tiles) return;
+    const EmitTile t = k_load(tiles + tile);
+    const DevCol c = k_load(d.cols + t.col);
+    const DevChunk ch = k_load(d.chunks + c.chunk);
+    K_AS(uint64_t) planes = K_PTR(uint64_t, d.planes);
+    K_AS(uint32_t) slot_total = K_PTR(uint32_t, d.slot_total);
+    const bool ancestor = (t.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
+    for (int idx = lane; idx < t.n; idx += WAVE) {
+        const uint64_t P[1] = {d.partition[t.cell_off + idx]};
+        uint32_t cost[1];
+        if (ancestor) cost[0] = column_cost_ancestor(c, ch, planes, slot_total, P[0]);
+        else column_cost_plain<1, false>(c, K_PTR(uint32_t, ch.allele_number), planes, slot_total, P, cost);
+        d.cell_cost[t.cell_off + idx] = cost[0];
+    }
+}
+
+hipError_t mrp_launch_emission(const MrpBatchDev &d, const EmitTile *tiles_dev, int64_t n_fast, int64_t n_general,
+                               hipStream_t stream) {
     const int waves = 4;
-    hipLaunchKernelGGL(mrp_emission_kernel, dim3((unsigned) ((n_tiles + waves - 1) / waves)), dim3(waves * WAVE), 0,
-                       stream, d, tiles_dev, n_tiles);
+    if (n_fast > 0)
+        hipLaunchKernelGGL(mrp_emission_kernel, dim3((unsigned) ((n_fast + waves - 1) / waves)), dim3(waves * WAVE), 0,
+                           stream, d, tiles_dev, n_fast);
+    if (n_general > 0)
+        hipLaunchKernelGGL(mrp_emission_general_kernel, dim3((unsigned) ((n_general + waves - 1) / waves)),
+                           dim3(waves * WAVE), 0, stream, d, tiles_dev + n_fast, n_general);
     return hipGetLastError();
 }
 
 /* ------------------------------------------------------------------------------------------ */
 /* max-plus recursion, int32 merge arrays in LDS                                               */
 /* ------------------------------------------------------------------------------------------ */
-/* per-thread registers for one column's share of cells: emission cost, next / previous merge index */
-template <int CPT>
-struct CellRegs {
-    uint32_t cost[CPT], nxt[CPT], prv[CPT];
+/*
+ * One persistent workgroup per hmm.  The cells of an hmm are ONE contiguous stream in HBM (column
+ * after column), so the kernel prefetches by stream ROUNDS of T cells -- full-width, unconditional,
+ * perfectly coalesced loads of (cost, next|prev) held in a ring of SWEEP_R register pairs -- and the
+ * sequential column walk merely consumes them: a wide column spans several rounds (no barrier in
+ * between), a round may hold many narrow columns.  Nothing on the recursion's dependency chain
+ * waits for HBM.  Column descriptors are staged through LDS in windows of SWEEP_WIN columns.
+ *
+ * Column totals: in max-plus arithmetic max_c(f_c + b_c) is the score of the best complete path
+ * for EVERY column, i.e. stRPColumn.totalLogProb == stRPHmm.forwardLogProb exactly (the reference
+ * computes the same integers, hmm.c:906-907), so col_total is a broadcast of the forward score.
+ */
+#define SWEEP_R 8
+#define SWEEP_WIN 256
+
+struct SweepShared {
+    int32_t *cur;  /* merge column read by the column being processed */
+    int32_t *nxt;  /* merge column being accumulated */
+    int32_t *red;  /* [0] hmm forward, [1] hmm backward */
+    int2 *dsc;     /* staged {n_cells, n_merge} of columns [win0, win0 + SWEEP_WIN) */
+    int win0;
 };
-template <int CPT>
-static __device__ __forceinline__ void load_cells(CellRegs<CPT> &r, const MrpBatchDev &d, int64_t cell_off,
-                                                  int n_cells, int tid, int T) {
-#pragma unroll
-    for (int j = 0; j < CPT; j++) {
-        const int idx = j * T + tid;
-        if (idx < n_cells) {
-            const int64_t g = cell_off + idx;
-            r.cost[j] = d.cell_cost[g];
-            r.nxt[j] = d.cell_next[g];
-            r.prv[j] = d.cell_prev[g];
-        }
+
+static __device__ __forceinline__ void stage_window(SweepShared &S, const SweepCol *cols, int K, int win0, int tid, int T) {
+    __syncthreads(); /* everybody is done with the old window (also a full memory fence; rare) */
+    for (int i = tid; i < SWEEP_WIN; i += T) {
+        const int k = win0 + i;
+        if (k >= 0 && k < K) S.dsc[i] = make_int2(cols[k].n_cells, cols[k].n_merge);
     }
+    S.win0 = win0;
+    __syncthreads();
+}
+static __device__ __forceinline__ int2 col_desc(const SweepShared &S, int k) {
+    const int2 v = S.dsc[k - S.win0];
+    return make_int2(__builtin_amdgcn_readfirstlane(v.x), __builtin_amdgcn_readfirstlane(v.y));
 }
 
-template <int CPT>
 __global__ void __launch_bounds__(1024)
 mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_merge) {
     extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-    int32_t *cur = lds;                 /* merge column read by the column being processed */
-    int32_t *nxt = lds + max_merge;     /* merge column being accumulated */
-    int32_t *red = lds + 2 * max_merge; /* [0] hmm forward, [1] hmm backward, [2] column total */
+    SweepShared S;
+    S.cur = lds;
+    S.nxt = lds + max_merge;
+    S.red = lds + 2 * max_merge;
+    S.dsc = reinterpret_cast<int2 *>(lds + 2 * max_merge + 4);
+    S.win0 = 0;
 
     const int tid = threadIdx.x, T = blockDim.x;
     const int64_t hmm_index = K_PTR(int32_t, order)[blockIdx.x];
     const DevHmm h = k_load(d.hmms + hmm_index);
-    const DevCol *cols = d.cols + h.col0;
+    const SweepCol *cols = d.scols + h.col0;
     const int K = h.n_cols;
+    const SweepCol first_col = k_load(cols);
+    const int N = (int) h.n_cells;                 /* cells of this hmm (stream length) */
+    const int Q = (N + T - 1) / T;                 /* rounds */
+    const uint32_t *__restrict__ cost = d.cell_cost + first_col.cell_off;
+    const uint32_t *__restrict__ np = d.cell_np + first_col.cell_off;
+    double *__restrict__ out_f = d.cell_f + first_col.cell_off;
+    double *__restrict__ out_b = d.cell_b + first_col.cell_off;
+    double *__restrict__ out_mf = d.merge_f + first_col.mcell_off;
+    double *__restrict__ out_mb = d.merge_b + first_col.mcell_off;
+
+    uint32_t rc0, rc1, rc2, rc3, rc4, rc5, rc6, rc7, rn0, rn1, rn2, rn3, rn4, rn5, rn6, rn7;
+    /* The ring loads are issued by inline asm so that hipcc's waitcnt pass does not see them (through
+     * this control flow it would wait with vmcnt(0), i.e. drain the whole ring, before every use).
+     * We wait ourselves: entry i is always the OLDEST outstanding ring load when round i starts and
+     * at most 2*(SWEEP_R-1) ring loads are younger, so vmcnt(14) guarantees it has landed; memory
+     * operations retire in issue order and compiler-issued stores in between only make the wait
+     * stricter.  RING_WAIT ties the registers so no use can be scheduled above the wait. */
+#define RING_LOAD(i, q)                                                                              \
+    {                                                                                                \
+        int p_ = (q) * T + tid;                                                                      \
+        p_ = p_ < 0 ? 0 : (p_ > N - 1 ? N - 1 : p_);                                                 \
+        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off"                \
+                     : "=&v"(rc##i), "=&v"(rn##i)                                                    \
+                     : "v"(cost + p_), "v"(np + p_)                                                  \
+                     : "memory");                                                                    \
+    }
+#define RING_WAIT(i) asm volatile("s_waitcnt vmcnt(14)" : "+v"(rc##i), "+v"(rn##i)::"memory");
+    RING_LOAD(0, 0) RING_LOAD(1, 1) RING_LOAD(2, 2) RING_LOAD(3, 3)
+    RING_LOAD(4, 4) RING_LOAD(5, 5) RING_LOAD(6, 6) RING_LOAD(7, 7)
 
     for (int i = tid; i < 2 * max_merge; i += T) lds[i] = MRP_NEG_I32;
-    if (tid < 4) red[tid] = MRP_NEG_I32;
+    if (tid < 4) S.red[tid] = MRP_NEG_I32;
+    stage_window(S, cols, K, 0, tid, T);
 
     /* ---------------- forward (hmm.c:827-879) ---------------- */
-    DevCol c = k_load(cols);
-    CellRegs<CPT> ra, rb;
-    load_cells<CPT>(ra, d, c.cell_off, c.n_cells, tid, T);
-    __syncthreads();
-    for (int k = 0; k < K; k++) {
-        const bool first = (k == 0), last = (k == K - 1);
-        /* the next column's descriptor and cells do not depend on the recursion: fetch them now */
-        DevCol cn = c;
-        if (!last) {
-            cn = k_load(cols + k + 1);
-            load_cells<CPT>(rb, d, cn.cell_off, cn.n_cells, tid, T);
-        }
+    {
+        int k = 0;
+        int2 dk = col_desc(S, 0);
+        int cs = 0, ce = dk.x;   /* stream interval of column k */
+        int mo = 0;              /* merge cells before merge column k */
         int32_t local_max = MRP_NEG_I32;
-#pragma unroll
-        for (int j = 0; j < CPT; j++) {
-            const int idx = j * T + tid;
-            if (idx < c.n_cells) {
-                const int32_t fp = first ? 0 : cur[ra.prv[j]];
-                const int32_t fv = add_i32(fp, -(int32_t) ra.cost[j]);    /* forwardCellCalc1, hmm.c:791-812 */
-                d.cell_f[c.cell_off + idx] = i32_to_log(fv);
-                if (!last) atomicMax(&nxt[ra.nxt[j]], fv);                /* forwardCellCalc2, hmm.c:814-825 */
-                else local_max = max(local_max, fv);
-            }
+#define FWD_ROUND(i, qq)                                                                                   \
+    RING_WAIT(i)                                                                                             \
+    if ((qq) < Q && k < K) {                                                                                 \
+        const int pos = (qq) * T + tid;                                                                      \
+        const int rend = ((qq) + 1) * T;                                                                     \
+        for (;;) {                                                                                           \
+            const bool first = (k == 0), last = (k == K - 1);                                                \
+            if (pos >= cs && pos < ce) {                                                                     \
+                const int32_t fp = first ? 0 : S.cur[rn##i >> 16];          /* forwardCellCalc1 :791 */       \
+                const int32_t fv = add_i32(fp, -(int32_t) rc##i);                                            \
+                out_f[pos] = i32_to_log(fv);                                                                 \
+                if (!last) atomicMax(&S.nxt[rn##i & 0xFFFFu], fv);          /* forwardCellCalc2 :814 */       \
+                else local_max = max(local_max, fv);                                                         \
+            }                                                                                                \
+            if (ce > rend) break; /* the column continues in the next round */                               \
+            /* column k is complete */                                                                       \
+            if (last) {                                                                                      \
+                local_max = wave_max_i32(local_max);                                                         \
+                if ((tid & (WAVE - 1)) == 0) atomicMax(&S.red[0], local_max);                                \
+                k = K;                                                                                       \
+                break;                                                                                       \
+            }                                                                                                \
+            if (k + 1 >= S.win0 + SWEEP_WIN) stage_window(S, cols, K, k, tid, T);                            \
+            const int2 dn = col_desc(S, k + 1);                                                              \
+            lds_barrier();                                                                                   \
+            for (int m = tid; m < dk.y; m += T) out_mf[mo + m] = i32_to_log(S.nxt[m]);                       \
+            if (k + 2 < K) for (int m = tid; m < dn.y; m += T) S.cur[m] = MRP_NEG_I32;                       \
+            lds_barrier();                                                                                   \
+            { int32_t *t_ = S.cur; S.cur = S.nxt; S.nxt = t_; }                                              \
+            mo += dk.y;                                                                                      \
+            k++;                                                                                             \
+            dk = dn;                                                                                         \
+            cs = ce;                                                                                         \
+            ce = cs + dk.x;                                                                                  \
+            if (cs >= rend) break;                                                                           \
+        }                                                                                                    \
+    }                                                                                                        \
+    RING_LOAD(i, (qq) + SWEEP_R)
+        for (int q0 = 0; q0 < Q; q0 += SWEEP_R) {
+            FWD_ROUND(0, q0) FWD_ROUND(1, q0 + 1) FWD_ROUND(2, q0 + 2) FWD_ROUND(3, q0 + 3)
+            FWD_ROUND(4, q0 + 4) FWD_ROUND(5, q0 + 5) FWD_ROUND(6, q0 + 6) FWD_ROUND(7, q0 + 7)
         }
-        for (int idx = CPT * T + tid; idx < c.n_cells; idx += T) {        /* columns wider than CPT*T */
-            const int64_t g = c.cell_off + idx;
-            const int32_t fp = first ? 0 : cur[d.cell_prev[g]];
-            const int32_t fv = add_i32(fp, -(int32_t) d.cell_cost[g]);
-            d.cell_f[g] = i32_to_log(fv);
-            if (!last) atomicMax(&nxt[d.cell_next[g]], fv);
-            else local_max = max(local_max, fv);
-        }
-        if (last) {
-            local_max = wave_max_i32(local_max);
-            if ((tid & (WAVE - 1)) == 0) atomicMax(&red[0], local_max);
-        }
-        __syncthreads();
-        if (!last) {
-            for (int m = tid; m < c.n_merge; m += T) d.merge_f[c.mcell_off + m] = i32_to_log(nxt[m]);
-            const int n_clear = (k + 2 < K) ? cn.n_merge : 0;
-            for (int m = tid; m < n_clear; m += T) cur[m] = MRP_NEG_I32;
-        }
-        __syncthreads();
-        int32_t *t = cur; cur = nxt; nxt = t;
-        c = cn;
-        ra = rb;
+#undef FWD_ROUND
     }
-    const int32_t hmm_forward = red[0];
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* retire the forward ring before it is re-issued */
+    __syncthreads();
+    const int32_t hmm_forward = S.red[0];
 
     /* ---------------- backward (hmm.c:910-929) ---------------- */
-    /* c is the last column.  cur = mb of the merge column after column k (read), nxt = mb of the
-     * merge column before it (accumulated). */
-    DevCol pc = c;
-    if (K >= 2) {
-        pc = k_load(cols + K - 2);
-        for (int m = tid; m < pc.n_merge; m += T) nxt[m] = MRP_NEG_I32;
-    }
-    load_cells<CPT>(ra, d, c.cell_off, c.n_cells, tid, T);
-    __syncthreads();
-    for (int k = K - 1; k >= 0; k--) {
-        const bool first = (k == 0), last = (k == K - 1);
-        /* pc = column k-1 (already loaded); fetch its cells and the descriptor of column k-2 */
-        DevCol ppc = pc;
-        if (!first) {
-            load_cells<CPT>(rb, d, pc.cell_off, pc.n_cells, tid, T);
-            if (k >= 2) ppc = k_load(cols + k - 2);
+    /* cur = mb of the merge column after column k (read), nxt = mb of the one before (accumulated) */
+    {
+        RING_LOAD(0, Q - 1) RING_LOAD(1, Q - 2) RING_LOAD(2, Q - 3) RING_LOAD(3, Q - 4)
+        RING_LOAD(4, Q - 5) RING_LOAD(5, Q - 6) RING_LOAD(6, Q - 7) RING_LOAD(7, Q - 8)
+        int k = K - 1;
+        if (k < S.win0) stage_window(S, cols, K, max(0, K - SWEEP_WIN), tid, T);
+        else if (k >= S.win0 + SWEEP_WIN) stage_window(S, cols, K, max(0, K - SWEEP_WIN), tid, T);
+        int2 dk = col_desc(S, k);
+        int ce = N, cs = N - dk.x;
+        int mo = (int) h.n_merge;  /* merge cells up to and including merge column k-1 end here */
+        if (K >= 2) {
+            if (k - 1 < S.win0) stage_window(S, cols, K, max(0, k - SWEEP_WIN + 1), tid, T);
+            const int2 dp = col_desc(S, k - 1);
+            for (int m = tid; m < dp.y; m += T) S.nxt[m] = MRP_NEG_I32;
         }
+        lds_barrier();
         int32_t local_max = MRP_NEG_I32;
-#pragma unroll
-        for (int j = 0; j < CPT; j++) {
-            const int idx = j * T + tid;
-            if (idx < c.n_cells) {
-                const int32_t bv = last ? 0 : cur[ra.nxt[j]];             /* backwardCellCalc, hmm.c:881-908 */
-                d.cell_b[c.cell_off + idx] = i32_to_log(bv);
-                const int32_t p = add_i32(bv, -(int32_t) ra.cost[j]);
-                if (!first) atomicMax(&nxt[ra.prv[j]], p);
-                else local_max = max(local_max, p);
-            }
+#define BWD_ROUND(i, qq)                                                                                     \
+    RING_WAIT(i)                                                                                             \
+    if ((qq) >= 0 && k >= 0) {                                                                               \
+        const int pos = (qq) * T + tid;                                                                      \
+        const int rbeg = (qq) * T;                                                                           \
+        for (;;) {                                                                                           \
+            const bool first = (k == 0), last = (k == K - 1);                                                \
+            if (pos >= cs && pos < ce) {                                                                     \
+                const int32_t bv = last ? 0 : S.cur[rn##i & 0xFFFFu];       /* backwardCellCalc :881 */       \
+                out_b[pos] = i32_to_log(bv);                                                                 \
+                const int32_t pv = add_i32(bv, -(int32_t) rc##i);                                            \
+                if (!first) atomicMax(&S.nxt[rn##i >> 16], pv);                                              \
+                else local_max = max(local_max, pv);                                                         \
+            }                                                                                                \
+            if (cs < rbeg) break; /* the column continues in the previous round */                           \
+            if (first) {                                                                                     \
+                local_max = wave_max_i32(local_max);                                                         \
+                if ((tid & (WAVE - 1)) == 0) atomicMax(&S.red[1], local_max);                                \
+                k = -1;                                                                                      \
+                break;                                                                                       \
+            }                                                                                                \
+            if (k - 2 >= 0 && k - 2 < S.win0) stage_window(S, cols, K, max(0, k - SWEEP_WIN + 1), tid, T);   \
+            else if (k - 1 < S.win0) stage_window(S, cols, K, max(0, k - SWEEP_WIN + 1), tid, T);            \
+            const int2 dp = col_desc(S, k - 1);                                                              \
+            const int n_clear = (k >= 2) ? col_desc(S, k - 2).y : 0;                                         \
+            lds_barrier();                                                                                   \
+            for (int m = tid; m < dp.y; m += T) out_mb[mo - dp.y + m] = i32_to_log(S.nxt[m]);                \
+            for (int m = tid; m < n_clear; m += T) S.cur[m] = MRP_NEG_I32;                                   \
+            lds_barrier();                                                                                   \
+            { int32_t *t_ = S.cur; S.cur = S.nxt; S.nxt = t_; }                                              \
+            mo -= dp.y;                                                                                      \
+            k--;                                                                                             \
+            dk = dp;                                                                                         \
+            ce = cs;                                                                                         \
+            cs = ce - dk.x;                                                                                  \
+            if (ce <= rbeg) break;                                                                           \
+        }                                                                                                    \
+    }                                                                                                        \
+    RING_LOAD(i, (qq) - SWEEP_R)
+        for (int q0 = Q - 1; q0 >= 0; q0 -= SWEEP_R) {
+            BWD_ROUND(0, q0) BWD_ROUND(1, q0 - 1) BWD_ROUND(2, q0 - 2) BWD_ROUND(3, q0 - 3)
+            BWD_ROUND(4, q0 - 4) BWD_ROUND(5, q0 - 5) BWD_ROUND(6, q0 - 6) BWD_ROUND(7, q0 - 7)
         }
-        for (int idx = CPT * T + tid; idx < c.n_cells; idx += T) {
-            const int64_t g = c.cell_off + idx;
-            const int32_t bv = last ? 0 : cur[d.cell_next[g]];
-            d.cell_b[g] = i32_to_log(bv);
-            const int32_t p = add_i32(bv, -(int32_t) d.cell_cost[g]);
-            if (!first) atomicMax(&nxt[d.cell_prev[g]], p);
-            else local_max = max(local_max, p);
-        }
-        if (first) {
-            local_max = wave_max_i32(local_max);
-            if ((tid & (WAVE - 1)) == 0) atomicMax(&red[1], local_max);
-        }
-        __syncthreads();
-        if (!first) {
-            int32_t tot = MRP_NEG_I32;
-            for (int m = tid; m < pc.n_merge; m += T) {
-                const int32_t mbv = nxt[m];
-                d.merge_b[pc.mcell_off + m] = i32_to_log(mbv);
-                const int32_t mfv = log_to_i32(d.merge_f[pc.mcell_off + m]);
-                if (mbv != MRP_NEG_I32 && mfv != MRP_NEG_I32) tot = max(tot, mbv + mfv);
-            }
-            tot = wave_max_i32(tot);
-            if ((tid & (WAVE - 1)) == 0) atomicMax(&red[2], tot);
-            const int n_clear = (k >= 2) ? ppc.n_merge : 0;
-            for (int m = tid; m < n_clear; m += T) cur[m] = MRP_NEG_I32;
-        }
-        __syncthreads();
-        if (!first && tid == 0) {
-            d.col_total[h.col0 + k - 1] = i32_to_log(red[2]);
-            red[2] = MRP_NEG_I32;
-        }
-        int32_t *t = cur; cur = nxt; nxt = t;
-        c = pc;
-        pc = ppc;
-        ra = rb;
+#undef BWD_ROUND
     }
+#undef RING_LOAD
+#undef RING_WAIT
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    /* stRPColumn.totalLogProb of every column == forward score (see the header comment) */
+    const double total = i32_to_log(hmm_forward);
+    for (int k = tid; k < K; k += T) d.col_total[h.col0 + k] = total;
     if (tid == 0) {
-        d.col_total[h.col0 + K - 1] = i32_to_log(hmm_forward);
-        d.hmm_fb[2 * hmm_index] = i32_to_log(hmm_forward);
-        d.hmm_fb[2 * hmm_index + 1] = i32_to_log(red[1]);
+        d.hmm_fb[2 * hmm_index] = total;
+        d.hmm_fb[2 * hmm_index + 1] = i32_to_log(S.red[1]);
     }
 }
 
@@ -403,8 +519,8 @@ hipError_t mrp_launch_sweep_i32(const MrpBatchDev &d, const int32_t *order_dev, 
                                 int max_merge, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     if (max_merge < 1) max_merge = 1;
-    const size_t lds = (size_t) (2 * max_merge + 4) * sizeof(int32_t);
-    auto k = mrp_sweep_i32_kernel<4>;
+    const size_t lds = (size_t) (2 * max_merge + 4) * sizeof(int32_t) + SWEEP_WIN * sizeof(int2);
+    auto k = mrp_sweep_i32_kernel;
     hipError_t e = hipFuncSetAttribute((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(k, dim3((unsigned) n), dim3(block_threads), lds, stream, d, order_dev, max_merge);
@@ -453,25 +569,28 @@ __global__ void __launch_bounds__(1024) mrp_sweep_f64_kernel(MrpBatchDev d, cons
     const int tid = threadIdx.x, T = blockDim.x;
     const int64_t hmm_index = K_PTR(int32_t, order)[blockIdx.x];
     const DevHmm h = k_load(d.hmms + hmm_index);
-    const DevCol *cols = d.cols + h.col0;
+    const SweepCol *cols = d.scols + h.col0;
     const int K = h.n_cols;
+    const bool wide = h.wide_idx != 0;
     const bool max_not_sum = (h.flags & MRP_FLAG_MAX_NOT_SUM) != 0;
     const double NEG = -__builtin_inf();
     double *hmm_f = d.hmm_fb + 2 * hmm_index, *hmm_b = hmm_f + 1;
     /* merge_f / merge_b / col_total / hmm_fb were filled with -inf before the launch (hmm.c:752-789) */
 
     for (int k = 0; k < K; k++) {
-        const DevCol c = k_load(cols + k);
+        const SweepCol c = k_load(cols + k);
         const bool first = (k == 0), last = (k == K - 1);
-        const DevCol pc = k_load(cols + (first ? k : k - 1));
+        const SweepCol pc = k_load(cols + (first ? k : k - 1));
         double local = NEG;
         for (int idx = tid; idx < c.n_cells; idx += T) {
             const int64_t g = c.cell_off + idx;
             const double e = -((double) d.cell_cost[g]);                         /* emissions.c:239 */
-            double fv = first ? 0.0 : load_agent(&d.merge_f[pc.mcell_off + d.cell_prev[g]]);
+            const uint32_t nx = wide ? d.cell_next[g] : (d.cell_np[g] & 0xFFFFu);
+            const uint32_t pv = wide ? d.cell_prev[g] : (d.cell_np[g] >> 16);
+            double fv = first ? 0.0 : load_agent(&d.merge_f[pc.mcell_off + pv]);
             fv += e;
             d.cell_f[g] = fv;
-            if (!last) atomic_log_add_p(&d.merge_f[c.mcell_off + d.cell_next[g]], fv, max_not_sum);
+            if (!last) atomic_log_add_p(&d.merge_f[c.mcell_off + nx], fv, max_not_sum);
             else local = log_add_p(local, fv, max_not_sum);
         }
         if (last) {
@@ -481,17 +600,19 @@ __global__ void __launch_bounds__(1024) mrp_sweep_f64_kernel(MrpBatchDev d, cons
         __syncthreads();
     }
     for (int k = K - 1; k >= 0; k--) {
-        const DevCol c = k_load(cols + k);
+        const SweepCol c = k_load(cols + k);
         const bool first = (k == 0), last = (k == K - 1);
-        const DevCol pc = k_load(cols + (first ? k : k - 1));
+        const SweepCol pc = k_load(cols + (first ? k : k - 1));
         double local_b = NEG, local_t = NEG;
         for (int idx = tid; idx < c.n_cells; idx += T) {
             const int64_t g = c.cell_off + idx;
+            const uint32_t nx = wide ? d.cell_next[g] : (d.cell_np[g] & 0xFFFFu);
+            const uint32_t pv = wide ? d.cell_prev[g] : (d.cell_np[g] >> 16);
             double p = -((double) d.cell_cost[g]);
             double bv = 0.0;
-            if (!last) { bv = load_agent(&d.merge_b[c.mcell_off + d.cell_next[g]]); p += bv; }
+            if (!last) { bv = load_agent(&d.merge_b[c.mcell_off + nx]); p += bv; }
             d.cell_b[g] = bv;
-            if (!first) atomic_log_add_p(&d.merge_b[pc.mcell_off + d.cell_prev[g]], p, max_not_sum);
+            if (!first) atomic_log_add_p(&d.merge_b[pc.mcell_off + pv], p, max_not_sum);
             else local_b = log_add_p(local_b, p, max_not_sum);
             local_t = log_add_p(local_t, d.cell_f[g] + bv, max_not_sum);  /* hmm.c:906-907 */
         }
