@@ -117,7 +117,7 @@ struct mrp_batch {
     DevBuf<int64_t> d_read_byte_off;
     DevBuf<uint64_t> d_partition, d_planes;
     DevBuf<SweepCol> d_scols;
-    DevBuf<uint32_t> d_next, d_prev, d_np, d_slot_total, d_cost;
+    DevBuf<uint32_t> d_next, d_prev, d_np, d_slot_total, d_slot_bytes, d_cost;
     DevBuf<double> d_f, d_b, d_mf, d_mb, d_total, d_hmm_fb;
     DevBuf<int32_t> d_order_wide, d_order_mid, d_order_narrow, d_order_f64;
     DevBuf<EmitTile> d_tiles;
@@ -564,6 +564,7 @@ int mrp_batch_upload(mrp_batch *b) {
     const size_t nC = b->partition.size();
     HIP_TRY(b->d_planes.alloc((size_t) b->n_slots * 8));
     HIP_TRY(b->d_slot_total.alloc((size_t) b->n_slots));
+    HIP_TRY(b->d_slot_bytes.alloc((size_t) b->n_slots * 16));
     HIP_TRY(b->d_cost.alloc(nC));
     HIP_TRY(b->d_f.alloc(nC));
     HIP_TRY(b->d_b.alloc(nC));
@@ -585,6 +586,7 @@ int mrp_batch_upload(mrp_batch *b) {
     d.cell_prev = b->d_prev.p;
     d.planes = b->d_planes.p;
     d.slot_total = b->d_slot_total.p;
+    d.slot_bytes = b->d_slot_bytes.p;
     d.cell_cost = b->d_cost.p;
     d.cell_f = b->d_f.p;
     d.cell_b = b->d_b.p;
@@ -736,6 +738,7 @@ static int one_column(mrp_context *ctx, const mrp_chunk *chunk, int32_t first_si
 static int run_planes(mrp_context *ctx, const mrp_chunk *chunk, const DevCol &col, const int64_t *read_byte_off,
                       DevBuf<DevCol> &d_col, DevBuf<DevChunk> &d_chunk, DevBuf<int64_t> &d_off,
                       DevBuf<uint64_t> &d_planes, DevBuf<uint32_t> &d_tot) {
+    static thread_local DevBuf<uint32_t> d_bytes;
     hipStream_t s = ctx->stream;
     std::vector<DevCol> hc(1, col);
     std::vector<DevChunk> hch(1, chunk->dev);
@@ -745,12 +748,14 @@ static int run_planes(mrp_context *ctx, const mrp_chunk *chunk, const DevCol &co
     HIP_TRY(d_off.upload(ho, s));
     HIP_TRY(d_planes.alloc((size_t) col.n_slots * 8));
     HIP_TRY(d_tot.alloc((size_t) col.n_slots));
+    HIP_TRY(d_bytes.alloc((size_t) col.n_slots * 16));
     MrpBatchDev d{};
     d.cols = d_col.p;
     d.chunks = d_chunk.p;
     d.read_byte_off = d_off.p;
     d.planes = d_planes.p;
     d.slot_total = d_tot.p;
+    d.slot_bytes = d_bytes.p;
     d.n_cols = 1;
     HIP_TRY(mrp_launch_planes(d, s));
     return MRP_OK;

@@ -21,6 +21,7 @@ struct MrpBatchDev {
     /* scratch */
     uint64_t *planes;
     uint32_t *slot_total;
+    uint32_t *slot_bytes; /* [n_slots * 16] read-major packed profile bytes (4 reads per word) */
     uint32_t *cell_cost;
     /* outputs */
     double *cell_f;

@@ -73,7 +73,8 @@ __global__ void __launch_bounds__(256) mrp_planes_kernel(const DevCol *__restric
                                                          const DevChunk *__restrict__ chunks,
                                                          const int64_t *__restrict__ read_byte_off,
                                                          uint64_t *__restrict__ planes,
-                                                         uint32_t *__restrict__ slot_total) {
+                                                         uint32_t *__restrict__ slot_total,
+                                                         uint32_t *__restrict__ slot_bytes) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int64_t col = (int64_t) blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
     if (col >= n_cols) return;
@@ -93,6 +94,11 @@ __global__ void __launch_bounds__(256) mrp_planes_kernel(const DevCol *__restric
         }
         if (lane < MRP_ALLELE_LOG_PROB_BITS) planes[(c.slot_off + s) * MRP_ALLELE_LOG_PROB_BITS + lane] = mine;
         if (lane == 0) slot_total[c.slot_off + s] = total;
+        /* read-major copy for the dot-product emission kernel: word w = bytes of reads 4w..4w+3 */
+        uint32_t packed = byte << (8 * (lane & 3));
+        packed |= __shfl_xor(packed, 1, WAVE);
+        packed |= __shfl_xor(packed, 2, WAVE);
+        if ((lane & 3) == 0) slot_bytes[(c.slot_off + s) * 16 + (lane >> 2)] = packed;
     }
 }
 
@@ -101,7 +107,7 @@ hipError_t mrp_launch_planes(const MrpBatchDev &d, hipStream_t stream) {
     const int waves = 4;
     const int64_t grid = (d.n_cols + waves - 1) / waves;
     hipLaunchKernelGGL(mrp_planes_kernel, dim3((unsigned) grid), dim3(waves * WAVE), 0, stream, d.cols, d.n_cols,
-                       d.chunks, d.read_byte_off, d.planes, d.slot_total);
+                       d.chunks, d.read_byte_off, d.planes, d.slot_total, d.slot_bytes);
     return hipGetLastError();
 }
 
@@ -193,72 +199,136 @@ static __device__ uint32_t column_cost_ancestor(const DevCol &c, const DevChunk 
 /* ------------------------------------------------------------------------------------------ */
 /* emission kernel: every cell of every column of every HMM of the batch, fully parallel       */
 /* ------------------------------------------------------------------------------------------ */
-/* cost of CPT partitions over one column whose sites all have A alleles, no ancestor model */
-template <int CPT, bool NARROW>
-static __device__ __forceinline__ void column_cost_uniform(int64_t slot, int n_sites, int A, K_AS(uint64_t) planes,
-                                                           K_AS(uint32_t) slot_total, const uint64_t *P,
-                                                           uint32_t *cost) {
+/* getLogProbOfAllele (emissions.c:125-138) as a dot product: sum_{i in P} prob_i[a] =
+ * sum_w dot4(bytes of reads 4w..4w+3, the four partition bits expanded to 0/1 bytes).  The
+ * expansion is done once per cell and reused for every site and allele of the column. */
+template <int NW>
+static __device__ __forceinline__ void expand_partition(uint64_t P, uint32_t (&sel)[NW]) {
+    const uint32_t lo = (uint32_t) P, hi = (uint32_t) (P >> 32);
 #pragma unroll
-    for (int j = 0; j < CPT; j++) cost[j] = 0;
-    for (int s = 0; s < n_sites; s++) {
-        uint32_t m1[CPT], m2[CPT];
-#pragma unroll
-        for (int j = 0; j < CPT; j++) { m1[j] = 0xFFFFFFFFu; m2[j] = 0xFFFFFFFFu; }
-        for (int a = 0; a < A; a++) {
-            K_AS(uint64_t) pl = planes + (slot + a) * 8;
-            uint64_t w[8];
-#pragma unroll
-            for (int b = 0; b < 8; b++) w[b] = pl[b];
-            const uint32_t t = slot_total[slot + a];
-#pragma unroll
-            for (int j = 0; j < CPT; j++) {
-                const uint32_t lp = allele_cost<NARROW>(w, P[j]);
-                m1[j] = min(m1[j], lp);
-                m2[j] = min(m2[j], t - lp);
-            }
-        }
-#pragma unroll
-        for (int j = 0; j < CPT; j++) cost[j] += m1[j] + m2[j];
-        slot += A;
+    for (int w = 0; w < NW; w++) {
+        const uint32_t nib = w < 8 ? ((lo >> (4 * w)) & 0xFu) : ((hi >> (4 * (w - 8))) & 0xFu);
+        sel[w] = (nib * 0x00204081u) & 0x01010101u; /* bit k of the nibble -> byte k = 0/1 */
     }
 }
 
-/* One wave per tile of up to MRP_EMIT_TILE consecutive cells of ONE column: the column's bit
- * planes are wave-uniform (scalar loads, SGPR operands of v_and) and the partition loads are
- * coalesced.  The tile descriptor carries everything the common case needs (one dependent load
- * level: descriptor -> {planes, partitions}); all partitions of the tile are requested up front. */
-#define EMIT_CPT 4
-#define EMIT_ROUNDS (MRP_EMIT_TILE / (WAVE * EMIT_CPT))
+/* cost of CP partitions over one column whose sites all have A alleles, no ancestor model
+ * (emissions.c:187-207, :221-240).  NW = ceil(depth / 4) rounded up to 4, 8, 12 or 16. */
+template <int CP, int NW>
+static __device__ __forceinline__ void column_cost_dot(int64_t slot0, int n_slots, int A, K_AS(uint32_t) slot_bytes,
+                                                       K_AS(uint32_t) slot_total, const uint64_t (&P)[CP],
+                                                       uint32_t (&cost)[CP]) {
+    uint32_t sel[CP][NW];
+    uint32_t m1[CP], m2[CP];
+#pragma unroll
+    for (int j = 0; j < CP; j++) {
+        expand_partition<NW>(P[j], sel[j]);
+        cost[j] = 0;
+        m1[j] = 0xFFFFFFFFu;
+        m2[j] = 0xFFFFFFFFu;
+    }
+    /* scalar double buffer: the bytes of the next allele slot are requested before this one is used */
+    uint32_t B[NW], Bn[NW];
+    uint32_t tot, totn;
+    {
+        K_AS(uint32_t) p = slot_bytes + slot0 * 16;
+#pragma unroll
+        for (int w = 0; w < NW; w++) B[w] = p[w];
+        tot = slot_total[slot0];
+    }
+    int a = 0;
+    for (int g = 0; g < n_slots; g++) {
+        const int gn = g + 1 < n_slots ? g + 1 : g;
+        {
+            K_AS(uint32_t) p = slot_bytes + (slot0 + gn) * 16;
+#pragma unroll
+            for (int w = 0; w < NW; w++) Bn[w] = p[w];
+            totn = slot_total[slot0 + gn];
+        }
+#pragma unroll
+        for (int j = 0; j < CP; j++) {
+            uint32_t lp = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) lp = __builtin_amdgcn_udot4(B[w], sel[j][w], lp, false);
+            m1[j] = min(m1[j], lp);
+            m2[j] = min(m2[j], tot - lp);
+        }
+        if (++a == A) { /* site boundary */
+            a = 0;
+#pragma unroll
+            for (int j = 0; j < CP; j++) {
+                cost[j] += m1[j] + m2[j];
+                m1[j] = 0xFFFFFFFFu;
+                m2[j] = 0xFFFFFFFFu;
+            }
+        }
+#pragma unroll
+        for (int w = 0; w < NW; w++) B[w] = Bn[w];
+        tot = totn;
+    }
+}
+
+/* One wave per tile of up to MRP_EMIT_TILE consecutive cells of ONE column (uniform allele count,
+ * no ancestor model): the column's packed bytes are wave-uniform (scalar loads, SGPR operands of
+ * v_dot4_u32_u8).  Each lane owns EMIT_CP PAIRS of adjacent cells.  The emission cost is symmetric
+ * under complement (hap1 <-> hap2, emissions.c:197-218) and the cross product stores every
+ * partition next to its complement (hmm.c:627-655), so when cell 2i+1 is the complement of cell 2i
+ * -- checked per lane -- the cost is computed once; otherwise a second pass handles the odd cells. */
+template <int NW, int EMIT_CP>
+static __device__ __forceinline__ void emit_tile(const MrpBatchDev &d, const EmitTile &t, int lane, int pair0) {
+    K_AS(uint32_t) slot_bytes = K_PTR(uint32_t, d.slot_bytes);
+    K_AS(uint32_t) slot_total = K_PTR(uint32_t, d.slot_total);
+    const uint64_t mask = t.depth < 64 ? ~(0xFFFFFFFFFFFFFFFFull << t.depth) : 0xFFFFFFFFFFFFFFFFull;
+    const int n_slots = t.n_sites * t.uniform_alleles;
+    uint64_t Pe[EMIT_CP], Po[EMIT_CP];
+    bool has_odd[EMIT_CP], paired[EMIT_CP];
+    bool any_unpaired = false;
+#pragma unroll
+    for (int u = 0; u < EMIT_CP; u++) {
+        const int e = 2 * (pair0 + u * WAVE + lane);
+        Pe[u] = e < t.n ? d.partition[t.cell_off + e] : 0ull;
+        has_odd[u] = e + 1 < t.n;
+        Po[u] = has_odd[u] ? d.partition[t.cell_off + e + 1] : 0ull;
+        paired[u] = has_odd[u] && Po[u] == (~Pe[u] & mask);
+        any_unpaired |= has_odd[u] && !paired[u];
+    }
+    uint32_t cost[EMIT_CP];
+    column_cost_dot<EMIT_CP, NW>(t.slot_off, n_slots, t.uniform_alleles, slot_bytes, slot_total, Pe, cost);
+#pragma unroll
+    for (int u = 0; u < EMIT_CP; u++) {
+        const int e = 2 * (pair0 + u * WAVE + lane);
+        if (e < t.n) d.cell_cost[t.cell_off + e] = cost[u];
+        if (paired[u]) d.cell_cost[t.cell_off + e + 1] = cost[u];
+    }
+    if (__any(any_unpaired)) { /* wave-uniform: rare (pruned hmms, non-inverted mode) */
+        column_cost_dot<EMIT_CP, NW>(t.slot_off, n_slots, t.uniform_alleles, slot_bytes, slot_total, Po, cost);
+#pragma unroll
+        for (int u = 0; u < EMIT_CP; u++) {
+            const int e = 2 * (pair0 + u * WAVE + lane);
+            if (has_odd[u] && !paired[u]) d.cell_cost[t.cell_off + e + 1] = cost[u];
+        }
+    }
+}
+
 __global__ void __launch_bounds__(256) mrp_emission_kernel(MrpBatchDev d, const EmitTile *__restrict__ tiles,
                                                            int64_t n_tiles) {
     const int lane = threadIdx.x & (WAVE - 1);
-    const int64_t tile = (int64_t) blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
+    /* threadIdx.x / 64 is wave-uniform but hipcc cannot prove it: without readfirstlane every
+     * "scalar" load below degrades to 64 identical vector loads */
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / WAVE));
+    const int64_t tile = (int64_t) blockIdx.x * (blockDim.x / WAVE) + wave;
     if (tile >= n_tiles) return;
     const EmitTile t = k_load(tiles + tile);
-    K_AS(uint64_t) planes = K_PTR(uint64_t, d.planes);
-    K_AS(uint32_t) slot_total = K_PTR(uint32_t, d.slot_total);
-    uint64_t P[EMIT_ROUNDS * EMIT_CPT];
-#pragma unroll
-    for (int j = 0; j < EMIT_ROUNDS * EMIT_CPT; j++) {
-        const int idx = j * WAVE + lane;
-        P[j] = idx < t.n ? d.partition[t.cell_off + idx] : 0ull;
-    }
-#pragma unroll
-    for (int r = 0; r < EMIT_ROUNDS; r++) {
-        if (r * WAVE * EMIT_CPT < t.n) {
-            uint32_t cost[EMIT_CPT];
-            if (t.depth <= 32)
-                column_cost_uniform<EMIT_CPT, true>(t.slot_off, t.n_sites, t.uniform_alleles, planes, slot_total,
-                                                    &P[r * EMIT_CPT], cost);
-            else
-                column_cost_uniform<EMIT_CPT, false>(t.slot_off, t.n_sites, t.uniform_alleles, planes, slot_total,
-                                                     &P[r * EMIT_CPT], cost);
-#pragma unroll
-            for (int j = 0; j < EMIT_CPT; j++) {
-                const int idx = (r * EMIT_CPT + j) * WAVE + lane;
-                if (idx < t.n) d.cell_cost[t.cell_off + idx] = cost[j];
-            }
-        }
+    /* MRP_EMIT_TILE = 512 cells = 256 pairs: four pairs per lane, or two passes of two pairs per
+     * lane for deep columns (their expanded partitions need 12-16 registers per pair) */
+    if (t.depth <= 16) emit_tile<4, 4>(d, t, lane, 0);
+    else if (t.depth <= 32) emit_tile<8, 4>(d, t, lane, 0);
+    else if (t.depth <= 48) {
+        emit_tile<12, 2>(d, t, lane, 0);
+        if (t.n > 256) emit_tile<12, 2>(d, t, lane, 128);
+    } else {
+        emit_tile<16, 2>(d, t, lane, 0);
+        if (t.n > 256) emit_tile<16, 2>(d, t, lane, 128);
     }
 }
 
@@ -266,7 +336,8 @@ __global__ void __launch_bounds__(256) mrp_emission_kernel(MrpBatchDev d, const 
 __global__ void __launch_bounds__(256) mrp_emission_general_kernel(MrpBatchDev d, const EmitTile *__restrict__ tiles,
                                                                    int64_t n_tiles) {
     const int lane = threadIdx.x & (WAVE - 1);
-    const int64_t tile = (int64_t) blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / WAVE));
+    const int64_t tile = (int64_t) blockIdx.x * (blockDim.x / WAVE) + wave;
     if (tile >= n_tiles) return;
     const EmitTile t = k_load(tiles + tile);
     const DevCol c = k_load(d.cols + t.col);
