@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <new>
@@ -53,7 +54,7 @@ struct DevBuf {
     hipError_t alloc(size_t count) {
         release();
         n = count;
-        return hipMalloc((void **) &p, std::max<size_t>(count, 1) * sizeof(T) + 16);
+        return hipMalloc((void **) &p, std::max<size_t>(count, 1) * sizeof(T) + 64);
     }
     hipError_t upload(const std::vector<T> &h, hipStream_t s) {
         hipError_t e = alloc(h.size());
@@ -384,6 +385,13 @@ int mrp_batch_add(mrp_batch *b, const mrp_hmm_job *job) {
 
     const int64_t n_cells = job->col_cell_off[K];
     const int64_t n_merge = K > 1 ? job->mcol_cell_off[K - 1] : 0;
+    /* every hmm starts at a multiple of 4 cells: the recursion kernel moves 4 cells per lane (16 B) */
+    while (b->partition.size() % 4 != 0) {
+        b->partition.push_back(0);
+        b->cell_next.push_back(0);
+        b->cell_prev.push_back(0);
+        b->cell_np.push_back(0);
+    }
     const int64_t cell0 = (int64_t) b->partition.size();
     const int64_t mcell0 = b->n_merge;
     const int64_t col0 = (int64_t) b->cols.size();
@@ -513,7 +521,7 @@ int mrp_batch_upload(mrp_batch *b) {
         const DevHmm &h = b->hmms[i];
         const int64_t work = b->outs[i].n_cells;
         const bool max_mode = (h.flags & MRP_FLAG_MAX_NOT_SUM) != 0;
-        const size_t lds = (size_t) (2 * (int64_t) h.max_merge + 4) * sizeof(int32_t) + 256 * 8;
+        const size_t lds = (size_t) (2 * (int64_t) std::max(h.max_merge, 64) + 4) * sizeof(int32_t) + 128 * 8;
         if (max_mode && !h.wide_idx && b->outs[i].n_cells < (1ll << 30) && h.cost_bound < (1ll << 30) && lds <= (size_t) MRP_LDS_BUDGET) {
             if (h.max_cells <= 256) narrow.push_back({-work, (int32_t) i});
             else if (h.max_merge <= 4096) mid.push_back({-work, (int32_t) i});
@@ -636,9 +644,14 @@ int mrp_batch_launch(mrp_batch *b) {
     HIP_TRY(hipEventRecord(ctx->fork, s));
     HIP_TRY(hipStreamWaitEvent(ctx->aux[0], ctx->fork, 0));
     HIP_TRY(hipStreamWaitEvent(ctx->aux[1], ctx->fork, 0));
-    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_wide.p, (int64_t) b->order_wide.size(), 1024, b->max_merge_wide, s));
-    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_mid.p, (int64_t) b->order_mid.size(), 512, b->max_merge_mid, ctx->aux[0]));
-    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), 64, b->max_merge_narrow, ctx->aux[1]));
+    static const int t_wide = getenv("MRP_T_WIDE") ? atoi(getenv("MRP_T_WIDE")) : 256;   /* tuning knobs */
+    static const int t_mid = getenv("MRP_T_MID") ? atoi(getenv("MRP_T_MID")) : 128;
+    static const int t_narrow = getenv("MRP_T_NARROW") ? atoi(getenv("MRP_T_NARROW")) : 64;
+    static const int skip_env = getenv("MRP_SKIP") ? atoi(getenv("MRP_SKIP")) : 0; /* experiment only: bit0 wide, bit1 mid, bit2 narrow */
+    const int skip = b->hmms.size() > 2000 ? skip_env : 0;
+    if (!(skip & 1)) HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_wide.p, (int64_t) b->order_wide.size(), t_wide, b->max_merge_wide, s));
+    if (!(skip & 2)) HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_mid.p, (int64_t) b->order_mid.size(), t_mid, b->max_merge_mid, ctx->aux[0]));
+    if (!(skip & 4)) HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), t_narrow, b->max_merge_narrow, ctx->aux[1]));
     HIP_TRY(mrp_launch_sweep_f64(d, b->d_order_f64.p, (int64_t) b->order_f64.size(), 256, s));
     HIP_TRY(hipEventRecord(ctx->join[0], ctx->aux[0]));
     HIP_TRY(hipEventRecord(ctx->join[1], ctx->aux[1]));

@@ -76,10 +76,11 @@ __global__ void __launch_bounds__(256) mrp_planes_kernel(const DevCol *__restric
                                                          uint32_t *__restrict__ slot_total,
                                                          uint32_t *__restrict__ slot_bytes) {
     const int lane = threadIdx.x & (WAVE - 1);
-    const int64_t col = (int64_t) blockIdx.x * (blockDim.x / WAVE) + (threadIdx.x / WAVE);
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / WAVE));
+    const int64_t col = (int64_t) blockIdx.x * (blockDim.x / WAVE) + wave;
     if (col >= n_cols) return;
-    const DevCol c = cols[col];
-    const uint8_t *__restrict__ pool = chunks[c.chunk].pool;
+    const DevCol c = k_load(cols + col);
+    const uint8_t *__restrict__ pool = k_load(chunks + c.chunk).pool;
     const bool active = lane < c.depth;
     const int64_t off = active ? read_byte_off[c.read_off + lane] : 0;
     for (int s = 0; s < c.n_slots; s++) {
@@ -371,8 +372,8 @@ hipError_t mrp_launch_emission(const MrpBatchDev &d, const EmitTile *tiles_dev, 
 /* ------------------------------------------------------------------------------------------ */
 /*
  * One persistent workgroup per hmm.  The cells of an hmm are ONE contiguous stream in HBM (column
- * after column), so the kernel prefetches by stream ROUNDS of T cells -- full-width, unconditional,
- * perfectly coalesced loads of (cost, next|prev) held in a ring of SWEEP_R register pairs -- and the
+ * after column), so the kernel prefetches by stream ROUNDS of 4*T cells -- full-width, unconditional,
+ * 16-byte-per-lane loads of (cost, next|prev) held in a ring of SWEEP_R register sets -- and the
  * sequential column walk merely consumes them: a wide column spans several rounds (no barrier in
  * between), a round may hold many narrow columns.  Nothing on the recursion's dependency chain
  * waits for HBM.  Column descriptors are staged through LDS in windows of SWEEP_WIN columns.
@@ -382,7 +383,7 @@ hipError_t mrp_launch_emission(const MrpBatchDev &d, const EmitTile *tiles_dev, 
  * computes the same integers, hmm.c:906-907), so col_total is a broadcast of the forward score.
  */
 #define SWEEP_R 8
-#define SWEEP_WIN 256
+#define SWEEP_WIN 128
 
 struct SweepShared {
     int32_t *cur;  /* merge column read by the column being processed */
@@ -416,14 +417,16 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
     S.dsc = reinterpret_cast<int2 *>(lds + 2 * max_merge + 4);
     S.win0 = 0;
 
-    const int tid = threadIdx.x, T = blockDim.x;
+    const int tid = threadIdx.x, T = blockDim.x, lane = threadIdx.x & (WAVE - 1);
     const int64_t hmm_index = K_PTR(int32_t, order)[blockIdx.x];
     const DevHmm h = k_load(d.hmms + hmm_index);
     const SweepCol *cols = d.scols + h.col0;
     const int K = h.n_cols;
     const SweepCol first_col = k_load(cols);
     const int N = (int) h.n_cells;                 /* cells of this hmm (stream length) */
-    const int Q = (N + T - 1) / T;                 /* rounds */
+    const int G = (N + 3) / 4;                     /* groups of 4 consecutive cells: one per thread per round */
+    const int Q = (G + T - 1) / T;                 /* rounds */
+    /* every hmm starts at a multiple of 4 cells in the batch arrays: 16-byte aligned vector access */
     const uint32_t *__restrict__ cost = d.cell_cost + first_col.cell_off;
     const uint32_t *__restrict__ np = d.cell_np + first_col.cell_off;
     double *__restrict__ out_f = d.cell_f + first_col.cell_off;
@@ -431,29 +434,50 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
     double *__restrict__ out_mf = d.merge_f + first_col.mcell_off;
     double *__restrict__ out_mb = d.merge_b + first_col.mcell_off;
 
-    uint32_t rc0, rc1, rc2, rc3, rc4, rc5, rc6, rc7, rn0, rn1, rn2, rn3, rn4, rn5, rn6, rn7;
+    typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    u32x4 rc0, rc1, rc2, rc3, rc4, rc5, rc6, rc7, rn0, rn1, rn2, rn3, rn4, rn5, rn6, rn7;
     /* The ring loads are issued by inline asm so that hipcc's waitcnt pass does not see them (through
      * this control flow it would wait with vmcnt(0), i.e. drain the whole ring, before every use).
-     * We wait ourselves: entry i is always the OLDEST outstanding ring load when round i starts and
-     * at most 2*(SWEEP_R-1) ring loads are younger, so vmcnt(14) guarantees it has landed; memory
-     * operations retire in issue order and compiler-issued stores in between only make the wait
-     * stricter.  RING_WAIT ties the registers so no use can be scheduled above the wait. */
+     * We wait ourselves.  Memory operations retire in issue order and stores share the counter, so
+     * the count of operations issued AFTER the wanted ring entry must be known exactly: every round
+     * issues exactly 2 vector stores (unconditional; lanes without a valid group write to a scratch
+     * slot) followed by exactly 2 ring loads, plus a variable number of merge-column stores that
+     * can only make the wait stricter.  Entry i is the oldest ring entry when its round starts:
+     * in steady state 7 rounds * 4 operations are younger -> vmcnt(28); in the first lap round i has
+     * only i rounds of stores behind it -> vmcnt(14 + 2 i).  RING_WAIT ties the registers so no use
+     * can be scheduled above the wait. */
 #define RING_LOAD(i, q)                                                                              \
     {                                                                                                \
-        int p_ = (q) * T + tid;                                                                      \
-        p_ = p_ < 0 ? 0 : (p_ > N - 1 ? N - 1 : p_);                                                 \
-        asm volatile("global_load_dword %0, %2, off\n\tglobal_load_dword %1, %3, off"                \
+        int g_ = (q) * T + tid;                                                                      \
+        g_ = g_ < 0 ? 0 : (g_ > G - 1 ? G - 1 : g_);                                                 \
+        asm volatile("global_load_dwordx4 %0, %2, off\n\tglobal_load_dwordx4 %1, %3, off"            \
                      : "=&v"(rc##i), "=&v"(rn##i)                                                    \
-                     : "v"(cost + p_), "v"(np + p_)                                                  \
+                     : "v"(cost + 4 * g_), "v"(np + 4 * g_)                                          \
                      : "memory");                                                                    \
     }
-#define RING_WAIT(i) asm volatile("s_waitcnt vmcnt(14)" : "+v"(rc##i), "+v"(rn##i)::"memory");
+#ifdef MRP_SAFE_WAIT /* debugging aid: drain everything */
+#define RING_WAIT(i, n) asm volatile("s_waitcnt vmcnt(0)" : "+v"(rc##i), "+v"(rn##i)::"memory");
+#else
+#define RING_WAIT(i, n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(rc##i), "+v"(rn##i)::"memory");
+#endif
     RING_LOAD(0, 0) RING_LOAD(1, 1) RING_LOAD(2, 2) RING_LOAD(3, 3)
     RING_LOAD(4, 4) RING_LOAD(5, 5) RING_LOAD(6, 6) RING_LOAD(7, 7)
 
     for (int i = tid; i < 2 * max_merge; i += T) lds[i] = MRP_NEG_I32;
     if (tid < 4) S.red[tid] = MRP_NEG_I32;
     stage_window(S, cols, K, 0, tid, T);
+
+    /* exactly two 16-byte stores per lane per round; the hmm's cell range is padded to a multiple of 4
+     * cells, so a partial last group spills into padding; lanes past the stream use the scratch slot */
+#define STORE4(out, p0, ok, v)                                                                               \
+    {                                                                                                        \
+        double *dst_ = (ok) ? (out) + (p0) : scratch;                                                        \
+        f64x2 lo_ = {i32_to_log(v[0]), i32_to_log(v[1])}, hi_ = {i32_to_log(v[2]), i32_to_log(v[3])};       \
+        *reinterpret_cast<f64x2 *>(dst_) = lo_;                                                              \
+        *reinterpret_cast<f64x2 *>(dst_ + 2) = hi_;                                                          \
+    }
+    double *scratch = d.cell_f + d.n_cells; /* 64 bytes of slack behind the batch array, never read */
 
     /* ---------------- forward (hmm.c:827-879) ---------------- */
     {
@@ -462,19 +486,38 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
         int cs = 0, ce = dk.x;   /* stream interval of column k */
         int mo = 0;              /* merge cells before merge column k */
         int32_t local_max = MRP_NEG_I32;
-#define FWD_ROUND(i, qq)                                                                                   \
-    RING_WAIT(i)                                                                                             \
+#define FWD_ROUND(i, qq, nw)                                                                               \
+    RING_WAIT(i, nw)                                                                                         \
+    {                                                                                                        \
+    const int pos0 = 4 * ((qq) * T + tid);                                                                   \
+    int32_t fv[4] = {MRP_NEG_I32, MRP_NEG_I32, MRP_NEG_I32, MRP_NEG_I32};                                    \
     if ((qq) < Q && k < K) {                                                                                 \
-        const int pos = (qq) * T + tid;                                                                      \
-        const int rend = ((qq) + 1) * T;                                                                     \
+        const int rend = 4 * ((qq) + 1) * T;                                                                 \
         for (;;) {                                                                                           \
             const bool first = (k == 0), last = (k == K - 1);                                                \
-            if (pos >= cs && pos < ce) {                                                                     \
-                const int32_t fp = first ? 0 : S.cur[rn##i >> 16];          /* forwardCellCalc1 :791 */       \
-                const int32_t fv = add_i32(fp, -(int32_t) rc##i);                                            \
-                out_f[pos] = i32_to_log(fv);                                                                 \
-                if (!last) atomicMax(&S.nxt[rn##i & 0xFFFFu], fv);          /* forwardCellCalc2 :814 */       \
-                else local_max = max(local_max, fv);                                                         \
+            /* batched and branch-free inside the wave: four independent LDS gathers, one wait, four     \
+             * ds_max.  Cells outside the column use a per-lane dummy slot and the value log(0), for   \
+             * which max is a no-op; waves without any cell of the column skip the block. */            \
+            bool act[4];                                                                                     \
+            bool any_act = false;                                                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                  \
+                const int p = pos0 + j;                                                                      \
+                act[j] = (p >= cs) & (p < ce);                                                               \
+                any_act |= act[j];                                                                           \
+            }                                                                                                \
+            if (__any(any_act)) {                                                                            \
+                int32_t fp[4] = {0, 0, 0, 0};                                                                \
+                if (!first) {                                                                                \
+                    _Pragma("unroll") for (int j = 0; j < 4; j++)                                            \
+                        fp[j] = S.cur[act[j] ? (rn##i[j] >> 16) : lane];     /* forwardCellCalc1 :791 */      \
+                }                                                                                            \
+                _Pragma("unroll") for (int j = 0; j < 4; j++) {                                              \
+                    const int32_t v = add_i32(fp[j], -(int32_t) rc##i[j]);                                   \
+                    fv[j] = act[j] ? v : fv[j];                                                              \
+                    const int32_t val = act[j] ? v : MRP_NEG_I32;                                            \
+                    if (!last) atomicMax(&S.nxt[act[j] ? (rn##i[j] & 0xFFFFu) : lane], val); /* :814 */      \
+                    else local_max = max(local_max, val);                                                    \
+                }                                                                                            \
             }                                                                                                \
             if (ce > rend) break; /* the column continues in the next round */                               \
             /* column k is complete */                                                                       \
@@ -499,14 +542,27 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
             if (cs >= rend) break;                                                                           \
         }                                                                                                    \
     }                                                                                                        \
+    STORE4(out_f, pos0, (qq) < Q && pos0 < N, fv)                                                            \
+    }                                                                                                        \
     RING_LOAD(i, (qq) + SWEEP_R)
-        for (int q0 = 0; q0 < Q; q0 += SWEEP_R) {
-            FWD_ROUND(0, q0) FWD_ROUND(1, q0 + 1) FWD_ROUND(2, q0 + 2) FWD_ROUND(3, q0 + 3)
-            FWD_ROUND(4, q0 + 4) FWD_ROUND(5, q0 + 5) FWD_ROUND(6, q0 + 6) FWD_ROUND(7, q0 + 7)
+        /* first lap: round i has only i rounds of stores behind its ring entry */
+        FWD_ROUND(0, 0, 14) FWD_ROUND(1, 1, 16) FWD_ROUND(2, 2, 18) FWD_ROUND(3, 3, 20)
+        FWD_ROUND(4, 4, 22) FWD_ROUND(5, 5, 24) FWD_ROUND(6, 6, 26) FWD_ROUND(7, 7, 28)
+        for (int q0 = SWEEP_R; q0 < Q; q0 += SWEEP_R) {
+            FWD_ROUND(0, q0, 28) FWD_ROUND(1, q0 + 1, 28) FWD_ROUND(2, q0 + 2, 28) FWD_ROUND(3, q0 + 3, 28)
+            FWD_ROUND(4, q0 + 4, 28) FWD_ROUND(5, q0 + 5, 28) FWD_ROUND(6, q0 + 6, 28) FWD_ROUND(7, q0 + 7, 28)
         }
 #undef FWD_ROUND
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* retire the forward ring before it is re-issued */
+    /* Retire the ring.  The last loads of each entry are never consumed, so for the compiler their
+     * registers are dead: the drain must NAME them, otherwise register-only instructions hoisted above
+     * a plain "s_waitcnt" asm could be allocated into registers a load in flight still overwrites. */
+#define RING_DRAIN() asm volatile("s_waitcnt vmcnt(0)"                                                                          \
+                 : "+v"(rc0), "+v"(rc1), "+v"(rc2), "+v"(rc3), "+v"(rc4), "+v"(rc5), "+v"(rc6), "+v"(rc7),       \
+                   "+v"(rn0), "+v"(rn1), "+v"(rn2), "+v"(rn3), "+v"(rn4), "+v"(rn5), "+v"(rn6), "+v"(rn7)        \
+                 :                                                                                             \
+                 : "memory");
+    RING_DRAIN()
     __syncthreads();
     const int32_t hmm_forward = S.red[0];
 
@@ -516,8 +572,7 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
         RING_LOAD(0, Q - 1) RING_LOAD(1, Q - 2) RING_LOAD(2, Q - 3) RING_LOAD(3, Q - 4)
         RING_LOAD(4, Q - 5) RING_LOAD(5, Q - 6) RING_LOAD(6, Q - 7) RING_LOAD(7, Q - 8)
         int k = K - 1;
-        if (k < S.win0) stage_window(S, cols, K, max(0, K - SWEEP_WIN), tid, T);
-        else if (k >= S.win0 + SWEEP_WIN) stage_window(S, cols, K, max(0, K - SWEEP_WIN), tid, T);
+        if (k < S.win0 || k >= S.win0 + SWEEP_WIN) stage_window(S, cols, K, max(0, K - SWEEP_WIN), tid, T);
         int2 dk = col_desc(S, k);
         int ce = N, cs = N - dk.x;
         int mo = (int) h.n_merge;  /* merge cells up to and including merge column k-1 end here */
@@ -528,19 +583,34 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
         }
         lds_barrier();
         int32_t local_max = MRP_NEG_I32;
-#define BWD_ROUND(i, qq)                                                                                     \
-    RING_WAIT(i)                                                                                             \
+#define BWD_ROUND(i, qq, nw)                                                                                 \
+    RING_WAIT(i, nw)                                                                                         \
+    {                                                                                                        \
+    const int pos0 = 4 * ((qq) * T + tid);                                                                   \
+    int32_t bv[4] = {MRP_NEG_I32, MRP_NEG_I32, MRP_NEG_I32, MRP_NEG_I32};                                    \
     if ((qq) >= 0 && k >= 0) {                                                                               \
-        const int pos = (qq) * T + tid;                                                                      \
-        const int rbeg = (qq) * T;                                                                           \
+        const int rbeg = 4 * (qq) * T;                                                                       \
         for (;;) {                                                                                           \
             const bool first = (k == 0), last = (k == K - 1);                                                \
-            if (pos >= cs && pos < ce) {                                                                     \
-                const int32_t bv = last ? 0 : S.cur[rn##i & 0xFFFFu];       /* backwardCellCalc :881 */       \
-                out_b[pos] = i32_to_log(bv);                                                                 \
-                const int32_t pv = add_i32(bv, -(int32_t) rc##i);                                            \
-                if (!first) atomicMax(&S.nxt[rn##i >> 16], pv);                                              \
-                else local_max = max(local_max, pv);                                                         \
+            bool act[4];                                                                                     \
+            bool any_act = false;                                                                            \
+            _Pragma("unroll") for (int j = 0; j < 4; j++) {                                                  \
+                const int p = pos0 + j;                                                                      \
+                act[j] = (p >= cs) & (p < ce);                                                               \
+                any_act |= act[j];                                                                           \
+            }                                                                                                \
+            if (__any(any_act)) {                                                                            \
+                int32_t bn[4] = {0, 0, 0, 0};                                                                \
+                if (!last) {                                                                                 \
+                    _Pragma("unroll") for (int j = 0; j < 4; j++)                                            \
+                        bn[j] = S.cur[act[j] ? (rn##i[j] & 0xFFFFu) : lane]; /* backwardCellCalc :881 */      \
+                }                                                                                            \
+                _Pragma("unroll") for (int j = 0; j < 4; j++) {                                              \
+                    bv[j] = act[j] ? bn[j] : bv[j];                                                          \
+                    const int32_t pv = act[j] ? add_i32(bn[j], -(int32_t) rc##i[j]) : MRP_NEG_I32;           \
+                    if (!first) atomicMax(&S.nxt[act[j] ? (rn##i[j] >> 16) : lane], pv);                     \
+                    else local_max = max(local_max, pv);                                                     \
+                }                                                                                            \
             }                                                                                                \
             if (cs < rbeg) break; /* the column continues in the previous round */                           \
             if (first) {                                                                                     \
@@ -566,16 +636,22 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
             if (ce <= rbeg) break;                                                                           \
         }                                                                                                    \
     }                                                                                                        \
+    STORE4(out_b, pos0, (qq) >= 0 && pos0 < N, bv)                                                           \
+    }                                                                                                        \
     RING_LOAD(i, (qq) - SWEEP_R)
-        for (int q0 = Q - 1; q0 >= 0; q0 -= SWEEP_R) {
-            BWD_ROUND(0, q0) BWD_ROUND(1, q0 - 1) BWD_ROUND(2, q0 - 2) BWD_ROUND(3, q0 - 3)
-            BWD_ROUND(4, q0 - 4) BWD_ROUND(5, q0 - 5) BWD_ROUND(6, q0 - 6) BWD_ROUND(7, q0 - 7)
+        BWD_ROUND(0, Q - 1, 14) BWD_ROUND(1, Q - 2, 16) BWD_ROUND(2, Q - 3, 18) BWD_ROUND(3, Q - 4, 20)
+        BWD_ROUND(4, Q - 5, 22) BWD_ROUND(5, Q - 6, 24) BWD_ROUND(6, Q - 7, 26) BWD_ROUND(7, Q - 8, 28)
+        for (int q0 = Q - 1 - SWEEP_R; q0 >= 0; q0 -= SWEEP_R) {
+            BWD_ROUND(0, q0, 28) BWD_ROUND(1, q0 - 1, 28) BWD_ROUND(2, q0 - 2, 28) BWD_ROUND(3, q0 - 3, 28)
+            BWD_ROUND(4, q0 - 4, 28) BWD_ROUND(5, q0 - 5, 28) BWD_ROUND(6, q0 - 6, 28) BWD_ROUND(7, q0 - 7, 28)
         }
 #undef BWD_ROUND
     }
+    RING_DRAIN()
+#undef RING_DRAIN
 #undef RING_LOAD
 #undef RING_WAIT
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#undef STORE4
     __syncthreads();
     /* stRPColumn.totalLogProb of every column == forward score (see the header comment) */
     const double total = i32_to_log(hmm_forward);
@@ -589,11 +665,14 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
 hipError_t mrp_launch_sweep_i32(const MrpBatchDev &d, const int32_t *order_dev, int64_t n, int block_threads,
                                 int max_merge, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    if (max_merge < 1) max_merge = 1;
+    if (max_merge < WAVE) max_merge = WAVE; /* per-lane dummy slots of the branch-free cell step */
     const size_t lds = (size_t) (2 * max_merge + 4) * sizeof(int32_t) + SWEEP_WIN * sizeof(int2);
     auto k = mrp_sweep_i32_kernel;
-    hipError_t e = hipFuncSetAttribute((const void *) k, hipFuncAttributeMaxDynamicSharedMemorySize, (int) lds);
-    if (e != hipSuccess) return e;
+    /* the attribute is process-wide state: raise it once to the device maximum, never per launch
+     * (concurrent host threads launch different size classes) */
+    static const hipError_t attr_status =
+        hipFuncSetAttribute((const void *) mrp_sweep_i32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (attr_status != hipSuccess) return attr_status;
     hipLaunchKernelGGL(k, dim3((unsigned) n), dim3(block_threads), lds, stream, d, order_dev, max_merge);
     return hipGetLastError();
 }
