@@ -644,8 +644,8 @@ int mrp_batch_launch(mrp_batch *b) {
     HIP_TRY(hipEventRecord(ctx->fork, s));
     HIP_TRY(hipStreamWaitEvent(ctx->aux[0], ctx->fork, 0));
     HIP_TRY(hipStreamWaitEvent(ctx->aux[1], ctx->fork, 0));
-    static const int t_wide = getenv("MRP_T_WIDE") ? atoi(getenv("MRP_T_WIDE")) : 256;   /* tuning knobs */
-    static const int t_mid = getenv("MRP_T_MID") ? atoi(getenv("MRP_T_MID")) : 128;
+    static const int t_wide = getenv("MRP_T_WIDE") ? atoi(getenv("MRP_T_WIDE")) : 512;   /* tuning knobs */
+    static const int t_mid = getenv("MRP_T_MID") ? atoi(getenv("MRP_T_MID")) : 512;
     static const int t_narrow = getenv("MRP_T_NARROW") ? atoi(getenv("MRP_T_NARROW")) : 64;
     static const int skip_env = getenv("MRP_SKIP") ? atoi(getenv("MRP_SKIP")) : 0; /* experiment only: bit0 wide, bit1 mid, bit2 narrow */
     const int skip = b->hmms.size() > 2000 ? skip_env : 0;

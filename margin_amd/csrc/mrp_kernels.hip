@@ -418,7 +418,10 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
     S.win0 = 0;
 
     const int tid = threadIdx.x, T = blockDim.x, lane = threadIdx.x & (WAVE - 1);
-    const int64_t hmm_index = K_PTR(int32_t, order)[blockIdx.x];
+    /* the forward and the backward recursion do not depend on each other (only the posteriors combine
+     * them): they run as two workgroups, halving the sequential chain per workgroup */
+    const bool backward = (blockIdx.x & 1) != 0;
+    const int64_t hmm_index = K_PTR(int32_t, order)[blockIdx.x >> 1];
     const DevHmm h = k_load(d.hmms + hmm_index);
     const SweepCol *cols = d.scols + h.col0;
     const int K = h.n_cols;
@@ -461,8 +464,13 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
 #else
 #define RING_WAIT(i, n) asm volatile("s_waitcnt vmcnt(" #n ")" : "+v"(rc##i), "+v"(rn##i)::"memory");
 #endif
-    RING_LOAD(0, 0) RING_LOAD(1, 1) RING_LOAD(2, 2) RING_LOAD(3, 3)
-    RING_LOAD(4, 4) RING_LOAD(5, 5) RING_LOAD(6, 6) RING_LOAD(7, 7)
+    if (!backward) {
+        RING_LOAD(0, 0) RING_LOAD(1, 1) RING_LOAD(2, 2) RING_LOAD(3, 3)
+        RING_LOAD(4, 4) RING_LOAD(5, 5) RING_LOAD(6, 6) RING_LOAD(7, 7)
+    } else {
+        RING_LOAD(0, Q - 1) RING_LOAD(1, Q - 2) RING_LOAD(2, Q - 3) RING_LOAD(3, Q - 4)
+        RING_LOAD(4, Q - 5) RING_LOAD(5, Q - 6) RING_LOAD(6, Q - 7) RING_LOAD(7, Q - 8)
+    }
 
     for (int i = tid; i < 2 * max_merge; i += T) lds[i] = MRP_NEG_I32;
     if (tid < 4) S.red[tid] = MRP_NEG_I32;
@@ -479,8 +487,17 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
     }
     double *scratch = d.cell_f + d.n_cells; /* 64 bytes of slack behind the batch array, never read */
 
+    /* Retire the ring.  The last loads of each entry are never consumed, so for the compiler their
+     * registers are dead: the drain must NAME them, otherwise register-only instructions hoisted above
+     * a plain "s_waitcnt" asm could be allocated into registers a load in flight still overwrites. */
+#define RING_DRAIN() asm volatile("s_waitcnt vmcnt(0)"                                                                          \
+                 : "+v"(rc0), "+v"(rc1), "+v"(rc2), "+v"(rc3), "+v"(rc4), "+v"(rc5), "+v"(rc6), "+v"(rc7),       \
+                   "+v"(rn0), "+v"(rn1), "+v"(rn2), "+v"(rn3), "+v"(rn4), "+v"(rn5), "+v"(rn6), "+v"(rn7)        \
+                 :                                                                                             \
+                 : "memory");
+
     /* ---------------- forward (hmm.c:827-879) ---------------- */
-    {
+    if (!backward) {
         int k = 0;
         int2 dk = col_desc(S, 0);
         int cs = 0, ce = dk.x;   /* stream interval of column k */
@@ -553,24 +570,16 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
             FWD_ROUND(4, q0 + 4, 28) FWD_ROUND(5, q0 + 5, 28) FWD_ROUND(6, q0 + 6, 28) FWD_ROUND(7, q0 + 7, 28)
         }
 #undef FWD_ROUND
+        RING_DRAIN()
+        __syncthreads();
+        /* stRPColumn.totalLogProb of every column == forward score (see the header comment) */
+        const double total = i32_to_log(S.red[0]);
+        for (int kk = tid; kk < K; kk += T) d.col_total[h.col0 + kk] = total;
+        if (tid == 0) d.hmm_fb[2 * hmm_index] = total;
     }
-    /* Retire the ring.  The last loads of each entry are never consumed, so for the compiler their
-     * registers are dead: the drain must NAME them, otherwise register-only instructions hoisted above
-     * a plain "s_waitcnt" asm could be allocated into registers a load in flight still overwrites. */
-#define RING_DRAIN() asm volatile("s_waitcnt vmcnt(0)"                                                                          \
-                 : "+v"(rc0), "+v"(rc1), "+v"(rc2), "+v"(rc3), "+v"(rc4), "+v"(rc5), "+v"(rc6), "+v"(rc7),       \
-                   "+v"(rn0), "+v"(rn1), "+v"(rn2), "+v"(rn3), "+v"(rn4), "+v"(rn5), "+v"(rn6), "+v"(rn7)        \
-                 :                                                                                             \
-                 : "memory");
-    RING_DRAIN()
-    __syncthreads();
-    const int32_t hmm_forward = S.red[0];
-
     /* ---------------- backward (hmm.c:910-929) ---------------- */
     /* cur = mb of the merge column after column k (read), nxt = mb of the one before (accumulated) */
-    {
-        RING_LOAD(0, Q - 1) RING_LOAD(1, Q - 2) RING_LOAD(2, Q - 3) RING_LOAD(3, Q - 4)
-        RING_LOAD(4, Q - 5) RING_LOAD(5, Q - 6) RING_LOAD(6, Q - 7) RING_LOAD(7, Q - 8)
+    else {
         int k = K - 1;
         if (k < S.win0 || k >= S.win0 + SWEEP_WIN) stage_window(S, cols, K, max(0, K - SWEEP_WIN), tid, T);
         int2 dk = col_desc(S, k);
@@ -646,20 +655,14 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
             BWD_ROUND(4, q0 - 4, 28) BWD_ROUND(5, q0 - 5, 28) BWD_ROUND(6, q0 - 6, 28) BWD_ROUND(7, q0 - 7, 28)
         }
 #undef BWD_ROUND
+        RING_DRAIN()
+        __syncthreads();
+        if (tid == 0) d.hmm_fb[2 * hmm_index + 1] = i32_to_log(S.red[1]);
     }
-    RING_DRAIN()
 #undef RING_DRAIN
 #undef RING_LOAD
 #undef RING_WAIT
 #undef STORE4
-    __syncthreads();
-    /* stRPColumn.totalLogProb of every column == forward score (see the header comment) */
-    const double total = i32_to_log(hmm_forward);
-    for (int k = tid; k < K; k += T) d.col_total[h.col0 + k] = total;
-    if (tid == 0) {
-        d.hmm_fb[2 * hmm_index] = total;
-        d.hmm_fb[2 * hmm_index + 1] = i32_to_log(S.red[1]);
-    }
 }
 
 hipError_t mrp_launch_sweep_i32(const MrpBatchDev &d, const int32_t *order_dev, int64_t n, int block_threads,
@@ -673,7 +676,7 @@ hipError_t mrp_launch_sweep_i32(const MrpBatchDev &d, const int32_t *order_dev, 
     static const hipError_t attr_status =
         hipFuncSetAttribute((const void *) mrp_sweep_i32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (attr_status != hipSuccess) return attr_status;
-    hipLaunchKernelGGL(k, dim3((unsigned) n), dim3(block_threads), lds, stream, d, order_dev, max_merge);
+    hipLaunchKernelGGL(k, dim3((unsigned) (2 * n)), dim3(block_threads), lds, stream, d, order_dev, max_merge);
     return hipGetLastError();
 }
 
