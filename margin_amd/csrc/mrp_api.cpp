@@ -100,6 +100,7 @@ struct mrp_batch {
     std::vector<int64_t> read_byte_off;
     std::vector<uint64_t> partition;
     std::vector<SweepCol> scols;
+    std::vector<PlaneCol> pcols;
     std::vector<uint32_t> cell_next, cell_prev, cell_np;
     std::vector<EmitTile> tiles;
     int64_t n_fast_tiles = 0;
@@ -118,6 +119,7 @@ struct mrp_batch {
     DevBuf<int64_t> d_read_byte_off;
     DevBuf<uint64_t> d_partition, d_planes;
     DevBuf<SweepCol> d_scols;
+    DevBuf<PlaneCol> d_pcols;
     DevBuf<uint32_t> d_next, d_prev, d_np, d_slot_total, d_slot_bytes, d_cost;
     DevBuf<double> d_f, d_b, d_mf, d_mb, d_total, d_hmm_fb;
     DevBuf<int32_t> d_order_wide, d_order_mid, d_order_narrow, d_order_f64;
@@ -469,6 +471,14 @@ int mrp_batch_add(mrp_batch *b, const mrp_hmm_job *job) {
         sc.n_cells = c.n_cells;
         sc.n_merge = c.n_merge;
         b->scols.push_back(sc);
+        PlaneCol pc{};
+        pc.pool = ch->dev.pool;
+        pc.read_off = c.read_off;
+        pc.slot_off = c.slot_off;
+        pc.depth = c.depth;
+        pc.n_slots = c.n_slots;
+        pc.need_planes = (uniform == 0 || ancestor) ? 1 : 0;
+        b->pcols.push_back(pc);
         b->cols.push_back(c);
         h.max_merge = std::max(h.max_merge, c.n_merge);
         h.max_cells = std::max(h.max_cells, c.n_cells);
@@ -554,6 +564,7 @@ int mrp_batch_upload(mrp_batch *b) {
     HIP_TRY(b->d_read_byte_off.upload(b->read_byte_off, s));
     HIP_TRY(b->d_partition.upload(b->partition, s));
     HIP_TRY(b->d_scols.upload(b->scols, s));
+    HIP_TRY(b->d_pcols.upload(b->pcols, s));
     HIP_TRY(b->d_np.upload(b->cell_np, s));
     if (b->need_wide) {
         HIP_TRY(b->d_next.upload(b->cell_next, s));
@@ -589,6 +600,7 @@ int mrp_batch_upload(mrp_batch *b) {
     d.read_byte_off = b->d_read_byte_off.p;
     d.partition = b->d_partition.p;
     d.scols = b->d_scols.p;
+    d.pcols = b->d_pcols.p;
     d.cell_np = b->d_np.p;
     d.cell_next = b->d_next.p;
     d.cell_prev = b->d_prev.p;
@@ -752,6 +764,7 @@ static int run_planes(mrp_context *ctx, const mrp_chunk *chunk, const DevCol &co
                       DevBuf<DevCol> &d_col, DevBuf<DevChunk> &d_chunk, DevBuf<int64_t> &d_off,
                       DevBuf<uint64_t> &d_planes, DevBuf<uint32_t> &d_tot) {
     static thread_local DevBuf<uint32_t> d_bytes;
+    static thread_local DevBuf<PlaneCol> d_pcol;
     hipStream_t s = ctx->stream;
     std::vector<DevCol> hc(1, col);
     std::vector<DevChunk> hch(1, chunk->dev);
@@ -762,7 +775,17 @@ static int run_planes(mrp_context *ctx, const mrp_chunk *chunk, const DevCol &co
     HIP_TRY(d_planes.alloc((size_t) col.n_slots * 8));
     HIP_TRY(d_tot.alloc((size_t) col.n_slots));
     HIP_TRY(d_bytes.alloc((size_t) col.n_slots * 16));
+    PlaneCol pc{};
+    pc.pool = chunk->dev.pool;
+    pc.read_off = 0;
+    pc.slot_off = 0;
+    pc.depth = col.depth;
+    pc.n_slots = col.n_slots;
+    pc.need_planes = 1;
+    std::vector<PlaneCol> hpc(1, pc);
+    HIP_TRY(d_pcol.upload(hpc, s));
     MrpBatchDev d{};
+    d.pcols = d_pcol.p;
     d.cols = d_col.p;
     d.chunks = d_chunk.p;
     d.read_byte_off = d_off.p;

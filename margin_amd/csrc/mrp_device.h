@@ -39,6 +39,17 @@ struct DevCol {
     uint32_t flags;     /* MRP_FLAG_* of the owning hmm */
 };
 
+/* what the bit-plane kernel needs of a column (read through the scalar cache) */
+struct PlaneCol {
+    const uint8_t *pool; /* profile pool of the column's chunk */
+    int64_t read_off;    /* first entry of the column in read_byte_off */
+    int64_t slot_off;    /* first allele slot of the column */
+    int32_t depth;
+    int32_t n_slots;
+    int32_t need_planes; /* the column is handled by the general emission path (mixed allele counts / ancestor model) */
+    int32_t pad;
+};
+
 /* what the recursion kernels need of a column (read through the scalar cache) */
 struct SweepCol {
     int64_t cell_off;

@@ -12,6 +12,7 @@ struct MrpBatchDev {
     const DevHmm *hmms;
     const DevCol *cols;
     const SweepCol *scols;
+    const PlaneCol *pcols;
     const DevChunk *chunks;
     const int64_t *read_byte_off;
     const uint64_t *partition;
@@ -39,6 +40,8 @@ struct MrpBatchDev {
 hipError_t mrp_launch_planes(const MrpBatchDev &d, hipStream_t stream);
 /* MRP_EMIT_TILE cells per tile */
 #define MRP_EMIT_TILE 512
+/* workgroups of the grid-striding kernels: 256 CUs x 8 workgroups of 256 threads */
+#define MRP_PERSISTENT_GRID 2048
 /* tiles_dev[0..n_fast) take the uniform-allele fast path, the next n_general the general path */
 hipError_t mrp_launch_emission(const MrpBatchDev &d, const EmitTile *tiles_dev, int64_t n_fast, int64_t n_general,
                                hipStream_t stream);

@@ -69,46 +69,75 @@ static __device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
 /* ------------------------------------------------------------------------------------------ */
 /* bit planes                                                                                  */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(256) mrp_planes_kernel(const DevCol *__restrict__ cols, int64_t n_cols,
-                                                         const DevChunk *__restrict__ chunks,
+__global__ void __launch_bounds__(256) mrp_planes_kernel(const PlaneCol *__restrict__ pcols, int64_t n_cols,
                                                          const int64_t *__restrict__ read_byte_off,
                                                          uint64_t *__restrict__ planes,
                                                          uint32_t *__restrict__ slot_total,
                                                          uint32_t *__restrict__ slot_bytes) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / WAVE));
-    const int64_t col = (int64_t) blockIdx.x * (blockDim.x / WAVE) + wave;
+    /* Persistent waves striding over the columns.  Per column there are three dependent memory levels
+     * (descriptor -> per-read byte offset -> profile bytes); the first two of the NEXT column are
+     * requested while the current column is processed, and the bytes of up to PLANE_U allele slots
+     * are requested together. */
+    const int64_t wave_stride = (int64_t) gridDim.x * (blockDim.x / WAVE);
+    int64_t col = (int64_t) blockIdx.x * (blockDim.x / WAVE) + wave;
     if (col >= n_cols) return;
-    const DevCol c = k_load(cols + col);
-    const uint8_t *__restrict__ pool = k_load(chunks + c.chunk).pool;
+    PlaneCol c = k_load(pcols + col);
+    int64_t my_off = lane < c.depth ? read_byte_off[c.read_off + lane] : 0;
+    for (; col < n_cols; col += wave_stride) {
+    const int64_t ncol = col + wave_stride < n_cols ? col + wave_stride : col;
+    const PlaneCol cn = k_load(pcols + ncol);
+    const int64_t next_off = lane < cn.depth ? read_byte_off[cn.read_off + lane] : 0;
     const bool active = lane < c.depth;
-    const int64_t off = active ? read_byte_off[c.read_off + lane] : 0;
-    for (int s = 0; s < c.n_slots; s++) {
-        const uint32_t byte = active ? pool[off + s] : 0u;
-        uint64_t mine = 0;
-        uint32_t total = 0;
+    const uint8_t *__restrict__ src = c.pool + my_off;
+#define PLANE_U 8
+    for (int s0 = 0; s0 < c.n_slots; s0 += PLANE_U) {
+        uint32_t bytes[PLANE_U];
 #pragma unroll
-        for (int b = 0; b < MRP_ALLELE_LOG_PROB_BITS; b++) {
-            const uint64_t v = __ballot((byte >> b) & 1u);
-            if (lane == b) mine = v;
-            total += (uint32_t) __popcll(v) << b;
+        for (int u = 0; u < PLANE_U; u++) bytes[u] = (active && s0 + u < c.n_slots) ? src[s0 + u] : 0u;
+#pragma unroll
+        for (int u = 0; u < PLANE_U; u++) {
+            const int s = s0 + u;
+            if (s < c.n_slots) { /* wave-uniform */
+                const uint32_t byte = bytes[u];
+                /* read-major copy for the dot-product emission kernel: word w = bytes of reads 4w..4w+3 */
+                uint32_t packed = byte << (8 * (lane & 3));
+                packed |= __shfl_xor(packed, 1, WAVE);
+                packed |= __shfl_xor(packed, 2, WAVE);
+                if ((lane & 3) == 0) slot_bytes[(c.slot_off + s) * 16 + (lane >> 2)] = packed;
+                /* column-wide byte sum (the hap2 cost is total - hap1 cost) */
+                uint32_t total = __builtin_amdgcn_udot4(packed, 0x01010101u, 0u, false);
+                total += __shfl_xor(total, 4, WAVE);
+                total += __shfl_xor(total, 8, WAVE);
+                total += __shfl_xor(total, 16, WAVE);
+                total += __shfl_xor(total, 32, WAVE);
+                if (lane == 0) slot_total[c.slot_off + s] = total;
+                if (c.need_planes) { /* bit planes: only the general / ancestor emission path reads them */
+                    uint64_t mine = 0;
+#pragma unroll
+                    for (int b = 0; b < MRP_ALLELE_LOG_PROB_BITS; b++) {
+                        const uint64_t v = __ballot((byte >> b) & 1u);
+                        if (lane == b) mine = v;
+                    }
+                    if (lane < MRP_ALLELE_LOG_PROB_BITS) planes[(c.slot_off + s) * MRP_ALLELE_LOG_PROB_BITS + lane] = mine;
+                }
+            }
         }
-        if (lane < MRP_ALLELE_LOG_PROB_BITS) planes[(c.slot_off + s) * MRP_ALLELE_LOG_PROB_BITS + lane] = mine;
-        if (lane == 0) slot_total[c.slot_off + s] = total;
-        /* read-major copy for the dot-product emission kernel: word w = bytes of reads 4w..4w+3 */
-        uint32_t packed = byte << (8 * (lane & 3));
-        packed |= __shfl_xor(packed, 1, WAVE);
-        packed |= __shfl_xor(packed, 2, WAVE);
-        if ((lane & 3) == 0) slot_bytes[(c.slot_off + s) * 16 + (lane >> 2)] = packed;
     }
+    c = cn;
+    my_off = next_off;
+    }
+#undef PLANE_U
 }
 
 hipError_t mrp_launch_planes(const MrpBatchDev &d, hipStream_t stream) {
     if (d.n_cols == 0) return hipSuccess;
     const int waves = 4;
-    const int64_t grid = (d.n_cols + waves - 1) / waves;
-    hipLaunchKernelGGL(mrp_planes_kernel, dim3((unsigned) grid), dim3(waves * WAVE), 0, stream, d.cols, d.n_cols,
-                       d.chunks, d.read_byte_off, d.planes, d.slot_total, d.slot_bytes);
+    int64_t grid = (d.n_cols + waves - 1) / waves;
+    if (grid > MRP_PERSISTENT_GRID) grid = MRP_PERSISTENT_GRID;
+    hipLaunchKernelGGL(mrp_planes_kernel, dim3((unsigned) grid), dim3(waves * WAVE), 0, stream, d.pcols, d.n_cols,
+                       d.read_byte_off, d.planes, d.slot_total, d.slot_bytes);
     return hipGetLastError();
 }
 
