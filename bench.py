@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--threads", type=int, default=int(os.environ.get("MRP_BENCH_THREADS", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--split", type=int, default=int(os.environ.get("MRP_BENCH_SPLIT", "1")),
+                    help="record the chunks into this many device batches launched on separate streams (their kernels overlap)")
     return ap.parse_args()
 
 
@@ -72,8 +74,9 @@ def main():
     cpu_share = max(1, (os.cpu_count() or 8) // max(1, world if world > 1 else 1))
     n_threads = args.threads or min(16, cpu_share, n_chunks)
 
-    main_ctx = capi.Context(local_rank)
-    big = capi.Batch(main_ctx)
+    ctxs = [capi.Context(local_rank) for _ in range(max(1, args.split))]
+    bigs = [capi.Batch(c) for c in ctxs]
+    main_ctx, big = ctxs[0], bigs[0]
     keep = []           # device chunks must outlive the batch
     units_lock = threading.Lock()
     totals = dict(units=0, sweeps=0, reads=0)
@@ -88,7 +91,7 @@ def main():
         chunk = synth.make_ont_chunk(seed=seed, region_bp=args.sites * 500, n_sites=args.sites,
                                      coverage=args.coverage)
         dchunk = capi.DeviceChunk.from_chunk(tls.ctx, chunk)
-        res = capi.phase_reads(tls.ctx, dchunk, chunk, params, record=big)
+        res = capi.phase_reads(tls.ctx, dchunk, chunk, params, record=bigs[i % len(bigs)])
         with units_lock:
             keep.append(dchunk)
             totals["units"] += chunk.units
@@ -100,8 +103,10 @@ def main():
     with ThreadPoolExecutor(max_workers=n_threads) as ex:
         first = list(ex.map(build_one, range(n_chunks)))[0]
     t_build = time.time() - t0
-    big.upload()
-    main_ctx.synchronize()
+    for b_ in bigs:
+        b_.upload()
+    for c_ in ctxs:
+        c_.synchronize()
 
     def barrier():
         if dist is not None:
@@ -109,24 +114,33 @@ def main():
         torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        big.launch()
-    main_ctx.synchronize()
+        for b_ in bigs:
+            b_.launch()
+    for c_ in ctxs:
+        c_.synchronize()
     barrier()
     planes_ms, emission_ms, sweep_ms = [], [], []
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        big.launch()
-        s = big.stats()  # waits for this launch (HIP events on the library's stream)
+        for b_ in bigs:
+            b_.launch()
+        for b_ in bigs:
+            s = b_.stats()  # waits for this launch (HIP events on the library's stream)
         planes_ms.append(s.planes_ms)
         emission_ms.append(s.emission_ms)
         sweep_ms.append(s.sweep_ms)
-    main_ctx.synchronize()
+    for c_ in ctxs:
+        c_.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
     elapsed, units_all = sharding.reduce_elapsed_and_units(dist, elapsed, float(totals["units"]),
                                                            device="cuda" if dist is not None else None)
 
-    st = big.stats()
+    sts = [b_.stats() for b_ in bigs]
+    st = sts[0]
+    for o_ in sts[1:]:
+        for f_ in ("n_hmms", "n_columns", "n_cells", "n_merge_cells", "profile_bytes", "algorithmic_bytes", "popcount_ops"):
+            setattr(st, f_, getattr(st, f_) + getattr(o_, f_))
     value = units_all * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
     sweep_avg = float(np.mean(sweep_ms))
@@ -168,7 +182,8 @@ def main():
                                           f"({first.units} units, {r['fb_seconds']:.2f} s in forward/backward)")
     if rank == 0:
         print(json.dumps(out))
-    big.close()
+    for b_ in bigs:
+        b_.close()
     for d in keep:
         d.close()
     if dist is not None:

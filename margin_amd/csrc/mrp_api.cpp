@@ -89,6 +89,7 @@ struct mrp_chunk {
 struct JobOut {
     double *cell_f, *cell_b, *merge_f, *merge_b, *col_total, *hmm_f, *hmm_b;
     int64_t cell0, n_cells, mcell0, n_merge, col0, n_cols;
+    bool int_path = false; /* swept by the max-plus int32 kernel (decided in mrp_batch_upload) */
 };
 
 struct mrp_batch {
@@ -122,6 +123,7 @@ struct mrp_batch {
     DevBuf<PlaneCol> d_pcols;
     DevBuf<uint32_t> d_next, d_prev, d_np, d_slot_total, d_slot_bytes, d_cost;
     DevBuf<double> d_f, d_b, d_mf, d_mb, d_total, d_hmm_fb;
+    DevBuf<int32_t> d_f32, d_b32, d_mf32, d_mb32;
     DevBuf<int32_t> d_order_wide, d_order_mid, d_order_narrow, d_order_f64;
     DevBuf<EmitTile> d_tiles;
     MrpBatchDev dev{};
@@ -533,6 +535,7 @@ int mrp_batch_upload(mrp_batch *b) {
         const bool max_mode = (h.flags & MRP_FLAG_MAX_NOT_SUM) != 0;
         const size_t lds = (size_t) (2 * (int64_t) std::max(h.max_merge, 64) + 4) * sizeof(int32_t) + 128 * 8;
         if (max_mode && !h.wide_idx && b->outs[i].n_cells < (1ll << 30) && h.cost_bound < (1ll << 30) && lds <= (size_t) MRP_LDS_BUDGET) {
+            b->outs[i].int_path = true;
             if (h.max_cells <= 256) narrow.push_back({-work, (int32_t) i});
             else if (h.max_merge <= 4096) mid.push_back({-work, (int32_t) i});
             else wide.push_back({-work, (int32_t) i});
@@ -585,10 +588,16 @@ int mrp_batch_upload(mrp_batch *b) {
     HIP_TRY(b->d_slot_total.alloc((size_t) b->n_slots));
     HIP_TRY(b->d_slot_bytes.alloc((size_t) b->n_slots * 16));
     HIP_TRY(b->d_cost.alloc(nC));
-    HIP_TRY(b->d_f.alloc(nC));
-    HIP_TRY(b->d_b.alloc(nC));
-    HIP_TRY(b->d_mf.alloc((size_t) b->n_merge));
-    HIP_TRY(b->d_mb.alloc((size_t) b->n_merge));
+    HIP_TRY(b->d_f32.alloc(nC));
+    HIP_TRY(b->d_b32.alloc(nC));
+    HIP_TRY(b->d_mf32.alloc((size_t) b->n_merge));
+    HIP_TRY(b->d_mb32.alloc((size_t) b->n_merge));
+    if (!b->order_f64.empty()) { /* fp64 result arrays only when some hmm takes the fp64 path */
+        HIP_TRY(b->d_f.alloc(nC));
+        HIP_TRY(b->d_b.alloc(nC));
+        HIP_TRY(b->d_mf.alloc((size_t) b->n_merge));
+        HIP_TRY(b->d_mb.alloc((size_t) b->n_merge));
+    }
     HIP_TRY(b->d_total.alloc(b->cols.size()));
     HIP_TRY(b->d_hmm_fb.alloc(2 * b->hmms.size()));
     HIP_TRY(hipStreamSynchronize(s));
@@ -608,6 +617,10 @@ int mrp_batch_upload(mrp_batch *b) {
     d.slot_total = b->d_slot_total.p;
     d.slot_bytes = b->d_slot_bytes.p;
     d.cell_cost = b->d_cost.p;
+    d.cell_f32 = b->d_f32.p;
+    d.cell_b32 = b->d_b32.p;
+    d.merge_f32 = b->d_mf32.p;
+    d.merge_b32 = b->d_mb32.p;
     d.cell_f = b->d_f.p;
     d.cell_b = b->d_b.p;
     d.merge_f = b->d_mf.p;
@@ -699,27 +712,53 @@ int mrp_batch_download(mrp_batch *b) {
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const MrpBatchDev &d = b->dev;
-    std::vector<double> f((size_t) d.n_cells), bb((size_t) d.n_cells), mf((size_t) d.n_merge), mb((size_t) d.n_merge),
-        tot((size_t) d.n_cols), fb((size_t) (2 * d.n_hmms));
-    auto pull = [&](std::vector<double> &h, const double *p) -> hipError_t {
-        if (h.empty()) return hipSuccess;
-        return hipMemcpyAsync(h.data(), p, h.size() * sizeof(double), hipMemcpyDeviceToHost, s);
+    const bool any_out = std::any_of(b->outs.begin(), b->outs.end(), [](const JobOut &o) { return o.cell_f != nullptr; });
+    if (!any_out) {
+        HIP_TRY(hipStreamSynchronize(s));
+        return MRP_OK;
+    }
+    const bool has_f64 = !b->order_f64.empty();
+    std::vector<double> f, bb, mf, mb, tot((size_t) d.n_cols), fb((size_t) (2 * d.n_hmms));
+    std::vector<int32_t> f32((size_t) d.n_cells), b32((size_t) d.n_cells), mf32((size_t) d.n_merge), mb32((size_t) d.n_merge);
+    if (has_f64) { f.resize((size_t) d.n_cells); bb.resize((size_t) d.n_cells); mf.resize((size_t) d.n_merge); mb.resize((size_t) d.n_merge); }
+    auto pull = [&](void *h, const void *p, size_t bytes) -> hipError_t {
+        if (bytes == 0) return hipSuccess;
+        return hipMemcpyAsync(h, p, bytes, hipMemcpyDeviceToHost, s);
     };
-    HIP_TRY(pull(f, d.cell_f));
-    HIP_TRY(pull(bb, d.cell_b));
-    HIP_TRY(pull(mf, d.merge_f));
-    HIP_TRY(pull(mb, d.merge_b));
-    HIP_TRY(pull(tot, d.col_total));
-    HIP_TRY(pull(fb, d.hmm_fb));
+    HIP_TRY(pull(f32.data(), d.cell_f32, f32.size() * 4));
+    HIP_TRY(pull(b32.data(), d.cell_b32, b32.size() * 4));
+    HIP_TRY(pull(mf32.data(), d.merge_f32, mf32.size() * 4));
+    HIP_TRY(pull(mb32.data(), d.merge_b32, mb32.size() * 4));
+    if (has_f64) {
+        HIP_TRY(pull(f.data(), d.cell_f, f.size() * 8));
+        HIP_TRY(pull(bb.data(), d.cell_b, bb.size() * 8));
+        HIP_TRY(pull(mf.data(), d.merge_f, mf.size() * 8));
+        HIP_TRY(pull(mb.data(), d.merge_b, mb.size() * 8));
+    }
+    HIP_TRY(pull(tot.data(), d.col_total, tot.size() * 8));
+    HIP_TRY(pull(fb.data(), d.hmm_fb, fb.size() * 8));
     HIP_TRY(hipStreamSynchronize(s));
+    /* widen the max-plus integers to the reference's doubles (exact); MRP_NEG_I32 is log(0) */
+    auto widen = [](double *dst, const int32_t *src, int64_t n) {
+        for (int64_t i = 0; i < n; i++) dst[i] = src[i] == MRP_NEG_I32 ? -__builtin_inf() : (double) src[i];
+    };
     for (size_t i = 0; i < b->outs.size(); i++) {
         const JobOut &o = b->outs[i];
         if (!o.cell_f) continue; /* device-only job */
-        memcpy(o.cell_f, f.data() + o.cell0, sizeof(double) * (size_t) o.n_cells);
-        memcpy(o.cell_b, bb.data() + o.cell0, sizeof(double) * (size_t) o.n_cells);
-        if (o.n_merge > 0) {
-            memcpy(o.merge_f, mf.data() + o.mcell0, sizeof(double) * (size_t) o.n_merge);
-            memcpy(o.merge_b, mb.data() + o.mcell0, sizeof(double) * (size_t) o.n_merge);
+        if (o.int_path) {
+            widen(o.cell_f, f32.data() + o.cell0, o.n_cells);
+            widen(o.cell_b, b32.data() + o.cell0, o.n_cells);
+            if (o.n_merge > 0) {
+                widen(o.merge_f, mf32.data() + o.mcell0, o.n_merge);
+                widen(o.merge_b, mb32.data() + o.mcell0, o.n_merge);
+            }
+        } else {
+            memcpy(o.cell_f, f.data() + o.cell0, sizeof(double) * (size_t) o.n_cells);
+            memcpy(o.cell_b, bb.data() + o.cell0, sizeof(double) * (size_t) o.n_cells);
+            if (o.n_merge > 0) {
+                memcpy(o.merge_f, mf.data() + o.mcell0, sizeof(double) * (size_t) o.n_merge);
+                memcpy(o.merge_b, mb.data() + o.mcell0, sizeof(double) * (size_t) o.n_merge);
+            }
         }
         memcpy(o.col_total, tot.data() + o.col0, sizeof(double) * (size_t) o.n_cols);
         *o.hmm_f = fb[2 * i];

@@ -24,7 +24,11 @@ struct MrpBatchDev {
     uint32_t *slot_total;
     uint32_t *slot_bytes; /* [n_slots * 16] read-major packed profile bytes (4 reads per word) */
     uint32_t *cell_cost;
-    /* outputs */
+    /* outputs: int32 for hmms swept by the max-plus kernel, fp64 for the log-sum-exp kernel */
+    int32_t *cell_f32;
+    int32_t *cell_b32;
+    int32_t *merge_f32;
+    int32_t *merge_b32;
     double *cell_f;
     double *cell_b;
     double *merge_f;

@@ -461,23 +461,25 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
     /* every hmm starts at a multiple of 4 cells in the batch arrays: 16-byte aligned vector access */
     const uint32_t *__restrict__ cost = d.cell_cost + first_col.cell_off;
     const uint32_t *__restrict__ np = d.cell_np + first_col.cell_off;
-    double *__restrict__ out_f = d.cell_f + first_col.cell_off;
-    double *__restrict__ out_b = d.cell_b + first_col.cell_off;
-    double *__restrict__ out_mf = d.merge_f + first_col.mcell_off;
-    double *__restrict__ out_mb = d.merge_b + first_col.mcell_off;
+    /* max-plus results are exact integers: they stay in HBM as int32 (log(0) = MRP_NEG_I32) and are
+     * widened to the reference's doubles when they cross the host boundary (mrp_batch_download) */
+    int32_t *__restrict__ out_f = d.cell_f32 + first_col.cell_off;
+    int32_t *__restrict__ out_b = d.cell_b32 + first_col.cell_off;
+    int32_t *__restrict__ out_mf = d.merge_f32 + first_col.mcell_off;
+    int32_t *__restrict__ out_mb = d.merge_b32 + first_col.mcell_off;
 
     typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-    typedef double f64x2 __attribute__((ext_vector_type(2)));
+    typedef int32_t i32x4 __attribute__((ext_vector_type(4)));
     u32x4 rc0, rc1, rc2, rc3, rc4, rc5, rc6, rc7, rn0, rn1, rn2, rn3, rn4, rn5, rn6, rn7;
     /* The ring loads are issued by inline asm so that hipcc's waitcnt pass does not see them (through
      * this control flow it would wait with vmcnt(0), i.e. drain the whole ring, before every use).
      * We wait ourselves.  Memory operations retire in issue order and stores share the counter, so
      * the count of operations issued AFTER the wanted ring entry must be known exactly: every round
-     * issues exactly 2 vector stores (unconditional; lanes without a valid group write to a scratch
+     * issues exactly 1 vector store (unconditional; lanes without a valid group write to a scratch
      * slot) followed by exactly 2 ring loads, plus a variable number of merge-column stores that
      * can only make the wait stricter.  Entry i is the oldest ring entry when its round starts:
-     * in steady state 7 rounds * 4 operations are younger -> vmcnt(28); in the first lap round i has
-     * only i rounds of stores behind it -> vmcnt(14 + 2 i).  RING_WAIT ties the registers so no use
+     * in steady state 7 rounds * 3 operations are younger -> vmcnt(21); in the first lap round i has
+     * only i rounds of stores behind it -> vmcnt(14 + i).  RING_WAIT ties the registers so no use
      * can be scheduled above the wait. */
 #define RING_LOAD(i, q)                                                                              \
     {                                                                                                \
@@ -505,16 +507,15 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
     if (tid < 4) S.red[tid] = MRP_NEG_I32;
     stage_window(S, cols, K, 0, tid, T);
 
-    /* exactly two 16-byte stores per lane per round; the hmm's cell range is padded to a multiple of 4
+    /* exactly ONE 16-byte store per lane per round; the hmm's cell range is padded to a multiple of 4
      * cells, so a partial last group spills into padding; lanes past the stream use the scratch slot */
 #define STORE4(out, p0, ok, v)                                                                               \
     {                                                                                                        \
-        double *dst_ = (ok) ? (out) + (p0) : scratch;                                                        \
-        f64x2 lo_ = {i32_to_log(v[0]), i32_to_log(v[1])}, hi_ = {i32_to_log(v[2]), i32_to_log(v[3])};       \
-        *reinterpret_cast<f64x2 *>(dst_) = lo_;                                                              \
-        *reinterpret_cast<f64x2 *>(dst_ + 2) = hi_;                                                          \
+        int32_t *dst_ = (ok) ? (out) + (p0) : scratch;                                                       \
+        const i32x4 q_ = {v[0], v[1], v[2], v[3]};                                                           \
+        *reinterpret_cast<i32x4 *>(dst_) = q_;                                                               \
     }
-    double *scratch = d.cell_f + d.n_cells; /* 64 bytes of slack behind the batch array, never read */
+    int32_t *scratch = d.cell_f32 + d.n_cells; /* 64 bytes of slack behind the batch array, never read */
 
     /* Retire the ring.  The last loads of each entry are never consumed, so for the compiler their
      * registers are dead: the drain must NAME them, otherwise register-only instructions hoisted above
@@ -576,7 +577,7 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
             if (k + 1 >= S.win0 + SWEEP_WIN) stage_window(S, cols, K, k, tid, T);                            \
             const int2 dn = col_desc(S, k + 1);                                                              \
             lds_barrier();                                                                                   \
-            for (int m = tid; m < dk.y; m += T) out_mf[mo + m] = i32_to_log(S.nxt[m]);                       \
+            for (int m = tid; m < dk.y; m += T) out_mf[mo + m] = S.nxt[m];                       \
             if (k + 2 < K) for (int m = tid; m < dn.y; m += T) S.cur[m] = MRP_NEG_I32;                       \
             lds_barrier();                                                                                   \
             { int32_t *t_ = S.cur; S.cur = S.nxt; S.nxt = t_; }                                              \
@@ -592,11 +593,11 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
     }                                                                                                        \
     RING_LOAD(i, (qq) + SWEEP_R)
         /* first lap: round i has only i rounds of stores behind its ring entry */
-        FWD_ROUND(0, 0, 14) FWD_ROUND(1, 1, 16) FWD_ROUND(2, 2, 18) FWD_ROUND(3, 3, 20)
-        FWD_ROUND(4, 4, 22) FWD_ROUND(5, 5, 24) FWD_ROUND(6, 6, 26) FWD_ROUND(7, 7, 28)
+        FWD_ROUND(0, 0, 14) FWD_ROUND(1, 1, 15) FWD_ROUND(2, 2, 16) FWD_ROUND(3, 3, 17)
+        FWD_ROUND(4, 4, 18) FWD_ROUND(5, 5, 19) FWD_ROUND(6, 6, 20) FWD_ROUND(7, 7, 21)
         for (int q0 = SWEEP_R; q0 < Q; q0 += SWEEP_R) {
-            FWD_ROUND(0, q0, 28) FWD_ROUND(1, q0 + 1, 28) FWD_ROUND(2, q0 + 2, 28) FWD_ROUND(3, q0 + 3, 28)
-            FWD_ROUND(4, q0 + 4, 28) FWD_ROUND(5, q0 + 5, 28) FWD_ROUND(6, q0 + 6, 28) FWD_ROUND(7, q0 + 7, 28)
+            FWD_ROUND(0, q0, 21) FWD_ROUND(1, q0 + 1, 21) FWD_ROUND(2, q0 + 2, 21) FWD_ROUND(3, q0 + 3, 21)
+            FWD_ROUND(4, q0 + 4, 21) FWD_ROUND(5, q0 + 5, 21) FWD_ROUND(6, q0 + 6, 21) FWD_ROUND(7, q0 + 7, 21)
         }
 #undef FWD_ROUND
         RING_DRAIN()
@@ -662,7 +663,7 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
             const int2 dp = col_desc(S, k - 1);                                                              \
             const int n_clear = (k >= 2) ? col_desc(S, k - 2).y : 0;                                         \
             lds_barrier();                                                                                   \
-            for (int m = tid; m < dp.y; m += T) out_mb[mo - dp.y + m] = i32_to_log(S.nxt[m]);                \
+            for (int m = tid; m < dp.y; m += T) out_mb[mo - dp.y + m] = S.nxt[m];                \
             for (int m = tid; m < n_clear; m += T) S.cur[m] = MRP_NEG_I32;                                   \
             lds_barrier();                                                                                   \
             { int32_t *t_ = S.cur; S.cur = S.nxt; S.nxt = t_; }                                              \
@@ -677,11 +678,11 @@ mrp_sweep_i32_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_m
     STORE4(out_b, pos0, (qq) >= 0 && pos0 < N, bv)                                                           \
     }                                                                                                        \
     RING_LOAD(i, (qq) - SWEEP_R)
-        BWD_ROUND(0, Q - 1, 14) BWD_ROUND(1, Q - 2, 16) BWD_ROUND(2, Q - 3, 18) BWD_ROUND(3, Q - 4, 20)
-        BWD_ROUND(4, Q - 5, 22) BWD_ROUND(5, Q - 6, 24) BWD_ROUND(6, Q - 7, 26) BWD_ROUND(7, Q - 8, 28)
+        BWD_ROUND(0, Q - 1, 14) BWD_ROUND(1, Q - 2, 15) BWD_ROUND(2, Q - 3, 16) BWD_ROUND(3, Q - 4, 17)
+        BWD_ROUND(4, Q - 5, 18) BWD_ROUND(5, Q - 6, 19) BWD_ROUND(6, Q - 7, 20) BWD_ROUND(7, Q - 8, 21)
         for (int q0 = Q - 1 - SWEEP_R; q0 >= 0; q0 -= SWEEP_R) {
-            BWD_ROUND(0, q0, 28) BWD_ROUND(1, q0 - 1, 28) BWD_ROUND(2, q0 - 2, 28) BWD_ROUND(3, q0 - 3, 28)
-            BWD_ROUND(4, q0 - 4, 28) BWD_ROUND(5, q0 - 5, 28) BWD_ROUND(6, q0 - 6, 28) BWD_ROUND(7, q0 - 7, 28)
+            BWD_ROUND(0, q0, 21) BWD_ROUND(1, q0 - 1, 21) BWD_ROUND(2, q0 - 2, 21) BWD_ROUND(3, q0 - 3, 21)
+            BWD_ROUND(4, q0 - 4, 21) BWD_ROUND(5, q0 - 5, 21) BWD_ROUND(6, q0 - 6, 21) BWD_ROUND(7, q0 - 7, 21)
         }
 #undef BWD_ROUND
         RING_DRAIN()
