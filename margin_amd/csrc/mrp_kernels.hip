@@ -257,45 +257,48 @@ static __device__ __forceinline__ void column_cost_dot(int64_t slot0, int n_slot
         m1[j] = 0xFFFFFFFFu;
         m2[j] = 0xFFFFFFFFu;
     }
-    /* scalar double buffer: the bytes of the next allele slot are requested before this one is used */
-    uint32_t B[NW], Bn[NW];
-    uint32_t tot, totn;
+    /* scalar ping-pong: the bytes of the next allele slot are requested at the top of the step that
+     * consumes the current one, into the other register set (no copies in between) */
+    uint32_t B0[NW], B1[NW];
+    uint32_t tot0, tot1 = 0;
     {
         K_AS(uint32_t) p = slot_bytes + slot0 * 16;
 #pragma unroll
-        for (int w = 0; w < NW; w++) B[w] = p[w];
-        tot = slot_total[slot0];
+        for (int w = 0; w < NW; w++) B0[w] = p[w];
+        tot0 = slot_total[slot0];
     }
     int a = 0;
-    for (int g = 0; g < n_slots; g++) {
-        const int gn = g + 1 < n_slots ? g + 1 : g;
-        {
-            K_AS(uint32_t) p = slot_bytes + (slot0 + gn) * 16;
-#pragma unroll
-            for (int w = 0; w < NW; w++) Bn[w] = p[w];
-            totn = slot_total[slot0 + gn];
-        }
-#pragma unroll
-        for (int j = 0; j < CP; j++) {
-            uint32_t lp = 0;
-#pragma unroll
-            for (int w = 0; w < NW; w++) lp = __builtin_amdgcn_udot4(B[w], sel[j][w], lp, false);
-            m1[j] = min(m1[j], lp);
-            m2[j] = min(m2[j], tot - lp);
-        }
-        if (++a == A) { /* site boundary */
-            a = 0;
-#pragma unroll
-            for (int j = 0; j < CP; j++) {
-                cost[j] += m1[j] + m2[j];
-                m1[j] = 0xFFFFFFFFu;
-                m2[j] = 0xFFFFFFFFu;
-            }
-        }
-#pragma unroll
-        for (int w = 0; w < NW; w++) B[w] = Bn[w];
-        tot = totn;
+#define DOT_STEP(BC, TC, BN, TN, g)                                                            \
+    {                                                                                            \
+        const int gn_ = (g) + 1 < n_slots ? (g) + 1 : (g);                                       \
+        K_AS(uint32_t) p_ = slot_bytes + (slot0 + gn_) * 16;                                     \
+        _Pragma("unroll") for (int w = 0; w < NW; w++) BN[w] = p_[w];                            \
+        TN = slot_total[slot0 + gn_];                                                            \
+        uint32_t lp_[CP];                                                                        \
+        _Pragma("unroll") for (int j = 0; j < CP; j++) lp_[j] = 0;                               \
+        /* the CP accumulation chains are interleaved word by word */                           \
+        _Pragma("unroll") for (int w = 0; w < NW; w++) {                                         \
+            _Pragma("unroll") for (int j = 0; j < CP; j++)                                       \
+                lp_[j] = __builtin_amdgcn_udot4(BC[w], sel[j][w], lp_[j], false);                \
+        }                                                                                        \
+        _Pragma("unroll") for (int j = 0; j < CP; j++) {                                         \
+            m1[j] = min(m1[j], lp_[j]);                                                          \
+            m2[j] = min(m2[j], TC - lp_[j]);                                                     \
+        }                                                                                        \
+        if (++a == A) { /* site boundary */                                                      \
+            a = 0;                                                                               \
+            _Pragma("unroll") for (int j = 0; j < CP; j++) {                                     \
+                cost[j] += m1[j] + m2[j];                                                        \
+                m1[j] = 0xFFFFFFFFu;                                                             \
+                m2[j] = 0xFFFFFFFFu;                                                             \
+            }                                                                                    \
+        }                                                                                        \
     }
+    for (int g = 0; g < n_slots; g += 2) {
+        DOT_STEP(B0, tot0, B1, tot1, g)
+        if (g + 1 < n_slots) DOT_STEP(B1, tot1, B0, tot0, g + 1)
+    }
+#undef DOT_STEP
 }
 
 /* One wave per tile of up to MRP_EMIT_TILE consecutive cells of ONE column (uniform allele count,
