@@ -60,8 +60,15 @@ def main():
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
+        # rehearsal knobs (not used by the driver): several ranks may share one card with gloo
+        backend = os.environ.get("MRP_BENCH_BACKEND", "nccl")
+        if "MRP_BENCH_DEVICE" in os.environ:
+            local_rank = int(os.environ["MRP_BENCH_DEVICE"])
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
 
@@ -133,8 +140,8 @@ def main():
         c_.synchronize()
     barrier()
     elapsed = time.perf_counter() - t0
-    elapsed, units_all = sharding.reduce_elapsed_and_units(dist, elapsed, float(totals["units"]),
-                                                           device="cuda" if dist is not None else None)
+    reduce_dev = "cuda" if (dist is not None and dist.get_backend() == "nccl") else None
+    elapsed, units_all = sharding.reduce_elapsed_and_units(dist, elapsed, float(totals["units"]), device=reduce_dev)
 
     sts = [b_.stats() for b_ in bigs]
     st = sts[0]
@@ -147,14 +154,26 @@ def main():
     emis_avg = float(np.mean(emission_ms))
     planes_avg = float(np.mean(planes_ms))
     alg = float(st.algorithmic_bytes)
-    # dominant kernel = recursion sweep; SURVEY.md 8(d): B = sum_k 24*C_k + 32*M_k + D_k*Al_k + 8
-    achieved = alg / (sweep_avg * 1e-3) / 1e9
+    # B = sum_k 24*C_k + 32*M_k + D_k*Al_k + 8 for the whole sweep.  The sweep is three
+    # kernels here; each is credited with the algorithmic bytes it is responsible for:
+    #   emission kernel : partition read 8*C (+ the profile bytes D*Al via the plane kernel)
+    #   recursion kernel: f and b 16*C, merge cells 32*M, column totals 8*K      <- dominant kernel
+    C, M, K = float(st.n_cells), float(st.n_merge_cells), float(st.n_columns)
+    alg_sweep = 16.0 * C + 32.0 * M + 8.0 * K
+    alg_emission = 8.0 * C
+    achieved = alg_sweep / (sweep_avg * 1e-3) / 1e9
+    whole = alg / (ms_per_step * 1e-3) / 1e9
+    # HBM bytes the kernels actually move per launch (by construction; PMC cross-check in profiles/):
+    #   emission 8*C read + 4*C write; recursion 2 * (8*C read + 4*C write) + 2 * 4*M write
+    moved = 12.0 * C + 24.0 * C + 8.0 * M
     roofline = dict(bound="hbm", kernel="mrp_sweep_i32_kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                     frac=achieved / HBM_PEAK_GBS, traffic=None,
-                    algorithmic_bytes_per_launch=alg, kernel_ms=sweep_avg,
-                    whole_step=dict(achieved=alg / (ms_per_step * 1e-3) / 1e9,
-                                    frac=alg / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                    planes_ms=planes_avg, emission_ms=emis_avg, sweep_ms=sweep_avg),
+                    algorithmic_bytes_per_launch=alg_sweep, kernel_ms=sweep_avg,
+                    whole_step=dict(achieved=whole, frac=whole / HBM_PEAK_GBS, algorithmic_bytes=alg,
+                                    moved_bytes_model=moved, moved_GBps=moved / (ms_per_step * 1e-3) / 1e9,
+                                    planes_ms=planes_avg, emission_ms=emis_avg, sweep_ms=sweep_avg,
+                                    emission_kernel=dict(algorithmic_bytes=alg_emission,
+                                                         achieved=alg_emission / (emis_avg * 1e-3) / 1e9)),
                     popcount64_per_s=float(st.popcount_ops) / (ms_per_step * 1e-3))
 
     out = dict(metric="het-sites x reads phased/sec (stRPHmm forward/backward sweeps, 30x ONT synthetic)",
