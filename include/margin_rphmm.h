@@ -235,6 +235,31 @@ int mrp_phase_reads(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *re
                     const mrp_params *params, mrp_batch *record, mrp_phase_result **out);
 void mrp_phase_result_destroy(mrp_phase_result *r);
 
+/* ---- device-resident merge --------------------------------------------------
+ * The same results as mrp_get_rp_hmms / mrp_phase_reads, but the hmms stay in HBM across
+ *   stRPHmm_createCrossProductOfTwoAlignedHmm (hmm.c:534) -> stRPHmm_forwardBackward (hmm.c:931)
+ *   -> stRPHmm_prune (hmm.c:1160)
+ * of every merge level (coordination.c:263-409); only per-column cell counts return to the host between
+ * levels and only the final, pruned hmms are copied back.  Max-plus mode (maxNotSumTransitions, every
+ * shipped parameter file) with at most 128 partitions per column; otherwise MRP_ERR_UNSUPPORTED
+ * (mrp_get_rp_hmms_resident) or the per-chunk path is taken (mrp_phase_reads_many, stats->resident = 0). */
+int mrp_get_rp_hmms_resident(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *reads, const int32_t *read_index,
+                             int64_t n, const mrp_params *params, mrp_hmm ***hmms_out, int64_t *n_out);
+
+typedef struct mrp_phase_many_stats {
+    int32_t resident;  /* 1: the device-resident merge was used */
+    int32_t reserved;
+    int64_t levels, hmms, columns, cells, merge_cells; /* of the merge levels */
+    double device_ms, cross_ms, sweep_ms, prune_ms;    /* summed HIP-event times of the merge levels */
+} mrp_phase_many_stats;
+
+/* bubbleGraph_phaseBubbleGraph (bubbleGraph.c:2673-2801) for n_chunks independent chunks in one call: the
+ * body of the chunk loop of phase.c:276-473.  Merge levels of all chunks (and both strands) are batched
+ * into the same kernel launches.  out[n_chunks] receives one result per chunk; stats may be NULL. */
+int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *const *chunks, const mrp_read *const *reads,
+                         const int64_t *n_reads, const mrp_params *params, mrp_phase_result **out,
+                         mrp_phase_many_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,7 +27,7 @@ EXPORTED_SYMBOLS = [
     "mrp_batch_add", "mrp_batch_upload", "mrp_batch_launch", "mrp_batch_download", "mrp_batch_destroy",
     "mrp_batch_stats", "mrp_count_bit_vectors", "mrp_emissions", "mrp_get_rp_hmms", "mrp_hmm_destroy", "mrp_free",
     "mrp_hmm_view", "mrp_hmm_forward_backward", "mrp_hmm_prune", "mrp_hmm_forward_trace_back", "mrp_phase_reads",
-    "mrp_phase_result_destroy",
+    "mrp_phase_result_destroy", "mrp_get_rp_hmms_resident", "mrp_phase_reads_many",
 ]
 
 
@@ -100,6 +100,12 @@ class PhaseResult(C.Structure):
                 ("hmm_forward", C.c_double), ("hmm_backward", C.c_double), ("n_sweeps", C.c_int64)]
 
 
+class PhaseManyStats(C.Structure):
+    _fields_ = [("resident", C.c_int32), ("reserved", C.c_int32), ("levels", C.c_int64), ("hmms", C.c_int64),
+                ("columns", C.c_int64), ("cells", C.c_int64), ("merge_cells", C.c_int64), ("device_ms", C.c_double),
+                ("cross_ms", C.c_double), ("sweep_ms", C.c_double), ("prune_ms", C.c_double)]
+
+
 _lib = None
 
 
@@ -146,6 +152,8 @@ def load():
     L.mrp_phase_reads.argtypes = [vp, vp, P(ReadRec), i64, P(Params), vp, P(P(PhaseResult))]
     L.mrp_phase_result_destroy.argtypes = [P(PhaseResult)]
     L.mrp_phase_result_destroy.restype = None
+    L.mrp_get_rp_hmms_resident.argtypes = [vp, vp, P(ReadRec), vp, i64, P(Params), P(P(vp)), P(i64)]
+    L.mrp_phase_reads_many.argtypes = [vp, i64, P(vp), P(P(ReadRec)), P(i64), P(Params), P(P(PhaseResult)), P(PhaseManyStats)]
     _lib = L
     return L
 
@@ -374,6 +382,20 @@ def get_rp_hmms(ctx: Context, dchunk: DeviceChunk, chunk, params: Params, read_i
     return hmms
 
 
+def get_rp_hmms_resident(ctx: Context, dchunk: DeviceChunk, chunk, params: Params, read_index=None):
+    """mrp_get_rp_hmms_resident: same result as get_rp_hmms, merge levels resident on the device."""
+    L = load()
+    recs, _keep = read_records(chunk)
+    idx = np.arange(len(chunk.reads), dtype=np.int32) if read_index is None else np.ascontiguousarray(read_index, dtype=np.int32)
+    out = C.POINTER(C.c_void_p)()
+    n_out = C.c_int64(0)
+    _check(L.mrp_get_rp_hmms_resident(ctx.h, dchunk.h, recs, idx.ctypes.data if idx.size else None, idx.shape[0],
+                                      C.byref(params), C.byref(out), C.byref(n_out)))
+    hmms = [C.c_void_p(out[i]) for i in range(n_out.value)]
+    L.mrp_free(out)
+    return hmms
+
+
 def hmm_destroy(h):
     load().mrp_hmm_destroy(h)
 
@@ -388,16 +410,9 @@ def hmm_forward_trace_back(h, n_columns: int) -> np.ndarray:
     return path
 
 
-def phase_reads(ctx: Context, dchunk: DeviceChunk, chunk, params: Params, record: Optional[Batch] = None) -> dict:
-    """mrp_phase_reads (bubbleGraph.c:2673 driver) -> dict with the same keys as the oracle's."""
-    L = load()
-    recs, _keep = read_records(chunk)
-    res = C.POINTER(PhaseResult)()
-    _check(L.mrp_phase_reads(ctx.h, dchunk.h, recs, len(chunk.reads), C.byref(params), record.h if record else None,
-                             C.byref(res)))
-    g = res.contents
+def _phase_result_dict(g) -> dict:
     n = int(g.length)
-    out = dict(ref_start=int(g.ref_start), length=n,
+    return dict(ref_start=int(g.ref_start), length=n,
                reads1=[int(g.reads1[i]) for i in range(g.n_reads1)], reads2=[int(g.reads2[i]) for i in range(g.n_reads2)],
                hap1=_as_np(g.haplotype_string1, n, np.uint64), hap2=_as_np(g.haplotype_string2, n, np.uint64),
                genotype=_as_np(g.genotype_string, n, np.uint64), ancestor=_as_np(g.ancestor_string, n, np.uint64),
@@ -406,5 +421,33 @@ def phase_reads(ctx: Context, dchunk: DeviceChunk, chunk, params: Params, record
                support1=_as_np(g.reads_supporting_haplotype1, n, np.uint64),
                support2=_as_np(g.reads_supporting_haplotype2, n, np.uint64),
                hmm_forward=float(g.hmm_forward), hmm_backward=float(g.hmm_backward), n_sweeps=int(g.n_sweeps))
+
+
+def phase_reads(ctx: Context, dchunk: DeviceChunk, chunk, params: Params, record: Optional[Batch] = None) -> dict:
+    """mrp_phase_reads (bubbleGraph.c:2673 driver) -> dict with the same keys as the oracle's."""
+    L = load()
+    recs, _keep = read_records(chunk)
+    res = C.POINTER(PhaseResult)()
+    _check(L.mrp_phase_reads(ctx.h, dchunk.h, recs, len(chunk.reads), C.byref(params), record.h if record else None,
+                             C.byref(res)))
+    out = _phase_result_dict(res.contents)
     L.mrp_phase_result_destroy(res)
     return out
+
+
+def phase_reads_many(ctx: Context, dchunks: Sequence[DeviceChunk], chunks: Sequence, params: Params):
+    """mrp_phase_reads_many -> (list of result dicts, PhaseManyStats)."""
+    L = load()
+    n = len(chunks)
+    keep = [read_records(c) for c in chunks]
+    ch = (C.c_void_p * max(n, 1))(*[d.h for d in dchunks])
+    rd = (C.POINTER(ReadRec) * max(n, 1))(*[C.cast(k[0], C.POINTER(ReadRec)) for k in keep])
+    nr = (C.c_int64 * max(n, 1))(*[len(c.reads) for c in chunks])
+    res = (C.POINTER(PhaseResult) * max(n, 1))()
+    st = PhaseManyStats()
+    _check(L.mrp_phase_reads_many(ctx.h, n, ch, rd, nr, C.byref(params), res, C.byref(st)))
+    out = []
+    for i in range(n):
+        out.append(_phase_result_dict(res[i].contents))
+        L.mrp_phase_result_destroy(res[i])
+    return out, st

@@ -18,10 +18,7 @@
 #include <new>
 #include <vector>
 
-#include "../../include/margin_rphmm.h"
-#include "mrp_device.h"
-#include "mrp_kernels.h"
-#include "rphmm_host.h"
+#include "mrp_internal.h"
 
 namespace {
 
@@ -41,93 +38,7 @@ int fail(int code, const char *fmt, ...) {
         if (e_ != hipSuccess) return fail(MRP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_)); \
     } while (0)
 
-template <typename T>
-struct DevBuf {
-    T *p = nullptr;
-    size_t n = 0;
-    ~DevBuf() { release(); }
-    void release() {
-        if (p) (void) hipFree(p);
-        p = nullptr;
-        n = 0;
-    }
-    hipError_t alloc(size_t count) {
-        release();
-        n = count;
-        return hipMalloc((void **) &p, std::max<size_t>(count, 1) * sizeof(T) + 64);
-    }
-    hipError_t upload(const std::vector<T> &h, hipStream_t s) {
-        hipError_t e = alloc(h.size());
-        if (e != hipSuccess || h.empty()) return e;
-        return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
-    }
-};
-
 }  // namespace
-
-struct mrp_context {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipStream_t aux[2] = {nullptr, nullptr}; /* size classes of the recursion kernel run side by side */
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
-};
-
-struct mrp_chunk {
-    mrp_context *ctx = nullptr;
-    int64_t n_sites = 0, pool_bytes = 0;
-    std::vector<uint32_t> allele_number, allele_offset, sub_offset;
-    std::vector<uint16_t> sub, prior; /* host copies for the structural code (rphmm_host.c) */
-    std::vector<uint8_t> pool;
-    uint32_t max_sub = 0, max_prior = 0;
-    DevBuf<uint32_t> d_allele_number, d_allele_offset, d_sub_offset;
-    DevBuf<uint16_t> d_sub, d_prior;
-    DevBuf<uint8_t> d_pool;
-    DevChunk dev{};
-};
-
-struct JobOut {
-    double *cell_f, *cell_b, *merge_f, *merge_b, *col_total, *hmm_f, *hmm_b;
-    int64_t cell0, n_cells, mcell0, n_merge, col0, n_cols;
-    bool int_path = false; /* swept by the max-plus int32 kernel (decided in mrp_batch_upload) */
-};
-
-struct mrp_batch {
-    mrp_context *ctx = nullptr;
-    std::mutex mu; /* mrp_batch_add may be called from several host threads (recording) */
-    std::vector<const mrp_chunk *> chunks;
-    std::vector<DevHmm> hmms;
-    std::vector<DevCol> cols;
-    std::vector<int64_t> read_byte_off;
-    std::vector<uint64_t> partition;
-    std::vector<SweepCol> scols;
-    std::vector<PlaneCol> pcols;
-    std::vector<uint32_t> cell_next, cell_prev, cell_np;
-    std::vector<EmitTile> tiles;
-    int64_t n_fast_tiles = 0;
-    bool need_wide = false;
-    std::vector<JobOut> outs;
-    int64_t n_merge = 0, n_slots = 0;
-    mrp_launch_stats stats{};
-    /* launch plan */
-    std::vector<int32_t> order_wide, order_mid, order_narrow, order_f64;
-    int max_merge_wide = 1, max_merge_mid = 1, max_merge_narrow = 1;
-    /* device */
-    bool uploaded = false, launched = false;
-    DevBuf<DevHmm> d_hmms;
-    DevBuf<DevCol> d_cols;
-    DevBuf<DevChunk> d_chunks;
-    DevBuf<int64_t> d_read_byte_off;
-    DevBuf<uint64_t> d_partition, d_planes;
-    DevBuf<SweepCol> d_scols;
-    DevBuf<PlaneCol> d_pcols;
-    DevBuf<uint32_t> d_next, d_prev, d_np, d_slot_total, d_slot_bytes, d_cost;
-    DevBuf<double> d_f, d_b, d_mf, d_mb, d_total, d_hmm_fb;
-    DevBuf<int32_t> d_f32, d_b32, d_mf32, d_mb32;
-    DevBuf<int32_t> d_order_wide, d_order_mid, d_order_narrow, d_order_f64;
-    DevBuf<EmitTile> d_tiles;
-    MrpBatchDev dev{};
-};
 
 extern "C" {
 
@@ -325,15 +236,18 @@ static int resolve_column(const uint64_t *part, int64_t n_cells, uint64_t mask, 
     return MRP_OK;
 }
 
-int mrp_batch_add(mrp_batch *b, const mrp_hmm_job *job) {
+}  /* extern "C" */
+
+int mrp_batch_add_impl(mrp_batch *b, const mrp_hmm_job *job, bool resident, int64_t *cell0_out, int64_t *mcell0_out,
+                       int64_t *col0_out) {
     if (!b || !job) return fail(MRP_ERR_ARG, "mrp_batch_add: NULL argument");
     if (b->uploaded) return fail(MRP_ERR_ARG, "mrp_batch_add: batch already uploaded");
     const int K = job->n_columns;
     if (K < 1) return fail(MRP_ERR_ARG, "hmm has %d columns", K);
     if (!job->chunk || !job->col_ref_start || !job->col_length || !job->col_depth || !job->col_cell_off ||
-        !job->col_read_off || !job->partition)
+        !job->col_read_off || (!resident && !job->partition))
         return fail(MRP_ERR_ARG, "hmm job is missing required arrays");
-    if (K > 1 && (!job->mcol_cell_off || ((!job->cell_next || !job->cell_prev) &&
+    if (K > 1 && (!job->mcol_cell_off || (!resident && (!job->cell_next || !job->cell_prev) &&
                                           (!job->mask_from || !job->mask_to || !job->merge_from || !job->merge_to))))
         return fail(MRP_ERR_ARG, "hmm job is missing its merge column arrays");
     const bool device_only = !job->cell_forward && !job->cell_backward && !job->col_total && !job->hmm_forward &&
@@ -344,6 +258,8 @@ int mrp_batch_add(mrp_batch *b, const mrp_hmm_job *job) {
     const mrp_chunk *ch = job->chunk;
     if (ch->ctx->device != b->ctx->device) return fail(MRP_ERR_ARG, "chunk lives on a different device");
     std::lock_guard<std::mutex> lock(b->mu);
+    if (b->stats.n_hmms > 0 && b->resident != resident) return fail(MRP_ERR_ARG, "a batch is either host-fed or device-resident");
+    b->resident = resident;
     const bool ancestor = (job->flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
 
     int chunk_index = -1;
@@ -390,19 +306,22 @@ int mrp_batch_add(mrp_batch *b, const mrp_hmm_job *job) {
     const int64_t n_cells = job->col_cell_off[K];
     const int64_t n_merge = K > 1 ? job->mcol_cell_off[K - 1] : 0;
     /* every hmm starts at a multiple of 4 cells: the recursion kernel moves 4 cells per lane (16 B) */
-    while (b->partition.size() % 4 != 0) {
-        b->partition.push_back(0);
-        b->cell_next.push_back(0);
-        b->cell_prev.push_back(0);
-        b->cell_np.push_back(0);
+    while (b->n_cells_total % 4 != 0) {
+        b->n_cells_total++;
+        if (!resident) {
+            b->partition.push_back(0);
+            b->cell_next.push_back(0);
+            b->cell_prev.push_back(0);
+            b->cell_np.push_back(0);
+        }
     }
-    const int64_t cell0 = (int64_t) b->partition.size();
+    const int64_t cell0 = b->n_cells_total;
     const int64_t mcell0 = b->n_merge;
     const int64_t col0 = (int64_t) b->cols.size();
     const int64_t read0 = (int64_t) b->read_byte_off.size();
 
-    std::vector<uint32_t> nxt((size_t) n_cells, 0), prv((size_t) n_cells, 0);
-    for (int k = 0; k < K; k++) {
+    std::vector<uint32_t> nxt((size_t) (resident ? 0 : n_cells), 0), prv((size_t) (resident ? 0 : n_cells), 0);
+    for (int k = 0; k < K && !resident; k++) {
         const int64_t c0 = job->col_cell_off[k], nc = job->col_cell_off[k + 1] - c0;
         if (k + 1 < K) {
             const int64_t m0 = job->mcol_cell_off[k], nm = job->mcol_cell_off[k + 1] - m0;
@@ -497,10 +416,12 @@ int mrp_batch_add(mrp_batch *b, const mrp_hmm_job *job) {
     h.wide_idx = h.max_merge > 65535 ? 1 : 0;
     if (h.wide_idx) b->need_wide = true;
     b->hmms.push_back(h);
-    b->partition.insert(b->partition.end(), job->partition, job->partition + n_cells);
-    b->cell_next.insert(b->cell_next.end(), nxt.begin(), nxt.end());
-    b->cell_prev.insert(b->cell_prev.end(), prv.begin(), prv.end());
-    {
+    b->n_cells_total += n_cells;
+    if (resident && h.wide_idx) return fail(MRP_ERR_UNSUPPORTED, "device-resident hmm with more than 65535 merge cells in a column");
+    if (!resident) {
+        b->partition.insert(b->partition.end(), job->partition, job->partition + n_cells);
+        b->cell_next.insert(b->cell_next.end(), nxt.begin(), nxt.end());
+        b->cell_prev.insert(b->cell_prev.end(), prv.begin(), prv.end());
         const size_t base = b->cell_np.size();
         b->cell_np.resize(base + (size_t) n_cells);
         for (int64_t c = 0; c < n_cells; c++) b->cell_np[base + c] = (nxt[c] & 0xFFFFu) | (prv[c] << 16);
@@ -515,8 +436,15 @@ int mrp_batch_add(mrp_batch *b, const mrp_hmm_job *job) {
     b->stats.n_columns += K;
     b->stats.n_cells += n_cells;
     b->stats.n_merge_cells += n_merge;
+    if (cell0_out) *cell0_out = cell0;
+    if (mcell0_out) *mcell0_out = mcell0;
+    if (col0_out) *col0_out = col0;
     return MRP_OK;
 }
+
+extern "C" {
+
+int mrp_batch_add(mrp_batch *b, const mrp_hmm_job *job) { return mrp_batch_add_impl(b, job, false, nullptr, nullptr, nullptr); }
 
 int mrp_batch_upload(mrp_batch *b) {
     if (!b) return fail(MRP_ERR_ARG, "batch is NULL");
@@ -565,10 +493,15 @@ int mrp_batch_upload(mrp_batch *b) {
     HIP_TRY(b->d_cols.upload(b->cols, s));
     HIP_TRY(b->d_chunks.upload(chunks, s));
     HIP_TRY(b->d_read_byte_off.upload(b->read_byte_off, s));
-    HIP_TRY(b->d_partition.upload(b->partition, s));
+    if (b->resident) { /* filled by the cross product kernel (mrp_engine.cpp) */
+        HIP_TRY(b->d_partition.alloc((size_t) b->n_cells_total));
+        HIP_TRY(b->d_np.alloc((size_t) b->n_cells_total));
+    } else {
+        HIP_TRY(b->d_partition.upload(b->partition, s));
+        HIP_TRY(b->d_np.upload(b->cell_np, s));
+    }
     HIP_TRY(b->d_scols.upload(b->scols, s));
     HIP_TRY(b->d_pcols.upload(b->pcols, s));
-    HIP_TRY(b->d_np.upload(b->cell_np, s));
     if (b->need_wide) {
         HIP_TRY(b->d_next.upload(b->cell_next, s));
         HIP_TRY(b->d_prev.upload(b->cell_prev, s));
@@ -583,7 +516,7 @@ int mrp_batch_upload(mrp_batch *b) {
         b->n_fast_tiles = mid_it - b->tiles.begin();
     }
     HIP_TRY(b->d_tiles.upload(b->tiles, s));
-    const size_t nC = b->partition.size();
+    const size_t nC = (size_t) b->n_cells_total;
     HIP_TRY(b->d_planes.alloc((size_t) b->n_slots * 8));
     HIP_TRY(b->d_slot_total.alloc((size_t) b->n_slots));
     HIP_TRY(b->d_slot_bytes.alloc((size_t) b->n_slots * 16));

@@ -1,0 +1,94 @@
+/*
+ * mrp_engine.h -- device structures and launch wrappers of the device-resident merge level
+ * (cross product -> forward/backward -> prune), SURVEY.md 8(f-1).
+ *
+ * A pruned hmm lives in HBM with a fixed stride of S cells / S merge cells per column
+ * (S = max(minPartitionsInAColumn, maxPartitionsInAColumn) rounded up to 4):
+ *     part[k*S + i]  u64   partition of cell i of column k
+ *     np[k*S + i]    u32   next | prev << 16 (merge cell indices)
+ *     mfrom/mto[k*S + m]   u64 keys of merge cell m of the merge column that follows column k
+ *     n_cells[k], n_merge[k]
+ * The unpruned cross product of a level lives in that level's batch arrays (mrp_kernels.h).
+ */
+#ifndef MRP_ENGINE_H_
+#define MRP_ENGINE_H_
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mrp_kernels.h"
+
+#include "rphmm_host.h" /* MRP_CONN_*: connector kinds between consecutive aligned pieces */
+
+/* CrossCol.flags */
+#define MRP_XF_INVERTED 1u      /* includeInvertedPartitions: partition/complement pair order (hmm.c:627-655) */
+#define MRP_XF_OUT_A_PAIRED 2u  /* the merge cells of side A's out connector come in complement pairs */
+#define MRP_XF_OUT_B_PAIRED 4u
+#define MRP_XF_IN_A_PAIRED 8u
+#define MRP_XF_IN_B_PAIRED 16u
+
+/* one column of stRPHmm_createCrossProductOfTwoAlignedHmm (hmm.c:534-750) */
+struct CrossCol {
+    const uint64_t *a_part; /* cells of side A's column; NULL = gap column (one cell, partition 0, depth 0) */
+    const uint64_t *b_part;
+    const uint32_t *a_np;
+    const uint32_t *b_np;
+    int64_t x_cell_off;     /* first cell of the column in the level's batch arrays */
+    uint16_t C1, C2;        /* cells per side */
+    uint16_t Ma, Mb;        /* merge cells per side of the connector that leaves the column */
+    uint16_t Pa, Pb;        /* merge cells per side of the connector that enters the column */
+    uint8_t d1, d2;         /* depth per side */
+    uint8_t out_a, out_b, in_a, in_b; /* MRP_CONN_* */
+    uint8_t flags;
+    uint8_t pad;
+};
+
+/* one cross product hmm of a level, as the prune kernels see it */
+struct PruneHmm {
+    int64_t col0;           /* first column in the level's batch column arrays / in the scratch lists */
+    int32_t n_cols;
+    int32_t hmm_index;      /* index into MrpBatchDev.hmm_fb */
+    uint64_t *out_part;     /* pruned hmm, column k at + k * S */
+    uint32_t *out_np;
+    uint64_t *out_mfrom;
+    uint64_t *out_mto;
+    int32_t *out_n_cells;   /* [n_cols] */
+    int32_t *out_n_merge;   /* [n_cols] (last entry 0) */
+};
+
+struct PruneParams {
+    int32_t S;              /* stride of the pruned layout and capacity of the kept lists */
+    int32_t min_p, max_p;   /* min/maxPartitionsInAColumn */
+    int32_t n_bins;         /* posterior keys: bin = min(total - f - b, n_bins - 1); exp(-(n_bins - 1)) == 0 */
+    int32_t thr_bin;        /* bins <= thr_bin have posterior >= minPosteriorProbabilityForPartition */
+    int32_t max_cells, max_merge; /* largest column / merge column of the level (LDS sizing) */
+    int32_t pad;
+};
+
+struct PruneScratch {
+    uint16_t *kept;         /* [n_cols * S] kept cells of each column (index within the column), in kept order */
+    uint32_t *kept_np;      /* [n_cols * S] their next | prev << 16 */
+    uint16_t *keptm;        /* [n_cols * S] kept merge cells of the merge column after each column */
+    int32_t *n_kept;        /* [n_cols] */
+    int32_t *n_keptm;       /* [n_cols] */
+    const uint64_t *mask_from; /* [n_cols] masks of the merge column after each column */
+    const uint64_t *mask_to;
+    int32_t *err;           /* [4] bit flags: MRP_ENGINE_ERR_* */
+};
+
+#define MRP_ENGINE_ERR_STRUCTURE 1 /* a parent is not in complement-pair order: closed-form cross product not valid */
+#define MRP_ENGINE_ERR_POSTERIOR 2 /* f + b > total (column.c:183 "invalid prob") */
+#define MRP_ENGINE_ERR_RANGE 4     /* index out of range */
+
+/* largest column the prune kernel handles (LDS candidate list) */
+#define MRP_PRUNE_MAX_CELLS 16384
+#define MRP_PRUNE_MAX_S 128
+
+hipError_t mrp_launch_cross(const CrossCol *cols_dev, int64_t n_cols, uint64_t *partition, uint32_t *cell_np, int32_t *err,
+                            hipStream_t stream);
+hipError_t mrp_launch_prune(const MrpBatchDev &d, const PruneHmm *hmms_dev, int64_t n_hmms, PruneParams p, PruneScratch s,
+                            hipStream_t stream);
+hipError_t mrp_launch_compact(const MrpBatchDev &d, const PruneHmm *hmms_dev, const int32_t *col_hmm_dev, int64_t n_cols,
+                              PruneParams p, PruneScratch s, hipStream_t stream);
+
+#endif

@@ -1,0 +1,527 @@
+/*
+ * mrp_engine_kernels.hip -- gfx950 kernels of the device-resident merge level.
+ *
+ *  mrp_cross_kernel    stRPHmm_createCrossProductOfTwoAlignedHmm (hmm.c:534-750) in closed form.
+ *                      The reference builds each column by hashing merged partitions in (c1, c2)
+ *                      row-major order and, with includeInvertedPartitions, appending the complement
+ *                      right after every new partition (hmm.c:627-655; merge cells :686-740).  When the
+ *                      two parents keep their cells / merge cells in adjacent complement pairs (they do
+ *                      by construction: hmm.c:97-133 builds {1, 0}, the prune keeps both or neither of a
+ *                      pair and its sort is stable) the resulting order is a pure function of the index
+ *                      pair, so a cell's partition and the indices of the merge cells it feeds / is fed
+ *                      by are computed without any hash table.  The kernel VERIFIES the pair order of
+ *                      every parent column it reads and raises MRP_ENGINE_ERR_STRUCTURE otherwise (the
+ *                      host then redoes the chunk through the hashing path of rphmm_host.c).
+ *  mrp_prune_kernel    stRPHmm_prune (hmm.c:1049-1163): pruneForwards walks the columns keeping the
+ *                      best linked cells and merge cells by posterior (stable order on ties),
+ *                      pruneBackwards removes what became unreachable.  Max-plus mode only: the
+ *                      posterior exp(f + b - total) is monotone in the integer f + b - total, which
+ *                      is what is ranked (bins; everything at or below the underflow point of exp
+ *                      shares the last bin, exactly as equal doubles tie in the reference).
+ *  mrp_compact_kernel  filterMergeCells / relinkCells (hmm.c:964-1019): writes the pruned hmm in the
+ *                      fixed-stride resident layout (mrp_engine.h).
+ */
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "mrp_engine.h"
+#include "../../include/margin_rphmm.h"
+
+#define WAVE 64
+
+#define K_AS(T) const __attribute__((address_space(4))) T *
+#define K_PTR(T, p) ((K_AS(T)) (p))
+template <typename T>
+static __device__ __forceinline__ T k_load(const T *p) {
+    static_assert(sizeof(T) % 4 == 0, "dword sized");
+    T v;
+    K_AS(uint32_t) s = K_PTR(uint32_t, p);
+    uint32_t *dst = reinterpret_cast<uint32_t *>(&v);
+#pragma unroll
+    for (unsigned i = 0; i < sizeof(T) / 4; i++) dst[i] = s[i];
+    return v;
+}
+
+static __device__ __forceinline__ uint64_t accept_mask(uint32_t depth) { /* partitions.c:13-19 */
+    return depth < 64 ? ~(0xFFFFFFFFFFFFFFFFull << depth) : 0xFFFFFFFFFFFFFFFFull;
+}
+static __device__ __forceinline__ uint32_t lanemask_lt_count(uint64_t m, int lane) {
+    return (uint32_t) __popcll(m & ((1ull << lane) - 1ull));
+}
+
+/* Position of the pair (i, j) in the list the reference builds by visiting pairs in row-major order
+ * and appending the complement pair right after each new one.  i indexes side A (Ma entries),
+ * j side B (Mb entries); a side is "paired" when its entries come as (x, complement of x) at (2t, 2t+1),
+ * otherwise it has exactly one, self-complementary entry. */
+static __device__ __forceinline__ uint32_t pair_index(uint32_t i, uint32_t j, uint32_t Mb, bool inv, bool a_paired,
+                                                      bool b_paired) {
+    if (!inv) return i * Mb + j;
+    if (!a_paired) return j;
+    const uint32_t pj = b_paired ? (j ^ 1u) : j;
+    return (i & 1u) ? (i - 1u) * Mb + 2u * pj + 1u : i * Mb + 2u * j;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* cross product                                                                               */
+/* ------------------------------------------------------------------------------------------ */
+static __device__ int verify_side(const uint64_t *part, const uint32_t *np, uint32_t C, uint32_t depth, uint32_t M_out,
+                                  uint32_t M_in, uint32_t out_kind, uint32_t in_kind, bool inv, bool out_paired,
+                                  bool in_paired) {
+    if (!part) return 0;
+    int bad = 0;
+    const bool cells_paired = inv && depth > 0;
+    if (cells_paired && (C & 1u)) return MRP_ENGINE_ERR_STRUCTURE;
+    const uint64_t acc = accept_mask(depth);
+    for (uint32_t e = threadIdx.x; e < C; e += blockDim.x) {
+        const uint32_t v = np[e], nx = v & 0xFFFFu, pv = v >> 16;
+        uint32_t vo = v;
+        if (cells_paired) {
+            if (part[e ^ 1u] != (~part[e] & acc)) bad |= MRP_ENGINE_ERR_STRUCTURE;
+            vo = np[e ^ 1u];
+        }
+        if (out_kind == MRP_CONN_REAL) {
+            if (nx >= M_out) bad |= MRP_ENGINE_ERR_RANGE;
+            if (inv) {
+                if (out_paired) { if ((M_out & 1u) || (vo & 0xFFFFu) != (nx ^ 1u)) bad |= MRP_ENGINE_ERR_STRUCTURE; }
+                else if (M_out != 1u) bad |= MRP_ENGINE_ERR_STRUCTURE;
+            }
+        }
+        if (in_kind == MRP_CONN_REAL) {
+            if (pv >= M_in) bad |= MRP_ENGINE_ERR_RANGE;
+            if (inv) {
+                if (in_paired) { if ((M_in & 1u) || (vo >> 16) != (pv ^ 1u)) bad |= MRP_ENGINE_ERR_STRUCTURE; }
+                else if (M_in != 1u) bad |= MRP_ENGINE_ERR_STRUCTURE;
+            }
+        }
+    }
+    return bad;
+}
+
+__global__ void __launch_bounds__(256) mrp_cross_kernel(const CrossCol *__restrict__ cols, int64_t n_cols,
+                                                        uint64_t *__restrict__ partition, uint32_t *__restrict__ cell_np,
+                                                        int32_t *__restrict__ err) {
+    for (int64_t col = blockIdx.x; col < n_cols; col += gridDim.x) {
+        const CrossCol c = k_load(cols + col);
+        const bool inv = (c.flags & MRP_XF_INVERTED) != 0;
+        const uint32_t C1 = c.C1, C2 = c.C2, C = C1 * C2;
+        const bool a_cells_paired = inv && c.a_part && c.d1 > 0, b_cells_paired = inv && c.b_part && c.d2 > 0;
+        int bad = verify_side(c.a_part, c.a_np, C1, c.d1, c.Ma, c.Pa, c.out_a, c.in_a, inv,
+                              (c.flags & MRP_XF_OUT_A_PAIRED) != 0, (c.flags & MRP_XF_IN_A_PAIRED) != 0);
+        bad |= verify_side(c.b_part, c.b_np, C2, c.d2, c.Mb, c.Pb, c.out_b, c.in_b, inv,
+                           (c.flags & MRP_XF_OUT_B_PAIRED) != 0, (c.flags & MRP_XF_IN_B_PAIRED) != 0);
+        if ((!c.a_part && C1 != 1u) || (!c.b_part && C2 != 1u)) bad |= MRP_ENGINE_ERR_RANGE;
+        if (bad) atomicOr(err, bad);
+        if (__syncthreads_or(bad)) { /* the level is discarded by the host; keep the arrays defined meanwhile */
+            for (uint32_t e = threadIdx.x; e < C; e += blockDim.x) {
+                partition[c.x_cell_off + e] = 0ull;
+                cell_np[c.x_cell_off + e] = 0u;
+            }
+            continue;
+        }
+        for (uint32_t e = threadIdx.x; e < C; e += blockDim.x) {
+            uint32_t c1, c2;
+            if (!inv) { c1 = e / C2; c2 = e - c1 * C2; }
+            else if (!a_cells_paired) { c1 = 0; c2 = e; }
+            else {
+                const uint32_t r = e / (2u * C2), t = e - r * 2u * C2, h = t >> 1;
+                if (t & 1u) { c1 = 2u * r + 1u; c2 = b_cells_paired ? (h ^ 1u) : h; }
+                else { c1 = 2u * r; c2 = h; }
+            }
+            const uint64_t p1 = c.a_part ? c.a_part[c1] : 0ull, p2 = c.b_part ? c.b_part[c2] : 0ull;
+            const uint32_t n1 = c.a_part ? c.a_np[c1] : 0u, n2 = c.b_part ? c.b_np[c2] : 0u;
+            uint32_t nxt = 0, prv = 0;
+            if (c.out_a != MRP_CONN_NONE) {
+                const uint32_t i = c.out_a == MRP_CONN_REAL ? (n1 & 0xFFFFu) : (c.out_a == MRP_CONN_IDENT ? c1 : 0u);
+                const uint32_t j = c.out_b == MRP_CONN_REAL ? (n2 & 0xFFFFu) : (c.out_b == MRP_CONN_IDENT ? c2 : 0u);
+                nxt = pair_index(i, j, c.Mb, inv, (c.flags & MRP_XF_OUT_A_PAIRED) != 0, (c.flags & MRP_XF_OUT_B_PAIRED) != 0);
+            }
+            if (c.in_a != MRP_CONN_NONE) {
+                const uint32_t i = c.in_a == MRP_CONN_REAL ? (n1 >> 16) : (c.in_a == MRP_CONN_IDENT ? c1 : 0u);
+                const uint32_t j = c.in_b == MRP_CONN_REAL ? (n2 >> 16) : (c.in_b == MRP_CONN_IDENT ? c2 : 0u);
+                prv = pair_index(i, j, c.Pb, inv, (c.flags & MRP_XF_IN_A_PAIRED) != 0, (c.flags & MRP_XF_IN_B_PAIRED) != 0);
+            }
+            partition[c.x_cell_off + e] = c.d1 < 64 ? (p1 | (p2 << c.d1)) : p1; /* mergePartitionsOrMasks partitions.c:21-28 */
+            cell_np[c.x_cell_off + e] = nxt | (prv << 16);
+        }
+    }
+}
+
+hipError_t mrp_launch_cross(const CrossCol *cols_dev, int64_t n_cols, uint64_t *partition, uint32_t *cell_np, int32_t *err,
+                            hipStream_t stream) {
+    if (n_cols <= 0) return hipSuccess;
+    const int64_t grid = n_cols < 65536 ? n_cols : 65536;
+    hipLaunchKernelGGL(mrp_cross_kernel, dim3((unsigned) grid), dim3(256), 0, stream, cols_dev, n_cols, partition, cell_np, err);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* prune                                                                                       */
+/* ------------------------------------------------------------------------------------------ */
+#define PRUNE_T 256
+#define PRUNE_W (PRUNE_T / WAVE)
+
+/* n kept of n_link candidates whose first g pass the posterior threshold: the loop of hmm.c:1073-1079 /
+ * :1094-1100 ("while n > min && (n > max || last.posterior < threshold) drop last") in closed form */
+static __device__ __forceinline__ int kept_count(int n_link, int g, int min_p, int max_p) {
+    if (n_link <= min_p) return n_link;
+    int n = g < max_p ? g : max_p;
+    return n > min_p ? n : min_p;
+}
+
+static __device__ __forceinline__ int posterior_bin(int32_t f, int32_t b, int64_t total, int n_bins, int *errbits) {
+    if (f == MRP_NEG_I32 || b == MRP_NEG_I32) return n_bins - 1; /* exp(-inf) = 0 */
+    const int64_t s = total - (int64_t) f - (int64_t) b;
+    if (s < 0) { *errbits |= MRP_ENGINE_ERR_POSTERIOR; return 0; }
+    return s < n_bins - 1 ? (int) s : n_bins - 1;
+}
+
+__global__ void __launch_bounds__(PRUNE_T) mrp_prune_kernel(MrpBatchDev d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
+                                                            PruneParams p, PruneScratch sc) {
+    extern __shared__ uint32_t lds[];
+    const int S = p.S;
+    const int nb = p.n_bins;
+    const int nb_r = (nb + 63) & ~63;
+    const int cap_c = (p.max_cells + 3) & ~3;
+    /* LDS layout (dwords) */
+    uint32_t *gsel = lds;             /* [S] selected candidates above the cutoff bin: bin << 16 | cell */
+    uint32_t *esel = gsel + S;        /* [S] selected candidates in the cutoff bin: cell */
+    uint32_t *ksort = esel + S;       /* [S] kept cells in kept order */
+    uint32_t *knp = ksort + S;        /* [S] their next | prev << 16 */
+    uint32_t *firstf = knp + S;       /* [S] first occurrence of a merge cell */
+    uint32_t *um = firstf + S;        /* [S] linked merge cells in first-occurrence order */
+    uint32_t *umbin = um + S;         /* [S] their posterior bins */
+    uint32_t *msort = umbin + S;      /* [S] kept merge cells in kept order */
+    uint32_t *oldm = msort + S;       /* [S] kept merge cells of the previous merge column (flag owners) */
+    uint32_t *sh = oldm + S;          /* [64] small shared scalars and per-wave counters */
+    uint32_t *hist = sh + 64;         /* [nb_r] */
+    uint32_t *cand = hist + nb_r;     /* [cap_c] linked cells of the column, list order per wave segment */
+    uint8_t *flags = reinterpret_cast<uint8_t *>(cand + cap_c); /* [max_merge] kept flag per merge cell */
+
+    const int tid = threadIdx.x, lane = tid & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    int errbits = 0;
+
+    for (int64_t hi_ = blockIdx.x; hi_ < n_hmms; hi_ += gridDim.x) {
+        const PruneHmm h = k_load(hmms + hi_);
+        const int K = h.n_cols;
+        const int64_t total = (int64_t) d.hmm_fb[2 * h.hmm_index]; /* max mode: the same integer for every column */
+        for (int i = tid; i < nb_r; i += PRUNE_T) hist[i] = 0;
+        for (int i = tid; i < (p.max_merge + 3) / 4; i += PRUNE_T) reinterpret_cast<uint32_t *>(flags)[i] = 0;
+        int n_old = 0;
+        __syncthreads();
+
+        /* ---- stRPHmm_pruneForwards hmm.c:1049-1109 ---- */
+        for (int k = 0; k < K; k++) {
+            const SweepCol col = k_load(d.scols + h.col0 + k);
+            const int C = col.n_cells;
+            const int per = ((C + PRUNE_W - 1) / PRUNE_W + 63) & ~63;
+            const int lo = wave * per < C ? wave * per : C;
+            const int hi = lo + per < C ? lo + per : C;
+            /* pass 1: linked cells (getLinkedCells :1021-1047) in list order, posterior bins, histogram */
+            int cnt = 0;
+            for (int base = lo; base < hi; base += WAVE) {
+                const int c = base + lane;
+                bool linked = false;
+                uint32_t entry = 0;
+                if (c < hi) {
+                    const uint32_t np = d.cell_np[col.cell_off + c];
+                    linked = k == 0 || flags[np >> 16] != 0;
+                    if (linked) {
+                        const int bin = posterior_bin(d.cell_f32[col.cell_off + c], d.cell_b32[col.cell_off + c], total, nb, &errbits);
+                        entry = ((uint32_t) bin << 16) | (uint32_t) c;
+                        atomicAdd(&hist[bin], 1u);
+                    }
+                }
+                const uint64_t m = __ballot(linked);
+                if (linked) cand[lo + cnt + lanemask_lt_count(m, lane)] = entry;
+                cnt += __popcll(m);
+            }
+            if (lane == 0) sh[8 + wave] = (uint32_t) cnt;
+            __syncthreads();
+            /* cutoff bin and quota (wave 0) */
+            if (wave == 0) {
+                int n_link = 0;
+                for (int w = 0; w < PRUNE_W; w++) n_link += (int) sh[8 + w];
+                const int bpl = nb_r / WAVE;
+                int tot = 0, pass = 0;
+                for (int q = 0; q < bpl; q++) {
+                    const int b = lane * bpl + q;
+                    const int v = b < nb ? (int) hist[b] : 0;
+                    tot += v;
+                    if (b <= p.thr_bin) pass += v;
+                }
+                int incl = tot, g = pass;
+#pragma unroll
+                for (int o = 1; o < WAVE; o <<= 1) {
+                    const int t = __shfl_up(incl, o, WAVE);
+                    if (lane >= o) incl += t;
+                }
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o, WAVE);
+                const int n = kept_count(n_link, g, p.min_p, p.max_p);
+                const int ex = incl - tot;
+                if (n > 0 && ex < n && n <= incl) {
+                    int cum = ex;
+                    for (int q = 0; q < bpl; q++) {
+                        const int b = lane * bpl + q;
+                        const int v = b < nb ? (int) hist[b] : 0;
+                        if (cum + v >= n) { sh[0] = (uint32_t) b; sh[1] = (uint32_t) (n - cum); break; }
+                        cum += v;
+                    }
+                }
+                if (lane == 0) {
+                    sh[2] = (uint32_t) n;
+                    if (n == 0) { sh[0] = 0xFFFFFFFFu; sh[1] = 0; }
+                }
+            }
+            __syncthreads();
+            const int B = (int) sh[0], quota = (int) sh[1], n = (int) sh[2];
+            for (int i = tid; i < nb_r; i += PRUNE_T) hist[i] = 0;
+            /* pass 2a: per-wave counts above / in the cutoff bin */
+            {
+                int cg = 0, ce = 0;
+                for (int base = 0; base < cnt; base += WAVE) {
+                    const int i = base + lane;
+                    const bool valid = i < cnt;
+                    const int bin = valid ? (int) (cand[lo + i] >> 16) : 0;
+                    cg += __popcll(__ballot(valid && bin < B));
+                    ce += __popcll(__ballot(valid && bin == B));
+                }
+                if (lane == 0) { sh[16 + wave] = (uint32_t) cg; sh[24 + wave] = (uint32_t) ce; }
+            }
+            __syncthreads();
+            int nG = 0;
+            {
+                int base_g = 0, base_e = 0;
+                for (int w = 0; w < PRUNE_W; w++) {
+                    if (w < wave) { base_g += (int) sh[16 + w]; base_e += (int) sh[24 + w]; }
+                    nG += (int) sh[16 + w];
+                }
+                /* pass 2b: ordered selection */
+                for (int base = 0; base < cnt; base += WAVE) {
+                    const int i = base + lane;
+                    const bool valid = i < cnt;
+                    const uint32_t e = valid ? cand[lo + i] : 0u;
+                    const int bin = (int) (e >> 16);
+                    const bool is_g = valid && bin < B, is_e = valid && bin == B;
+                    const uint64_t mg = __ballot(is_g), me = __ballot(is_e);
+                    if (is_g) gsel[base_g + lanemask_lt_count(mg, lane)] = e;
+                    if (is_e) {
+                        const int pe = base_e + (int) lanemask_lt_count(me, lane);
+                        if (pe < quota) esel[pe] = e & 0xFFFFu;
+                    }
+                    base_g += __popcll(mg);
+                    base_e += __popcll(me);
+                }
+            }
+            __syncthreads();
+            /* stable descending sort of the kept cells (stList_sort :1071): smaller bin = larger posterior */
+            for (int i = tid; i < nG; i += PRUNE_T) {
+                const uint32_t e = gsel[i];
+                const uint32_t bin = e >> 16;
+                int r = 0;
+                for (int j = 0; j < nG; j++) {
+                    const uint32_t bj = gsel[j] >> 16;
+                    r += (bj < bin || (bj == bin && j < i)) ? 1 : 0;
+                }
+                ksort[r] = e & 0xFFFFu;
+            }
+            for (int i = tid; i < quota; i += PRUNE_T) ksort[nG + i] = esel[i];
+            __syncthreads();
+            const int64_t lcol = h.col0 + k;
+            for (int i = tid; i < n; i += PRUNE_T) {
+                const uint32_t c = ksort[i];
+                const uint32_t np = d.cell_np[col.cell_off + c];
+                knp[i] = np;
+                sc.kept[lcol * S + i] = (uint16_t) c;
+                sc.kept_np[lcol * S + i] = np;
+            }
+            if (tid == 0) sc.n_kept[lcol] = n;
+            /* the kept flags of the previous merge column are no longer needed */
+            for (int i = tid; i < n_old; i += PRUNE_T) flags[oldm[i]] = 0;
+            __syncthreads();
+            int mn = 0;
+            if (k + 1 < K) {
+                /* getLinkedMergeCells :989-1004: distinct next merge cells in order of first use */
+                for (int i = tid; i < n; i += PRUNE_T) {
+                    const uint32_t m = knp[i] & 0xFFFFu;
+                    uint32_t first = 1;
+                    for (int j = 0; j < i; j++)
+                        if ((knp[j] & 0xFFFFu) == m) { first = 0; break; }
+                    firstf[i] = first;
+                }
+                __syncthreads();
+                int mnl = 0;
+                for (int j = 0; j < n; j++) mnl += (int) firstf[j];
+                for (int i = tid; i < n; i += PRUNE_T) {
+                    if (firstf[i]) {
+                        int pos = 0;
+                        for (int j = 0; j < i; j++) pos += (int) firstf[j];
+                        const uint32_t m = knp[i] & 0xFFFFu;
+                        um[pos] = m;
+                        umbin[pos] = (uint32_t) posterior_bin(d.merge_f32[col.mcell_off + m], d.merge_b32[col.mcell_off + m], total, nb, &errbits);
+                    }
+                }
+                __syncthreads();
+                int gm = 0;
+                for (int j = 0; j < mnl; j++) gm += ((int) umbin[j] <= p.thr_bin) ? 1 : 0;
+                mn = kept_count(mnl, gm, p.min_p, p.max_p);
+                for (int i = tid; i < mnl; i += PRUNE_T) {
+                    const uint32_t bin = umbin[i];
+                    int r = 0;
+                    for (int j = 0; j < mnl; j++) {
+                        const uint32_t bj = umbin[j];
+                        r += (bj < bin || (bj == bin && j < i)) ? 1 : 0;
+                    }
+                    if (r < mn) msort[r] = um[i];
+                }
+                __syncthreads();
+                for (int i = tid; i < mn; i += PRUNE_T) {
+                    const uint32_t m = msort[i];
+                    flags[m] = 1;
+                    oldm[i] = m;
+                    sc.keptm[lcol * S + i] = (uint16_t) m;
+                }
+            }
+            if (tid == 0) sc.n_keptm[lcol] = mn;
+            n_old = mn;
+            __syncthreads();
+        }
+        /* clear the flags left by the last merge column */
+        for (int i = tid; i < n_old; i += PRUNE_T) flags[oldm[i]] = 0;
+        __syncthreads(); /* also makes this workgroup's global lists visible to wave 0 below */
+
+        /* ---- stRPHmm_pruneBackwards hmm.c:1111-1158: lists of at most S entries, one wave ---- */
+        if (wave == 0) {
+            uint32_t pm[2] = {0u, 0u}; /* kept merge cells of the merge column after column k: they own the flags */
+            bool pmk[2] = {false, false};
+            for (int k = K - 1; k >= 0; k--) {
+                const int64_t lcol = h.col0 + k;
+                const int nk = sc.n_kept[lcol];
+                uint32_t cc[2], cn[2];
+                bool keep[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int i = lane + u * WAVE;
+                    const bool valid = i < nk;
+                    cc[u] = valid ? sc.kept[lcol * S + i] : 0u;
+                    cn[u] = valid ? sc.kept_np[lcol * S + i] : 0u;
+                    keep[u] = valid && (k + 1 == K || flags[cn[u] & 0xFFFFu] != 0);
+                }
+                const uint64_t m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
+                const int ns = __popcll(m0) + __popcll(m1);
+                if (pmk[0]) flags[pm[0]] = 0;
+                if (pmk[1]) flags[pm[1]] = 0;
+                if (ns != nk) {
+                    if (keep[0]) {
+                        const int pos = (int) lanemask_lt_count(m0, lane);
+                        sc.kept[lcol * S + pos] = (uint16_t) cc[0];
+                        sc.kept_np[lcol * S + pos] = cn[0];
+                    }
+                    if (keep[1]) {
+                        const int pos = __popcll(m0) + (int) lanemask_lt_count(m1, lane);
+                        sc.kept[lcol * S + pos] = (uint16_t) cc[1];
+                        sc.kept_np[lcol * S + pos] = cn[1];
+                    }
+                    if (lane == 0) sc.n_kept[lcol] = ns;
+                }
+                if (k == 0) break;
+                /* merge column k - 1 keeps the merge cells some surviving cell comes from (:1141-1155) */
+                if (keep[0]) flags[cn[0] >> 16] = 1;
+                if (keep[1]) flags[cn[1] >> 16] = 1;
+                const int nmp = sc.n_keptm[lcol - 1];
+                uint32_t mm[2];
+                bool mk[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int i = lane + u * WAVE;
+                    const bool valid = i < nmp;
+                    mm[u] = valid ? sc.keptm[(lcol - 1) * S + i] : 0u;
+                    mk[u] = valid && flags[mm[u]] != 0;
+                }
+                const uint64_t q0 = __ballot(mk[0]), q1 = __ballot(mk[1]);
+                const int nms = __popcll(q0) + __popcll(q1);
+                if (nms != nmp) {
+                    if (mk[0]) sc.keptm[(lcol - 1) * S + (int) lanemask_lt_count(q0, lane)] = (uint16_t) mm[0];
+                    if (mk[1]) sc.keptm[(lcol - 1) * S + __popcll(q0) + (int) lanemask_lt_count(q1, lane)] = (uint16_t) mm[1];
+                    if (lane == 0) sc.n_keptm[lcol - 1] = nms;
+                }
+                /* leave flagged exactly the surviving merge cells of column k - 1 */
+                if (keep[0]) flags[cn[0] >> 16] = 0;
+                if (keep[1]) flags[cn[1] >> 16] = 0;
+                if (mk[0]) flags[mm[0]] = 1;
+                if (mk[1]) flags[mm[1]] = 1;
+                pm[0] = mm[0]; pm[1] = mm[1];
+                pmk[0] = mk[0]; pmk[1] = mk[1];
+            }
+        }
+        __syncthreads();
+    }
+    if (errbits) atomicOr(sc.err, errbits);
+}
+
+hipError_t mrp_launch_prune(const MrpBatchDev &d, const PruneHmm *hmms_dev, int64_t n_hmms, PruneParams p, PruneScratch s,
+                            hipStream_t stream) {
+    if (n_hmms <= 0) return hipSuccess;
+    const size_t lds = (size_t) (9 * p.S + 64 + ((p.n_bins + 63) & ~63) + ((p.max_cells + 3) & ~3)) * 4 + (size_t) ((p.max_merge + 3) & ~3) + 16;
+    static bool configured = false;
+    if (!configured) {
+        hipError_t e = hipFuncSetAttribute((const void *) mrp_prune_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return e;
+        configured = true;
+    }
+    if (lds > (size_t) MRP_LDS_BUDGET) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(mrp_prune_kernel, dim3((unsigned) (n_hmms < 65536 ? n_hmms : 65536)), dim3(PRUNE_T), lds, stream, d,
+                       hmms_dev, n_hmms, p, s);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* compaction: the pruned hmm in the resident layout                                           */
+/* ------------------------------------------------------------------------------------------ */
+__global__ void __launch_bounds__(256) mrp_compact_kernel(MrpBatchDev d, const PruneHmm *__restrict__ hmms,
+                                                          const int32_t *__restrict__ col_hmm, int64_t n_cols, PruneParams p,
+                                                          PruneScratch sc) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / WAVE));
+    const int S = p.S;
+    const int64_t stride = (int64_t) gridDim.x * (blockDim.x / WAVE);
+    for (int64_t lcol = (int64_t) blockIdx.x * (blockDim.x / WAVE) + wave; lcol < n_cols; lcol += stride) {
+        const PruneHmm h = k_load(hmms + col_hmm[lcol]);
+        const int k = (int) (lcol - h.col0);
+        const int K = h.n_cols;
+        const SweepCol col = k_load(d.scols + lcol);
+        const int nk = sc.n_kept[lcol];
+        const int nm = k + 1 < K ? sc.n_keptm[lcol] : 0;
+        const int nmp = k > 0 ? sc.n_keptm[lcol - 1] : 0;
+        const uint64_t mask_from = k + 1 < K ? sc.mask_from[lcol] : 0ull;
+        const uint64_t mask_to = k > 0 ? sc.mask_to[lcol - 1] : 0ull;
+        for (int i = lane; i < nk; i += WAVE) {
+            const uint32_t c = sc.kept[lcol * S + i];
+            const uint32_t np = sc.kept_np[lcol * S + i];
+            const uint32_t nx = np & 0xFFFFu, pv = np >> 16;
+            /* filterMergeCells keeps the merge cells in their original relative order */
+            uint32_t new_next = 0, new_prev = 0;
+            for (int j = 0; j < nm; j++) new_next += sc.keptm[lcol * S + j] < nx ? 1u : 0u;
+            for (int j = 0; j < nmp; j++) new_prev += sc.keptm[(lcol - 1) * S + j] < pv ? 1u : 0u;
+            const uint64_t part = d.partition[col.cell_off + c];
+            h.out_part[(int64_t) k * S + i] = part;
+            h.out_np[(int64_t) k * S + i] = new_next | (new_prev << 16);
+            if (k + 1 < K) h.out_mfrom[(int64_t) k * S + new_next] = part & mask_from;
+            if (k > 0) h.out_mto[(int64_t) (k - 1) * S + new_prev] = part & mask_to;
+        }
+        if (lane == 0) {
+            h.out_n_cells[k] = nk;
+            h.out_n_merge[k] = nm;
+        }
+    }
+}
+
+hipError_t mrp_launch_compact(const MrpBatchDev &d, const PruneHmm *hmms_dev, const int32_t *col_hmm_dev, int64_t n_cols,
+                              PruneParams p, PruneScratch s, hipStream_t stream) {
+    if (n_cols <= 0) return hipSuccess;
+    const int64_t wgs = (n_cols + 3) / 4;
+    hipLaunchKernelGGL(mrp_compact_kernel, dim3((unsigned) (wgs < 65536 ? wgs : 65536)), dim3(256), 0, stream, d, hmms_dev,
+                       col_hmm_dev, n_cols, p, s);
+    return hipGetLastError();
+}

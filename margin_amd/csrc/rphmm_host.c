@@ -123,6 +123,13 @@ struct mrp_hmm {
     double *f, *b, *mf, *mb, *total;
     double fwd, bwd;
     int has_results;
+    /* device-resident form (mrp_engine.cpp): no host cell arrays; column k's cells are at
+     * d_part + k * stride, its counts in rc_cells / rc_merge (merge column after column k) */
+    int resident;
+    int32_t stride;
+    const uint64_t *d_part, *d_mfrom, *d_mto;
+    const uint32_t *d_np;
+    VEC(int32_t) rc_cells, rc_merge;
 };
 
 static int64_t hmm_K(const mrp_hmm *h) { return h->col_start.n; }
@@ -144,6 +151,7 @@ void mrp_hmm_destroy(mrp_hmm *h) {
     free(h->reads.a); free(h->col_start.a); free(h->col_len.a); free(h->col_depth.a); free(h->cell_off.a);
     free(h->read_off.a); free(h->col_reads.a); free(h->read_byte_off.a); free(h->part.a); free(h->next.a);
     free(h->prev.a); free(h->mask_from.a); free(h->mask_to.a); free(h->mcell_off.a); free(h->mfrom.a); free(h->mto.a);
+    free(h->rc_cells.a); free(h->rc_merge.a);
     hmm_free_results(h);
     free(h);
 }
@@ -1107,6 +1115,26 @@ static void filter_reads_by_coverage_depth(const world *w, const mrp_params *par
     free(paths.a); free(a); free(t);
 }
 
+/* bubbleGraph.c:2755-2779: trace back, genome fragment, refinement, re-adding the filtered reads */
+static int finish_phase(world *w, mrp_hmm *hmm, const mrp_params *params, const int32_t *discarded, int64_t nd,
+                        mrp_phase_result **out) {
+    int32_t *path = xmalloc(sizeof(int32_t) * (size_t) hmm_K(hmm));
+    int rc = mrp_hmm_forward_trace_back(hmm, path); /* :2755 */
+    if (rc == MRP_OK) {
+        mrp_phase_result *g = result_new(hmm->ref_start, hmm->ref_length, w->n_reads);
+        genome_fragment(w, g, hmm, path, params->rounds_of_iterative_refinement); /* :2761-2764 */
+        for (int64_t i = 0; i < nd; i++) { /* :2772-2779 */
+            const double x = read_log_prob(w, g->haplotype_string1, g->ref_start, g->length, discarded[i]);
+            const double y = read_log_prob(w, g->haplotype_string2, g->ref_start, g->length, discarded[i]);
+            if (x < y) g->reads2[g->n_reads2++] = discarded[i]; else g->reads1[g->n_reads1++] = discarded[i];
+        }
+        g->hmm_forward = hmm->fwd; g->hmm_backward = hmm->bwd; g->n_sweeps = w->n_sweeps;
+        *out = g;
+    }
+    free(path);
+    return rc;
+}
+
 /* bubbleGraph_phaseBubbleGraph bubbleGraph.c:2673-2801 */
 int mrp_phase_reads(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *reads, int64_t n_reads,
                     const mrp_params *params, mrp_batch *record, mrp_phase_result **out) {
@@ -1131,7 +1159,6 @@ int mrp_phase_reads(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *re
     pc.include_ancestor_sub_prob = 0; /* :2733 */
     hmm_vec *tpF = NULL, *tpR = NULL, *joined = NULL;
     mrp_hmm *hmm = NULL;
-    int32_t *path = NULL;
     rc = get_rp_hmms(&w, fwd, nfwd, &pc, &tpF);                  /* :2736 */
     if (rc == MRP_OK) rc = get_rp_hmms(&w, rev, nrev, &pc, &tpR); /* :2740 */
     if (rc == MRP_OK) { rc = merge_two_tiling_paths(&w, tpF, tpR, &pc, &joined); tpF = tpR = NULL; } /* :2745 */
@@ -1140,26 +1167,446 @@ int mrp_phase_reads(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *re
         free(joined->a); free(joined); joined = NULL;
         pc.include_ancestor_sub_prob = 1; /* :2748 */
         rc = sweep_many(&w, &hmm, 1, &pc); /* :2749 */
-        if (rc == MRP_OK) {
-            path = xmalloc(sizeof(int32_t) * (size_t) hmm_K(hmm));
-            rc = mrp_hmm_forward_trace_back(hmm, path); /* :2755 */
-        }
-        if (rc == MRP_OK) {
-            mrp_phase_result *g = result_new(hmm->ref_start, hmm->ref_length, n_reads);
-            genome_fragment(&w, g, hmm, path, params->rounds_of_iterative_refinement); /* :2761-2764 */
-            for (int64_t i = 0; i < nd; i++) { /* :2772-2779 */
-                const double x = read_log_prob(&w, g->haplotype_string1, g->ref_start, g->length, discarded[i]);
-                const double y = read_log_prob(&w, g->haplotype_string2, g->ref_start, g->length, discarded[i]);
-                if (x < y) g->reads2[g->n_reads2++] = discarded[i]; else g->reads1[g->n_reads1++] = discarded[i];
-            }
-            g->hmm_forward = hmm->fwd; g->hmm_backward = hmm->bwd; g->n_sweeps = w.n_sweeps;
-            *out = g;
-        }
+        if (rc == MRP_OK) rc = finish_phase(&w, hmm, params, discarded, nd, out);
     } else if (rc == MRP_OK) {
         *out = result_new(0, 0, n_reads);
     }
     free_path(tpF, 1); free_path(tpR, 1); free_path(joined, 1);
     mrp_hmm_destroy(hmm);
-    free(path); free(filtered); free(discarded); free(is_disc); free(fwd); free(rev);
+    free(filtered); free(discarded); free(is_disc); free(fwd); free(rev);
+    return rc;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* device-resident merge                                                     */
+/*                                                                                             */
+/* The same recursion as merge_tiling_paths / merge_two_tiling_paths above, but the hmms never  */
+/* leave HBM: the structural decisions (tiling paths, overlap components, column alignment)     */
+/* depend on read intervals only and are taken here on "shadow" hmms that carry the column      */
+/* structure, per-column cell counts and device pointers; cross product, sweep and prune of     */
+/* every overlap component of a recursion level -- of every chunk and strand handed in -- run    */
+/* as ONE batch of kernels (mrp_engine_level).                                                 */
+/* ------------------------------------------------------------------------------------------ */
+static mrp_hmm *r_hmm_from_read(const world *w, int32_t read, const mrp_engine *e) { /* stRPHmm_construct hmm.c:97-133 */
+    mrp_hmm *h = hmm_new();
+    const mrp_read *r = &w->reads[read];
+    h->ref_start = r->ref_start;
+    h->ref_length = r->length;
+    VEC_PUSH(h->reads, read);
+    hmm_begin_column(h, w, r->ref_start, r->length, 1, &read);
+    hmm_end_column(h);
+    h->resident = 1;
+    h->stride = 4;
+    mrp_engine_leaf(e, &h->d_part, &h->d_np);
+    VEC_PUSH(h->rc_cells, 2);
+    return h;
+}
+
+static inline int32_t r_piece_cells(const piece *p) { return p->h ? p->h->rc_cells.a[p->k] : 1; }
+
+/* what one side contributes to the connector that leaves piece p */
+static void r_conn_of(const piece *p, uint8_t *kind, uint16_t *M, uint8_t *paired, uint64_t *mask_from, uint64_t *mask_to) {
+    switch (p->out) {
+        case CONN_REAL:
+            *kind = MRP_CONN_REAL; *M = (uint16_t) p->h->rc_merge.a[p->k];
+            *mask_from = p->h->mask_from.a[p->k]; *mask_to = p->h->mask_to.a[p->k];
+            break;
+        case CONN_IDENT: /* column.c:86-101 */
+            *kind = MRP_CONN_IDENT; *M = (uint16_t) r_piece_cells(p);
+            *mask_from = *mask_to = accept_mask(piece_depth(p));
+            break;
+        case CONN_ZERO: /* hmm.c:324-331 */
+            *kind = MRP_CONN_ZERO; *M = 1; *mask_from = *mask_to = 0;
+            break;
+        default:
+            *kind = MRP_CONN_NONE; *M = 0; *mask_from = *mask_to = 0;
+    }
+    *paired = *mask_from != 0;
+}
+
+typedef struct { mrp_hmm *x; mrp_xcol *cols; const world *w; } xbuild;
+typedef VEC(xbuild) xbuild_vec;
+
+/* the column structure of stRPHmm_createCrossProductOfTwoAlignedHmm (hmm.c:534-750) over two aligned
+ * piece lists; the cells are produced on the device from the mrp_xcol descriptors */
+static int r_cross_shadow(const world *w, const piece_vec *A, const piece_vec *B, const hmm_vec *tpA, const hmm_vec *tpB,
+                          int32_t S, int32_t E, xbuild *out) {
+    mrp_hmm *h = hmm_new();
+    h->resident = 1;
+    h->ref_start = S; h->ref_length = E - S;
+    for (int64_t i = 0; i < tpA->n; i++) for (int64_t r = 0; r < tpA->a[i]->reads.n; r++) VEC_PUSH(h->reads, tpA->a[i]->reads.a[r]);
+    for (int64_t i = 0; i < tpB->n; i++) for (int64_t r = 0; r < tpB->a[i]->reads.n; r++) VEC_PUSH(h->reads, tpB->a[i]->reads.a[r]);
+    const int64_t n = A->n;
+    mrp_xcol *xc = xcalloc((size_t) n, sizeof(*xc));
+    int32_t colreads[MRP_MAX_READ_PARTITIONING_DEPTH];
+    for (int64_t s = 0; s < n; s++) {
+        const piece *pa = &A->a[s], *pb = &B->a[s];
+        const int32_t d1 = piece_depth(pa), d2 = piece_depth(pb), depth = d1 + d2;
+        if (depth > MRP_MAX_READ_PARTITIONING_DEPTH) {
+            mrp_hmm_destroy(h); free(xc);
+            return mrp_set_error(MRP_ERR_ARG, "cross product column depth %d exceeds %d", depth, MRP_MAX_READ_PARTITIONING_DEPTH);
+        }
+        if (d1) memcpy(colreads, piece_reads(pa), sizeof(int32_t) * (size_t) d1);
+        if (d2) memcpy(colreads + d1, piece_reads(pb), sizeof(int32_t) * (size_t) d2);
+        hmm_begin_column(h, w, pa->start, pa->len, depth, colreads);
+        hmm_end_column(h);
+        mrp_xcol *c = &xc[s];
+        c->a_part = pa->h ? pa->h->d_part + (int64_t) pa->k * pa->h->stride : NULL;
+        c->a_np = pa->h ? pa->h->d_np + (int64_t) pa->k * pa->h->stride : NULL;
+        c->b_part = pb->h ? pb->h->d_part + (int64_t) pb->k * pb->h->stride : NULL;
+        c->b_np = pb->h ? pb->h->d_np + (int64_t) pb->k * pb->h->stride : NULL;
+        c->C1 = (uint16_t) r_piece_cells(pa); c->C2 = (uint16_t) r_piece_cells(pb);
+        c->d1 = (uint8_t) d1; c->d2 = (uint8_t) d2;
+        if (s + 1 < n) { /* merge column hmm.c:686-740 */
+            uint64_t fa, ta, fb, tb;
+            r_conn_of(pa, &c->out_a, &c->Ma, &c->out_a_paired, &fa, &ta);
+            r_conn_of(pb, &c->out_b, &c->Mb, &c->out_b_paired, &fb, &tb);
+            const int32_t d1n = piece_depth(&A->a[s + 1]);
+            c->mask_from = merge_bits(fa, fb, d1);
+            c->mask_to = merge_bits(ta, tb, d1n);
+            hmm_begin_merge(h, c->mask_from, c->mask_to);
+            hmm_end_merge(h);
+        }
+    }
+    out->x = h; out->cols = xc; out->w = w;
+    return MRP_OK;
+}
+
+/* mergeTwoTilingPaths coordination.c:263-339, structure only: the overlap components that need a cross
+ * product are appended to xs (and, unpruned, to res); the others pass through */
+static int r_prepare_merge(const world *w, hmm_vec *tp1, hmm_vec *tp2, hmm_vec *res, xbuild_vec *xs) {
+    comp_vec comps = overlapping_components(w, tp1, tp2);
+    free(tp1->a); free(tp1); free(tp2->a); free(tp2);
+    int rc = MRP_OK;
+    for (int64_t i = 0; i < comps.n; i++) {
+        component *comp = comps.a[i];
+        if (rc == MRP_OK) {
+            path_vec sub = tiling_paths_from(w, comp->members.a, comp->members.n);
+            if (sub.n == 2) {
+                hmm_vec *a = sub.a[0], *b = sub.a[1];
+                int32_t S = a->a[0]->ref_start < b->a[0]->ref_start ? a->a[0]->ref_start : b->a[0]->ref_start;
+                int32_t Ea = a->a[a->n - 1]->ref_start + a->a[a->n - 1]->ref_length;
+                int32_t Eb = b->a[b->n - 1]->ref_start + b->a[b->n - 1]->ref_length;
+                int32_t E = Ea > Eb ? Ea : Eb;
+                piece_vec pa = {0}, pb = {0}, qa = {0}, qb = {0};
+                pieces_of_path(a, S, E, &pa);
+                pieces_of_path(b, S, E, &pb);
+                align_pieces(&pa, &pb, &qa, &qb);
+                xbuild xb = {0};
+                rc = r_cross_shadow(w, &qa, &qb, a, b, S, E, &xb);
+                free(pa.a); free(pb.a); free(qa.a); free(qb.a);
+                /* the parents' shadows are no longer needed; their cells stay in the engine's segments */
+                for (int64_t t = 0; t < a->n; t++) mrp_hmm_destroy(a->a[t]);
+                for (int64_t t = 0; t < b->n; t++) mrp_hmm_destroy(b->a[t]);
+                if (rc == MRP_OK) { VEC_PUSH(*xs, xb); VEC_PUSH(*res, xb.x); }
+            } else if (sub.n == 1 && sub.a[0]->n == 1) {
+                VEC_PUSH(*res, sub.a[0]->a[0]);
+            } else {
+                rc = mrp_set_error(MRP_ERR_ARG, "overlap component with %lld tiling paths", (long long) sub.n);
+            }
+            for (int64_t t = 0; t < sub.n; t++) { free(sub.a[t]->a); free(sub.a[t]); }
+            free(sub.a);
+        }
+        free(comp->members.a); free(comp);
+    }
+    free(comps.a);
+    return rc;
+}
+
+/* the recursion tree of mergeTilingPaths (coordination.c:341-409) over all problems of a run */
+typedef struct {
+    int left, right;   /* children (node indices) or -1 */
+    int height;        /* 0: a tiling path as it is; h > 0: merged at level h */
+    const world *w;
+    hmm_vec *path;     /* the node's tiling path once its level is done (owned) */
+} rnode;
+typedef VEC(rnode) rnode_vec;
+
+static int r_leaf_node(rnode_vec *t, const world *w, hmm_vec *path) {
+    rnode nd = {-1, -1, 0, w, path};
+    VEC_PUSH(*t, nd);
+    return (int) t->n - 1;
+}
+static int r_merge_node(rnode_vec *t, const world *w, int l, int r) {
+    const int hl = t->a[l].height, hr = t->a[r].height;
+    rnode nd = {l, r, 1 + (hl > hr ? hl : hr), w, NULL};
+    VEC_PUSH(*t, nd);
+    return (int) t->n - 1;
+}
+static int r_tree_of_paths(rnode_vec *t, const world *w, hmm_vec **paths, int64_t n) {
+    if (n == 0) return r_leaf_node(t, w, xcalloc(1, sizeof(hmm_vec)));
+    if (n == 1) return r_leaf_node(t, w, paths[0]);
+    if (n == 2) return r_merge_node(t, w, r_leaf_node(t, w, paths[0]), r_leaf_node(t, w, paths[1]));
+    const int l = r_tree_of_paths(t, w, paths, n / 2);
+    const int r = r_tree_of_paths(t, w, paths + n / 2, n - n / 2);
+    return r_merge_node(t, w, l, r);
+}
+/* getRPHmms coordination.c:490-516 as a subtree; returns the root node or -1 */
+static int r_tree_of_reads(rnode_vec *t, const world *w, const mrp_engine *e, const int32_t *read_index, int64_t n,
+                           const mrp_params *params) {
+    mrp_hmm **hmms = xmalloc(sizeof(*hmms) * (size_t) (n + 1));
+    for (int64_t i = 0; i < n; i++) hmms[i] = r_hmm_from_read(w, read_index[i], e);
+    path_vec paths = tiling_paths_from(w, hmms, n);
+    free(hmms);
+    if (paths.n > MRP_MAX_READ_PARTITIONING_DEPTH || paths.n > params->max_coverage_depth) { /* :500-504 */
+        const int64_t np = paths.n;
+        for (int64_t i = 0; i < paths.n; i++) free_path(paths.a[i], 1);
+        free(paths.a);
+        mrp_set_error(MRP_ERR_ARG, "Coverage depth: read depth of %lld exceeds hard maximum of %d with configured maximum of %lld",
+                      (long long) np, MRP_MAX_READ_PARTITIONING_DEPTH, (long long) params->max_coverage_depth);
+        return -1;
+    }
+    const int root = r_tree_of_paths(t, w, paths.a, paths.n);
+    free(paths.a);
+    return root;
+}
+
+static void r_free_tree(rnode_vec *t) {
+    for (int64_t i = 0; i < t->n; i++) free_path(t->a[i].path, 1);
+    free(t->a);
+    t->a = NULL; t->n = t->cap = 0;
+}
+
+/* run every merge node, level by level */
+static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params) {
+    int max_h = 0;
+    for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > max_h) max_h = t->a[i].height;
+    const uint32_t flags = sweep_flags(params);
+    int rc = MRP_OK;
+    for (int h = 1; h <= max_h && rc == MRP_OK; h++) {
+        xbuild_vec xs = {0};
+        VEC(int64_t) owner = {0}; /* node of each result path */
+        VEC(hmm_vec *) results = {0};
+        for (int64_t i = 0; i < t->n && rc == MRP_OK; i++) {
+            rnode *nd = &t->a[i];
+            if (nd->height != h) continue;
+            hmm_vec *res = xcalloc(1, sizeof(*res));
+            hmm_vec *l = t->a[nd->left].path, *r = t->a[nd->right].path;
+            t->a[nd->left].path = NULL; t->a[nd->right].path = NULL;
+            rc = r_prepare_merge(nd->w, l, r, res, &xs);
+            VEC_PUSH(owner, i);
+            VEC_PUSH(results, res);
+        }
+        mrp_xhmm *xh = xcalloc((size_t) xs.n + 1, sizeof(*xh));
+        for (int64_t i = 0; i < xs.n; i++) {
+            mrp_hmm *x = xs.a[i].x;
+            const int64_t K = hmm_K(x);
+            VEC_RESERVE(x->rc_cells, K); VEC_RESERVE(x->rc_merge, K);
+            x->rc_cells.n = K; x->rc_merge.n = K;
+            xh[i].chunk = xs.a[i].w->chunk;
+            xh[i].n_cols = (int32_t) K;
+            xh[i].flags = flags;
+            xh[i].cols = xs.a[i].cols;
+            xh[i].col_ref_start = x->col_start.a; xh[i].col_length = x->col_len.a; xh[i].col_depth = x->col_depth.a;
+            xh[i].col_read_off = x->read_off.a; xh[i].read_byte_off = x->read_byte_off.a;
+            xh[i].n_cells = x->rc_cells.a; xh[i].n_merge = x->rc_merge.a;
+        }
+        if (rc == MRP_OK) rc = mrp_engine_level(e, xs.n, xh);
+        for (int64_t i = 0; i < xs.n; i++) {
+            mrp_hmm *x = xs.a[i].x;
+            x->stride = mrp_engine_stride(e);
+            x->d_part = xh[i].d_part; x->d_np = xh[i].d_np; x->d_mfrom = xh[i].d_mfrom; x->d_mto = xh[i].d_mto;
+            free(xs.a[i].cols);
+        }
+        free(xh); free(xs.a);
+        for (int64_t i = 0; i < results.n; i++) {
+            hmm_vec *res = results.a[i];
+            rnode *nd = &t->a[owner.a[i]];
+            if (rc == MRP_OK) sort_hmms(nd->w, res->a, res->n); /* coordination.c:336 */
+            nd->path = res;
+        }
+        free(owner.a); free(results.a);
+    }
+    return rc;
+}
+
+/* resident shadow -> ordinary flat hmm on the host; phase 0 queues the copies, phase 1 (after
+ * mrp_engine_sync) unpacks them */
+typedef struct { uint64_t *part, *mfrom, *mto; uint32_t *np; } r_staging;
+static int r_download_begin(mrp_engine *e, const mrp_hmm *h, r_staging *st) {
+    const int64_t K = hmm_K(h), n = K * h->stride;
+    memset(st, 0, sizeof(*st));
+    if (h->d_mfrom == NULL) return MRP_OK; /* a stRPHmm_construct hmm: nothing to fetch */
+    st->part = xmalloc(sizeof(uint64_t) * (size_t) n); st->mfrom = xmalloc(sizeof(uint64_t) * (size_t) n);
+    st->mto = xmalloc(sizeof(uint64_t) * (size_t) n); st->np = xmalloc(sizeof(uint32_t) * (size_t) n);
+    int rc = mrp_engine_fetch(e, st->part, h->d_part, (int64_t) sizeof(uint64_t) * n);
+    if (rc == MRP_OK) rc = mrp_engine_fetch(e, st->np, h->d_np, (int64_t) sizeof(uint32_t) * n);
+    if (rc == MRP_OK) rc = mrp_engine_fetch(e, st->mfrom, h->d_mfrom, (int64_t) sizeof(uint64_t) * n);
+    if (rc == MRP_OK) rc = mrp_engine_fetch(e, st->mto, h->d_mto, (int64_t) sizeof(uint64_t) * n);
+    return rc;
+}
+static void r_download_end(mrp_hmm *h, r_staging *st) {
+    const int64_t K = hmm_K(h);
+    h->cell_off.n = 0; h->mcell_off.n = 0;
+    VEC_PUSH(h->cell_off, 0);
+    VEC_PUSH(h->mcell_off, 0);
+    if (h->d_mfrom == NULL) { /* hmm.c:97-133 */
+        hmm_add_cell(h, 1, 0);
+        hmm_add_cell(h, 0, 0);
+        VEC_PUSH(h->cell_off, h->part.n);
+    } else {
+        for (int64_t k = 0; k < K; k++) {
+            const int64_t o = k * h->stride;
+            for (int32_t i = 0; i < h->rc_cells.a[k]; i++) {
+                hmm_add_cell(h, st->part[o + i], st->np[o + i] >> 16);
+                h->next.a[h->next.n - 1] = st->np[o + i] & 0xFFFFu;
+            }
+            VEC_PUSH(h->cell_off, h->part.n);
+            if (k + 1 < K) {
+                for (int32_t m = 0; m < h->rc_merge.a[k]; m++) { VEC_PUSH(h->mfrom, st->mfrom[o + m]); VEC_PUSH(h->mto, st->mto[o + m]); }
+                VEC_PUSH(h->mcell_off, h->mfrom.n);
+            }
+        }
+    }
+    free(st->part); free(st->mfrom); free(st->mto); free(st->np);
+    h->resident = 0;
+    h->d_part = h->d_mfrom = h->d_mto = NULL; h->d_np = NULL;
+}
+static int r_download_path(mrp_engine *e, hmm_vec *tp) {
+    r_staging *st = xcalloc((size_t) tp->n + 1, sizeof(*st));
+    int rc = MRP_OK;
+    for (int64_t i = 0; i < tp->n && rc == MRP_OK; i++) rc = r_download_begin(e, tp->a[i], &st[i]);
+    if (rc == MRP_OK) rc = mrp_engine_sync(e);
+    for (int64_t i = 0; i < tp->n; i++) {
+        if (rc == MRP_OK) r_download_end(tp->a[i], &st[i]);
+        else { free(st[i].part); free(st[i].mfrom); free(st[i].mto); free(st[i].np); }
+    }
+    free(st);
+    return rc;
+}
+
+int mrp_get_rp_hmms_resident(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *reads, const int32_t *read_index,
+                             int64_t n, const mrp_params *params, mrp_hmm ***hmms_out, int64_t *n_out) {
+    if (!params || !hmms_out || !n_out || n < 0 || (n > 0 && !read_index)) return mrp_set_error(MRP_ERR_ARG, "mrp_get_rp_hmms_resident: bad arguments");
+    int64_t max_idx = -1;
+    for (int64_t i = 0; i < n; i++) { if (read_index[i] < 0) return mrp_set_error(MRP_ERR_ARG, "negative read index"); if (read_index[i] > max_idx) max_idx = read_index[i]; }
+    world w;
+    int rc = world_init(&w, ctx, chunk, reads, max_idx + 1, NULL);
+    if (rc != MRP_OK) return rc;
+    mrp_engine *e = NULL;
+    rc = mrp_engine_create(ctx, params, &e);
+    if (rc != MRP_OK) return rc;
+    rnode_vec tree = {0};
+    const int root = r_tree_of_reads(&tree, &w, e, read_index, n, params);
+    rc = root < 0 ? MRP_ERR_ARG : r_run_tree(e, &tree, params);
+    if (rc == MRP_OK) rc = r_download_path(e, tree.a[root].path);
+    if (rc == MRP_OK) {
+        hmm_vec *tp = tree.a[root].path;
+        tree.a[root].path = NULL;
+        *n_out = tp->n;
+        *hmms_out = tp->a ? tp->a : xmalloc(sizeof(mrp_hmm *));
+        free(tp);
+    }
+    r_free_tree(&tree);
+    mrp_engine_destroy(e);
+    return rc;
+}
+
+/* bubbleGraph_phaseBubbleGraph (bubbleGraph.c:2673-2801) for a set of chunks at once: the loop body of
+ * phase.c:276-473 that phases one chunk, with the merge levels of all chunks run together */
+typedef struct {
+    world w;
+    int32_t *discarded; int64_t nd;
+    int root;            /* node of the joined tiling path */
+    mrp_hmm *hmm;        /* fused final hmm */
+} many_state;
+
+static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *const *chunks, const mrp_read *const *reads,
+                               const int64_t *n_reads, const mrp_params *params, mrp_phase_result **out,
+                               mrp_phase_many_stats *stats) {
+    mrp_params pc = *params;
+    pc.include_ancestor_sub_prob = 0; /* bubbleGraph.c:2733 */
+    mrp_engine *e = NULL;
+    int rc = mrp_engine_create(ctx, &pc, &e);
+    if (rc != MRP_OK) return rc;
+    many_state *st = xcalloc((size_t) n_chunks + 1, sizeof(*st));
+    rnode_vec tree = {0};
+    for (int64_t c = 0; c < n_chunks && rc == MRP_OK; c++) {
+        many_state *m = &st[c];
+        m->root = -1;
+        rc = world_init(&m->w, ctx, chunks[c], reads[c], n_reads[c], NULL);
+        if (rc != MRP_OK || n_reads[c] == 0) continue;
+        const int64_t nr = n_reads[c];
+        int32_t *filtered = xmalloc(sizeof(int32_t) * (size_t) nr);
+        m->discarded = xmalloc(sizeof(int32_t) * (size_t) nr);
+        int64_t nf;
+        filter_reads_by_coverage_depth(&m->w, params, filtered, &nf, m->discarded, &m->nd); /* :2699 */
+        uint8_t *is_disc = xcalloc((size_t) nr, 1);
+        for (int64_t i = 0; i < m->nd; i++) is_disc[m->discarded[i]] = 1;
+        int32_t *fwd = xmalloc(sizeof(int32_t) * (size_t) nr), *rev = xmalloc(sizeof(int32_t) * (size_t) nr);
+        int64_t nfwd = 0, nrev = 0;
+        for (int64_t i = 0; i < nr; i++) { /* :2705-2716 */
+            if (is_disc[i]) continue;
+            if (reads[c][i].forward_strand) fwd[nfwd++] = (int32_t) i; else rev[nrev++] = (int32_t) i;
+        }
+        const int rf = r_tree_of_reads(&tree, &m->w, e, fwd, nfwd, &pc);   /* :2736 */
+        const int rr = rf < 0 ? -1 : r_tree_of_reads(&tree, &m->w, e, rev, nrev, &pc); /* :2740 */
+        if (rf < 0 || rr < 0) rc = MRP_ERR_ARG;
+        else m->root = r_merge_node(&tree, &m->w, rf, rr);               /* :2745 */
+        free(filtered); free(is_disc); free(fwd); free(rev);
+    }
+    if (rc == MRP_OK) rc = r_run_tree(e, &tree, &pc);
+    /* final hmms to the host (a few thousand cells each) */
+    for (int64_t c = 0; c < n_chunks && rc == MRP_OK; c++)
+        if (st[c].root >= 0) rc = r_download_path(e, tree.a[st[c].root].path);
+    /* final sweep with the ancestor model (:2748-2749), all chunks in one device batch */
+    pc.include_ancestor_sub_prob = 1;
+    if (rc == MRP_OK) {
+        mrp_hmm_job *jobs = xcalloc((size_t) n_chunks + 1, sizeof(*jobs));
+        int64_t nj = 0;
+        for (int64_t c = 0; c < n_chunks; c++) {
+            many_state *m = &st[c];
+            if (m->root < 0) continue;
+            hmm_vec *joined = tree.a[m->root].path;
+            tree.a[m->root].path = NULL;
+            if (joined->n > 0) {
+                m->hmm = fuse_path(&m->w, joined);
+                hmm_alloc_results(m->hmm);
+                hmm_job(&m->w, m->hmm, sweep_flags(&pc), &jobs[nj++], 1);
+                m->w.n_sweeps += 1;
+            }
+            free(joined->a); free(joined);
+        }
+        rc = mrp_fb_run(ctx, nj, jobs);
+        free(jobs);
+    }
+    for (int64_t c = 0; c < n_chunks && rc == MRP_OK; c++) {
+        many_state *m = &st[c];
+        if (m->hmm) rc = finish_phase(&m->w, m->hmm, params, m->discarded, m->nd, &out[c]);
+        else out[c] = result_new(0, 0, n_reads[c]);
+    }
+    if (stats) {
+        mrp_engine_stats es;
+        mrp_engine_get_stats(e, &es);
+        stats->resident = 1;
+        stats->levels = es.levels; stats->hmms = es.hmms; stats->columns = es.columns; stats->cells = es.cells;
+        stats->merge_cells = es.merge_cells;
+        stats->device_ms = es.device_ms; stats->cross_ms = es.cross_ms; stats->sweep_ms = es.sweep_ms; stats->prune_ms = es.prune_ms;
+    }
+    for (int64_t c = 0; c < n_chunks; c++) { mrp_hmm_destroy(st[c].hmm); free(st[c].discarded); }
+    free(st);
+    r_free_tree(&tree);
+    mrp_engine_destroy(e);
+    return rc;
+}
+
+int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *const *chunks, const mrp_read *const *reads,
+                         const int64_t *n_reads, const mrp_params *params, mrp_phase_result **out,
+                         mrp_phase_many_stats *stats) {
+    if (!ctx || n_chunks < 0 || !params || (n_chunks > 0 && (!chunks || !reads || !n_reads || !out)))
+        return mrp_set_error(MRP_ERR_ARG, "mrp_phase_reads_many: bad arguments");
+    if (stats) memset(stats, 0, sizeof(*stats));
+    for (int64_t c = 0; c < n_chunks; c++) out[c] = NULL;
+    int rc = phase_many_resident(ctx, n_chunks, chunks, reads, n_reads, params, out, stats);
+    if (rc == MRP_ERR_UNSUPPORTED) {
+        /* parameters or hmm shapes outside the resident path: the hashing path, chunk by chunk */
+        if (stats) memset(stats, 0, sizeof(*stats));
+        rc = MRP_OK;
+        for (int64_t c = 0; c < n_chunks; c++) { mrp_phase_result_destroy(out[c]); out[c] = NULL; }
+        for (int64_t c = 0; c < n_chunks && rc == MRP_OK; c++)
+            rc = mrp_phase_reads(ctx, chunks[c], reads[c], n_reads[c], params, NULL, &out[c]);
+    }
+    if (rc != MRP_OK)
+        for (int64_t c = 0; c < n_chunks; c++) { mrp_phase_result_destroy(out[c]); out[c] = NULL; }
     return rc;
 }

@@ -29,6 +29,62 @@ void mrp_chunk_host_view(const mrp_chunk *chunk, mrp_chunk_host *out);
 mrp_context *mrp_chunk_context(const mrp_chunk *chunk);
 int mrp_set_error(int code, const char *fmt, ...);
 
+/* ---- device-resident merge levels (mrp_engine.cpp), driven by the structural code of rphmm_host.c ---- */
+typedef struct mrp_engine mrp_engine;
+
+/* one column of a cross product to build on the device (one step of the aligned piece lists) */
+typedef struct mrp_xcol {
+    const uint64_t *a_part, *b_part; /* device: cells of each side's column; NULL = gap column */
+    const uint32_t *a_np, *b_np;     /* device: next | prev << 16 of those cells */
+    uint16_t C1, C2;                 /* cells per side */
+    uint16_t Ma, Mb;                 /* merge cells per side of the connector to the next step */
+    uint8_t d1, d2;                  /* depth per side */
+    uint8_t out_a, out_b;            /* connector kinds (MRP_CONN_*) */
+    uint8_t out_a_paired, out_b_paired; /* connector mask != 0: its merge cells come in complement pairs */
+    uint8_t pad[2];
+    uint64_t mask_from, mask_to;     /* masks of the cross product's merge column after this column */
+} mrp_xcol;
+
+/* one cross product hmm of a level */
+typedef struct mrp_xhmm {
+    const mrp_chunk *chunk;
+    int32_t n_cols;
+    uint32_t flags;
+    const mrp_xcol *cols;
+    const int32_t *col_ref_start, *col_length, *col_depth;
+    const int64_t *col_read_off;  /* [n_cols + 1] */
+    const int64_t *read_byte_off;
+    /* results: the pruned hmm in the resident layout (device) and its per-column counts (host, caller-allocated) */
+    uint64_t *d_part, *d_mfrom, *d_mto;
+    uint32_t *d_np;
+    int32_t *n_cells, *n_merge;   /* [n_cols] */
+} mrp_xhmm;
+
+typedef struct mrp_engine_stats {
+    int64_t levels, hmms, columns, cells, merge_cells;
+    double device_ms; /* summed over levels: cross + planes + emission + recursion + prune + compaction */
+    double cross_ms, sweep_ms, prune_ms;
+} mrp_engine_stats;
+
+/* MRP_ERR_UNSUPPORTED when the parameters are outside what the resident path handles (log-sum-exp mode,
+ * more than MRP_PRUNE_MAX_S partitions per column): the caller then uses the hashing path. */
+int mrp_engine_create(mrp_context *ctx, const mrp_params *params, mrp_engine **out);
+void mrp_engine_destroy(mrp_engine *e);
+int32_t mrp_engine_stride(const mrp_engine *e);
+/* the column every stRPHmm_construct hmm consists of (hmm.c:97-133): cells {1, 0} */
+void mrp_engine_leaf(const mrp_engine *e, const uint64_t **part, const uint32_t **np);
+/* cross product -> forward/backward -> prune for n independent hmms; fills the result fields */
+int mrp_engine_level(mrp_engine *e, int64_t n, mrp_xhmm *x);
+/* device -> host copy of resident arrays (queued), and the wait for all queued copies */
+int mrp_engine_fetch(mrp_engine *e, void *dst, const void *src_dev, int64_t bytes);
+int mrp_engine_sync(mrp_engine *e);
+void mrp_engine_get_stats(const mrp_engine *e, mrp_engine_stats *out);
+
+#define MRP_CONN_NONE 0
+#define MRP_CONN_REAL 1
+#define MRP_CONN_ZERO 2
+#define MRP_CONN_IDENT 3
+
 #ifdef __cplusplus
 }
 #endif
