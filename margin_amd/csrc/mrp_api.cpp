@@ -16,6 +16,7 @@
 #include <cstring>
 #include <mutex>
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "mrp_internal.h"
@@ -96,6 +97,9 @@ int mrp_context_create(int device, mrp_context **out) {
 void mrp_context_destroy(mrp_context *ctx) {
     if (!ctx) return;
     (void) hipSetDevice(ctx->device);
+    if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
+    ctx->pool.destroy();
+    if (ctx->pinned) (void) hipHostFree(ctx->pinned);
     for (auto &e : ctx->ev)
         if (e) (void) hipEventDestroy(e);
     if (ctx->fork) (void) hipEventDestroy(ctx->fork);
@@ -191,6 +195,7 @@ int mrp_batch_create(mrp_context *ctx, mrp_batch **out) {
     mrp_batch *b = new (std::nothrow) mrp_batch();
     if (!b) return fail(MRP_ERR_NOMEM, "out of host memory");
     b->ctx = ctx;
+    b->bind_pool(&ctx->pool);
     *out = b;
     return MRP_OK;
 }
@@ -198,8 +203,10 @@ int mrp_batch_create(mrp_context *ctx, mrp_batch **out) {
 void mrp_batch_destroy(mrp_batch *batch) {
     if (!batch) return;
     (void) hipSetDevice(batch->ctx->device);
-    (void) hipStreamSynchronize(batch->ctx->stream);
+    mrp_context *ctx = batch->ctx;
+    (void) hipStreamSynchronize(ctx->stream); /* the auxiliary streams were joined into it */
     delete batch;
+    ctx->pool.reclaim();
 }
 
 /* resolve cell -> merge cell indices from keys: stHash_search of mergeColumn.c:63-79 */
@@ -439,6 +446,165 @@ int mrp_batch_add_impl(mrp_batch *b, const mrp_hmm_job *job, bool resident, int6
     if (cell0_out) *cell0_out = cell0;
     if (mcell0_out) *mcell0_out = mcell0;
     if (col0_out) *col0_out = col0;
+    return MRP_OK;
+}
+
+int mrp_host_threads(void) {
+    static const int n = []() {
+        const char *e = getenv("MRP_HOST_THREADS");
+        int v = e ? atoi(e) : 0;
+        if (v <= 0) v = (int) std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        return v;
+    }();
+    return n;
+}
+
+int mrp_batch_add_resident_bulk(mrp_batch *b, int64_t n, const mrp_xhmm *x, int64_t *cell0_out, int64_t *col0_out) {
+    if (!b || n < 0 || (n > 0 && (!x || !cell0_out || !col0_out))) return fail(MRP_ERR_ARG, "mrp_batch_add_resident_bulk: bad arguments");
+    if (b->uploaded || b->stats.n_hmms > 0) return fail(MRP_ERR_ARG, "mrp_batch_add_resident_bulk: batch not empty");
+    b->resident = true;
+    /* chunk table */
+    std::vector<int32_t> chunk_index((size_t) n);
+    for (int64_t i = 0; i < n; i++) {
+        const mrp_chunk *ch = x[i].chunk;
+        if (!ch || ch->ctx->device != b->ctx->device) return fail(MRP_ERR_ARG, "chunk missing or on a different device");
+        int idx = -1;
+        if (!b->chunks.empty() && b->chunks.back() == ch) idx = (int) b->chunks.size() - 1;
+        for (size_t c = 0; idx < 0 && c < b->chunks.size(); c++)
+            if (b->chunks[c] == ch) idx = (int) c;
+        if (idx < 0) { idx = (int) b->chunks.size(); b->chunks.push_back(ch); }
+        chunk_index[(size_t) i] = idx;
+    }
+    /* pass 1: sizes per hmm */
+    struct Sz { int64_t cells, merge, cols, reads, slots, tiles; int bad; };
+    std::vector<Sz> sz((size_t) n);
+    mrp_parallel_for(n, 64, [&](int64_t i) {
+        const mrp_xhmm &h = x[i];
+        const mrp_chunk *ch = h.chunk;
+        Sz s{0, 0, h.n_cols, 0, 0, 0, 0};
+        if (h.n_cols < 1 || !h.cols || !h.col_ref_start || !h.col_length || !h.col_depth || !h.col_read_off) s.bad = 1;
+        for (int k = 0; k < h.n_cols && !s.bad; k++) {
+            const int64_t C = (int64_t) h.cols[k].C1 * h.cols[k].C2;
+            const int32_t st = h.col_ref_start[k], ln = h.col_length[k], dp = h.col_depth[k];
+            if (C < 1 || ln < 1 || st < 0 || (int64_t) st + ln > ch->n_sites || dp < 0 || dp > MRP_MAX_READ_PARTITIONING_DEPTH ||
+                h.col_read_off[k + 1] - h.col_read_off[k] != dp) { s.bad = 1; break; }
+            s.cells += C;
+            if (k + 1 < h.n_cols) s.merge += (int64_t) h.cols[k].Ma * h.cols[k].Mb;
+            s.slots += ch->allele_offset[st + ln] - ch->allele_offset[st];
+            s.tiles += (C + MRP_EMIT_TILE - 1) / MRP_EMIT_TILE;
+        }
+        s.reads = s.bad ? 0 : h.col_read_off[h.n_cols];
+        sz[(size_t) i] = s;
+    });
+    std::vector<int64_t> cell0((size_t) n), mcell0((size_t) n), col0((size_t) n), read0((size_t) n), slot0((size_t) n), tile0((size_t) n);
+    int64_t cells = 0, merge = 0, cols = 0, reads = 0, slots = 0, tiles = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (sz[(size_t) i].bad) return fail(MRP_ERR_ARG, "device-resident hmm %lld: inconsistent column description", (long long) i);
+        cells = (cells + 3) & ~3ll; /* every hmm starts at a multiple of 4 cells */
+        cell0[(size_t) i] = cells; mcell0[(size_t) i] = merge; col0[(size_t) i] = cols; read0[(size_t) i] = reads;
+        slot0[(size_t) i] = slots; tile0[(size_t) i] = tiles;
+        cells += sz[(size_t) i].cells; merge += sz[(size_t) i].merge; cols += sz[(size_t) i].cols; reads += sz[(size_t) i].reads;
+        slots += sz[(size_t) i].slots; tiles += sz[(size_t) i].tiles;
+    }
+    b->hmms.resize((size_t) n);
+    b->outs.resize((size_t) n);
+    b->cols.resize((size_t) cols);
+    b->scols.resize((size_t) cols);
+    b->pcols.resize((size_t) cols);
+    b->tiles.resize((size_t) tiles);
+    b->read_byte_off.resize((size_t) reads);
+    std::vector<int> unsupported((size_t) n, 0);
+    std::vector<int64_t> alg((size_t) n, 0), prof((size_t) n, 0), pops((size_t) n, 0);
+    /* pass 2: descriptors */
+    mrp_parallel_for(n, 64, [&](int64_t i) {
+        const mrp_xhmm &xh = x[i];
+        const mrp_chunk *ch = xh.chunk;
+        const int K = xh.n_cols;
+        const bool ancestor = (xh.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
+        DevHmm h{};
+        h.col0 = col0[(size_t) i];
+        h.n_cols = K;
+        h.flags = xh.flags;
+        h.max_merge = 1;
+        h.max_cells = 1;
+        int64_t c_off = cell0[(size_t) i], m_off = mcell0[(size_t) i], s_off = slot0[(size_t) i], t_off = tile0[(size_t) i];
+        for (int k = 0; k < K; k++) {
+            const int64_t col = col0[(size_t) i] + k;
+            DevCol c{};
+            c.cell_off = c_off;
+            c.n_cells = (int32_t) ((int64_t) xh.cols[k].C1 * xh.cols[k].C2);
+            c.n_merge = k + 1 < K ? (int32_t) ((int64_t) xh.cols[k].Ma * xh.cols[k].Mb) : 0;
+            c.mcell_off = k + 1 < K ? m_off : 0;
+            c.slot_off = s_off;
+            c.read_off = read0[(size_t) i] + xh.col_read_off[k];
+            c.site_start = xh.col_ref_start[k];
+            c.n_sites = xh.col_length[k];
+            c.depth = xh.col_depth[k];
+            c.n_slots = (int32_t) (ch->allele_offset[c.site_start + c.n_sites] - ch->allele_offset[c.site_start]);
+            c.chunk = chunk_index[(size_t) i];
+            c.flags = xh.flags;
+            int32_t uniform = (int32_t) ch->allele_number[c.site_start];
+            for (int s2 = 1; s2 < c.n_sites; s2++)
+                if ((int32_t) ch->allele_number[c.site_start + s2] != uniform) uniform = 0;
+            if (ancestor)
+                for (int s2 = 0; s2 < c.n_sites; s2++)
+                    if (ch->allele_number[c.site_start + s2] > MRP_MAX_ALLELES) unsupported[(size_t) i] = 1;
+            for (int t0 = 0; t0 < c.n_cells; t0 += MRP_EMIT_TILE) {
+                EmitTile t{};
+                t.cell_off = c.cell_off + t0;
+                t.slot_off = c.slot_off;
+                t.n = std::min<int32_t>(MRP_EMIT_TILE, c.n_cells - t0);
+                t.col = (int32_t) col;
+                t.n_sites = c.n_sites;
+                t.uniform_alleles = uniform;
+                t.depth = c.depth;
+                t.flags = xh.flags;
+                b->tiles[(size_t) t_off++] = t;
+            }
+            SweepCol sc{};
+            sc.cell_off = c.cell_off; sc.mcell_off = c.mcell_off; sc.n_cells = c.n_cells; sc.n_merge = c.n_merge;
+            b->scols[(size_t) col] = sc;
+            PlaneCol pc{};
+            pc.pool = ch->dev.pool; pc.read_off = c.read_off; pc.slot_off = c.slot_off; pc.depth = c.depth; pc.n_slots = c.n_slots;
+            pc.need_planes = (uniform == 0 || ancestor) ? 1 : 0;
+            b->pcols[(size_t) col] = pc;
+            b->cols[(size_t) col] = c;
+            h.max_merge = std::max(h.max_merge, c.n_merge);
+            h.max_cells = std::max(h.max_cells, c.n_cells);
+            int64_t per_site = 255ll * c.depth;
+            if (ancestor) per_site += 2ll * ch->max_sub + ch->max_prior;
+            h.cost_bound += per_site * c.n_sites;
+            prof[(size_t) i] += (int64_t) c.depth * c.n_slots;
+            alg[(size_t) i] += 24ll * c.n_cells + 32ll * c.n_merge + (int64_t) c.depth * c.n_slots + 8;
+            pops[(size_t) i] += (int64_t) c.n_cells * 2 * c.n_slots * 8;
+            c_off += c.n_cells; m_off += c.n_merge; s_off += c.n_slots;
+        }
+        h.n_cells = sz[(size_t) i].cells;
+        h.n_merge = sz[(size_t) i].merge;
+        h.wide_idx = h.max_merge > 65535 ? 1 : 0;
+        if (h.wide_idx) unsupported[(size_t) i] = 1;
+        b->hmms[(size_t) i] = h;
+        if (sz[(size_t) i].reads > 0)
+            memcpy(&b->read_byte_off[(size_t) read0[(size_t) i]], xh.read_byte_off, sizeof(int64_t) * (size_t) sz[(size_t) i].reads);
+        JobOut o{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cell0[(size_t) i], sz[(size_t) i].cells, mcell0[(size_t) i],
+                 sz[(size_t) i].merge, col0[(size_t) i], K};
+        b->outs[(size_t) i] = o;
+    });
+    for (int64_t i = 0; i < n; i++) {
+        if (unsupported[(size_t) i]) return fail(MRP_ERR_UNSUPPORTED, "device-resident hmm %lld is outside the kernels' range", (long long) i);
+        b->stats.profile_bytes += prof[(size_t) i];
+        b->stats.algorithmic_bytes += alg[(size_t) i];
+        b->stats.popcount_ops += pops[(size_t) i];
+        cell0_out[i] = cell0[(size_t) i];
+        col0_out[i] = col0[(size_t) i];
+    }
+    b->n_cells_total = cells;
+    b->n_merge = merge;
+    b->n_slots = slots;
+    b->stats.n_hmms = n;
+    b->stats.n_columns = cols;
+    b->stats.n_cells = cells;
+    b->stats.n_merge_cells = merge;
     return MRP_OK;
 }
 

@@ -17,6 +17,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <memory>
 #include <new>
 #include <vector>
@@ -32,7 +33,7 @@
 
 namespace {
 struct Segment { /* the pruned hmms produced by one level */
-    DevBuf<uint64_t> part, mfrom, mto;
+    DevBuf<uint64_t> part;
     DevBuf<uint32_t> np;
     DevBuf<int32_t> n_cells, n_merge;
 };
@@ -47,7 +48,10 @@ struct mrp_engine {
     std::vector<std::unique_ptr<Segment>> segments;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     mrp_engine_stats stats{};
+    struct mrp_engine_level_state *cur = nullptr; /* a level between begin and end */
 };
+
+static void mrp_engine_level_abandon(mrp_engine *e);
 
 extern "C" {
 
@@ -106,7 +110,10 @@ void mrp_engine_destroy(mrp_engine *e) {
     (void) hipStreamSynchronize(e->ctx->stream);
     for (auto &ev : e->ev)
         if (ev) (void) hipEventDestroy(ev);
+    mrp_context *ctx = e->ctx;
+    mrp_engine_level_abandon(e);
     delete e;
+    ctx->pool.reclaim();
 }
 
 int32_t mrp_engine_stride(const mrp_engine *e) { return e->pp.S; }
@@ -131,86 +138,111 @@ int mrp_engine_sync(mrp_engine *e) {
     return MRP_OK;
 }
 
-int mrp_engine_level(mrp_engine *e, int64_t n, mrp_xhmm *x) {
+}  /* extern "C" */
+
+/* everything one level keeps between its launch and its completion */
+struct mrp_engine_level_state {
+    mrp_batch *b = nullptr;
+    std::unique_ptr<Segment> seg;
+    DevBuf<CrossCol> d_cc;
+    DevBuf<PruneHmm> d_ph;
+    DevBuf<int32_t> d_col_hmm, d_nkept, d_nkeptm, d_err;
+    DevBuf<uint16_t> d_kept, d_keptm;
+    DevBuf<uint32_t> d_kept_np;
+    /* results, in the context's page-locked staging buffer (so the copies are asynchronous) */
+    int32_t *nc = nullptr, *nm = nullptr, *err = nullptr;
+    uint64_t *path_part = nullptr; /* final level */
+    double *fb = nullptr;
+    bool final_level = false;
+    mrp_xhmm *x = nullptr;
+    int64_t n = 0, total_cols = 0, level_cells = 0, level_merge = 0;
+    double t_begin = 0, t_launched = 0;
+    ~mrp_engine_level_state() {
+        if (b) mrp_batch_destroy(b); /* synchronizes the stream before the buffers go back to the pool */
+    }
+};
+
+static void mrp_engine_level_abandon(mrp_engine *e) {
+    delete e->cur;
+    e->cur = nullptr;
+}
+
+extern "C" {
+
+static double eng_now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return 1e3 * ts.tv_sec + 1e-6 * ts.tv_nsec;
+}
+
+static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) {
     if (!e || n < 0 || (n > 0 && !x)) return mrp_set_error(MRP_ERR_ARG, "mrp_engine_level: bad arguments");
+    if (e->cur) return mrp_set_error(MRP_ERR_ARG, "mrp_engine_level_begin: the previous level was not completed");
     if (n == 0) return MRP_OK;
     mrp_context *ctx = e->ctx;
     ENG_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const int S = e->pp.S;
     const bool inv = e->params.include_inverted_partitions != 0;
+    std::unique_ptr<mrp_engine_level_state> L(new (std::nothrow) mrp_engine_level_state());
+    if (!L) return mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
+    L->t_begin = eng_now();
+    L->x = x;
+    L->n = n;
 
     int64_t total_cols = 0;
     for (int64_t i = 0; i < n; i++) {
-        if (x[i].n_cols < 1 || !x[i].cols || !x[i].n_cells || !x[i].n_merge) return mrp_set_error(MRP_ERR_ARG, "mrp_engine_level: bad hmm %lld", (long long) i);
+        if (x[i].n_cols < 1 || !x[i].cols || !x[i].n_cells || (!final_level && !x[i].n_merge)) return mrp_set_error(MRP_ERR_ARG, "mrp_engine_level: bad hmm %lld", (long long) i);
         total_cols += x[i].n_cols;
+        for (int k = 0; k < x[i].n_cols; k++) { /* range checks the kernels rely on */
+            const mrp_xcol &c = x[i].cols[k];
+            const int64_t C = (int64_t) c.C1 * c.C2, M = (int64_t) c.Ma * c.Mb;
+            if (C < 1 || C > MRP_PRUNE_MAX_CELLS) return mrp_set_error(MRP_ERR_UNSUPPORTED, "cross product column with %lld cells", (long long) C);
+            if (k + 1 < x[i].n_cols && (M < 1 || M > 65535)) return mrp_set_error(MRP_ERR_UNSUPPORTED, "cross product merge column with %lld cells", (long long) M);
+        }
     }
-    std::unique_ptr<Segment> seg(new (std::nothrow) Segment());
-    if (!seg) return mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
-    ENG_TRY(seg->part.alloc((size_t) total_cols * S));
-    ENG_TRY(seg->mfrom.alloc((size_t) total_cols * S));
-    ENG_TRY(seg->mto.alloc((size_t) total_cols * S));
-    ENG_TRY(seg->np.alloc((size_t) total_cols * S));
+    L->total_cols = total_cols;
+    ENG_TRY(hipStreamSynchronize(s)); /* nothing of an earlier level or sweep is in flight: */
+    ctx->pool.reclaim();              /* blocks released since then can be reused */
+    L->seg.reset(new (std::nothrow) Segment());
+    if (!L->seg) return mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
+    Segment *seg = L->seg.get();
+    seg->part.pool = &ctx->pool;
+    seg->np.pool = &ctx->pool;
+    seg->n_cells.pool = seg->n_merge.pool = &ctx->pool;
+    const int64_t out_stride = final_level ? 1 : S; /* the final level keeps one traced-back cell per column */
+    ENG_TRY(seg->part.alloc((size_t) (total_cols * out_stride)));
+    ENG_TRY(seg->np.alloc((size_t) (final_level ? 1 : total_cols * S)));
     ENG_TRY(seg->n_cells.alloc((size_t) total_cols));
     ENG_TRY(seg->n_merge.alloc((size_t) total_cols));
 
-    mrp_batch *b = nullptr;
-    int rc = mrp_batch_create(ctx, &b);
+    int rc = mrp_batch_create(ctx, &L->b);
     if (rc != MRP_OK) return rc;
-    struct BatchGuard { mrp_batch *b; ~BatchGuard() { mrp_batch_destroy(b); } } guard{b};
-
+    mrp_batch *b = L->b;
+    std::vector<int64_t> cell0((size_t) n), col0((size_t) n);
+    rc = mrp_batch_add_resident_bulk(b, n, x, cell0.data(), col0.data());
+    if (rc != MRP_OK) return rc;
     std::vector<CrossCol> cc((size_t) total_cols);
     std::vector<PruneHmm> ph((size_t) n);
     std::vector<int32_t> col_hmm((size_t) total_cols);
-    std::vector<uint64_t> mask_from((size_t) total_cols, 0), mask_to((size_t) total_cols, 0);
-    std::vector<int64_t> cell_off, mcell_off;
-    int64_t colbase = 0, level_cells = 0, level_merge = 0;
-    for (int64_t i = 0; i < n; i++) {
+    mrp_parallel_for(n, 64, [&](int64_t i) {
         mrp_xhmm &h = x[i];
         const int K = h.n_cols;
-        cell_off.assign((size_t) K + 1, 0);
-        mcell_off.assign((size_t) K, 0);
-        for (int k = 0; k < K; k++) {
-            const mrp_xcol &c = h.cols[k];
-            const int64_t C = (int64_t) c.C1 * c.C2;
-            if (C < 1 || C > MRP_PRUNE_MAX_CELLS) return mrp_set_error(MRP_ERR_UNSUPPORTED, "cross product column with %lld cells", (long long) C);
-            cell_off[k + 1] = cell_off[k] + C;
-            if (k + 1 < K) {
-                const int64_t M = (int64_t) c.Ma * c.Mb;
-                if (M < 1 || M > 65535) return mrp_set_error(MRP_ERR_UNSUPPORTED, "cross product merge column with %lld cells", (long long) M);
-                mcell_off[k + 1] = mcell_off[k] + M;
-            }
-        }
-        mrp_hmm_job job;
-        memset(&job, 0, sizeof(job));
-        job.chunk = h.chunk;
-        job.n_columns = K;
-        job.flags = h.flags;
-        job.col_ref_start = h.col_ref_start;
-        job.col_length = h.col_length;
-        job.col_depth = h.col_depth;
-        job.col_cell_off = cell_off.data();
-        job.col_read_off = h.col_read_off;
-        job.read_byte_off = h.read_byte_off;
-        job.mcol_cell_off = mcell_off.data();
-        int64_t cell0 = 0, mcell0 = 0, col0 = 0;
-        rc = mrp_batch_add_impl(b, &job, true, &cell0, &mcell0, &col0);
-        if (rc != MRP_OK) return rc;
-        if (col0 != colbase) return mrp_set_error(MRP_ERR_ARG, "engine: column bookkeeping out of step");
+        const int64_t colbase = col0[(size_t) i];
+        int64_t c_off = cell0[(size_t) i];
         for (int k = 0; k < K; k++) {
             const mrp_xcol &c = h.cols[k];
             CrossCol &o = cc[(size_t) (colbase + k)];
             memset(&o, 0, sizeof(o));
             o.a_part = c.a_part; o.b_part = c.b_part; o.a_np = c.a_np; o.b_np = c.b_np;
-            o.x_cell_off = cell0 + cell_off[k];
+            o.x_cell_off = c_off;
+            c_off += (int64_t) c.C1 * c.C2;
             o.C1 = c.C1; o.C2 = c.C2; o.d1 = c.d1; o.d2 = c.d2;
             uint8_t fl = inv ? MRP_XF_INVERTED : 0;
             if (k + 1 < K) {
                 o.Ma = c.Ma; o.Mb = c.Mb; o.out_a = c.out_a; o.out_b = c.out_b;
                 if (c.out_a_paired) fl |= MRP_XF_OUT_A_PAIRED;
                 if (c.out_b_paired) fl |= MRP_XF_OUT_B_PAIRED;
-                mask_from[(size_t) (colbase + k)] = c.mask_from;
-                mask_to[(size_t) (colbase + k)] = c.mask_to;
             }
             if (k > 0) {
                 const mrp_xcol &q = h.cols[k - 1];
@@ -225,17 +257,14 @@ int mrp_engine_level(mrp_engine *e, int64_t n, mrp_xhmm *x) {
         p.col0 = colbase;
         p.n_cols = K;
         p.hmm_index = (int32_t) i;
-        p.out_part = seg->part.p + colbase * S;
-        p.out_np = seg->np.p + colbase * S;
-        p.out_mfrom = seg->mfrom.p + colbase * S;
-        p.out_mto = seg->mto.p + colbase * S;
+        p.out_part = seg->part.p + colbase * out_stride;
+        p.out_np = final_level ? seg->np.p : seg->np.p + colbase * S;
         p.out_n_cells = seg->n_cells.p + colbase;
         p.out_n_merge = seg->n_merge.p + colbase;
-        h.d_part = p.out_part; h.d_np = p.out_np; h.d_mfrom = p.out_mfrom; h.d_mto = p.out_mto;
-        colbase += K;
-        level_cells += cell_off[K];
-        level_merge += mcell_off[K - 1];
-    }
+        h.d_part = p.out_part; h.d_np = p.out_np;
+    });
+    L->level_cells = b->stats.n_cells;
+    L->level_merge = b->stats.n_merge_cells;
 
     rc = mrp_batch_upload(b);
     if (rc != MRP_OK) return rc;
@@ -246,70 +275,120 @@ int mrp_engine_level(mrp_engine *e, int64_t n, mrp_xhmm *x) {
         pp.max_cells = std::max(pp.max_cells, b->hmms[i].max_cells);
         pp.max_merge = std::max(pp.max_merge, b->hmms[i].max_merge);
     }
-
-    DevBuf<CrossCol> d_cc;
-    DevBuf<PruneHmm> d_ph;
-    DevBuf<int32_t> d_col_hmm, d_nkept, d_nkeptm, d_err;
-    DevBuf<uint64_t> d_mask_from, d_mask_to;
-    DevBuf<uint16_t> d_kept, d_keptm;
-    DevBuf<uint32_t> d_kept_np;
-    ENG_TRY(d_cc.upload(cc, s));
-    ENG_TRY(d_ph.upload(ph, s));
-    ENG_TRY(d_col_hmm.upload(col_hmm, s));
-    ENG_TRY(d_mask_from.upload(mask_from, s));
-    ENG_TRY(d_mask_to.upload(mask_to, s));
-    ENG_TRY(d_kept.alloc((size_t) total_cols * S));
-    ENG_TRY(d_keptm.alloc((size_t) total_cols * S));
-    ENG_TRY(d_kept_np.alloc((size_t) total_cols * S));
-    ENG_TRY(d_nkept.alloc((size_t) total_cols));
-    ENG_TRY(d_nkeptm.alloc((size_t) total_cols));
-    ENG_TRY(d_err.alloc(4));
-    ENG_TRY(hipMemsetAsync(d_err.p, 0, 16, s));
+    DevPool *pl = &ctx->pool;
+    L->d_cc.pool = pl; L->d_ph.pool = pl; L->d_col_hmm.pool = L->d_nkept.pool = L->d_nkeptm.pool = L->d_err.pool = pl;
+    L->d_kept.pool = L->d_keptm.pool = pl; L->d_kept_np.pool = pl;
+    ENG_TRY(L->d_cc.upload(cc, s));
+    ENG_TRY(L->d_ph.upload(ph, s));
+    ENG_TRY(L->d_col_hmm.upload(col_hmm, s));
+    if (!final_level) {
+        ENG_TRY(L->d_kept.alloc((size_t) total_cols * S));
+        ENG_TRY(L->d_keptm.alloc((size_t) total_cols * S));
+        ENG_TRY(L->d_kept_np.alloc((size_t) total_cols * S));
+        ENG_TRY(L->d_nkept.alloc((size_t) total_cols));
+        ENG_TRY(L->d_nkeptm.alloc((size_t) total_cols));
+    }
+    ENG_TRY(L->d_err.alloc(4));
+    ENG_TRY(hipMemsetAsync(L->d_err.p, 0, 16, s));
     PruneScratch sc{};
-    sc.kept = d_kept.p; sc.kept_np = d_kept_np.p; sc.keptm = d_keptm.p; sc.n_kept = d_nkept.p; sc.n_keptm = d_nkeptm.p;
-    sc.mask_from = d_mask_from.p; sc.mask_to = d_mask_to.p; sc.err = d_err.p;
+    sc.kept = L->d_kept.p; sc.kept_np = L->d_kept_np.p; sc.keptm = L->d_keptm.p; sc.n_kept = L->d_nkept.p; sc.n_keptm = L->d_nkeptm.p;
+    sc.err = L->d_err.p;
+    /* the pageable host vectors above are read by the queued copies: wait for them before they go out of scope */
+    ENG_TRY(hipStreamSynchronize(s));
 
     ENG_TRY(hipEventRecord(e->ev[0], s));
-    ENG_TRY(mrp_launch_cross(d_cc.p, total_cols, b->d_partition.p, b->d_np.p, d_err.p, s));
+    ENG_TRY(mrp_launch_cross(L->d_cc.p, total_cols, b->d_partition.p, b->d_np.p, L->d_err.p, s));
     ENG_TRY(hipEventRecord(e->ev[1], s));
     rc = mrp_batch_launch(b);
     if (rc != MRP_OK) return rc;
     ENG_TRY(hipEventRecord(e->ev[2], s));
-    ENG_TRY(mrp_launch_prune(b->dev, d_ph.p, n, pp, sc, s));
-    ENG_TRY(mrp_launch_compact(b->dev, d_ph.p, d_col_hmm.p, total_cols, pp, sc, s));
+    if (final_level) {
+        ENG_TRY(mrp_launch_traceback(b->dev, L->d_ph.p, n, L->d_err.p, s));
+    } else {
+        ENG_TRY(mrp_launch_prune(b->dev, L->d_ph.p, n, pp, sc, s));
+        ENG_TRY(mrp_launch_compact(b->dev, L->d_ph.p, L->d_col_hmm.p, total_cols, pp, sc, s));
+    }
     ENG_TRY(hipEventRecord(e->ev[3], s));
+    L->final_level = final_level;
+    {
+        const size_t cols8 = ((size_t) total_cols + 1) & ~(size_t) 1; /* keep the 8-byte arrays aligned */
+        ENG_TRY(ctx->pinned_reserve(64 + cols8 * 4 * 2 + cols8 * 8 + (size_t) n * 16));
+        char *base = (char *) ctx->pinned;
+        L->err = (int32_t *) base;
+        L->path_part = (uint64_t *) (base + 64);
+        L->fb = (double *) (base + 64 + cols8 * 8);
+        L->nc = (int32_t *) (base + 64 + cols8 * 8 + (size_t) n * 16);
+        L->nm = L->nc + cols8;
+    }
+    ENG_TRY(hipMemcpyAsync(L->nc, seg->n_cells.p, sizeof(int32_t) * (size_t) total_cols, hipMemcpyDeviceToHost, s));
+    if (final_level) {
+        ENG_TRY(hipMemcpyAsync(L->path_part, seg->part.p, sizeof(uint64_t) * (size_t) total_cols, hipMemcpyDeviceToHost, s));
+        ENG_TRY(hipMemcpyAsync(L->fb, b->dev.hmm_fb, sizeof(double) * (size_t) (2 * n), hipMemcpyDeviceToHost, s));
+    } else {
+        ENG_TRY(hipMemcpyAsync(L->nm, seg->n_merge.p, sizeof(int32_t) * (size_t) total_cols, hipMemcpyDeviceToHost, s));
+    }
+    ENG_TRY(hipMemcpyAsync(L->err, L->d_err.p, 16, hipMemcpyDeviceToHost, s));
+    L->t_launched = eng_now();
+    e->cur = L.release();
+    return MRP_OK;
+}
 
-    std::vector<int32_t> nc((size_t) total_cols), nm((size_t) total_cols);
-    int32_t err[4] = {0, 0, 0, 0};
-    ENG_TRY(hipMemcpyAsync(nc.data(), seg->n_cells.p, sizeof(int32_t) * (size_t) total_cols, hipMemcpyDeviceToHost, s));
-    ENG_TRY(hipMemcpyAsync(nm.data(), seg->n_merge.p, sizeof(int32_t) * (size_t) total_cols, hipMemcpyDeviceToHost, s));
-    ENG_TRY(hipMemcpyAsync(err, d_err.p, sizeof(err), hipMemcpyDeviceToHost, s));
-    ENG_TRY(hipStreamSynchronize(s));
-    if (err[0] & MRP_ENGINE_ERR_POSTERIOR) return mrp_set_error(MRP_ERR_ARG, "ERROR: invalid prob (f + b exceeds the column total)");
-    if (err[0] & MRP_ENGINE_ERR_RANGE) return mrp_set_error(MRP_ERR_LOOKUP, "device-resident merge: transition index out of range");
-    if (err[0] & MRP_ENGINE_ERR_STRUCTURE)
+int mrp_engine_level_end(mrp_engine *e) {
+    if (!e) return mrp_set_error(MRP_ERR_ARG, "mrp_engine_level_end: NULL engine");
+    if (!e->cur) return MRP_OK; /* an empty level */
+    std::unique_ptr<mrp_engine_level_state> L(e->cur);
+    e->cur = nullptr;
+    mrp_context *ctx = e->ctx;
+    ENG_TRY(hipSetDevice(ctx->device));
+    ENG_TRY(hipStreamSynchronize(ctx->stream));
+    if (getenv("MRP_TIMING"))
+        fprintf(stderr, "  level: %lld hmms %lld cols %lld cells: host build + upload %.1f ms, kernels (after launch) %.1f ms\n",
+                (long long) L->n, (long long) L->total_cols, (long long) L->level_cells, L->t_launched - L->t_begin, eng_now() - L->t_launched);
+    if (L->err[0] & MRP_ENGINE_ERR_POSTERIOR) return mrp_set_error(MRP_ERR_ARG, "ERROR: invalid prob (f + b exceeds the column total)");
+    if (L->err[0] & MRP_ENGINE_ERR_RANGE) return mrp_set_error(MRP_ERR_LOOKUP, "device-resident merge: transition index out of range");
+    if (L->err[0] & MRP_ENGINE_ERR_STRUCTURE)
         return mrp_set_error(MRP_ERR_UNSUPPORTED, "device-resident merge: a parent hmm is not in complement-pair order");
-    colbase = 0;
-    for (int64_t i = 0; i < n; i++) {
-        memcpy(x[i].n_cells, nc.data() + colbase, sizeof(int32_t) * (size_t) x[i].n_cols);
-        memcpy(x[i].n_merge, nm.data() + colbase, sizeof(int32_t) * (size_t) x[i].n_cols);
-        colbase += x[i].n_cols;
+    int64_t colbase = 0;
+    for (int64_t i = 0; i < L->n; i++) {
+        memcpy(L->x[i].n_cells, L->nc + colbase, sizeof(int32_t) * (size_t) L->x[i].n_cols);
+        if (L->final_level) {
+            if (L->x[i].path_part) memcpy(L->x[i].path_part, L->path_part + colbase, sizeof(uint64_t) * (size_t) L->x[i].n_cols);
+            L->x[i].hmm_forward = L->fb[(size_t) (2 * i)];
+            L->x[i].hmm_backward = L->fb[(size_t) (2 * i + 1)];
+        } else {
+            memcpy(L->x[i].n_merge, L->nm + colbase, sizeof(int32_t) * (size_t) L->x[i].n_cols);
+        }
+        colbase += L->x[i].n_cols;
     }
     float t_cross = 0, t_sweep = 0, t_prune = 0;
     ENG_TRY(hipEventElapsedTime(&t_cross, e->ev[0], e->ev[1]));
     ENG_TRY(hipEventElapsedTime(&t_sweep, e->ev[1], e->ev[2]));
     ENG_TRY(hipEventElapsedTime(&t_prune, e->ev[2], e->ev[3]));
     e->stats.levels += 1;
-    e->stats.hmms += n;
-    e->stats.columns += total_cols;
-    e->stats.cells += level_cells;
-    e->stats.merge_cells += level_merge;
+    e->stats.hmms += L->n;
+    e->stats.columns += L->total_cols;
+    e->stats.cells += L->level_cells;
+    e->stats.merge_cells += L->level_merge;
     e->stats.cross_ms += t_cross;
     e->stats.sweep_ms += t_sweep;
     e->stats.prune_ms += t_prune;
     e->stats.device_ms += t_cross + t_sweep + t_prune;
-    e->segments.push_back(std::move(seg));
+    e->segments.push_back(std::move(L->seg));
     return MRP_OK;
+}
+
+int mrp_engine_level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x) { return level_begin(e, n, x, false); }
+
+int mrp_engine_level(mrp_engine *e, int64_t n, mrp_xhmm *x) {
+    int rc = level_begin(e, n, x, false);
+    if (rc == MRP_OK) rc = mrp_engine_level_end(e);
+    return rc;
+}
+
+int mrp_engine_final(mrp_engine *e, int64_t n, mrp_xhmm *x) {
+    int rc = level_begin(e, n, x, true);
+    if (rc == MRP_OK) rc = mrp_engine_level_end(e);
+    return rc;
 }
 
 }  /* extern "C" */

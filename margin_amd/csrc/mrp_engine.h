@@ -6,8 +6,8 @@
  * (S = max(minPartitionsInAColumn, maxPartitionsInAColumn) rounded up to 4):
  *     part[k*S + i]  u64   partition of cell i of column k
  *     np[k*S + i]    u32   next | prev << 16 (merge cell indices)
- *     mfrom/mto[k*S + m]   u64 keys of merge cell m of the merge column that follows column k
  *     n_cells[k], n_merge[k]
+ * (a merge cell's keys are part & mask of any cell that feeds it / is fed by it, so they are not stored)
  * The unpruned cross product of a level lives in that level's batch arrays (mrp_kernels.h).
  */
 #ifndef MRP_ENGINE_H_
@@ -48,11 +48,9 @@ struct PruneHmm {
     int64_t col0;           /* first column in the level's batch column arrays / in the scratch lists */
     int32_t n_cols;
     int32_t hmm_index;      /* index into MrpBatchDev.hmm_fb */
-    uint64_t *out_part;     /* pruned hmm, column k at + k * S */
+    uint64_t *out_part;     /* pruned hmm, column k at + k * S; final level: partition of the traced-back cell per column */
     uint32_t *out_np;
-    uint64_t *out_mfrom;
-    uint64_t *out_mto;
-    int32_t *out_n_cells;   /* [n_cols] */
+    int32_t *out_n_cells;   /* [n_cols]; final level: index of the traced-back cell per column */
     int32_t *out_n_merge;   /* [n_cols] (last entry 0) */
 };
 
@@ -71,8 +69,6 @@ struct PruneScratch {
     uint16_t *keptm;        /* [n_cols * S] kept merge cells of the merge column after each column */
     int32_t *n_kept;        /* [n_cols] */
     int32_t *n_keptm;       /* [n_cols] */
-    const uint64_t *mask_from; /* [n_cols] masks of the merge column after each column */
-    const uint64_t *mask_to;
     int32_t *err;           /* [4] bit flags: MRP_ENGINE_ERR_* */
 };
 
@@ -88,6 +84,9 @@ hipError_t mrp_launch_cross(const CrossCol *cols_dev, int64_t n_cols, uint64_t *
                             hipStream_t stream);
 hipError_t mrp_launch_prune(const MrpBatchDev &d, const PruneHmm *hmms_dev, int64_t n_hmms, PruneParams p, PruneScratch s,
                             hipStream_t stream);
+/* stRPHmm_forwardTraceBack (hmm.c:165-219) for every hmm of the level: out_n_cells[k] = cell index,
+ * out_part[k] = its partition */
+hipError_t mrp_launch_traceback(const MrpBatchDev &d, const PruneHmm *hmms_dev, int64_t n_hmms, int32_t *err, hipStream_t stream);
 hipError_t mrp_launch_compact(const MrpBatchDev &d, const PruneHmm *hmms_dev, const int32_t *col_hmm_dev, int64_t n_cols,
                               PruneParams p, PruneScratch s, hipStream_t stream);
 

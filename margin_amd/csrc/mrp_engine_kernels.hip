@@ -494,8 +494,6 @@ __global__ void __launch_bounds__(256) mrp_compact_kernel(MrpBatchDev d, const P
         const int nk = sc.n_kept[lcol];
         const int nm = k + 1 < K ? sc.n_keptm[lcol] : 0;
         const int nmp = k > 0 ? sc.n_keptm[lcol - 1] : 0;
-        const uint64_t mask_from = k + 1 < K ? sc.mask_from[lcol] : 0ull;
-        const uint64_t mask_to = k > 0 ? sc.mask_to[lcol - 1] : 0ull;
         for (int i = lane; i < nk; i += WAVE) {
             const uint32_t c = sc.kept[lcol * S + i];
             const uint32_t np = sc.kept_np[lcol * S + i];
@@ -507,14 +505,66 @@ __global__ void __launch_bounds__(256) mrp_compact_kernel(MrpBatchDev d, const P
             const uint64_t part = d.partition[col.cell_off + c];
             h.out_part[(int64_t) k * S + i] = part;
             h.out_np[(int64_t) k * S + i] = new_next | (new_prev << 16);
-            if (k + 1 < K) h.out_mfrom[(int64_t) k * S + new_next] = part & mask_from;
-            if (k > 0) h.out_mto[(int64_t) (k - 1) * S + new_prev] = part & mask_to;
         }
         if (lane == 0) {
             h.out_n_cells[k] = nk;
             h.out_n_merge[k] = nm;
         }
     }
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* trace back                                                                                  */
+/* ------------------------------------------------------------------------------------------ */
+/* argmax with the first index winning ties, over the lanes of a wave */
+static __device__ __forceinline__ void wave_argmax_first(int32_t &v, int32_t &idx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const int32_t ov = __shfl_xor(v, o, WAVE), oi = __shfl_xor(idx, o, WAVE);
+        if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
+    }
+}
+
+__global__ void __launch_bounds__(64) mrp_traceback_kernel(MrpBatchDev d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
+                                                           int32_t *__restrict__ err) {
+    const int lane = threadIdx.x;
+    for (int64_t hi = blockIdx.x; hi < n_hmms; hi += gridDim.x) {
+        const PruneHmm h = k_load(hmms + hi);
+        const int K = h.n_cols;
+        uint32_t want = 0; /* merge cell the chosen cell of column k + 1 comes from */
+        for (int k = K - 1; k >= 0; k--) {
+            const SweepCol col = k_load(d.scols + h.col0 + k);
+            /* hmm.c:173-186 (last column: best forward probability) / :196-214 (cells feeding the chosen merge cell) */
+            int32_t best = 0, best_i = -1;
+            for (int c = lane; c < col.n_cells; c += WAVE) {
+                if (k + 1 < K && (d.cell_np[col.cell_off + c] & 0xFFFFu) != want) continue;
+                const int32_t f = d.cell_f32[col.cell_off + c];
+                if (f == MRP_NEG_I32) continue; /* -inf never beats the initial -inf of the reference loop ... */
+                if (best_i < 0 || f > best) { best = f; best_i = c; }
+            }
+            wave_argmax_first(best, best_i);
+            if (best_i < 0) {
+                /* ... except in the last column, where the reference starts from the first cell */
+                if (k + 1 == K) best_i = 0;
+                else {
+                    if (lane == 0) atomicOr(err, MRP_ENGINE_ERR_RANGE);
+                    best_i = 0;
+                }
+            }
+            if (lane == 0) {
+                h.out_n_cells[k] = best_i;
+                h.out_part[k] = d.partition[col.cell_off + best_i];
+            }
+            want = d.cell_np[col.cell_off + best_i] >> 16;
+        }
+    }
+}
+
+hipError_t mrp_launch_traceback(const MrpBatchDev &d, const PruneHmm *hmms_dev, int64_t n_hmms, int32_t *err, hipStream_t stream) {
+    if (n_hmms <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mrp_traceback_kernel, dim3((unsigned) (n_hmms < 65536 ? n_hmms : 65536)), dim3(64), 0, stream, d, hmms_dev,
+                       n_hmms, err);
+    return hipGetLastError();
 }
 
 hipError_t mrp_launch_compact(const MrpBatchDev &d, const PruneHmm *hmms_dev, const int32_t *col_hmm_dev, int64_t n_cols,

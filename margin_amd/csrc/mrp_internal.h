@@ -8,7 +8,10 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <iterator>
+#include <map>
 #include <mutex>
+#include <utility>
 #include <vector>
 
 #include "../../include/margin_rphmm.h"
@@ -16,20 +19,94 @@
 #include "mrp_kernels.h"
 #include "rphmm_host.h"
 
+/* Caching device allocator of a context.  hipMalloc / hipFree of multi-GB arrays cost hundreds of
+ * milliseconds and hipFree synchronizes the device, so blocks are kept and handed out again by size
+ * class (1/8-octave rounding).  A released block becomes reusable only at the next reclaim(), which the
+ * owners call right after they synchronized the context's stream: nothing in flight can still touch it. */
+struct DevPool {
+    std::mutex mu;
+    std::multimap<size_t, void *> free_blocks;
+    std::vector<std::pair<size_t, void *>> pending;
+    size_t cached_bytes = 0;                 /* bytes in free_blocks */
+    size_t cache_limit = (size_t) 64 << 30;  /* beyond this the largest cached blocks go back to the driver */
+    static size_t size_class(size_t bytes) {
+        if (bytes < 256) bytes = 256;
+        const int lg = 63 - __builtin_clzll((unsigned long long) bytes);
+        const size_t step = (size_t) 1 << (lg > 3 ? lg - 3 : 0);
+        return (bytes + step - 1) & ~(step - 1);
+    }
+    hipError_t alloc(void **p, size_t bytes, size_t *cls_out) {
+        const size_t cls = size_class(bytes);
+        *cls_out = cls;
+        {
+            std::lock_guard<std::mutex> lock(mu);
+            auto it = free_blocks.find(cls);
+            if (it != free_blocks.end()) {
+                *p = it->second;
+                free_blocks.erase(it);
+                cached_bytes -= cls;
+                return hipSuccess;
+            }
+        }
+        hipError_t e = hipMalloc(p, cls);
+        if (e != hipSuccess) { /* give the cache back and try once more */
+            (void) hipGetLastError();
+            trim();
+            e = hipMalloc(p, cls);
+        }
+        return e;
+    }
+    void release(void *p, size_t cls) {
+        std::lock_guard<std::mutex> lock(mu);
+        pending.emplace_back(cls, p);
+    }
+    void reclaim() { /* only after the context's streams were synchronized */
+        std::lock_guard<std::mutex> lock(mu);
+        for (auto &b : pending) {
+            free_blocks.emplace(b.first, b.second);
+            cached_bytes += b.first;
+        }
+        pending.clear();
+        while (cached_bytes > cache_limit && !free_blocks.empty()) {
+            auto it = std::prev(free_blocks.end());
+            (void) hipFree(it->second);
+            cached_bytes -= it->first;
+            free_blocks.erase(it);
+        }
+    }
+    void trim() { /* frees the reusable blocks */
+        std::lock_guard<std::mutex> lock(mu);
+        for (auto &b : free_blocks) (void) hipFree(b.second);
+        free_blocks.clear();
+        cached_bytes = 0;
+    }
+    void destroy() { /* context teardown: everything, after a device synchronize */
+        reclaim();
+        trim();
+    }
+};
+
 template <typename T>
 struct DevBuf {
     T *p = nullptr;
     size_t n = 0;
+    DevPool *pool = nullptr; /* NULL: plain hipMalloc / hipFree */
+    size_t cls = 0;
     ~DevBuf() { release(); }
     void release() {
-        if (p) (void) hipFree(p);
+        if (p) {
+            if (pool) pool->release(p, cls);
+            else (void) hipFree(p);
+        }
         p = nullptr;
         n = 0;
     }
     hipError_t alloc(size_t count) {
         release();
         n = count;
-        return hipMalloc((void **) &p, std::max<size_t>(count, 1) * sizeof(T) + 64);
+        const size_t bytes = std::max<size_t>(count, 1) * sizeof(T) + 64;
+        if (pool) return pool->alloc((void **) &p, bytes, &cls);
+        return hipMalloc((void **) &p, bytes);
     }
     hipError_t upload(const std::vector<T> &h, hipStream_t s) {
         hipError_t e = alloc(h.size());
@@ -38,13 +115,26 @@ struct DevBuf {
     }
 };
 
-
 struct mrp_context {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t aux[2] = {nullptr, nullptr}; /* size classes of the recursion kernel run side by side */
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+    DevPool pool;
+    /* page-locked host staging for the small per-level results of the resident engine (grow-only) */
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
+    hipError_t pinned_reserve(size_t bytes) {
+        if (bytes <= pinned_bytes) return hipSuccess;
+        if (pinned) (void) hipHostFree(pinned);
+        pinned = nullptr;
+        pinned_bytes = 0;
+        const size_t want = std::max<size_t>(bytes + bytes / 2, (size_t) 1 << 20);
+        hipError_t e = hipHostMalloc(&pinned, want, hipHostMallocDefault);
+        if (e == hipSuccess) pinned_bytes = want;
+        return e;
+    }
 };
 
 struct mrp_chunk {
@@ -103,6 +193,13 @@ struct mrp_batch {
     DevBuf<int32_t> d_order_wide, d_order_mid, d_order_narrow, d_order_f64;
     DevBuf<EmitTile> d_tiles;
     MrpBatchDev dev{};
+    void bind_pool(DevPool *pl) {
+        d_hmms.pool = pl; d_cols.pool = pl; d_chunks.pool = pl; d_read_byte_off.pool = pl; d_partition.pool = pl; d_planes.pool = pl;
+        d_scols.pool = pl; d_pcols.pool = pl; d_next.pool = pl; d_prev.pool = pl; d_np.pool = pl; d_slot_total.pool = pl;
+        d_slot_bytes.pool = pl; d_cost.pool = pl; d_f.pool = pl; d_b.pool = pl; d_mf.pool = pl; d_mb.pool = pl; d_total.pool = pl;
+        d_hmm_fb.pool = pl; d_f32.pool = pl; d_b32.pool = pl; d_mf32.pool = pl; d_mb32.pool = pl; d_order_wide.pool = pl;
+        d_order_mid.pool = pl; d_order_narrow.pool = pl; d_order_f64.pool = pl; d_tiles.pool = pl;
+    }
 };
 
 
@@ -110,5 +207,35 @@ struct mrp_batch {
  * the device (mrp_engine.cpp): only the column structure is taken from the job. */
 int mrp_batch_add_impl(mrp_batch *b, const mrp_hmm_job *job, bool resident, int64_t *cell0_out, int64_t *mcell0_out,
                        int64_t *col0_out);
+
+
+/* appends n device-resident hmms (cells produced by mrp_cross_kernel) to an empty batch; descriptors are
+ * built by host threads in parallel.  cell0 / col0 [n] receive each hmm's first cell / column. */
+int mrp_batch_add_resident_bulk(mrp_batch *b, int64_t n, const mrp_xhmm *x, int64_t *cell0, int64_t *col0);
+
+
+#include <atomic>
+#include <thread>
+template <class F>
+static inline void mrp_parallel_for(int64_t n, int64_t grain, F f) {
+    const int nt = (int) std::min<int64_t>(mrp_host_threads(), (n + grain - 1) / std::max<int64_t>(grain, 1));
+    if (nt <= 1) {
+        for (int64_t i = 0; i < n; i++) f(i);
+        return;
+    }
+    std::atomic<int64_t> next{0};
+    auto work = [&]() {
+        for (;;) {
+            const int64_t lo = next.fetch_add(grain);
+            if (lo >= n) break;
+            const int64_t hi = std::min(n, lo + grain);
+            for (int64_t i = lo; i < hi; i++) f(i);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+}
 
 #endif

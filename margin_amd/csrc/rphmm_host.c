@@ -20,6 +20,41 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
+
+static double now_ms(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return 1e3 * (double) ts.tv_sec + 1e-6 * (double) ts.tv_nsec;
+}
+
+/* host worker threads: the structural code is independent per chunk / per merge node */
+#include <pthread.h>
+typedef void (*par_fn)(int64_t i, void *arg);
+typedef struct { par_fn fn; void *arg; int64_t n; int64_t next; pthread_mutex_t mu; } par_ctl;
+static void *par_worker(void *p) {
+    par_ctl *c = p;
+    for (;;) {
+        pthread_mutex_lock(&c->mu);
+        const int64_t i = c->next++;
+        pthread_mutex_unlock(&c->mu);
+        if (i >= c->n) break;
+        c->fn(i, c->arg);
+    }
+    return NULL;
+}
+static void parallel_for(int64_t n, par_fn fn, void *arg) {
+    int nt = mrp_host_threads();
+    if (nt > n) nt = (int) n;
+    if (nt <= 1) { for (int64_t i = 0; i < n; i++) fn(i, arg); return; }
+    par_ctl c = {fn, arg, n, 0, PTHREAD_MUTEX_INITIALIZER};
+    pthread_t th[64];
+    if (nt > 64) nt = 64;
+    int started = 0;
+    for (int t = 1; t < nt; t++) if (pthread_create(&th[started], NULL, par_worker, &c) == 0) started++;
+    par_worker(&c);
+    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
+}
 
 /* ------------------------------------------------------------------------------------------ */
 /* helpers                                                                                     */
@@ -125,11 +160,15 @@ struct mrp_hmm {
     int has_results;
     /* device-resident form (mrp_engine.cpp): no host cell arrays; column k's cells are at
      * d_part + k * stride, its counts in rc_cells / rc_merge (merge column after column k) */
-    int resident;
+    int resident, leaf; /* leaf: the single column {1, 0} of stRPHmm_construct, shared by all such hmms */
     int32_t stride;
-    const uint64_t *d_part, *d_mfrom, *d_mto;
+    const uint64_t *d_part;
     const uint32_t *d_np;
     VEC(int32_t) rc_cells, rc_merge;
+    /* shadows are one allocation: the struct followed by its exactly sized arrays (and the cross product
+     * descriptors of the level that builds it); arrays outside [this, this + arena_bytes) are malloc'd */
+    size_t arena_bytes;
+    mrp_xcol *xcols;
 };
 
 static int64_t hmm_K(const mrp_hmm *h) { return h->col_start.n; }
@@ -146,12 +185,15 @@ static void hmm_free_results(mrp_hmm *h) {
     h->f = h->b = h->mf = h->mb = h->total = NULL;
     h->has_results = 0;
 }
+static void hmm_free_array(const mrp_hmm *h, void *p) {
+    if (p && !((const char *) p >= (const char *) h && (const char *) p < (const char *) h + h->arena_bytes)) free(p);
+}
 void mrp_hmm_destroy(mrp_hmm *h) {
     if (!h) return;
-    free(h->reads.a); free(h->col_start.a); free(h->col_len.a); free(h->col_depth.a); free(h->cell_off.a);
-    free(h->read_off.a); free(h->col_reads.a); free(h->read_byte_off.a); free(h->part.a); free(h->next.a);
-    free(h->prev.a); free(h->mask_from.a); free(h->mask_to.a); free(h->mcell_off.a); free(h->mfrom.a); free(h->mto.a);
-    free(h->rc_cells.a); free(h->rc_merge.a);
+    void *arrays[] = {h->reads.a, h->col_start.a, h->col_len.a, h->col_depth.a, h->cell_off.a, h->read_off.a, h->col_reads.a,
+                      h->read_byte_off.a, h->part.a, h->next.a, h->prev.a, h->mask_from.a, h->mask_to.a, h->mcell_off.a,
+                      h->mfrom.a, h->mto.a, h->rc_cells.a, h->rc_merge.a};
+    for (size_t i = 0; i < sizeof(arrays) / sizeof(arrays[0]); i++) hmm_free_array(h, arrays[i]);
     hmm_free_results(h);
     free(h);
 }
@@ -1037,7 +1079,7 @@ static double read_log_prob(const world *w, const uint64_t *hap, int32_t start, 
 
 /* stGenomeFragment_construct genomeFragment.c:40-69 (+ hmm.c:221-248) then
  * stGenomeFragment_refineGenomeFragment genomeFragment.c:165-232 */
-static void genome_fragment(const world *w, mrp_phase_result *g, const mrp_hmm *h, const int32_t *path,
+static void genome_fragment(const world *w, mrp_phase_result *g, const mrp_hmm *h, const uint64_t *chosen,
                             int64_t max_iterations) {
     const int64_t K = hmm_K(h);
     /* side[read]: 0 = unseen, 1 = reads1, 2 = reads2; first sighting along the path wins per set
@@ -1045,7 +1087,7 @@ static void genome_fragment(const world *w, mrp_phase_result *g, const mrp_hmm *
     uint8_t *in1 = xcalloc((size_t) w->n_reads + 1, 1), *in2 = xcalloc((size_t) w->n_reads + 1, 1);
     uint64_t *p = xmalloc(sizeof(uint64_t) * (size_t) K);
     for (int64_t k = 0; k < K; k++) {
-        p[k] = h->part.a[h->cell_off.a[k] + path[k]];
+        p[k] = chosen[k]; /* partition of the traced-back cell of column k */
         const int32_t *cr = h->col_reads.a + h->read_off.a[k];
         for (int32_t i = 0; i < h->col_depth.a[k]; i++) {
             if ((p[k] >> i) & 1) { if (!in1[cr[i]]) { in1[cr[i]] = 1; g->reads1[g->n_reads1++] = cr[i]; } }
@@ -1115,21 +1157,30 @@ static void filter_reads_by_coverage_depth(const world *w, const mrp_params *par
     free(paths.a); free(a); free(t);
 }
 
-/* bubbleGraph.c:2755-2779: trace back, genome fragment, refinement, re-adding the filtered reads */
+/* bubbleGraph.c:2761-2779: genome fragment from the traced-back partitions, refinement, re-adding the filtered reads */
+static void finish_phase_parts(world *w, const mrp_hmm *hmm, const uint64_t *chosen, double fwd, double bwd, const mrp_params *params,
+                               const int32_t *discarded, int64_t nd, mrp_phase_result **out) {
+    mrp_phase_result *g = result_new(hmm->ref_start, hmm->ref_length, w->n_reads);
+    genome_fragment(w, g, hmm, chosen, params->rounds_of_iterative_refinement); /* :2761-2764 */
+    for (int64_t i = 0; i < nd; i++) { /* :2772-2779 */
+        const double x = read_log_prob(w, g->haplotype_string1, g->ref_start, g->length, discarded[i]);
+        const double y = read_log_prob(w, g->haplotype_string2, g->ref_start, g->length, discarded[i]);
+        if (x < y) g->reads2[g->n_reads2++] = discarded[i]; else g->reads1[g->n_reads1++] = discarded[i];
+    }
+    g->hmm_forward = fwd; g->hmm_backward = bwd; g->n_sweeps = w->n_sweeps;
+    *out = g;
+}
+/* bubbleGraph.c:2755-2779 on a swept host hmm */
 static int finish_phase(world *w, mrp_hmm *hmm, const mrp_params *params, const int32_t *discarded, int64_t nd,
                         mrp_phase_result **out) {
-    int32_t *path = xmalloc(sizeof(int32_t) * (size_t) hmm_K(hmm));
+    const int64_t K = hmm_K(hmm);
+    int32_t *path = xmalloc(sizeof(int32_t) * (size_t) K);
     int rc = mrp_hmm_forward_trace_back(hmm, path); /* :2755 */
     if (rc == MRP_OK) {
-        mrp_phase_result *g = result_new(hmm->ref_start, hmm->ref_length, w->n_reads);
-        genome_fragment(w, g, hmm, path, params->rounds_of_iterative_refinement); /* :2761-2764 */
-        for (int64_t i = 0; i < nd; i++) { /* :2772-2779 */
-            const double x = read_log_prob(w, g->haplotype_string1, g->ref_start, g->length, discarded[i]);
-            const double y = read_log_prob(w, g->haplotype_string2, g->ref_start, g->length, discarded[i]);
-            if (x < y) g->reads2[g->n_reads2++] = discarded[i]; else g->reads1[g->n_reads1++] = discarded[i];
-        }
-        g->hmm_forward = hmm->fwd; g->hmm_backward = hmm->bwd; g->n_sweeps = w->n_sweeps;
-        *out = g;
+        uint64_t *chosen = xmalloc(sizeof(uint64_t) * (size_t) K);
+        for (int64_t k = 0; k < K; k++) chosen[k] = hmm->part.a[hmm->cell_off.a[k] + path[k]];
+        finish_phase_parts(w, hmm, chosen, hmm->fwd, hmm->bwd, params, discarded, nd, out);
+        free(chosen);
     }
     free(path);
     return rc;
@@ -1187,18 +1238,60 @@ int mrp_phase_reads(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *re
 /* every overlap component of a recursion level -- of every chunk and strand handed in -- run    */
 /* as ONE batch of kernels (mrp_engine_level).                                                 */
 /* ------------------------------------------------------------------------------------------ */
+/* a shadow hmm with K columns, D column reads in total and n_reads reads: one allocation */
+static mrp_hmm *r_shadow_new(int64_t K, int64_t D, int64_t n_reads, int with_xcols) {
+#define AL8(x) (((size_t) (x) + 7) & ~(size_t) 7)
+    size_t bytes = AL8(sizeof(mrp_hmm));
+    const size_t o_reads = bytes; bytes += AL8(4 * n_reads);
+    const size_t o_start = bytes; bytes += AL8(4 * K);
+    const size_t o_len = bytes; bytes += AL8(4 * K);
+    const size_t o_depth = bytes; bytes += AL8(4 * K);
+    const size_t o_cell_off = bytes; bytes += AL8(8 * (K + 1));
+    const size_t o_read_off = bytes; bytes += AL8(8 * (K + 1));
+    const size_t o_mcell_off = bytes; bytes += AL8(8 * K);
+    const size_t o_col_reads = bytes; bytes += AL8(4 * D);
+    const size_t o_rbo = bytes; bytes += AL8(8 * D);
+    const size_t o_mask_from = bytes; bytes += AL8(8 * K);
+    const size_t o_mask_to = bytes; bytes += AL8(8 * K);
+    const size_t o_rc_cells = bytes; bytes += AL8(4 * K);
+    const size_t o_rc_merge = bytes; bytes += AL8(4 * K);
+    const size_t o_xcols = bytes; bytes += with_xcols ? AL8(sizeof(mrp_xcol) * (size_t) K) : 0;
+#undef AL8
+    char *blk = xmalloc(bytes);
+    mrp_hmm *h = (mrp_hmm *) blk;
+    memset(h, 0, sizeof(*h));
+    h->arena_bytes = bytes;
+    h->resident = 1;
+#define AT(vec, off, capacity) do { (vec).a = (void *) (blk + (off)); (vec).n = 0; (vec).cap = (capacity); } while (0)
+    AT(h->reads, o_reads, n_reads); AT(h->col_start, o_start, K); AT(h->col_len, o_len, K); AT(h->col_depth, o_depth, K);
+    AT(h->cell_off, o_cell_off, K + 1); AT(h->read_off, o_read_off, K + 1); AT(h->mcell_off, o_mcell_off, K);
+    AT(h->col_reads, o_col_reads, D); AT(h->read_byte_off, o_rbo, D); AT(h->mask_from, o_mask_from, K); AT(h->mask_to, o_mask_to, K);
+    AT(h->rc_cells, o_rc_cells, K); AT(h->rc_merge, o_rc_merge, K);
+#undef AT
+    h->cell_off.a[0] = 0; h->cell_off.n = 1;
+    h->read_off.a[0] = 0; h->read_off.n = 1;
+    h->mcell_off.a[0] = 0; h->mcell_off.n = 1;
+    if (with_xcols) { h->xcols = (mrp_xcol *) (blk + o_xcols); memset(h->xcols, 0, sizeof(mrp_xcol) * (size_t) K); }
+    return h;
+}
+
 static mrp_hmm *r_hmm_from_read(const world *w, int32_t read, const mrp_engine *e) { /* stRPHmm_construct hmm.c:97-133 */
-    mrp_hmm *h = hmm_new();
+    mrp_hmm *h = r_shadow_new(1, 1, 1, 0);
     const mrp_read *r = &w->reads[read];
     h->ref_start = r->ref_start;
     h->ref_length = r->length;
-    VEC_PUSH(h->reads, read);
-    hmm_begin_column(h, w, r->ref_start, r->length, 1, &read);
-    hmm_end_column(h);
-    h->resident = 1;
+    h->reads.a[h->reads.n++] = read;
+    h->col_start.a[0] = r->ref_start; h->col_len.a[0] = r->length; h->col_depth.a[0] = 1;
+    h->col_start.n = h->col_len.n = h->col_depth.n = 1;
+    h->col_reads.a[0] = read; h->col_reads.n = 1;
+    h->read_byte_off.a[0] = read_byte_offset(w, read, r->ref_start); h->read_byte_off.n = 1;
+    h->cell_off.a[1] = 0; h->cell_off.n = 2;
+    h->read_off.a[1] = 1; h->read_off.n = 2;
+    h->max_depth = 1;
     h->stride = 4;
+    h->leaf = 1;
     mrp_engine_leaf(e, &h->d_part, &h->d_np);
-    VEC_PUSH(h->rc_cells, 2);
+    h->rc_cells.a[0] = 2; h->rc_cells.n = 1;
     return h;
 }
 
@@ -1231,25 +1324,44 @@ typedef VEC(xbuild) xbuild_vec;
  * piece lists; the cells are produced on the device from the mrp_xcol descriptors */
 static int r_cross_shadow(const world *w, const piece_vec *A, const piece_vec *B, const hmm_vec *tpA, const hmm_vec *tpB,
                           int32_t S, int32_t E, xbuild *out) {
-    mrp_hmm *h = hmm_new();
-    h->resident = 1;
-    h->ref_start = S; h->ref_length = E - S;
-    for (int64_t i = 0; i < tpA->n; i++) for (int64_t r = 0; r < tpA->a[i]->reads.n; r++) VEC_PUSH(h->reads, tpA->a[i]->reads.a[r]);
-    for (int64_t i = 0; i < tpB->n; i++) for (int64_t r = 0; r < tpB->a[i]->reads.n; r++) VEC_PUSH(h->reads, tpB->a[i]->reads.a[r]);
     const int64_t n = A->n;
-    mrp_xcol *xc = xcalloc((size_t) n, sizeof(*xc));
-    int32_t colreads[MRP_MAX_READ_PARTITIONING_DEPTH];
+    int64_t D = 0, n_reads = 0;
     for (int64_t s = 0; s < n; s++) {
-        const piece *pa = &A->a[s], *pb = &B->a[s];
-        const int32_t d1 = piece_depth(pa), d2 = piece_depth(pb), depth = d1 + d2;
-        if (depth > MRP_MAX_READ_PARTITIONING_DEPTH) {
-            mrp_hmm_destroy(h); free(xc);
+        const int32_t depth = piece_depth(&A->a[s]) + piece_depth(&B->a[s]);
+        if (depth > MRP_MAX_READ_PARTITIONING_DEPTH)
             return mrp_set_error(MRP_ERR_ARG, "cross product column depth %d exceeds %d", depth, MRP_MAX_READ_PARTITIONING_DEPTH);
+        D += depth;
+    }
+    for (int64_t i = 0; i < tpA->n; i++) n_reads += tpA->a[i]->reads.n;
+    for (int64_t i = 0; i < tpB->n; i++) n_reads += tpB->a[i]->reads.n;
+    mrp_hmm *h = r_shadow_new(n, D, n_reads, 1);
+    h->ref_start = S; h->ref_length = E - S;
+    for (int64_t i = 0; i < tpA->n; i++) { memcpy(h->reads.a + h->reads.n, tpA->a[i]->reads.a, sizeof(int32_t) * (size_t) tpA->a[i]->reads.n); h->reads.n += tpA->a[i]->reads.n; }
+    for (int64_t i = 0; i < tpB->n; i++) { memcpy(h->reads.a + h->reads.n, tpB->a[i]->reads.a, sizeof(int32_t) * (size_t) tpB->a[i]->reads.n); h->reads.n += tpB->a[i]->reads.n; }
+    mrp_xcol *xc = h->xcols;
+    int64_t d_off = 0;
+    for (int64_t s = 0; s < n; s++) {
+        const piece *side[2] = {&A->a[s], &B->a[s]};
+        const piece *pa = side[0], *pb = side[1];
+        const int32_t d1 = piece_depth(pa), d2 = piece_depth(pb), depth = d1 + d2;
+        h->col_start.a[s] = pa->start; h->col_len.a[s] = pa->len; h->col_depth.a[s] = depth;
+        if (depth > h->max_depth) h->max_depth = depth;
+        /* the column's reads: side A's then side B's; their profile bytes start where the parent column's do,
+         * moved on by the alleles between the parent column's first site and the piece's (profileSeq.c:41-47) */
+        for (int q = 0; q < 2; q++) {
+            const piece *p = side[q];
+            const int32_t d = piece_depth(p);
+            if (d == 0) continue;
+            const int64_t ro = p->h->read_off.a[p->k];
+            const int64_t delta = (int64_t) w->ch.allele_offset[p->start] - (int64_t) w->ch.allele_offset[p->h->col_start.a[p->k]];
+            memcpy(h->col_reads.a + d_off, p->h->col_reads.a + ro, sizeof(int32_t) * (size_t) d);
+            const int64_t *src = p->h->read_byte_off.a + ro;
+            int64_t *dst = h->read_byte_off.a + d_off;
+            for (int32_t i = 0; i < d; i++) dst[i] = src[i] + delta;
+            d_off += d;
         }
-        if (d1) memcpy(colreads, piece_reads(pa), sizeof(int32_t) * (size_t) d1);
-        if (d2) memcpy(colreads + d1, piece_reads(pb), sizeof(int32_t) * (size_t) d2);
-        hmm_begin_column(h, w, pa->start, pa->len, depth, colreads);
-        hmm_end_column(h);
+        h->read_off.a[s + 1] = d_off;
+        h->cell_off.a[s + 1] = 0;
         mrp_xcol *c = &xc[s];
         c->a_part = pa->h ? pa->h->d_part + (int64_t) pa->k * pa->h->stride : NULL;
         c->a_np = pa->h ? pa->h->d_np + (int64_t) pa->k * pa->h->stride : NULL;
@@ -1264,24 +1376,36 @@ static int r_cross_shadow(const world *w, const piece_vec *A, const piece_vec *B
             const int32_t d1n = piece_depth(&A->a[s + 1]);
             c->mask_from = merge_bits(fa, fb, d1);
             c->mask_to = merge_bits(ta, tb, d1n);
-            hmm_begin_merge(h, c->mask_from, c->mask_to);
-            hmm_end_merge(h);
+            h->mask_from.a[s] = c->mask_from;
+            h->mask_to.a[s] = c->mask_to;
+            h->mcell_off.a[s + 1] = 0;
         }
     }
+    h->col_start.n = h->col_len.n = h->col_depth.n = n;
+    h->col_reads.n = h->read_byte_off.n = D;
+    h->read_off.n = h->cell_off.n = n + 1;
+    h->mcell_off.n = n;
+    h->mask_from.n = h->mask_to.n = n - 1;
     out->x = h; out->cols = xc; out->w = w;
     return MRP_OK;
 }
 
 /* mergeTwoTilingPaths coordination.c:263-339, structure only: the overlap components that need a cross
  * product are appended to xs (and, unpruned, to res); the others pass through */
-static int r_prepare_merge(const world *w, hmm_vec *tp1, hmm_vec *tp2, hmm_vec *res, xbuild_vec *xs) {
+static int64_t g_ns[6]; /* MRP_TIMING: components, tiling paths, pieces, cross shadow, destroy, other */
+#define T_ADD(slot, t0) __atomic_fetch_add(&g_ns[slot], (int64_t) ((now_ms() - (t0)) * 1e6), __ATOMIC_RELAXED)
+static int r_prepare_merge(const world *w, hmm_vec *tp1, hmm_vec *tp2, hmm_vec *res, xbuild_vec *xs, hmm_vec *garbage) {
+    double tq = now_ms();
     comp_vec comps = overlapping_components(w, tp1, tp2);
+    T_ADD(0, tq);
     free(tp1->a); free(tp1); free(tp2->a); free(tp2);
     int rc = MRP_OK;
     for (int64_t i = 0; i < comps.n; i++) {
         component *comp = comps.a[i];
         if (rc == MRP_OK) {
+            tq = now_ms();
             path_vec sub = tiling_paths_from(w, comp->members.a, comp->members.n);
+            T_ADD(1, tq);
             if (sub.n == 2) {
                 hmm_vec *a = sub.a[0], *b = sub.a[1];
                 int32_t S = a->a[0]->ref_start < b->a[0]->ref_start ? a->a[0]->ref_start : b->a[0]->ref_start;
@@ -1289,15 +1413,20 @@ static int r_prepare_merge(const world *w, hmm_vec *tp1, hmm_vec *tp2, hmm_vec *
                 int32_t Eb = b->a[b->n - 1]->ref_start + b->a[b->n - 1]->ref_length;
                 int32_t E = Ea > Eb ? Ea : Eb;
                 piece_vec pa = {0}, pb = {0}, qa = {0}, qb = {0};
+                tq = now_ms();
                 pieces_of_path(a, S, E, &pa);
                 pieces_of_path(b, S, E, &pb);
                 align_pieces(&pa, &pb, &qa, &qb);
+                T_ADD(2, tq);
                 xbuild xb = {0};
+                tq = now_ms();
                 rc = r_cross_shadow(w, &qa, &qb, a, b, S, E, &xb);
+                T_ADD(3, tq);
                 free(pa.a); free(pb.a); free(qa.a); free(qb.a);
                 /* the parents' shadows are no longer needed; their cells stay in the engine's segments */
-                for (int64_t t = 0; t < a->n; t++) mrp_hmm_destroy(a->a[t]);
-                for (int64_t t = 0; t < b->n; t++) mrp_hmm_destroy(b->a[t]);
+                /* (freed by the caller's thread while the device works: cross-thread frees contend in malloc) */
+                for (int64_t t = 0; t < a->n; t++) VEC_PUSH(*garbage, a->a[t]);
+                for (int64_t t = 0; t < b->n; t++) VEC_PUSH(*garbage, b->a[t]);
                 if (rc == MRP_OK) { VEC_PUSH(*xs, xb); VEC_PUSH(*res, xb.x); }
             } else if (sub.n == 1 && sub.a[0]->n == 1) {
                 VEC_PUSH(*res, sub.a[0]->a[0]);
@@ -1368,71 +1497,104 @@ static void r_free_tree(rnode_vec *t) {
 }
 
 /* run every merge node, level by level */
+static double g_t_prepare, g_t_level; /* MRP_TIMING diagnostics (single caller at a time) */
+typedef struct {
+    rnode_vec *t;
+    int64_t node;
+    hmm_vec *res;
+    xbuild_vec xs;
+    hmm_vec garbage;
+    int rc;
+    char err[256];
+} level_item;
+static void level_prepare(int64_t i, void *arg) {
+    level_item *it = &((level_item *) arg)[i];
+    rnode *nd = &it->t->a[it->node];
+    it->res = xcalloc(1, sizeof(*it->res));
+    hmm_vec *l = it->t->a[nd->left].path, *r = it->t->a[nd->right].path;
+    it->t->a[nd->left].path = NULL; it->t->a[nd->right].path = NULL;
+    it->rc = r_prepare_merge(nd->w, l, r, it->res, &it->xs, &it->garbage);
+    if (it->rc != MRP_OK) snprintf(it->err, sizeof(it->err), "%s", mrp_last_error());
+}
+static void level_finish(int64_t i, void *arg) {
+    level_item *it = &((level_item *) arg)[i];
+    rnode *nd = &it->t->a[it->node];
+    sort_hmms(nd->w, it->res->a, it->res->n); /* coordination.c:336 */
+}
 static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params) {
     int max_h = 0;
     for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > max_h) max_h = t->a[i].height;
     const uint32_t flags = sweep_flags(params);
     int rc = MRP_OK;
     for (int h = 1; h <= max_h && rc == MRP_OK; h++) {
-        xbuild_vec xs = {0};
-        VEC(int64_t) owner = {0}; /* node of each result path */
-        VEC(hmm_vec *) results = {0};
-        for (int64_t i = 0; i < t->n && rc == MRP_OK; i++) {
-            rnode *nd = &t->a[i];
-            if (nd->height != h) continue;
-            hmm_vec *res = xcalloc(1, sizeof(*res));
-            hmm_vec *l = t->a[nd->left].path, *r = t->a[nd->right].path;
-            t->a[nd->left].path = NULL; t->a[nd->right].path = NULL;
-            rc = r_prepare_merge(nd->w, l, r, res, &xs);
-            VEC_PUSH(owner, i);
-            VEC_PUSH(results, res);
+        const double t0 = now_ms();
+        int64_t n_items = 0;
+        for (int64_t i = 0; i < t->n; i++) if (t->a[i].height == h) n_items++;
+        level_item *items = xcalloc((size_t) n_items + 1, sizeof(*items));
+        n_items = 0;
+        for (int64_t i = 0; i < t->n; i++) if (t->a[i].height == h) { items[n_items].t = t; items[n_items].node = i; n_items++; }
+        /* the merges of a level touch disjoint nodes: structure in parallel, device work as one batch */
+        parallel_for(n_items, level_prepare, items);
+        int64_t n_x = 0;
+        for (int64_t i = 0; i < n_items; i++) {
+            n_x += items[i].xs.n;
+            if (items[i].rc != MRP_OK && rc == MRP_OK) rc = mrp_set_error(items[i].rc, "%s", items[i].err);
         }
-        mrp_xhmm *xh = xcalloc((size_t) xs.n + 1, sizeof(*xh));
-        for (int64_t i = 0; i < xs.n; i++) {
-            mrp_hmm *x = xs.a[i].x;
+        mrp_xhmm *xh = xcalloc((size_t) n_x + 1, sizeof(*xh));
+        xbuild *xb = xcalloc((size_t) n_x + 1, sizeof(*xb));
+        n_x = 0;
+        for (int64_t i = 0; i < n_items; i++) {
+            for (int64_t j = 0; j < items[i].xs.n; j++) xb[n_x++] = items[i].xs.a[j];
+            free(items[i].xs.a);
+        }
+        for (int64_t i = 0; i < n_x; i++) {
+            mrp_hmm *x = xb[i].x;
             const int64_t K = hmm_K(x);
-            VEC_RESERVE(x->rc_cells, K); VEC_RESERVE(x->rc_merge, K);
-            x->rc_cells.n = K; x->rc_merge.n = K;
-            xh[i].chunk = xs.a[i].w->chunk;
+            x->rc_cells.n = K; x->rc_merge.n = K; /* capacity K in the shadow's arena */
+            xh[i].chunk = xb[i].w->chunk;
             xh[i].n_cols = (int32_t) K;
             xh[i].flags = flags;
-            xh[i].cols = xs.a[i].cols;
+            xh[i].cols = xb[i].cols;
             xh[i].col_ref_start = x->col_start.a; xh[i].col_length = x->col_len.a; xh[i].col_depth = x->col_depth.a;
             xh[i].col_read_off = x->read_off.a; xh[i].read_byte_off = x->read_byte_off.a;
             xh[i].n_cells = x->rc_cells.a; xh[i].n_merge = x->rc_merge.a;
+            ((world *) xb[i].w)->n_sweeps += 1; /* coordination.c:312: one forward/backward per overlap component */
         }
-        if (rc == MRP_OK) rc = mrp_engine_level(e, xs.n, xh);
-        for (int64_t i = 0; i < xs.n; i++) {
-            mrp_hmm *x = xs.a[i].x;
+        const double t1 = now_ms();
+        if (rc == MRP_OK) rc = mrp_engine_level_begin(e, n_x, xh);
+        /* while the device works: drop the parents' shadows */
+        const double t2 = now_ms();
+        for (int64_t i = 0; i < n_items; i++) {
+            for (int64_t j = 0; j < items[i].garbage.n; j++) mrp_hmm_destroy(items[i].garbage.a[j]);
+            free(items[i].garbage.a);
+        }
+        T_ADD(4, t2);
+        if (rc == MRP_OK) rc = mrp_engine_level_end(e);
+        g_t_prepare += t1 - t0; g_t_level += now_ms() - t1;
+        for (int64_t i = 0; i < n_x; i++) {
+            mrp_hmm *x = xb[i].x;
             x->stride = mrp_engine_stride(e);
-            x->d_part = xh[i].d_part; x->d_np = xh[i].d_np; x->d_mfrom = xh[i].d_mfrom; x->d_mto = xh[i].d_mto;
-            free(xs.a[i].cols);
+            x->d_part = xh[i].d_part; x->d_np = xh[i].d_np;
         }
-        free(xh); free(xs.a);
-        for (int64_t i = 0; i < results.n; i++) {
-            hmm_vec *res = results.a[i];
-            rnode *nd = &t->a[owner.a[i]];
-            if (rc == MRP_OK) sort_hmms(nd->w, res->a, res->n); /* coordination.c:336 */
-            nd->path = res;
-        }
-        free(owner.a); free(results.a);
+        free(xh); free(xb);
+        if (rc == MRP_OK) parallel_for(n_items, level_finish, items);
+        for (int64_t i = 0; i < n_items; i++) t->a[items[i].node].path = items[i].res;
+        free(items);
     }
     return rc;
 }
 
 /* resident shadow -> ordinary flat hmm on the host; phase 0 queues the copies, phase 1 (after
  * mrp_engine_sync) unpacks them */
-typedef struct { uint64_t *part, *mfrom, *mto; uint32_t *np; } r_staging;
+typedef struct { uint64_t *part; uint32_t *np; } r_staging;
 static int r_download_begin(mrp_engine *e, const mrp_hmm *h, r_staging *st) {
     const int64_t K = hmm_K(h), n = K * h->stride;
     memset(st, 0, sizeof(*st));
-    if (h->d_mfrom == NULL) return MRP_OK; /* a stRPHmm_construct hmm: nothing to fetch */
-    st->part = xmalloc(sizeof(uint64_t) * (size_t) n); st->mfrom = xmalloc(sizeof(uint64_t) * (size_t) n);
-    st->mto = xmalloc(sizeof(uint64_t) * (size_t) n); st->np = xmalloc(sizeof(uint32_t) * (size_t) n);
+    if (h->leaf) return MRP_OK; /* a stRPHmm_construct hmm: nothing to fetch */
+    st->part = xmalloc(sizeof(uint64_t) * (size_t) n);
+    st->np = xmalloc(sizeof(uint32_t) * (size_t) n);
     int rc = mrp_engine_fetch(e, st->part, h->d_part, (int64_t) sizeof(uint64_t) * n);
     if (rc == MRP_OK) rc = mrp_engine_fetch(e, st->np, h->d_np, (int64_t) sizeof(uint32_t) * n);
-    if (rc == MRP_OK) rc = mrp_engine_fetch(e, st->mfrom, h->d_mfrom, (int64_t) sizeof(uint64_t) * n);
-    if (rc == MRP_OK) rc = mrp_engine_fetch(e, st->mto, h->d_mto, (int64_t) sizeof(uint64_t) * n);
     return rc;
 }
 static void r_download_end(mrp_hmm *h, r_staging *st) {
@@ -1440,7 +1602,7 @@ static void r_download_end(mrp_hmm *h, r_staging *st) {
     h->cell_off.n = 0; h->mcell_off.n = 0;
     VEC_PUSH(h->cell_off, 0);
     VEC_PUSH(h->mcell_off, 0);
-    if (h->d_mfrom == NULL) { /* hmm.c:97-133 */
+    if (h->leaf) { /* hmm.c:97-133 */
         hmm_add_cell(h, 1, 0);
         hmm_add_cell(h, 0, 0);
         VEC_PUSH(h->cell_off, h->part.n);
@@ -1453,14 +1615,21 @@ static void r_download_end(mrp_hmm *h, r_staging *st) {
             }
             VEC_PUSH(h->cell_off, h->part.n);
             if (k + 1 < K) {
-                for (int32_t m = 0; m < h->rc_merge.a[k]; m++) { VEC_PUSH(h->mfrom, st->mfrom[o + m]); VEC_PUSH(h->mto, st->mto[o + m]); }
+                for (int32_t m = 0; m < h->rc_merge.a[k]; m++) { VEC_PUSH(h->mfrom, 0); VEC_PUSH(h->mto, 0); }
                 VEC_PUSH(h->mcell_off, h->mfrom.n);
             }
         }
+        /* a merge cell's keys are the masked partition of any cell that feeds it / is fed by it
+         * (mergeColumn.c:63-79); every merge cell the prune keeps has both */
+        for (int64_t k = 0; k < K; k++)
+            for (int64_t c = h->cell_off.a[k]; c < h->cell_off.a[k + 1]; c++) {
+                if (k + 1 < K) h->mfrom.a[h->mcell_off.a[k] + h->next.a[c]] = h->part.a[c] & h->mask_from.a[k];
+                if (k > 0) h->mto.a[h->mcell_off.a[k - 1] + h->prev.a[c]] = h->part.a[c] & h->mask_to.a[k - 1];
+            }
     }
-    free(st->part); free(st->mfrom); free(st->mto); free(st->np);
+    free(st->part); free(st->np);
     h->resident = 0;
-    h->d_part = h->d_mfrom = h->d_mto = NULL; h->d_np = NULL;
+    h->d_part = NULL; h->d_np = NULL;
 }
 static int r_download_path(mrp_engine *e, hmm_vec *tp) {
     r_staging *st = xcalloc((size_t) tp->n + 1, sizeof(*st));
@@ -1469,7 +1638,7 @@ static int r_download_path(mrp_engine *e, hmm_vec *tp) {
     if (rc == MRP_OK) rc = mrp_engine_sync(e);
     for (int64_t i = 0; i < tp->n; i++) {
         if (rc == MRP_OK) r_download_end(tp->a[i], &st[i]);
-        else { free(st[i].part); free(st[i].mfrom); free(st[i].mto); free(st[i].np); }
+        else { free(st[i].part); free(st[i].np); }
     }
     free(st);
     return rc;
@@ -1507,9 +1676,99 @@ int mrp_get_rp_hmms_resident(mrp_context *ctx, const mrp_chunk *chunk, const mrp
 typedef struct {
     world w;
     int32_t *discarded; int64_t nd;
-    int root;            /* node of the joined tiling path */
-    mrp_hmm *hmm;        /* fused final hmm */
+    int root;            /* node of the joined tiling path (in the chunk's own tree, then in the run's tree) */
+    rnode_vec tree;      /* the chunk's subtree while it is being set up */
+    mrp_hmm *hmm;        /* shadow of the fused final hmm */
+    int32_t *path;       /* traced-back cell per column */
+    uint64_t *chosen;    /* and its partition */
+    double fwd, bwd;
+    int64_t final_index;
+    int rc;
+    char err[256];
 } many_state;
+
+typedef struct {
+    many_state *st;
+    mrp_context *ctx;
+    const mrp_chunk *const *chunks;
+    const mrp_read *const *reads;
+    const int64_t *n_reads;
+    const mrp_params *params, *pc;
+    mrp_engine *e;
+    rnode_vec *tree;
+    mrp_phase_result **out;
+    mrp_xhmm *xfinal;
+    uint32_t final_flags;
+} many_ctl;
+
+/* bubbleGraph.c:2699-2745 for one chunk: coverage filter, strand split, the two getRPHmms subtrees and their join */
+static void many_setup(int64_t c, void *arg) {
+    many_ctl *ctl = arg;
+    many_state *m = &ctl->st[c];
+    m->root = -1;
+    m->rc = world_init(&m->w, ctl->ctx, ctl->chunks[c], ctl->reads[c], ctl->n_reads[c], NULL);
+    if (m->rc == MRP_OK && ctl->n_reads[c] > 0) {
+        const int64_t nr = ctl->n_reads[c];
+        int32_t *filtered = xmalloc(sizeof(int32_t) * (size_t) nr);
+        m->discarded = xmalloc(sizeof(int32_t) * (size_t) nr);
+        int64_t nf;
+        filter_reads_by_coverage_depth(&m->w, ctl->params, filtered, &nf, m->discarded, &m->nd); /* :2699 */
+        uint8_t *is_disc = xcalloc((size_t) nr, 1);
+        for (int64_t i = 0; i < m->nd; i++) is_disc[m->discarded[i]] = 1;
+        int32_t *fwd = xmalloc(sizeof(int32_t) * (size_t) nr), *rev = xmalloc(sizeof(int32_t) * (size_t) nr);
+        int64_t nfwd = 0, nrev = 0;
+        for (int64_t i = 0; i < nr; i++) { /* :2705-2716 */
+            if (is_disc[i]) continue;
+            if (ctl->reads[c][i].forward_strand) fwd[nfwd++] = (int32_t) i; else rev[nrev++] = (int32_t) i;
+        }
+        const int rf = r_tree_of_reads(&m->tree, &m->w, ctl->e, fwd, nfwd, ctl->pc);   /* :2736 */
+        const int rr = rf < 0 ? -1 : r_tree_of_reads(&m->tree, &m->w, ctl->e, rev, nrev, ctl->pc); /* :2740 */
+        if (rf < 0 || rr < 0) m->rc = MRP_ERR_ARG;
+        else m->root = r_merge_node(&m->tree, &m->w, rf, rr);                         /* :2745 */
+        free(filtered); free(is_disc); free(fwd); free(rev);
+    }
+    if (m->rc != MRP_OK) snprintf(m->err, sizeof(m->err), "%s", mrp_last_error());
+}
+/* stRPHmm_fuse of the joined tiling path (hmm.c:283-372, gap columns :335-359) = its cross product with nothing:
+ * the shadow of the final hmm and the descriptors the device builds it from */
+static void many_final_shadow(int64_t c, void *arg) {
+    many_ctl *ctl = arg;
+    many_state *m = &ctl->st[c];
+    if (m->root < 0 || m->rc != MRP_OK) return;
+    hmm_vec *joined = ctl->tree->a[m->root].path;
+    if (joined->n == 0) return;
+    const int32_t S = joined->a[0]->ref_start, E = joined->a[joined->n - 1]->ref_start + joined->a[joined->n - 1]->ref_length;
+    piece_vec pa = {0}, pb = {0}, qa = {0}, qb = {0};
+    pieces_of_path(joined, S, E, &pa);
+    piece gap = {NULL, 0, S, E - S, CONN_NONE};
+    VEC_PUSH(pb, gap);
+    align_pieces(&pa, &pb, &qa, &qb);
+    hmm_vec nothing = {0};
+    xbuild xb = {0};
+    m->rc = r_cross_shadow(&m->w, &qa, &qb, joined, &nothing, S, E, &xb);
+    free(pa.a); free(pb.a); free(qa.a); free(qb.a);
+    if (m->rc != MRP_OK) { snprintf(m->err, sizeof(m->err), "%s", mrp_last_error()); return; }
+    m->hmm = xb.x;
+    const int64_t K = hmm_K(m->hmm);
+    m->path = xmalloc(sizeof(int32_t) * (size_t) K);
+    m->chosen = xmalloc(sizeof(uint64_t) * (size_t) K);
+    mrp_xhmm *x = &ctl->xfinal[c];
+    x->chunk = m->w.chunk;
+    x->n_cols = (int32_t) K;
+    x->flags = ctl->final_flags;
+    x->cols = xb.cols;
+    x->col_ref_start = m->hmm->col_start.a; x->col_length = m->hmm->col_len.a; x->col_depth = m->hmm->col_depth.a;
+    x->col_read_off = m->hmm->read_off.a; x->read_byte_off = m->hmm->read_byte_off.a;
+    x->n_cells = m->path;
+    x->path_part = m->chosen;
+    m->w.n_sweeps += 1; /* bubbleGraph.c:2749 */
+}
+static void many_finish(int64_t c, void *arg) {
+    many_ctl *ctl = arg;
+    many_state *m = &ctl->st[c];
+    if (m->hmm) finish_phase_parts(&m->w, m->hmm, m->chosen, m->fwd, m->bwd, ctl->params, m->discarded, m->nd, &ctl->out[c]);
+    else ctl->out[c] = result_new(0, 0, ctl->n_reads[c]);
+}
 
 static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *const *chunks, const mrp_read *const *reads,
                                const int64_t *n_reads, const mrp_params *params, mrp_phase_result **out,
@@ -1521,60 +1780,64 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
     if (rc != MRP_OK) return rc;
     many_state *st = xcalloc((size_t) n_chunks + 1, sizeof(*st));
     rnode_vec tree = {0};
-    for (int64_t c = 0; c < n_chunks && rc == MRP_OK; c++) {
+    const int timing = getenv("MRP_TIMING") != NULL;
+    double tt[6];
+    tt[0] = now_ms(); g_t_prepare = g_t_level = 0;
+    memset(g_ns, 0, sizeof(g_ns));
+    many_ctl ctl = {st, ctx, chunks, reads, n_reads, params, &pc, e, &tree, out, NULL, 0};
+    tt[3] = tt[2] = 0;
+    parallel_for(n_chunks, many_setup, &ctl);
+    for (int64_t c = 0; c < n_chunks; c++) { /* splice the chunks' subtrees into one tree */
         many_state *m = &st[c];
-        m->root = -1;
-        rc = world_init(&m->w, ctx, chunks[c], reads[c], n_reads[c], NULL);
-        if (rc != MRP_OK || n_reads[c] == 0) continue;
-        const int64_t nr = n_reads[c];
-        int32_t *filtered = xmalloc(sizeof(int32_t) * (size_t) nr);
-        m->discarded = xmalloc(sizeof(int32_t) * (size_t) nr);
-        int64_t nf;
-        filter_reads_by_coverage_depth(&m->w, params, filtered, &nf, m->discarded, &m->nd); /* :2699 */
-        uint8_t *is_disc = xcalloc((size_t) nr, 1);
-        for (int64_t i = 0; i < m->nd; i++) is_disc[m->discarded[i]] = 1;
-        int32_t *fwd = xmalloc(sizeof(int32_t) * (size_t) nr), *rev = xmalloc(sizeof(int32_t) * (size_t) nr);
-        int64_t nfwd = 0, nrev = 0;
-        for (int64_t i = 0; i < nr; i++) { /* :2705-2716 */
-            if (is_disc[i]) continue;
-            if (reads[c][i].forward_strand) fwd[nfwd++] = (int32_t) i; else rev[nrev++] = (int32_t) i;
+        if (m->rc != MRP_OK && rc == MRP_OK) rc = mrp_set_error(m->rc, "%s", m->err);
+        const int base = (int) tree.n;
+        for (int64_t i = 0; i < m->tree.n; i++) {
+            rnode nd = m->tree.a[i];
+            if (nd.left >= 0) nd.left += base;
+            if (nd.right >= 0) nd.right += base;
+            VEC_PUSH(tree, nd);
         }
-        const int rf = r_tree_of_reads(&tree, &m->w, e, fwd, nfwd, &pc);   /* :2736 */
-        const int rr = rf < 0 ? -1 : r_tree_of_reads(&tree, &m->w, e, rev, nrev, &pc); /* :2740 */
-        if (rf < 0 || rr < 0) rc = MRP_ERR_ARG;
-        else m->root = r_merge_node(&tree, &m->w, rf, rr);               /* :2745 */
-        free(filtered); free(is_disc); free(fwd); free(rev);
+        if (m->root >= 0) m->root += base;
+        free(m->tree.a);
+        m->tree.a = NULL; m->tree.n = m->tree.cap = 0;
     }
+    tt[1] = now_ms();
     if (rc == MRP_OK) rc = r_run_tree(e, &tree, &pc);
-    /* final hmms to the host (a few thousand cells each) */
-    for (int64_t c = 0; c < n_chunks && rc == MRP_OK; c++)
-        if (st[c].root >= 0) rc = r_download_path(e, tree.a[st[c].root].path);
-    /* final sweep with the ancestor model (:2748-2749), all chunks in one device batch */
+    tt[2] = now_ms();
+    tt[3] = now_ms();
+    /* fuse the joined path (:2745-2747), final sweep with the ancestor model (:2748-2749) and trace back (:2755) on
+     * the device, all chunks in one batch: only the traced-back partition of every column comes back */
     pc.include_ancestor_sub_prob = 1;
     if (rc == MRP_OK) {
-        mrp_hmm_job *jobs = xcalloc((size_t) n_chunks + 1, sizeof(*jobs));
+        ctl.final_flags = sweep_flags(&pc);
+        ctl.xfinal = xcalloc((size_t) n_chunks + 1, sizeof(*ctl.xfinal));
+        parallel_for(n_chunks, many_final_shadow, &ctl);
+        mrp_xhmm *xh = xcalloc((size_t) n_chunks + 1, sizeof(*xh));
         int64_t nj = 0;
         for (int64_t c = 0; c < n_chunks; c++) {
-            many_state *m = &st[c];
-            if (m->root < 0) continue;
-            hmm_vec *joined = tree.a[m->root].path;
-            tree.a[m->root].path = NULL;
-            if (joined->n > 0) {
-                m->hmm = fuse_path(&m->w, joined);
-                hmm_alloc_results(m->hmm);
-                hmm_job(&m->w, m->hmm, sweep_flags(&pc), &jobs[nj++], 1);
-                m->w.n_sweeps += 1;
-            }
-            free(joined->a); free(joined);
+            if (st[c].rc != MRP_OK && rc == MRP_OK) rc = mrp_set_error(st[c].rc, "%s", st[c].err);
+            if (st[c].hmm) { st[c].final_index = nj; xh[nj++] = ctl.xfinal[c]; }
         }
-        rc = mrp_fb_run(ctx, nj, jobs);
-        free(jobs);
+        if (rc == MRP_OK) rc = mrp_engine_final(e, nj, xh);
+        for (int64_t c = 0; c < n_chunks; c++)
+            if (st[c].hmm) { st[c].fwd = xh[st[c].final_index].hmm_forward; st[c].bwd = xh[st[c].final_index].hmm_backward; }
+        free(xh);
+        free(ctl.xfinal);
     }
-    for (int64_t c = 0; c < n_chunks && rc == MRP_OK; c++) {
-        many_state *m = &st[c];
-        if (m->hmm) rc = finish_phase(&m->w, m->hmm, params, m->discarded, m->nd, &out[c]);
-        else out[c] = result_new(0, 0, n_reads[c]);
+    tt[4] = now_ms();
+    if (rc == MRP_OK) {
+        parallel_for(n_chunks, many_finish, &ctl);
+        for (int64_t c = 0; c < n_chunks; c++)
+            if (st[c].rc != MRP_OK && rc == MRP_OK) rc = mrp_set_error(st[c].rc, "%s", st[c].err);
     }
+    tt[5] = now_ms();
+    if (timing)
+        fprintf(stderr, "mrp_phase_reads_many: setup %.1f ms, merge levels %.1f ms (host prepare %.1f, engine %.1f), download %.1f, "
+                        "final sweep %.1f, trace back + genome fragments %.1f\n", tt[1] - tt[0], tt[2] - tt[1], g_t_prepare, g_t_level,
+                tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4]);
+    if (timing)
+        fprintf(stderr, "  prepare (summed over threads): components %.1f ms, tiling paths %.1f, pieces %.1f, cross shadow %.1f, destroy %.1f\n",
+                g_ns[0] * 1e-6, g_ns[1] * 1e-6, g_ns[2] * 1e-6, g_ns[3] * 1e-6, g_ns[4] * 1e-6);
     if (stats) {
         mrp_engine_stats es;
         mrp_engine_get_stats(e, &es);
@@ -1583,7 +1846,7 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
         stats->merge_cells = es.merge_cells;
         stats->device_ms = es.device_ms; stats->cross_ms = es.cross_ms; stats->sweep_ms = es.sweep_ms; stats->prune_ms = es.prune_ms;
     }
-    for (int64_t c = 0; c < n_chunks; c++) { mrp_hmm_destroy(st[c].hmm); free(st[c].discarded); }
+    for (int64_t c = 0; c < n_chunks; c++) { mrp_hmm_destroy(st[c].hmm); free(st[c].discarded); free(st[c].tree.a); free(st[c].path); free(st[c].chosen); }
     free(st);
     r_free_tree(&tree);
     mrp_engine_destroy(e);

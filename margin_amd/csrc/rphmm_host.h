@@ -28,6 +28,8 @@ typedef struct mrp_chunk_host {
 void mrp_chunk_host_view(const mrp_chunk *chunk, mrp_chunk_host *out);
 mrp_context *mrp_chunk_context(const mrp_chunk *chunk);
 int mrp_set_error(int code, const char *fmt, ...);
+/* host worker threads for structural code and descriptor building (MRP_HOST_THREADS, default min(16, cores)) */
+int mrp_host_threads(void);
 
 /* ---- device-resident merge levels (mrp_engine.cpp), driven by the structural code of rphmm_host.c ---- */
 typedef struct mrp_engine mrp_engine;
@@ -55,9 +57,13 @@ typedef struct mrp_xhmm {
     const int64_t *col_read_off;  /* [n_cols + 1] */
     const int64_t *read_byte_off;
     /* results: the pruned hmm in the resident layout (device) and its per-column counts (host, caller-allocated) */
-    uint64_t *d_part, *d_mfrom, *d_mto;
+    uint64_t *d_part;
     uint32_t *d_np;
     int32_t *n_cells, *n_merge;   /* [n_cols] */
+    /* mrp_engine_final instead: n_cells[k] = index of the traced-back cell of column k, path_part[k] its
+     * partition (host, caller-allocated), and the totals of the final sweep */
+    uint64_t *path_part;
+    double hmm_forward, hmm_backward;
 } mrp_xhmm;
 
 typedef struct mrp_engine_stats {
@@ -75,6 +81,12 @@ int32_t mrp_engine_stride(const mrp_engine *e);
 void mrp_engine_leaf(const mrp_engine *e, const uint64_t **part, const uint32_t **np);
 /* cross product -> forward/backward -> prune for n independent hmms; fills the result fields */
 int mrp_engine_level(mrp_engine *e, int64_t n, mrp_xhmm *x);
+/* the same in two steps: begin returns once the kernels are queued, end waits and fills the results */
+int mrp_engine_level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x);
+int mrp_engine_level_end(mrp_engine *e);
+/* the last step of bubbleGraph_phaseBubbleGraph (bubbleGraph.c:2745-2755) for n fused hmms: cross product with
+ * nothing (= stRPHmm_fuse with its gap columns), forward/backward with the flags given, stRPHmm_forwardTraceBack */
+int mrp_engine_final(mrp_engine *e, int64_t n, mrp_xhmm *x);
 /* device -> host copy of resident arrays (queued), and the wait for all queued copies */
 int mrp_engine_fetch(mrp_engine *e, void *dst, const void *src_dev, int64_t bytes);
 int mrp_engine_sync(mrp_engine *e);
