@@ -320,7 +320,10 @@ def emissions(ctx: Context, dchunk: DeviceChunk, first_site: int, n_sites: int, 
 # ---- host pipeline (rphmm_host.c) -----------------------------------------------------------
 
 def read_records(chunk):
-    """mrp_read[] for a margin_amd.synth.Chunk; returns (ctypes array, keep-alive list)."""
+    """mrp_read[] for a margin_amd.synth.Chunk; returns (ctypes array, keep-alive list).  Cached on the chunk."""
+    cached = getattr(chunk, "_mrp_records", None)
+    if cached is not None and cached[2] == len(chunk.reads):
+        return cached[0], cached[1]
     n = len(chunk.reads)
     arr = (ReadRec * max(n, 1))()
     names = [r.name.encode() for r in chunk.reads]
@@ -330,6 +333,10 @@ def read_records(chunk):
         arr[i].length = r.length
         arr[i].forward_strand = r.strand
         arr[i].pool_offset = r.pool_off
+    try:
+        chunk._mrp_records = (arr, names, n)
+    except AttributeError:
+        pass
     return arr, names
 
 
@@ -435,8 +442,9 @@ def phase_reads(ctx: Context, dchunk: DeviceChunk, chunk, params: Params, record
     return out
 
 
-def phase_reads_many(ctx: Context, dchunks: Sequence[DeviceChunk], chunks: Sequence, params: Params):
-    """mrp_phase_reads_many -> (list of result dicts, PhaseManyStats)."""
+def phase_reads_many(ctx: Context, dchunks: Sequence[DeviceChunk], chunks: Sequence, params: Params, convert: bool = True):
+    """mrp_phase_reads_many -> (list of result dicts, PhaseManyStats).  convert=False skips the Python copies of the
+    results (timing runs)."""
     L = load()
     n = len(chunks)
     keep = [read_records(c) for c in chunks]
@@ -448,6 +456,6 @@ def phase_reads_many(ctx: Context, dchunks: Sequence[DeviceChunk], chunks: Seque
     _check(L.mrp_phase_reads_many(ctx.h, n, ch, rd, nr, C.byref(params), res, C.byref(st)))
     out = []
     for i in range(n):
-        out.append(_phase_result_dict(res[i].contents))
+        out.append(_phase_result_dict(res[i].contents) if convert else None)
         L.mrp_phase_result_destroy(res[i])
     return out, st

@@ -198,7 +198,7 @@ static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
             const mrp_xcol &c = x[i].cols[k];
             const int64_t C = (int64_t) c.C1 * c.C2, M = (int64_t) c.Ma * c.Mb;
             if (C < 1 || C > MRP_PRUNE_MAX_CELLS) return mrp_set_error(MRP_ERR_UNSUPPORTED, "cross product column with %lld cells", (long long) C);
-            if (k + 1 < x[i].n_cols && (M < 1 || M > 65535)) return mrp_set_error(MRP_ERR_UNSUPPORTED, "cross product merge column with %lld cells", (long long) M);
+            if (k + 1 < x[i].n_cols && (M < 1 || M > MRP_PRUNE_MAX_CELLS)) return mrp_set_error(MRP_ERR_UNSUPPORTED, "cross product merge column with %lld cells", (long long) M);
         }
     }
     L->total_cols = total_cols;

@@ -24,6 +24,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <algorithm>
+
 #include "mrp_engine.h"
 #include "../../include/margin_rphmm.h"
 
@@ -42,6 +44,11 @@ static __device__ __forceinline__ T k_load(const T *p) {
     return v;
 }
 
+/* Workgroup barrier that orders LDS traffic only (__syncthreads() also waits for every global load in
+ * flight, which would serialize the prefetch of the next column with the work on the current one). */
+static __device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 static __device__ __forceinline__ uint64_t accept_mask(uint32_t depth) { /* partitions.c:13-19 */
     return depth < 64 ? ~(0xFFFFFFFFFFFFFFFFull << depth) : 0xFFFFFFFFFFFFFFFFull;
 }
@@ -157,8 +164,7 @@ hipError_t mrp_launch_cross(const CrossCol *cols_dev, int64_t n_cols, uint64_t *
 /* ------------------------------------------------------------------------------------------ */
 /* prune                                                                                       */
 /* ------------------------------------------------------------------------------------------ */
-#define PRUNE_T 256
-#define PRUNE_W (PRUNE_T / WAVE)
+#define PRUNE_CPT 16 /* cells per lane held in registers: a column has at most 16 * (threads of the workgroup) cells */
 
 /* n kept of n_link candidates whose first g pass the posterior threshold: the loop of hmm.c:1073-1079 /
  * :1094-1100 ("while n > min && (n > max || last.posterior < threshold) drop last") in closed form */
@@ -175,27 +181,60 @@ static __device__ __forceinline__ int posterior_bin(int32_t f, int32_t b, int64_
     return s < n_bins - 1 ? (int) s : n_bins - 1;
 }
 
-__global__ void __launch_bounds__(PRUNE_T) mrp_prune_kernel(MrpBatchDev d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
-                                                            PruneParams p, PruneScratch sc) {
+/* Ascending bitonic sort of 128 distinct keys held two per lane (index lane and lane + 64) by one wave. */
+static __device__ __forceinline__ void wave_bitonic_sort128(uint32_t &k0, uint32_t &k1, int lane) {
+#pragma unroll
+    for (int k = 2; k <= 128; k <<= 1) {
+#pragma unroll
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            if (j == 64) { /* k == 128: the partner is the lane's other key */
+                const uint32_t lo = k0 < k1 ? k0 : k1, hi = k0 < k1 ? k1 : k0;
+                k0 = lo; k1 = hi;
+            } else {
+                const uint32_t p0 = __shfl_xor(k0, j, WAVE), p1 = __shfl_xor(k1, j, WAVE);
+                const bool lower = (lane & j) == 0;
+                const bool asc0 = (lane & k) == 0, asc1 = ((lane + 64) & k) == 0;
+                const uint32_t mn0 = k0 < p0 ? k0 : p0, mx0 = k0 < p0 ? p0 : k0;
+                const uint32_t mn1 = k1 < p1 ? k1 : p1, mx1 = k1 < p1 ? p1 : k1;
+                k0 = (lower == asc0) ? mn0 : mx0;
+                k1 = (lower == asc1) ? mn1 : mx1;
+            }
+        }
+    }
+}
+
+/* One workgroup per hmm.  Per column there are two phases separated by a barrier each:
+ *   [A] all waves: the column's cells (np, f, b were loaded into registers while the previous column was
+ *       processed) are tested against the kept flags of the previous merge column, binned by posterior and
+ *       appended, in list order, to the candidate list in LDS;
+ *   [B] wave 0 alone, without further barriers: cutoff bin from the histogram, ordered selection, stable
+ *       rank sort of the <= S kept cells, their distinct next merge cells, the merge cells' posteriors,
+ *       rank sort, new kept flags.  Meanwhile the other waves only wait; the loads of the next column are
+ *       already in flight. */
+template <int T>
+__global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
+                                                      PruneParams p, PruneScratch sc) {
+    constexpr int W = T / WAVE;
     extern __shared__ uint32_t lds[];
     const int S = p.S;
     const int nb = p.n_bins;
     const int nb_r = (nb + 63) & ~63;
-    const int cap_c = (p.max_cells + 3) & ~3;
+    const int cap_c = ((p.max_cells > p.max_merge ? p.max_cells : p.max_merge) + 3) & ~3;
     /* LDS layout (dwords) */
     uint32_t *gsel = lds;             /* [S] selected candidates above the cutoff bin: bin << 16 | cell */
-    uint32_t *esel = gsel + S;        /* [S] selected candidates in the cutoff bin: cell */
-    uint32_t *ksort = esel + S;       /* [S] kept cells in kept order */
+    uint32_t *gnp = gsel + S;         /* [S] their next | prev << 16 */
+    uint32_t *esel = gnp + S;         /* [S] selected candidates in the cutoff bin: cell */
+    uint32_t *enp = esel + S;         /* [S] */
+    uint32_t *ksort = enp + S;        /* [S] kept cells in kept order */
     uint32_t *knp = ksort + S;        /* [S] their next | prev << 16 */
-    uint32_t *firstf = knp + S;       /* [S] first occurrence of a merge cell */
-    uint32_t *um = firstf + S;        /* [S] linked merge cells in first-occurrence order */
+    uint32_t *um = knp + S;           /* [S] linked merge cells in first-occurrence order */
     uint32_t *umbin = um + S;         /* [S] their posterior bins */
-    uint32_t *msort = umbin + S;      /* [S] kept merge cells in kept order */
-    uint32_t *oldm = msort + S;       /* [S] kept merge cells of the previous merge column (flag owners) */
-    uint32_t *sh = oldm + S;          /* [64] small shared scalars and per-wave counters */
-    uint32_t *hist = sh + 64;         /* [nb_r] */
-    uint32_t *cand = hist + nb_r;     /* [cap_c] linked cells of the column, list order per wave segment */
-    uint8_t *flags = reinterpret_cast<uint8_t *>(cand + cap_c); /* [max_merge] kept flag per merge cell */
+    uint32_t *oldm = umbin + S;       /* [S] kept merge cells of the previous merge column (flag owners) */
+    uint32_t *sh = oldm + S;          /* [64] per-wave counters */
+    uint32_t *hist = sh + 64;         /* [2][nb_r] */
+    uint32_t *cand = hist + 2 * nb_r; /* [cap_c] linked cells of the column, list order per wave segment: bin << 16 | cell */
+    uint32_t *cand_np = cand + cap_c; /* [cap_c] */
+    uint8_t *flags = reinterpret_cast<uint8_t *>(cand_np + cap_c); /* [max_merge] kept flag per merge cell */
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
@@ -205,50 +244,88 @@ __global__ void __launch_bounds__(PRUNE_T) mrp_prune_kernel(MrpBatchDev d, const
         const PruneHmm h = k_load(hmms + hi_);
         const int K = h.n_cols;
         const int64_t total = (int64_t) d.hmm_fb[2 * h.hmm_index]; /* max mode: the same integer for every column */
-        for (int i = tid; i < nb_r; i += PRUNE_T) hist[i] = 0;
-        for (int i = tid; i < (p.max_merge + 3) / 4; i += PRUNE_T) reinterpret_cast<uint32_t *>(flags)[i] = 0;
+        for (int i = tid; i < 2 * nb_r; i += T) hist[i] = 0;
+        for (int i = tid; i < (p.max_merge + 3) / 4; i += T) reinterpret_cast<uint32_t *>(flags)[i] = 0;
         int n_old = 0;
+
+        uint32_t r_np[PRUNE_CPT];
+        int32_t r_f[PRUNE_CPT], r_b[PRUNE_CPT];
+        SweepCol col = k_load(d.scols + h.col0);
+        /* this wave's share of the column: [lo, hi), 64 cells per step */
+#define PRUNE_SHARE(colv, lo_, hi_v, nj_)                                                     \
+        const int per_##nj_ = (((colv).n_cells + W - 1) / W + 63) & ~63;                      \
+        const int lo_ = wave * per_##nj_ < (colv).n_cells ? wave * per_##nj_ : (colv).n_cells; \
+        const int hi_v = lo_ + per_##nj_ < (colv).n_cells ? lo_ + per_##nj_ : (colv).n_cells; \
+        const int nj_ = (hi_v - lo_ + 63) >> 6;
+#define PRUNE_LOAD(colv, lo_, hi_v, nj_)                                                      \
+        _Pragma("unroll") for (int j = 0; j < PRUNE_CPT; j++) {                               \
+            if (j < nj_) {                                                                    \
+                const int c = lo_ + j * WAVE + lane;                                          \
+                if (c < hi_v) {                                                               \
+                    r_np[j] = d.cell_np[(colv).cell_off + c];                                 \
+                    r_f[j] = d.cell_f32[(colv).cell_off + c];                                 \
+                    r_b[j] = d.cell_b32[(colv).cell_off + c];                                 \
+                }                                                                             \
+            }                                                                                 \
+        }
+        {
+            PRUNE_SHARE(col, lo0, hi0, nj0)
+            PRUNE_LOAD(col, lo0, hi0, nj0)
+        }
         __syncthreads();
 
         /* ---- stRPHmm_pruneForwards hmm.c:1049-1109 ---- */
         for (int k = 0; k < K; k++) {
-            const SweepCol col = k_load(d.scols + h.col0 + k);
-            const int C = col.n_cells;
-            const int per = ((C + PRUNE_W - 1) / PRUNE_W + 63) & ~63;
-            const int lo = wave * per < C ? wave * per : C;
-            const int hi = lo + per < C ? lo + per : C;
-            /* pass 1: linked cells (getLinkedCells :1021-1047) in list order, posterior bins, histogram */
+            uint32_t *hk = hist + (k & 1) * nb_r;
+            PRUNE_SHARE(col, lo, hi, nj)
+            /* [A] linked cells (getLinkedCells :1021-1047) in list order, posterior bins, histogram */
             int cnt = 0;
-            for (int base = lo; base < hi; base += WAVE) {
-                const int c = base + lane;
-                bool linked = false;
-                uint32_t entry = 0;
-                if (c < hi) {
-                    const uint32_t np = d.cell_np[col.cell_off + c];
-                    linked = k == 0 || flags[np >> 16] != 0;
-                    if (linked) {
-                        const int bin = posterior_bin(d.cell_f32[col.cell_off + c], d.cell_b32[col.cell_off + c], total, nb, &errbits);
-                        entry = ((uint32_t) bin << 16) | (uint32_t) c;
-                        atomicAdd(&hist[bin], 1u);
+#pragma unroll
+            for (int j = 0; j < PRUNE_CPT; j++) {
+                if (j < nj) {
+                    const int c = lo + j * WAVE + lane;
+                    bool linked = false;
+                    uint32_t entry = 0;
+                    if (c < hi) {
+                        linked = k == 0 || flags[r_np[j] >> 16] != 0;
+                        if (linked) {
+                            const int bin = posterior_bin(r_f[j], r_b[j], total, nb, &errbits);
+                            entry = ((uint32_t) bin << 16) | (uint32_t) c;
+                            atomicAdd(&hk[bin], 1u);
+                        }
                     }
+                    const uint64_t m = __ballot(linked);
+                    if (linked) {
+                        const int pos = lo + cnt + (int) lanemask_lt_count(m, lane);
+                        cand[pos] = entry;
+                        cand_np[pos] = r_np[j];
+                    }
+                    cnt += __popcll(m);
                 }
-                const uint64_t m = __ballot(linked);
-                if (linked) cand[lo + cnt + lanemask_lt_count(m, lane)] = entry;
-                cnt += __popcll(m);
             }
-            if (lane == 0) sh[8 + wave] = (uint32_t) cnt;
-            __syncthreads();
-            /* cutoff bin and quota (wave 0) */
-            if (wave == 0) {
+            if (lane == 0) sh[wave] = (uint32_t) cnt;
+            /* the next column's cells are requested now and consumed after the two barriers below */
+            const SweepCol cur = col;
+            if (k + 1 < K) {
+                col = k_load(d.scols + h.col0 + k + 1);
+                PRUNE_SHARE(col, lo1, hi1, nj1)
+                PRUNE_LOAD(col, lo1, hi1, nj1)
+            }
+            lds_barrier();
+            if (wave != 0) {
+                uint32_t *hn = hist + ((k + 1) & 1) * nb_r;
+                for (int i = tid - WAVE; i < nb_r; i += T - WAVE) hn[i] = 0;
+            } else {
+                /* [B] cutoff bin and quota */
                 int n_link = 0;
-                for (int w = 0; w < PRUNE_W; w++) n_link += (int) sh[8 + w];
+                for (int w = 0; w < W; w++) n_link += (int) sh[w];
                 const int bpl = nb_r / WAVE;
                 int tot = 0, pass = 0;
                 for (int q = 0; q < bpl; q++) {
-                    const int b = lane * bpl + q;
-                    const int v = b < nb ? (int) hist[b] : 0;
+                    const int bb = lane * bpl + q;
+                    const int v = bb < nb ? (int) hk[bb] : 0;
                     tot += v;
-                    if (b <= p.thr_bin) pass += v;
+                    if (bb <= p.thr_bin) pass += v;
                 }
                 int incl = tot, g = pass;
 #pragma unroll
@@ -260,153 +337,168 @@ __global__ void __launch_bounds__(PRUNE_T) mrp_prune_kernel(MrpBatchDev d, const
                 for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o, WAVE);
                 const int n = kept_count(n_link, g, p.min_p, p.max_p);
                 const int ex = incl - tot;
-                if (n > 0 && ex < n && n <= incl) {
+                int myB = -1, myQ = 0;
+                const bool owner = n > 0 && ex < n && n <= incl;
+                if (owner) {
                     int cum = ex;
                     for (int q = 0; q < bpl; q++) {
-                        const int b = lane * bpl + q;
-                        const int v = b < nb ? (int) hist[b] : 0;
-                        if (cum + v >= n) { sh[0] = (uint32_t) b; sh[1] = (uint32_t) (n - cum); break; }
+                        const int bb = lane * bpl + q;
+                        const int v = bb < nb ? (int) hk[bb] : 0;
+                        if (cum + v >= n) { myB = bb; myQ = n - cum; break; }
                         cum += v;
                     }
                 }
-                if (lane == 0) {
-                    sh[2] = (uint32_t) n;
-                    if (n == 0) { sh[0] = 0xFFFFFFFFu; sh[1] = 0; }
-                }
-            }
-            __syncthreads();
-            const int B = (int) sh[0], quota = (int) sh[1], n = (int) sh[2];
-            for (int i = tid; i < nb_r; i += PRUNE_T) hist[i] = 0;
-            /* pass 2a: per-wave counts above / in the cutoff bin */
-            {
-                int cg = 0, ce = 0;
-                for (int base = 0; base < cnt; base += WAVE) {
-                    const int i = base + lane;
-                    const bool valid = i < cnt;
-                    const int bin = valid ? (int) (cand[lo + i] >> 16) : 0;
-                    cg += __popcll(__ballot(valid && bin < B));
-                    ce += __popcll(__ballot(valid && bin == B));
-                }
-                if (lane == 0) { sh[16 + wave] = (uint32_t) cg; sh[24 + wave] = (uint32_t) ce; }
-            }
-            __syncthreads();
-            int nG = 0;
-            {
-                int base_g = 0, base_e = 0;
-                for (int w = 0; w < PRUNE_W; w++) {
-                    if (w < wave) { base_g += (int) sh[16 + w]; base_e += (int) sh[24 + w]; }
-                    nG += (int) sh[16 + w];
-                }
-                /* pass 2b: ordered selection */
-                for (int base = 0; base < cnt; base += WAVE) {
-                    const int i = base + lane;
-                    const bool valid = i < cnt;
-                    const uint32_t e = valid ? cand[lo + i] : 0u;
-                    const int bin = (int) (e >> 16);
-                    const bool is_g = valid && bin < B, is_e = valid && bin == B;
-                    const uint64_t mg = __ballot(is_g), me = __ballot(is_e);
-                    if (is_g) gsel[base_g + lanemask_lt_count(mg, lane)] = e;
-                    if (is_e) {
-                        const int pe = base_e + (int) lanemask_lt_count(me, lane);
-                        if (pe < quota) esel[pe] = e & 0xFFFFu;
-                    }
-                    base_g += __popcll(mg);
-                    base_e += __popcll(me);
-                }
-            }
-            __syncthreads();
-            /* stable descending sort of the kept cells (stList_sort :1071): smaller bin = larger posterior */
-            for (int i = tid; i < nG; i += PRUNE_T) {
-                const uint32_t e = gsel[i];
-                const uint32_t bin = e >> 16;
-                int r = 0;
-                for (int j = 0; j < nG; j++) {
-                    const uint32_t bj = gsel[j] >> 16;
-                    r += (bj < bin || (bj == bin && j < i)) ? 1 : 0;
-                }
-                ksort[r] = e & 0xFFFFu;
-            }
-            for (int i = tid; i < quota; i += PRUNE_T) ksort[nG + i] = esel[i];
-            __syncthreads();
-            const int64_t lcol = h.col0 + k;
-            for (int i = tid; i < n; i += PRUNE_T) {
-                const uint32_t c = ksort[i];
-                const uint32_t np = d.cell_np[col.cell_off + c];
-                knp[i] = np;
-                sc.kept[lcol * S + i] = (uint16_t) c;
-                sc.kept_np[lcol * S + i] = np;
-            }
-            if (tid == 0) sc.n_kept[lcol] = n;
-            /* the kept flags of the previous merge column are no longer needed */
-            for (int i = tid; i < n_old; i += PRUNE_T) flags[oldm[i]] = 0;
-            __syncthreads();
-            int mn = 0;
-            if (k + 1 < K) {
-                /* getLinkedMergeCells :989-1004: distinct next merge cells in order of first use */
-                for (int i = tid; i < n; i += PRUNE_T) {
-                    const uint32_t m = knp[i] & 0xFFFFu;
-                    uint32_t first = 1;
-                    for (int j = 0; j < i; j++)
-                        if ((knp[j] & 0xFFFFu) == m) { first = 0; break; }
-                    firstf[i] = first;
-                }
-                __syncthreads();
-                int mnl = 0;
-                for (int j = 0; j < n; j++) mnl += (int) firstf[j];
-                for (int i = tid; i < n; i += PRUNE_T) {
-                    if (firstf[i]) {
-                        int pos = 0;
-                        for (int j = 0; j < i; j++) pos += (int) firstf[j];
-                        const uint32_t m = knp[i] & 0xFFFFu;
-                        um[pos] = m;
-                        umbin[pos] = (uint32_t) posterior_bin(d.merge_f32[col.mcell_off + m], d.merge_b32[col.mcell_off + m], total, nb, &errbits);
+                const uint64_t om = __ballot(owner);
+                const int src = om ? __ffsll((unsigned long long) om) - 1 : 0;
+                const int B = om ? __shfl(myB, src, WAVE) : -1;
+                const int quota = om ? __shfl(myQ, src, WAVE) : 0;
+                const int nG = n - quota;
+                /* ordered selection over the wave segments (list order) */
+                {
+                    int gc = 0, ec = 0;
+                    for (int w = 0; w < W && (gc < nG || ec < quota); w++) {
+                        const int per_w = ((cur.n_cells + W - 1) / W + 63) & ~63;
+                        const int base = w * per_w;
+                        const int cw = (int) sh[w];
+                        for (int i0 = 0; i0 < cw && (gc < nG || ec < quota); i0 += WAVE) {
+                            const int i = i0 + lane;
+                            const bool valid = i < cw;
+                            const uint32_t e = valid ? cand[base + i] : 0u;
+                            const int bin = (int) (e >> 16);
+                            const bool is_g = valid && bin < B, is_e = valid && bin == B;
+                            const uint64_t mg = __ballot(is_g), me = __ballot(is_e);
+                            if (is_g) {
+                                const int pos = gc + (int) lanemask_lt_count(mg, lane);
+                                gsel[pos] = e;
+                                gnp[pos] = cand_np[base + i];
+                            }
+                            if (is_e) {
+                                const int pe = ec + (int) lanemask_lt_count(me, lane);
+                                if (pe < quota) { esel[pe] = e & 0xFFFFu; enp[pe] = cand_np[base + i]; }
+                            }
+                            gc += __popcll(mg);
+                            ec += __popcll(me);
+                        }
                     }
                 }
-                __syncthreads();
-                int gm = 0;
-                for (int j = 0; j < mnl; j++) gm += ((int) umbin[j] <= p.thr_bin) ? 1 : 0;
-                mn = kept_count(mnl, gm, p.min_p, p.max_p);
-                for (int i = tid; i < mnl; i += PRUNE_T) {
-                    const uint32_t bin = umbin[i];
-                    int r = 0;
-                    for (int j = 0; j < mnl; j++) {
-                        const uint32_t bj = umbin[j];
-                        r += (bj < bin || (bj == bin && j < i)) ? 1 : 0;
+                /* stable descending sort of the kept cells (stList_sort :1071): smaller bin = larger posterior; the key
+                 * bin | list position | cell is unique, so a bitonic sort in registers is stable by construction */
+                const int64_t lcol = h.col0 + k;
+                uint32_t key[2], my_np[2], my_c[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int i = lane + u * WAVE;
+                    key[u] = i < nG ? ((gsel[i] >> 16) << 21) | ((uint32_t) i << 14) | (gsel[i] & 0x3FFFu) : 0xFFFFFFFFu;
+                }
+                wave_bitonic_sort128(key[0], key[1], lane);
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int i = lane + u * WAVE;
+                    if (i < nG) { my_c[u] = key[u] & 0x3FFFu; my_np[u] = gnp[(key[u] >> 14) & 0x7Fu]; }
+                    else if (i < n) { my_c[u] = esel[i - nG]; my_np[u] = enp[i - nG]; }
+                    else { my_c[u] = 0u; my_np[u] = 0u; }
+                    if (i < n) {
+                        sc.kept[lcol * S + i] = (uint16_t) my_c[u];
+                        sc.kept_np[lcol * S + i] = my_np[u];
                     }
-                    if (r < mn) msort[r] = um[i];
                 }
-                __syncthreads();
-                for (int i = tid; i < mn; i += PRUNE_T) {
-                    const uint32_t m = msort[i];
-                    flags[m] = 1;
-                    oldm[i] = m;
-                    sc.keptm[lcol * S + i] = (uint16_t) m;
+                if (lane == 0) sc.n_kept[lcol] = n;
+                /* the kept flags of the previous merge column are no longer needed */
+                for (int i = lane; i < n_old; i += WAVE) flags[oldm[i]] = 0;
+                int mn = 0;
+                if (k + 1 < K) {
+                    /* getLinkedMergeCells :989-1004: distinct next merge cells in order of first use.  The candidate
+                     * list is consumed, its storage serves as "first kept cell that uses merge cell m" */
+                    uint32_t *owner = cand;
+                    bool first[2];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int i = lane + u * WAVE;
+                        if (i < n) owner[my_np[u] & 0xFFFFu] = 0xFFFFFFFFu;
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int i = lane + u * WAVE;
+                        if (i < n) atomicMin(&owner[my_np[u] & 0xFFFFu], (uint32_t) i);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int i = lane + u * WAVE;
+                        first[u] = i < n && owner[my_np[u] & 0xFFFFu] == (uint32_t) i;
+                    }
+                    const uint64_t f0 = __ballot(first[0]), f1 = __ballot(first[1]);
+                    const int mnl = __popcll(f0) + __popcll(f1);
+                    uint32_t mkey[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+                    int pass_thr[2] = {0, 0};
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        if (first[u]) {
+                            const int pos = u == 0 ? (int) lanemask_lt_count(f0, lane) : __popcll(f0) + (int) lanemask_lt_count(f1, lane);
+                            const uint32_t m = my_np[u] & 0xFFFFu;
+                            const int bin = posterior_bin(d.merge_f32[cur.mcell_off + m], d.merge_b32[cur.mcell_off + m], total, nb, &errbits);
+                            pass_thr[u] = bin <= p.thr_bin ? 1 : 0;
+                            mkey[u] = ((uint32_t) bin << 21) | ((uint32_t) pos << 14) | m;
+                        }
+                    }
+                    const int gm = __popcll(__ballot(pass_thr[0] != 0)) + __popcll(__ballot(pass_thr[1] != 0));
+                    mn = kept_count(mnl, gm, p.min_p, p.max_p);
+                    /* stable descending sort by posterior (:1090), the first mn stay */
+                    wave_bitonic_sort128(mkey[0], mkey[1], lane);
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int r = lane + u * WAVE;
+                        if (r < mn) {
+                            const uint32_t m = mkey[u] & 0x3FFFu;
+                            flags[m] = 1;
+                            oldm[r] = m;
+                            sc.keptm[lcol * S + r] = (uint16_t) m;
+                        }
+                    }
                 }
+                if (lane == 0) sc.n_keptm[lcol] = mn;
+                n_old = mn;
             }
-            if (tid == 0) sc.n_keptm[lcol] = mn;
-            n_old = mn;
-            __syncthreads();
+            lds_barrier();
         }
-        /* clear the flags left by the last merge column */
-        for (int i = tid; i < n_old; i += PRUNE_T) flags[oldm[i]] = 0;
-        __syncthreads(); /* also makes this workgroup's global lists visible to wave 0 below */
+        /* clear the flags left by the last merge column (n_old is only maintained by wave 0) */
+        if (wave == 0)
+            for (int i = lane; i < n_old; i += WAVE) flags[oldm[i]] = 0;
+        __syncthreads(); /* also makes the lists above visible in global memory */
 
-        /* ---- stRPHmm_pruneBackwards hmm.c:1111-1158: lists of at most S entries, one wave ---- */
+        /* ---- stRPHmm_pruneBackwards hmm.c:1111-1158: lists of at most S entries, one wave; the lists of
+         * column k - 1 are requested before column k is worked on ---- */
         if (wave == 0) {
             uint32_t pm[2] = {0u, 0u}; /* kept merge cells of the merge column after column k: they own the flags */
             bool pmk[2] = {false, false};
+            int nk = sc.n_kept[h.col0 + K - 1];
+            uint32_t cc[2], cn[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = lane + u * WAVE;
+                cc[u] = i < nk ? sc.kept[(h.col0 + K - 1) * S + i] : 0u;
+                cn[u] = i < nk ? sc.kept_np[(h.col0 + K - 1) * S + i] : 0u;
+            }
             for (int k = K - 1; k >= 0; k--) {
                 const int64_t lcol = h.col0 + k;
-                const int nk = sc.n_kept[lcol];
-                uint32_t cc[2], cn[2];
+                /* prefetch: the lists of column k - 1 and of the merge column between */
+                int nk_p = 0, nmp = 0;
+                uint32_t cc_p[2] = {0u, 0u}, cn_p[2] = {0u, 0u}, mm[2] = {0u, 0u};
+                if (k > 0) {
+                    nk_p = sc.n_kept[lcol - 1];
+                    nmp = sc.n_keptm[lcol - 1];
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int i = lane + u * WAVE;
+                        cc_p[u] = i < nk_p ? sc.kept[(lcol - 1) * S + i] : 0u;
+                        cn_p[u] = i < nk_p ? sc.kept_np[(lcol - 1) * S + i] : 0u;
+                        mm[u] = i < nmp ? sc.keptm[(lcol - 1) * S + i] : 0u;
+                    }
+                }
                 bool keep[2];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const int i = lane + u * WAVE;
-                    const bool valid = i < nk;
-                    cc[u] = valid ? sc.kept[lcol * S + i] : 0u;
-                    cn[u] = valid ? sc.kept_np[lcol * S + i] : 0u;
-                    keep[u] = valid && (k + 1 == K || flags[cn[u] & 0xFFFFu] != 0);
+                    keep[u] = i < nk && (k + 1 == K || flags[cn[u] & 0xFFFFu] != 0);
                 }
                 const uint64_t m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
                 const int ns = __popcll(m0) + __popcll(m1);
@@ -429,15 +521,11 @@ __global__ void __launch_bounds__(PRUNE_T) mrp_prune_kernel(MrpBatchDev d, const
                 /* merge column k - 1 keeps the merge cells some surviving cell comes from (:1141-1155) */
                 if (keep[0]) flags[cn[0] >> 16] = 1;
                 if (keep[1]) flags[cn[1] >> 16] = 1;
-                const int nmp = sc.n_keptm[lcol - 1];
-                uint32_t mm[2];
                 bool mk[2];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const int i = lane + u * WAVE;
-                    const bool valid = i < nmp;
-                    mm[u] = valid ? sc.keptm[(lcol - 1) * S + i] : 0u;
-                    mk[u] = valid && flags[mm[u]] != 0;
+                    mk[u] = i < nmp && flags[mm[u]] != 0;
                 }
                 const uint64_t q0 = __ballot(mk[0]), q1 = __ballot(mk[1]);
                 const int nms = __popcll(q0) + __popcll(q1);
@@ -453,26 +541,38 @@ __global__ void __launch_bounds__(PRUNE_T) mrp_prune_kernel(MrpBatchDev d, const
                 if (mk[1]) flags[mm[1]] = 1;
                 pm[0] = mm[0]; pm[1] = mm[1];
                 pmk[0] = mk[0]; pmk[1] = mk[1];
+                nk = nk_p;
+                cc[0] = cc_p[0]; cc[1] = cc_p[1];
+                cn[0] = cn_p[0]; cn[1] = cn_p[1];
             }
         }
         __syncthreads();
     }
+#undef PRUNE_SHARE
+#undef PRUNE_LOAD
     if (errbits) atomicOr(sc.err, errbits);
 }
 
 hipError_t mrp_launch_prune(const MrpBatchDev &d, const PruneHmm *hmms_dev, int64_t n_hmms, PruneParams p, PruneScratch s,
                             hipStream_t stream) {
     if (n_hmms <= 0) return hipSuccess;
-    const size_t lds = (size_t) (9 * p.S + 64 + ((p.n_bins + 63) & ~63) + ((p.max_cells + 3) & ~3)) * 4 + (size_t) ((p.max_merge + 3) & ~3) + 16;
+    if (p.S > MRP_PRUNE_MAX_S || p.max_cells > MRP_PRUNE_MAX_CELLS || p.max_merge > MRP_PRUNE_MAX_CELLS || p.n_bins > 1024) return hipErrorInvalidValue;
+    const size_t lds = (size_t) (9 * p.S + 64 + 2 * ((p.n_bins + 63) & ~63) + 2 * ((std::max(p.max_cells, p.max_merge) + 3) & ~3)) * 4 +
+                       (size_t) ((p.max_merge + 3) & ~3) + 16;
     static bool configured = false;
     if (!configured) {
-        hipError_t e = hipFuncSetAttribute((const void *) mrp_prune_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *) mrp_prune_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess)
+            e = hipFuncSetAttribute((const void *) mrp_prune_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return e;
         configured = true;
     }
     if (lds > (size_t) MRP_LDS_BUDGET) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(mrp_prune_kernel, dim3((unsigned) (n_hmms < 65536 ? n_hmms : 65536)), dim3(PRUNE_T), lds, stream, d,
-                       hmms_dev, n_hmms, p, s);
+    const dim3 grid((unsigned) (n_hmms < 65536 ? n_hmms : 65536));
+    if (p.max_cells <= 256 * PRUNE_CPT)
+        hipLaunchKernelGGL(mrp_prune_kernel<256>, grid, dim3(256), lds, stream, d, hmms_dev, n_hmms, p, s);
+    else
+        hipLaunchKernelGGL(mrp_prune_kernel<1024>, grid, dim3(1024), lds, stream, d, hmms_dev, n_hmms, p, s);
     return hipGetLastError();
 }
 

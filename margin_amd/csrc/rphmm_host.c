@@ -169,6 +169,7 @@ struct mrp_hmm {
      * descriptors of the level that builds it); arrays outside [this, this + arena_bytes) are malloc'd */
     size_t arena_bytes;
     mrp_xcol *xcols;
+    int in_block; /* the struct lives inside a block owned by someone else (the leaves of a run) */
 };
 
 static int64_t hmm_K(const mrp_hmm *h) { return h->col_start.n; }
@@ -195,7 +196,7 @@ void mrp_hmm_destroy(mrp_hmm *h) {
                       h->mfrom.a, h->mto.a, h->rc_cells.a, h->rc_merge.a};
     for (size_t i = 0; i < sizeof(arrays) / sizeof(arrays[0]); i++) hmm_free_array(h, arrays[i]);
     hmm_free_results(h);
-    free(h);
+    if (!h->in_block) free(h);
 }
 
 /* per-job view of the reads + chunk the structural code works against */
@@ -1239,7 +1240,7 @@ int mrp_phase_reads(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *re
 /* as ONE batch of kernels (mrp_engine_level).                                                 */
 /* ------------------------------------------------------------------------------------------ */
 /* a shadow hmm with K columns, D column reads in total and n_reads reads: one allocation */
-static mrp_hmm *r_shadow_new(int64_t K, int64_t D, int64_t n_reads, int with_xcols) {
+static mrp_hmm *r_shadow_new(int64_t K, int64_t D, int64_t n_reads, int with_xcols, void *place, size_t *bytes_out) {
 #define AL8(x) (((size_t) (x) + 7) & ~(size_t) 7)
     size_t bytes = AL8(sizeof(mrp_hmm));
     const size_t o_reads = bytes; bytes += AL8(4 * n_reads);
@@ -1257,10 +1258,13 @@ static mrp_hmm *r_shadow_new(int64_t K, int64_t D, int64_t n_reads, int with_xco
     const size_t o_rc_merge = bytes; bytes += AL8(4 * K);
     const size_t o_xcols = bytes; bytes += with_xcols ? AL8(sizeof(mrp_xcol) * (size_t) K) : 0;
 #undef AL8
-    char *blk = xmalloc(bytes);
+    if (bytes_out) *bytes_out = bytes;
+    if (bytes_out && !place) return NULL; /* size query */
+    char *blk = place ? place : xmalloc(bytes);
     mrp_hmm *h = (mrp_hmm *) blk;
     memset(h, 0, sizeof(*h));
     h->arena_bytes = bytes;
+    h->in_block = place != NULL;
     h->resident = 1;
 #define AT(vec, off, capacity) do { (vec).a = (void *) (blk + (off)); (vec).n = 0; (vec).cap = (capacity); } while (0)
     AT(h->reads, o_reads, n_reads); AT(h->col_start, o_start, K); AT(h->col_len, o_len, K); AT(h->col_depth, o_depth, K);
@@ -1275,8 +1279,8 @@ static mrp_hmm *r_shadow_new(int64_t K, int64_t D, int64_t n_reads, int with_xco
     return h;
 }
 
-static mrp_hmm *r_hmm_from_read(const world *w, int32_t read, const mrp_engine *e) { /* stRPHmm_construct hmm.c:97-133 */
-    mrp_hmm *h = r_shadow_new(1, 1, 1, 0);
+static mrp_hmm *r_hmm_from_read(const world *w, int32_t read, const mrp_engine *e, void *place) { /* stRPHmm_construct hmm.c:97-133 */
+    mrp_hmm *h = r_shadow_new(1, 1, 1, 0, place, NULL);
     const mrp_read *r = &w->reads[read];
     h->ref_start = r->ref_start;
     h->ref_length = r->length;
@@ -1334,7 +1338,7 @@ static int r_cross_shadow(const world *w, const piece_vec *A, const piece_vec *B
     }
     for (int64_t i = 0; i < tpA->n; i++) n_reads += tpA->a[i]->reads.n;
     for (int64_t i = 0; i < tpB->n; i++) n_reads += tpB->a[i]->reads.n;
-    mrp_hmm *h = r_shadow_new(n, D, n_reads, 1);
+    mrp_hmm *h = r_shadow_new(n, D, n_reads, 1, NULL, NULL);
     h->ref_start = S; h->ref_length = E - S;
     for (int64_t i = 0; i < tpA->n; i++) { memcpy(h->reads.a + h->reads.n, tpA->a[i]->reads.a, sizeof(int32_t) * (size_t) tpA->a[i]->reads.n); h->reads.n += tpA->a[i]->reads.n; }
     for (int64_t i = 0; i < tpB->n; i++) { memcpy(h->reads.a + h->reads.n, tpB->a[i]->reads.a, sizeof(int32_t) * (size_t) tpB->a[i]->reads.n); h->reads.n += tpB->a[i]->reads.n; }
@@ -1471,10 +1475,18 @@ static int r_tree_of_paths(rnode_vec *t, const world *w, hmm_vec **paths, int64_
     return r_merge_node(t, w, l, r);
 }
 /* getRPHmms coordination.c:490-516 as a subtree; returns the root node or -1 */
+typedef VEC(void *) block_vec;
 static int r_tree_of_reads(rnode_vec *t, const world *w, const mrp_engine *e, const int32_t *read_index, int64_t n,
-                           const mrp_params *params) {
+                           const mrp_params *params, block_vec *blocks) {
     mrp_hmm **hmms = xmalloc(sizeof(*hmms) * (size_t) (n + 1));
-    for (int64_t i = 0; i < n; i++) hmms[i] = r_hmm_from_read(w, read_index[i], e);
+    char *block = NULL;
+    size_t leaf_bytes = 0;
+    if (blocks && n > 0) { /* all leaves of the problem in one allocation, owned by the caller */
+        r_shadow_new(1, 1, 1, 0, NULL, &leaf_bytes);
+        block = xmalloc(leaf_bytes * (size_t) n);
+        VEC_PUSH(*blocks, block);
+    }
+    for (int64_t i = 0; i < n; i++) hmms[i] = r_hmm_from_read(w, read_index[i], e, block ? block + leaf_bytes * (size_t) i : NULL);
     path_vec paths = tiling_paths_from(w, hmms, n);
     free(hmms);
     if (paths.n > MRP_MAX_READ_PARTITIONING_DEPTH || paths.n > params->max_coverage_depth) { /* :500-504 */
@@ -1656,7 +1668,7 @@ int mrp_get_rp_hmms_resident(mrp_context *ctx, const mrp_chunk *chunk, const mrp
     rc = mrp_engine_create(ctx, params, &e);
     if (rc != MRP_OK) return rc;
     rnode_vec tree = {0};
-    const int root = r_tree_of_reads(&tree, &w, e, read_index, n, params);
+    const int root = r_tree_of_reads(&tree, &w, e, read_index, n, params, NULL);
     rc = root < 0 ? MRP_ERR_ARG : r_run_tree(e, &tree, params);
     if (rc == MRP_OK) rc = r_download_path(e, tree.a[root].path);
     if (rc == MRP_OK) {
@@ -1683,6 +1695,7 @@ typedef struct {
     uint64_t *chosen;    /* and its partition */
     double fwd, bwd;
     int64_t final_index;
+    block_vec blocks;    /* leaf shadows */
     int rc;
     char err[256];
 } many_state;
@@ -1721,8 +1734,8 @@ static void many_setup(int64_t c, void *arg) {
             if (is_disc[i]) continue;
             if (ctl->reads[c][i].forward_strand) fwd[nfwd++] = (int32_t) i; else rev[nrev++] = (int32_t) i;
         }
-        const int rf = r_tree_of_reads(&m->tree, &m->w, ctl->e, fwd, nfwd, ctl->pc);   /* :2736 */
-        const int rr = rf < 0 ? -1 : r_tree_of_reads(&m->tree, &m->w, ctl->e, rev, nrev, ctl->pc); /* :2740 */
+        const int rf = r_tree_of_reads(&m->tree, &m->w, ctl->e, fwd, nfwd, ctl->pc, &m->blocks);   /* :2736 */
+        const int rr = rf < 0 ? -1 : r_tree_of_reads(&m->tree, &m->w, ctl->e, rev, nrev, ctl->pc, &m->blocks); /* :2740 */
         if (rf < 0 || rr < 0) m->rc = MRP_ERR_ARG;
         else m->root = r_merge_node(&m->tree, &m->w, rf, rr);                         /* :2745 */
         free(filtered); free(is_disc); free(fwd); free(rev);
@@ -1847,8 +1860,9 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
         stats->device_ms = es.device_ms; stats->cross_ms = es.cross_ms; stats->sweep_ms = es.sweep_ms; stats->prune_ms = es.prune_ms;
     }
     for (int64_t c = 0; c < n_chunks; c++) { mrp_hmm_destroy(st[c].hmm); free(st[c].discarded); free(st[c].tree.a); free(st[c].path); free(st[c].chosen); }
-    free(st);
     r_free_tree(&tree);
+    for (int64_t c = 0; c < n_chunks; c++) { for (int64_t i = 0; i < st[c].blocks.n; i++) free(st[c].blocks.a[i]); free(st[c].blocks.a); }
+    free(st);
     mrp_engine_destroy(e);
     return rc;
 }
