@@ -43,6 +43,8 @@ def parse_args():
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--threads", type=int, default=int(os.environ.get("MRP_BENCH_THREADS", "0")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-pipeline", action="store_true", help="skip the end-to-end device-resident phasing leg")
+    ap.add_argument("--pipeline-runs", type=int, default=3)
     ap.add_argument("--split", type=int, default=int(os.environ.get("MRP_BENCH_SPLIT", "1")),
                     help="record the chunks into this many device batches launched on separate streams (their kernels overlap)")
     return ap.parse_args()
@@ -85,6 +87,7 @@ def main():
     bigs = [capi.Batch(c) for c in ctxs]
     main_ctx, big = ctxs[0], bigs[0]
     keep = []           # device chunks must outlive the batch
+    host_chunks = [None] * n_chunks
     units_lock = threading.Lock()
     totals = dict(units=0, sweeps=0, reads=0)
     tls = threading.local()
@@ -104,6 +107,7 @@ def main():
             totals["units"] += chunk.units
             totals["sweeps"] += res["n_sweeps"]
             totals["reads"] += len(chunk.reads)
+        host_chunks[i] = chunk
         return chunk if i == 0 else None
 
     t0 = time.time()
@@ -188,6 +192,33 @@ def main():
                            parallelism=f"{world} process(es), one per GPU, chunks sharded, no collectives",
                            host_build_s=t_build, host_threads=n_threads),
                roofline=roofline)
+
+    if not args.no_pipeline:
+        # End-to-end leg: the same chunks phased from profile sequences to haplotypes by
+        # mrp_phase_reads_many -- tiling paths, every merge level (cross product -> forward/backward -> prune, resident
+        # in HBM), fused final sweep, trace back, genome fragments.  Wall clock around the C call, inputs (profile bytes,
+        # site tables) already on the device; it is reported beside the headline value, not as it.
+        pdch = [capi.DeviceChunk.from_chunk(main_ctx, c) for c in host_chunks]
+        for c in host_chunks:
+            capi.read_records(c)
+        capi.phase_reads_many(main_ctx, pdch, host_chunks, params, convert=False)  # warm-up: allocator cache, pinned buffers
+        barrier()
+        t0 = time.perf_counter()
+        pst = None
+        for _ in range(args.pipeline_runs):
+            _, pst = capi.phase_reads_many(main_ctx, pdch, host_chunks, params, convert=False)
+        barrier()
+        p_el = time.perf_counter() - t0
+        p_el, p_units = sharding.reduce_elapsed_and_units(dist, p_el, float(totals["units"]), device=reduce_dev)
+        out["pipeline"] = dict(what="mrp_phase_reads_many: profile sequences -> haplotypes, all merge levels resident on the device",
+                               value=p_units * args.pipeline_runs / p_el, unit="het-site-reads/s",
+                               ms_per_batch=1e3 * p_el / args.pipeline_runs, chunks_per_gpu=n_chunks, runs=args.pipeline_runs,
+                               resident=int(pst.resident), levels=int(pst.levels), hmms=int(pst.hmms), columns=int(pst.columns),
+                               cells=int(pst.cells), device_ms=float(pst.device_ms), cross_ms=float(pst.cross_ms),
+                               sweep_ms=float(pst.sweep_ms), prune_ms=float(pst.prune_ms),
+                               host_threads=int(os.environ.get("MRP_HOST_THREADS", "0")) or min(16, os.cpu_count() or 1))
+        for d_ in pdch:
+            d_.close()
 
     if rank == 0 and not args.no_cpu_baseline and n_gpus == 1:
         # CPU baseline: the oracle (C restatement of the reference's linked-list/hash implementation,
