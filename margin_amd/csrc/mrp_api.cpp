@@ -682,6 +682,11 @@ int mrp_batch_upload(mrp_batch *b) {
         b->n_fast_tiles = mid_it - b->tiles.begin();
     }
     HIP_TRY(b->d_tiles.upload(b->tiles, s));
+    std::vector<int32_t> pack_list, plane_list;
+    pack_list.reserve(b->pcols.size());
+    for (size_t i = 0; i < b->pcols.size(); i++) (b->pcols[i].need_planes ? plane_list : pack_list).push_back((int32_t) i);
+    HIP_TRY(b->d_pack_list.upload(pack_list, s));
+    HIP_TRY(b->d_plane_list.upload(plane_list, s));
     const size_t nC = (size_t) b->n_cells_total;
     HIP_TRY(b->d_planes.alloc((size_t) b->n_slots * 8));
     HIP_TRY(b->d_slot_total.alloc((size_t) b->n_slots));
@@ -709,6 +714,10 @@ int mrp_batch_upload(mrp_batch *b) {
     d.partition = b->d_partition.p;
     d.scols = b->d_scols.p;
     d.pcols = b->d_pcols.p;
+    d.pack_list = b->d_pack_list.p;
+    d.plane_list = b->d_plane_list.p;
+    d.n_pack_list = (int64_t) b->d_pack_list.n;
+    d.n_plane_list = (int64_t) b->d_plane_list.n;
     d.cell_np = b->d_np.p;
     d.cell_next = b->d_next.p;
     d.cell_prev = b->d_prev.p;

@@ -190,7 +190,7 @@ struct mrp_batch {
     DevBuf<uint32_t> d_next, d_prev, d_np, d_slot_total, d_slot_bytes, d_cost;
     DevBuf<double> d_f, d_b, d_mf, d_mb, d_total, d_hmm_fb;
     DevBuf<int32_t> d_f32, d_b32, d_mf32, d_mb32;
-    DevBuf<int32_t> d_order_wide, d_order_mid, d_order_narrow, d_order_f64;
+    DevBuf<int32_t> d_order_wide, d_order_mid, d_order_narrow, d_order_f64, d_pack_list, d_plane_list;
     DevBuf<EmitTile> d_tiles;
     MrpBatchDev dev{};
     void bind_pool(DevPool *pl) {
@@ -198,7 +198,7 @@ struct mrp_batch {
         d_scols.pool = pl; d_pcols.pool = pl; d_next.pool = pl; d_prev.pool = pl; d_np.pool = pl; d_slot_total.pool = pl;
         d_slot_bytes.pool = pl; d_cost.pool = pl; d_f.pool = pl; d_b.pool = pl; d_mf.pool = pl; d_mb.pool = pl; d_total.pool = pl;
         d_hmm_fb.pool = pl; d_f32.pool = pl; d_b32.pool = pl; d_mf32.pool = pl; d_mb32.pool = pl; d_order_wide.pool = pl;
-        d_order_mid.pool = pl; d_order_narrow.pool = pl; d_order_f64.pool = pl; d_tiles.pool = pl;
+        d_order_mid.pool = pl; d_order_narrow.pool = pl; d_order_f64.pool = pl; d_tiles.pool = pl; d_pack_list.pool = pl; d_plane_list.pool = pl;
     }
 };
 

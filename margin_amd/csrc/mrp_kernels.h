@@ -15,6 +15,9 @@ struct MrpBatchDev {
     const PlaneCol *pcols;
     const DevChunk *chunks;
     const int64_t *read_byte_off;
+    const int32_t *pack_list;  /* columns of the uniform-allele fast path: packed bytes only (mrp_pack_kernel) */
+    const int32_t *plane_list; /* columns that also need the bit planes (general emission path) */
+    int64_t n_pack_list, n_plane_list;
     const uint64_t *partition;
     const uint32_t *cell_np;   /* next | prev << 16 */
     const uint32_t *cell_next; /* only when some hmm has > 65535 merge cells in a column */

@@ -69,7 +69,8 @@ static __device__ __forceinline__ int32_t wave_max_i32(int32_t v) {
 /* ------------------------------------------------------------------------------------------ */
 /* bit planes                                                                                  */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(256) mrp_planes_kernel(const PlaneCol *__restrict__ pcols, int64_t n_cols,
+__global__ void __launch_bounds__(256) mrp_planes_kernel(const PlaneCol *__restrict__ pcols_all,
+                                                         const int32_t *__restrict__ list, int64_t n_cols,
                                                          const int64_t *__restrict__ read_byte_off,
                                                          uint64_t *__restrict__ planes,
                                                          uint32_t *__restrict__ slot_total,
@@ -83,11 +84,13 @@ __global__ void __launch_bounds__(256) mrp_planes_kernel(const PlaneCol *__restr
     const int64_t wave_stride = (int64_t) gridDim.x * (blockDim.x / WAVE);
     int64_t col = (int64_t) blockIdx.x * (blockDim.x / WAVE) + wave;
     if (col >= n_cols) return;
-    PlaneCol c = k_load(pcols + col);
+    /* list == NULL: every column; otherwise the columns named by the list */
+#define PLANE_COL(i) (pcols_all + (list ? (int64_t) __builtin_amdgcn_readfirstlane(list[i]) : (i)))
+    PlaneCol c = k_load(PLANE_COL(col));
     int64_t my_off = lane < c.depth ? read_byte_off[c.read_off + lane] : 0;
     for (; col < n_cols; col += wave_stride) {
     const int64_t ncol = col + wave_stride < n_cols ? col + wave_stride : col;
-    const PlaneCol cn = k_load(pcols + ncol);
+    const PlaneCol cn = k_load(PLANE_COL(ncol));
     const int64_t next_off = lane < cn.depth ? read_byte_off[cn.read_off + lane] : 0;
     const bool active = lane < c.depth;
     const uint8_t *__restrict__ src = c.pool + my_off;
@@ -129,15 +132,56 @@ __global__ void __launch_bounds__(256) mrp_planes_kernel(const PlaneCol *__restr
     my_off = next_off;
     }
 #undef PLANE_U
+#undef PLANE_COL
+}
+
+/* The packed bytes and byte sums alone (columns of the fast emission path): 16 lanes per column, lane = word
+ * (4 reads); every load of a lane is independent of the other lanes, nothing is exchanged but the 16-lane sum. */
+__global__ void __launch_bounds__(256) mrp_pack_kernel(const PlaneCol *__restrict__ pcols, const int32_t *__restrict__ list,
+                                                       int64_t n_list, const int64_t *__restrict__ read_byte_off,
+                                                       uint32_t *__restrict__ slot_total, uint32_t *__restrict__ slot_bytes) {
+    const int64_t q = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int w = threadIdx.x & 15;
+    if (q >= n_list) return;
+    const PlaneCol c = pcols[list ? list[q] : q];
+    int64_t off[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int read = 4 * w + r;
+        off[r] = read < c.depth ? read_byte_off[c.read_off + read] : -1;
+    }
+    for (int s = 0; s < c.n_slots; s++) {
+        uint32_t packed = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if (off[r] >= 0) packed |= (uint32_t) c.pool[off[r] + s] << (8 * r);
+        slot_bytes[(c.slot_off + s) * 16 + w] = packed;
+        uint32_t total = __builtin_amdgcn_udot4(packed, 0x01010101u, 0u, false);
+        total += __shfl_xor(total, 1, WAVE);
+        total += __shfl_xor(total, 2, WAVE);
+        total += __shfl_xor(total, 4, WAVE);
+        total += __shfl_xor(total, 8, WAVE);
+        if (w == 0) slot_total[c.slot_off + s] = total;
+    }
 }
 
 hipError_t mrp_launch_planes(const MrpBatchDev &d, hipStream_t stream) {
     if (d.n_cols == 0) return hipSuccess;
     const int waves = 4;
-    int64_t grid = (d.n_cols + waves - 1) / waves;
-    if (grid > MRP_PERSISTENT_GRID) grid = MRP_PERSISTENT_GRID;
-    hipLaunchKernelGGL(mrp_planes_kernel, dim3((unsigned) grid), dim3(waves * WAVE), 0, stream, d.pcols, d.n_cols,
-                       d.read_byte_off, d.planes, d.slot_total, d.slot_bytes);
+    const bool split = d.pack_list != nullptr || d.plane_list != nullptr;
+    const int64_t n_planes = split ? d.n_plane_list : d.n_cols;
+    if (n_planes > 0) {
+        int64_t grid = (n_planes + waves - 1) / waves;
+        if (grid > MRP_PERSISTENT_GRID) grid = MRP_PERSISTENT_GRID;
+        hipLaunchKernelGGL(mrp_planes_kernel, dim3((unsigned) grid), dim3(waves * WAVE), 0, stream, d.pcols,
+                           split ? d.plane_list : (const int32_t *) nullptr, n_planes, d.read_byte_off, d.planes, d.slot_total,
+                           d.slot_bytes);
+    }
+    if (split && d.n_pack_list > 0) {
+        const int64_t grid = (d.n_pack_list * 16 + 255) / 256;
+        hipLaunchKernelGGL(mrp_pack_kernel, dim3((unsigned) grid), dim3(256), 0, stream, d.pcols, d.pack_list, d.n_pack_list,
+                           d.read_byte_off, d.slot_total, d.slot_bytes);
+    }
     return hipGetLastError();
 }
 

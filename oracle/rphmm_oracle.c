@@ -683,7 +683,7 @@ orc_hmm *orc_hmm_createCrossProductOfTwoAlignedHmm(orc_hmm *h1, orc_hmm *h2) { /
 /* hmm.c: forward / backward (the hot path)                                                    */
 /* ------------------------------------------------------------------------------------------ */
 static orc_fb_observer g_observer; static void *g_observer_user;
-static double g_fb_seconds; static int64_t g_fb_calls;
+static __thread double g_fb_seconds; static __thread int64_t g_fb_calls; /* per thread: one chunk per thread (phase.c:276) */
 void orc_set_fb_observer(orc_fb_observer fn, void *user) { g_observer = fn; g_observer_user = user; }
 void orc_fb_timer_reset(void) { g_fb_seconds = 0.0; g_fb_calls = 0; }
 double orc_fb_timer_seconds(void) { return g_fb_seconds; }
