@@ -260,6 +260,61 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
                          const int64_t *n_reads, const mrp_params *params, mrp_phase_result **out,
                          mrp_phase_many_stats *stats);
 
+/* ---- the frame around the path: host code, no device needed ----------------------- */
+
+/* BubbleGraph (inc/margin.h) as flat arrays: what bubbleGraph_getProfileSeqs / bubbleGraph_getReference read */
+typedef struct mrp_bubbles {
+    int64_t n_bubbles;
+    const uint32_t *allele_number;     /* [n_bubbles] Bubble.alleleNo */
+    const int64_t *read_off;           /* [n_bubbles + 1] prefix sum of Bubble.readNo */
+    const int32_t *reads;              /* read index of Bubble.reads[j]->read */
+    const int64_t *support_off;        /* [n_bubbles + 1] prefix sum of alleleNo * readNo */
+    const float *allele_read_supports; /* per bubble Bubble.alleleReadSupports[readNo * k + j] */
+} mrp_bubbles;
+
+/* bubbleGraph_getReference (bubbleGraph.c:2443-2474): the site tables mrp_chunk_create takes (malloc'd, mrp_free) */
+int mrp_reference_from_bubbles(const mrp_bubbles *bg, double het_substitution_probability, uint32_t **allele_number_out,
+                               uint16_t **substitution_out, uint16_t **prior_out);
+/* bubbleGraph_getProfileSeqs (bubbleGraph.c:2356-2441): one profile sequence per read that is in some bubble, in order
+ * of first appearance, its bytes in one pool (mrp_read.pool_offset).  read_of_seq_out[s] = read index of sequence s. */
+int mrp_profile_seqs_from_bubbles(const mrp_bubbles *bg, int64_t n_reads, const char *const *read_names,
+                                  const int32_t *forward_strand, mrp_read **seqs_out, int32_t **read_of_seq_out,
+                                  int64_t *n_seqs_out, uint8_t **pool_out, int64_t *pool_bytes_out);
+
+/* stGenomeFragment_phaseBamChunkReads (genomeFragment.c:234-276): hap_out[r] = 1 / 2, 0 = in the fragment but below
+ * minPhredScoreForHaplotypePartition, -1 = not in the fragment; phred_out (optional) the score of :260 */
+int mrp_assign_reads_to_haplotypes(int64_t n_sites, const uint32_t *allele_number, const uint8_t *profile_pool,
+                                   const mrp_read *reads, int64_t n_reads, const mrp_phase_result *gf, int64_t min_phred,
+                                   int8_t *hap_out, double *phred_out);
+
+/* chunkToStitch_phaseAdjacentChunks (stitching.c:345-403): the read sets seen so far per haplotype, and the decision
+ * whether the next chunk keeps its relative phasing (cis) or is switched (trans).  counts = cisH1, cisH2, transH1, transH2 */
+typedef struct mrp_stitch mrp_stitch;
+int mrp_stitch_create(mrp_stitch **out);
+void mrp_stitch_destroy(mrp_stitch *s);
+int mrp_stitch_chunk(mrp_stitch *s, int64_t n1, const char *const *names1, const double *probs1, int64_t n2,
+                     const char *const *names2, const double *probs2, int primary_reads_only, int do_not_switch,
+                     int *switched, int64_t counts[4]);
+int64_t mrp_stitch_size(const mrp_stitch *s, int hap);
+int mrp_stitch_lookup(const mrp_stitch *s, int hap, const char *name, double *prob);
+
+/* writePhasedVcf's phase set rules (vcf.c:869-953) over the variants of one contig that margin updated */
+typedef struct mrp_variant {
+    int32_t pos;                    /* VcfEntry.refPos */
+    int32_t gt1, gt2;               /* called genotype (allele indices) */
+    int32_t n_alleles;
+    const int64_t *allele_read_off; /* [n_alleles + 1] */
+    const int32_t *allele_reads;    /* VcfEntry.alleleIdxToReads, read ids */
+} mrp_variant;
+#define MRP_PS_SAME 0                 /* stays in the current phase set */
+#define MRP_PS_NO_HET 1               /* "NoHet" */
+#define MRP_PS_MISSING_CONCORDANCY 2  /* "MissingConcordancy" */
+#define MRP_PS_UNLIKELY_CONCORDANCY 3 /* "UnlikelyConcordancy" */
+#define MRP_PS_DISCORDANCY 4          /* "Discordancy" */
+int mrp_phase_sets(int64_t n_variants, const mrp_variant *v, int64_t min_spanning_reads, double min_binomial_read_split_likelihood,
+                   double max_discordant_ratio, int32_t *phase_set_out, int32_t *reason_out);
+double mrp_binomial_p_value(int64_t n, int64_t k); /* bubbleGraph.c:2876-2883 */
+
 #ifdef __cplusplus
 }
 #endif

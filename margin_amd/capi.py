@@ -27,7 +27,9 @@ EXPORTED_SYMBOLS = [
     "mrp_batch_add", "mrp_batch_upload", "mrp_batch_launch", "mrp_batch_download", "mrp_batch_destroy",
     "mrp_batch_stats", "mrp_count_bit_vectors", "mrp_emissions", "mrp_get_rp_hmms", "mrp_hmm_destroy", "mrp_free",
     "mrp_hmm_view", "mrp_hmm_forward_backward", "mrp_hmm_prune", "mrp_hmm_forward_trace_back", "mrp_phase_reads",
-    "mrp_phase_result_destroy", "mrp_get_rp_hmms_resident", "mrp_phase_reads_many",
+    "mrp_phase_result_destroy", "mrp_get_rp_hmms_resident", "mrp_phase_reads_many", "mrp_reference_from_bubbles",
+    "mrp_profile_seqs_from_bubbles", "mrp_assign_reads_to_haplotypes", "mrp_stitch_create", "mrp_stitch_destroy",
+    "mrp_stitch_chunk", "mrp_stitch_size", "mrp_stitch_lookup", "mrp_phase_sets", "mrp_binomial_p_value",
 ]
 
 
@@ -106,6 +108,16 @@ class PhaseManyStats(C.Structure):
                 ("cross_ms", C.c_double), ("sweep_ms", C.c_double), ("prune_ms", C.c_double)]
 
 
+class Bubbles(C.Structure):
+    _fields_ = [("n_bubbles", C.c_int64), ("allele_number", C.c_void_p), ("read_off", C.c_void_p), ("reads", C.c_void_p),
+                ("support_off", C.c_void_p), ("allele_read_supports", C.c_void_p)]
+
+
+class Variant(C.Structure):
+    _fields_ = [("pos", C.c_int32), ("gt1", C.c_int32), ("gt2", C.c_int32), ("n_alleles", C.c_int32),
+                ("allele_read_off", C.c_void_p), ("allele_reads", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -154,6 +166,19 @@ def load():
     L.mrp_phase_result_destroy.restype = None
     L.mrp_get_rp_hmms_resident.argtypes = [vp, vp, P(ReadRec), vp, i64, P(Params), P(P(vp)), P(i64)]
     L.mrp_phase_reads_many.argtypes = [vp, i64, P(vp), P(P(ReadRec)), P(i64), P(Params), P(P(PhaseResult)), P(PhaseManyStats)]
+    L.mrp_reference_from_bubbles.argtypes = [P(Bubbles), C.c_double, P(vp), P(vp), P(vp)]
+    L.mrp_profile_seqs_from_bubbles.argtypes = [P(Bubbles), i64, vp, vp, P(P(ReadRec)), P(vp), P(i64), P(vp), P(i64)]
+    L.mrp_assign_reads_to_haplotypes.argtypes = [i64, vp, vp, P(ReadRec), i64, P(PhaseResult), i64, vp, vp]
+    L.mrp_stitch_create.argtypes = [P(vp)]
+    L.mrp_stitch_destroy.argtypes = [vp]
+    L.mrp_stitch_destroy.restype = None
+    L.mrp_stitch_chunk.argtypes = [vp, i64, vp, vp, i64, vp, vp, C.c_int, C.c_int, P(C.c_int), vp]
+    L.mrp_stitch_size.argtypes = [vp, C.c_int]
+    L.mrp_stitch_size.restype = i64
+    L.mrp_stitch_lookup.argtypes = [vp, C.c_int, C.c_char_p, P(C.c_double)]
+    L.mrp_phase_sets.argtypes = [i64, P(Variant), i64, C.c_double, C.c_double, vp, vp]
+    L.mrp_binomial_p_value.argtypes = [i64, i64]
+    L.mrp_binomial_p_value.restype = C.c_double
     _lib = L
     return L
 
@@ -459,3 +484,129 @@ def phase_reads_many(ctx: Context, dchunks: Sequence[DeviceChunk], chunks: Seque
         out.append(_phase_result_dict(res[i].contents) if convert else None)
         L.mrp_phase_result_destroy(res[i])
     return out, st
+
+
+# ---- the frame around the path (rphmm_frame.c): host only -------------------------------------
+
+def _bubbles_struct(allele_number, bubble_reads, supports):
+    """allele_number[i]; bubble_reads[i] = list of read indices; supports[i] = float32 array [alleleNo][readNo]"""
+    an = np.ascontiguousarray(allele_number, dtype=np.uint32)
+    read_off = np.zeros(len(an) + 1, dtype=np.int64)
+    sup_off = np.zeros(len(an) + 1, dtype=np.int64)
+    for i, r in enumerate(bubble_reads):
+        read_off[i + 1] = read_off[i] + len(r)
+        sup_off[i + 1] = sup_off[i] + int(an[i]) * len(r)
+    reads = np.ascontiguousarray([x for r in bubble_reads for x in r], dtype=np.int32)
+    sup = np.ascontiguousarray(np.concatenate([np.asarray(s, dtype=np.float32).reshape(-1) for s in supports])
+                               if len(supports) else np.zeros(0, np.float32), dtype=np.float32)
+    b = Bubbles(len(an), an.ctypes.data, read_off.ctypes.data, reads.ctypes.data, sup_off.ctypes.data, sup.ctypes.data)
+    return b, (an, read_off, sup_off, reads, sup)
+
+
+def reference_from_bubbles(allele_number, bubble_reads, supports, het_substitution_probability):
+    L = load()
+    b, _keep = _bubbles_struct(allele_number, bubble_reads, supports)
+    an, sub, prior = C.c_void_p(), C.c_void_p(), C.c_void_p()
+    _check(L.mrp_reference_from_bubbles(C.byref(b), het_substitution_probability, C.byref(an), C.byref(sub), C.byref(prior)))
+    n = len(allele_number)
+    A = np.asarray(allele_number, dtype=np.int64)
+    out = (_as_np(an, n, np.uint32), _as_np(sub, int((A * A).sum()), np.uint16), _as_np(prior, int(A.sum()), np.uint16))
+    for p in (an, sub, prior):
+        L.mrp_free(p)
+    return out
+
+
+def profile_seqs_from_bubbles(allele_number, bubble_reads, supports, n_reads):
+    """-> (list of dict(read, ref_start, length, pool_offset), pool bytes)"""
+    L = load()
+    b, _keep = _bubbles_struct(allele_number, bubble_reads, supports)
+    seqs = C.POINTER(ReadRec)()
+    read_of = C.c_void_p()
+    n_seqs, pool_bytes = C.c_int64(0), C.c_int64(0)
+    pool = C.c_void_p()
+    _check(L.mrp_profile_seqs_from_bubbles(C.byref(b), n_reads, None, None, C.byref(seqs), C.byref(read_of), C.byref(n_seqs),
+                                           C.byref(pool), C.byref(pool_bytes)))
+    ro = _as_np(read_of, n_seqs.value, np.int32)
+    out = [dict(read=int(ro[i]), ref_start=int(seqs[i].ref_start), length=int(seqs[i].length), pool_offset=int(seqs[i].pool_offset))
+           for i in range(n_seqs.value)]
+    pb = _as_np(pool, pool_bytes.value, np.uint8)
+    L.mrp_free(seqs)
+    L.mrp_free(read_of)
+    L.mrp_free(pool)
+    return out, pb
+
+
+def assign_reads_to_haplotypes(allele_number, pool, recs, n_reads, gf: dict, min_phred: int):
+    """gf: dict(ref_start, length, hap1, hap2 (uint64 arrays), reads1, reads2) -> (hap int8[n_reads], phred f64[n_reads])"""
+    L = load()
+    an = np.ascontiguousarray(allele_number, dtype=np.uint32)
+    pl = np.ascontiguousarray(pool, dtype=np.uint8)
+    h1 = np.ascontiguousarray(gf["hap1"], dtype=np.uint64)
+    h2 = np.ascontiguousarray(gf["hap2"], dtype=np.uint64)
+    r1 = np.ascontiguousarray(gf["reads1"], dtype=np.int32)
+    r2 = np.ascontiguousarray(gf["reads2"], dtype=np.int32)
+    g = PhaseResult()
+    g.ref_start, g.length = int(gf["ref_start"]), int(gf["length"])
+    g.haplotype_string1 = C.cast(h1.ctypes.data, type(g.haplotype_string1))
+    g.haplotype_string2 = C.cast(h2.ctypes.data, type(g.haplotype_string2))
+    g.reads1 = C.cast(r1.ctypes.data, type(g.reads1))
+    g.reads2 = C.cast(r2.ctypes.data, type(g.reads2))
+    g.n_reads1, g.n_reads2 = len(r1), len(r2)
+    hap = np.zeros(n_reads, dtype=np.int8)
+    phred = np.zeros(n_reads, dtype=np.float64)
+    _check(L.mrp_assign_reads_to_haplotypes(len(an), an.ctypes.data, pl.ctypes.data, recs, n_reads, C.byref(g), int(min_phred),
+                                            hap.ctypes.data, phred.ctypes.data))
+    return hap, phred
+
+
+class Stitch:
+    def __init__(self):
+        self.h = C.c_void_p()
+        _check(load().mrp_stitch_create(C.byref(self.h)))
+
+    def chunk(self, hap1: dict, hap2: dict, primary_only=False, do_not_switch=False):
+        def pack(d):
+            names = [k.encode() for k in d]
+            arr = (C.c_char_p * max(len(names), 1))(*names)
+            pr = np.ascontiguousarray(list(d.values()), dtype=np.float64)
+            return arr, pr, names
+        a1, p1, k1 = pack(hap1)
+        a2, p2, k2 = pack(hap2)
+        sw = C.c_int(0)
+        counts = np.zeros(4, dtype=np.int64)
+        _check(load().mrp_stitch_chunk(self.h, len(hap1), a1, p1.ctypes.data, len(hap2), a2, p2.ctypes.data, int(primary_only),
+                                       int(do_not_switch), C.byref(sw), counts.ctypes.data))
+        return bool(sw.value), tuple(int(x) for x in counts)
+
+    def lookup(self, hap: int, name: str):
+        p = C.c_double(0)
+        return p.value if load().mrp_stitch_lookup(self.h, hap, name.encode(), C.byref(p)) else None
+
+    def size(self, hap: int) -> int:
+        return int(load().mrp_stitch_size(self.h, hap))
+
+    def close(self):
+        if self.h:
+            load().mrp_stitch_destroy(self.h)
+            self.h = None
+
+
+def phase_sets(variants, min_spanning, min_binomial, max_discordant):
+    """variants: list of dict(pos, gt1, gt2, alleleIdxToReads=[iterable of read ids per allele]) -> [(phase_set, reason code)]"""
+    L = load()
+    n = len(variants)
+    arr = (Variant * max(n, 1))()
+    keep = []
+    for i, v in enumerate(variants):
+        sets = [sorted(s) for s in v["alleleIdxToReads"]]
+        off = np.zeros(len(sets) + 1, dtype=np.int64)
+        for a, s_ in enumerate(sets):
+            off[a + 1] = off[a] + len(s_)
+        rd = np.ascontiguousarray([x for s_ in sets for x in s_], dtype=np.int32)
+        keep.append((off, rd))
+        arr[i].pos, arr[i].gt1, arr[i].gt2, arr[i].n_alleles = v["pos"], v["gt1"], v["gt2"], len(sets)
+        arr[i].allele_read_off, arr[i].allele_reads = off.ctypes.data, rd.ctypes.data
+    ps = np.zeros(n, dtype=np.int32)
+    rs = np.zeros(n, dtype=np.int32)
+    _check(L.mrp_phase_sets(n, arr, int(min_spanning), float(min_binomial), float(max_discordant), ps.ctypes.data, rs.ctypes.data))
+    return [(int(ps[i]), int(rs[i])) for i in range(n)]

@@ -216,12 +216,14 @@ static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     ENG_TRY(seg->n_cells.alloc((size_t) total_cols));
     ENG_TRY(seg->n_merge.alloc((size_t) total_cols));
 
+    const double tA = eng_now();
     int rc = mrp_batch_create(ctx, &L->b);
     if (rc != MRP_OK) return rc;
     mrp_batch *b = L->b;
     std::vector<int64_t> cell0((size_t) n), col0((size_t) n);
     rc = mrp_batch_add_resident_bulk(b, n, x, cell0.data(), col0.data());
     if (rc != MRP_OK) return rc;
+    const double tB = eng_now();
     std::vector<CrossCol> cc((size_t) total_cols);
     std::vector<PruneHmm> ph((size_t) n);
     std::vector<int32_t> col_hmm((size_t) total_cols);
@@ -266,8 +268,10 @@ static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     L->level_cells = b->stats.n_cells;
     L->level_merge = b->stats.n_merge_cells;
 
+    const double tC = eng_now();
     rc = mrp_batch_upload(b);
     if (rc != MRP_OK) return rc;
+    const double tD = eng_now();
     PruneParams pp = e->pp;
     pp.max_cells = 1; pp.max_merge = 1;
     for (size_t i = 0; i < b->hmms.size(); i++) {
@@ -296,6 +300,7 @@ static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     /* the pageable host vectors above are read by the queued copies: wait for them before they go out of scope */
     ENG_TRY(hipStreamSynchronize(s));
 
+    const double tE = eng_now();
     ENG_TRY(hipEventRecord(e->ev[0], s));
     ENG_TRY(mrp_launch_cross(L->d_cc.p, total_cols, b->d_partition.p, b->d_np.p, L->d_err.p, s));
     ENG_TRY(hipEventRecord(e->ev[1], s));
@@ -329,6 +334,9 @@ static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     }
     ENG_TRY(hipMemcpyAsync(L->err, L->d_err.p, 16, hipMemcpyDeviceToHost, s));
     L->t_launched = eng_now();
+    if (getenv("MRP_TIMING"))
+        fprintf(stderr, "    begin: checks+segment %.1f ms, bulk add %.1f, cross descriptors %.1f, batch upload %.1f, engine upload %.1f, launches %.1f\n",
+                tA - L->t_begin, tB - tA, tC - tB, tD - tC, tE - tD, L->t_launched - tE);
     e->cur = L.release();
     return MRP_OK;
 }

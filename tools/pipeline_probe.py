@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--repeat", type=int, default=2)
     ap.add_argument("--check-host", type=int, default=1, help="compare this many chunks with mrp_phase_reads")
     ap.add_argument("--check-oracle", type=int, default=0)
+    ap.add_argument("--groups", type=int, default=1, help="phase the chunks as this many concurrent batches (one host thread + context each)")
     args = ap.parse_args()
     pd = synth.shipped_phase_params()
     params = capi.Params.from_reference_names(pd)
@@ -41,6 +42,17 @@ def main():
     units = sum(c.units for c in chunks)
     for c in chunks:
         capi.read_records(c)
+    if args.groups > 1:
+        G = args.groups
+        gctx = [capi.Context(0) for _ in range(G)]
+        gd = [[capi.DeviceChunk.from_chunk(gctx[g], c) for c in chunks[g::G]] for g in range(G)]
+        for r in range(args.repeat):
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=G) as ex:
+                res = list(ex.map(lambda g: capi.phase_reads_many(gctx[g], gd[g], chunks[g::G], params, convert=False), range(G)))
+            dt = time.perf_counter() - t0
+            print(f"run {r} ({G} concurrent batches): {dt * 1e3:.1f} ms wall, {units / dt:.3e} units/s, device_ms per batch "
+                  f"{[round(x[1].device_ms, 1) for x in res]}", flush=True)
     for r in range(args.repeat):
         last = r + 1 == args.repeat
         t0 = time.perf_counter()
