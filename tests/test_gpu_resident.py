@@ -109,3 +109,65 @@ def test_resident_falls_back_outside_its_range(gpu_ctx, orc):
         assert (np.asarray(got[0][k]) == np.asarray(host[k])).all(), k
     assert got[0]["reads1"] == host["reads1"] and got[0]["reads2"] == host["reads2"]
     dchunk.close()
+
+
+def test_bubbles_to_haplotype_tags_end_to_end(gpu_ctx, orc):
+    """The whole chain a chunk goes through around and on the path: bubble graph -> profile sequences and site tables
+    (rphmm_frame.c) -> device-resident phasing -> read-to-haplotype assignment with phred scores, against the same chain
+    made of the oracles (frame_oracle.py builder -> rphmm_oracle phasing -> frame_oracle assignment)."""
+    from oracle import frame_oracle as fo
+    rng = np.random.default_rng(31)
+    n_sites, n_reads = 120, 90
+    truth = rng.integers(0, 2, size=n_sites)
+    spans, haps, strands = [], rng.integers(0, 2, size=n_reads), rng.integers(0, 2, size=n_reads)
+    for r in range(n_reads):
+        a = int(rng.integers(0, n_sites - 5))
+        spans.append((a, int(min(n_sites - 1, a + rng.integers(4, 40)))))
+    an, br, sup = [], [], []
+    for i in range(n_sites):
+        rs = [r for r, (a, b) in enumerate(spans) if a <= i <= b and (i in (a, b) or rng.random() < 0.9)]
+        s = np.zeros((2, len(rs)), dtype=np.float32)
+        for j, r in enumerate(rs):
+            allele = truth[i] if haps[r] == 0 else 1 - truth[i]
+            if rng.random() < 0.08:
+                allele = 1 - allele
+            s[allele, j] = np.float32(-rng.uniform(0.0, 0.3))
+            s[1 - allele, j] = np.float32(-rng.uniform(1.0, 9.0))
+        an.append(2); br.append(rs); sup.append(s)
+    # product chain
+    seqs, pool = capi.profile_seqs_from_bubbles(an, br, sup, n_reads)
+    a_num, sub, prior = capi.reference_from_bubbles(an, br, sup, 0.0)
+    off = np.concatenate([[0], np.cumsum(a_num)]).astype(np.int64)
+    reads = [synth.Read(name=f"r{q['read']:04d}", ref_start=q["ref_start"], length=q["length"], strand=int(strands[q["read"]]),
+                        hap=int(haps[q["read"]]), pool_off=q["pool_offset"], nbytes=int(off[q["ref_start"] + q["length"]] - off[q["ref_start"]]))
+             for q in seqs]
+    chunk = synth.Chunk(allele_number=a_num, allele_offset=off, sub=sub, prior=prior, pool=pool, reads=reads)
+    pd = _params()
+    params = capi.Params.from_reference_names(pd)
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    (got,), st = capi.phase_reads_many(gpu_ctx, [dchunk], [chunk], params)
+    assert st.resident == 1
+    recs, _ = capi.read_records(chunk)
+    hap, phred = capi.assign_reads_to_haplotypes(a_num, pool, recs, len(reads), got, min_phred=0)
+    # oracle chain
+    ref_seqs = fo.get_profile_seqs([fo.Bubble(2, rs, np.asarray(s).reshape(-1).tolist()) for rs, s in zip(br, sup)])
+    assert list(ref_seqs.keys()) == [q["read"] for q in seqs]
+    ref_pool = np.array([b for p in ref_seqs.values() for b in p["probs"]], dtype=np.uint8)
+    assert (ref_pool == pool).all()
+    oc = orc.OracleChunk(chunk)
+    ref = oc.phase(pd)
+    oc.close()
+    for k in PHASE_KEYS:
+        assert (np.asarray(got[k]) == np.asarray(ref[k])).all(), k
+    assert got["reads1"] == ref["reads1"] and got["reads2"] == ref["reads2"]
+    pseqs = {i: dict(refStart=p["refStart"], length=p["length"], probs=p["probs"]) for i, p in enumerate(ref_seqs.values())}
+    ogf = dict(refStart=ref["ref_start"], length=ref["length"], hap1=ref["hap1"], hap2=ref["hap2"], reads1=set(ref["reads1"]),
+               reads2=set(ref["reads2"]))
+    h1, h2, ph = fo.phase_bam_chunk_reads(ogf, pseqs, off.tolist(), 0)
+    assert {i for i in range(len(reads)) if hap[i] == 1} == h1 and {i for i in range(len(reads)) if hap[i] == 2} == h2
+    assert all(phred[i] == ph[i] for i in ph)
+    # the phasing is meaningful: reads agree with their true haplotype up to the global label
+    agree = sum(1 for i, r in enumerate(reads) if hap[i] in (1, 2) and (hap[i] - 1) == r.hap)
+    tagged = int(((hap == 1) | (hap == 2)).sum())
+    assert max(agree, tagged - agree) >= 0.85 * tagged
+    dchunk.close()
