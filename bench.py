@@ -45,6 +45,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the end-to-end device-resident phasing leg")
     ap.add_argument("--pipeline-runs", type=int, default=3)
+    ap.add_argument("--pipeline-groups", type=int, default=2,
+                    help="phase the chunks as this many concurrent batches (one host thread + context each): the host work "
+                         "of one batch overlaps the device work of the other")
     ap.add_argument("--split", type=int, default=int(os.environ.get("MRP_BENCH_SPLIT", "1")),
                     help="record the chunks into this many device batches launched on separate streams (their kernels overlap)")
     return ap.parse_args()
@@ -198,27 +201,40 @@ def main():
         # mrp_phase_reads_many -- tiling paths, every merge level (cross product -> forward/backward -> prune, resident
         # in HBM), fused final sweep, trace back, genome fragments.  Wall clock around the C call, inputs (profile bytes,
         # site tables) already on the device; it is reported beside the headline value, not as it.
-        pdch = [capi.DeviceChunk.from_chunk(main_ctx, c) for c in host_chunks]
+        G = max(1, min(args.pipeline_groups, n_chunks))
+        gctx = [capi.Context(local_rank) for _ in range(G)]
+        gchunks = [host_chunks[g::G] for g in range(G)]
+        pdch = [[capi.DeviceChunk.from_chunk(gctx[g], c) for c in gchunks[g]] for g in range(G)]
         for c in host_chunks:
             capi.read_records(c)
-        capi.phase_reads_many(main_ctx, pdch, host_chunks, params, convert=False)  # warm-up: allocator cache, pinned buffers
+
+        def run_groups():
+            with ThreadPoolExecutor(max_workers=G) as ex:
+                return list(ex.map(lambda g: capi.phase_reads_many(gctx[g], pdch[g], gchunks[g], params, convert=False)[1], range(G)))
+
+        run_groups()  # warm-up: allocator cache, pinned buffers
         barrier()
         t0 = time.perf_counter()
-        pst = None
+        psts = None
         for _ in range(args.pipeline_runs):
-            _, pst = capi.phase_reads_many(main_ctx, pdch, host_chunks, params, convert=False)
+            psts = run_groups()
         barrier()
         p_el = time.perf_counter() - t0
         p_el, p_units = sharding.reduce_elapsed_and_units(dist, p_el, float(totals["units"]), device=reduce_dev)
         out["pipeline"] = dict(what="mrp_phase_reads_many: profile sequences -> haplotypes, all merge levels resident on the device",
                                value=p_units * args.pipeline_runs / p_el, unit="het-site-reads/s",
                                ms_per_batch=1e3 * p_el / args.pipeline_runs, chunks_per_gpu=n_chunks, runs=args.pipeline_runs,
-                               resident=int(pst.resident), levels=int(pst.levels), hmms=int(pst.hmms), columns=int(pst.columns),
-                               cells=int(pst.cells), device_ms=float(pst.device_ms), cross_ms=float(pst.cross_ms),
-                               sweep_ms=float(pst.sweep_ms), prune_ms=float(pst.prune_ms),
+                               concurrent_batches=G, resident=int(all(p.resident for p in psts)), levels=int(psts[0].levels),
+                               hmms=int(sum(p.hmms for p in psts)), columns=int(sum(p.columns for p in psts)),
+                               cells=int(sum(p.cells for p in psts)), device_ms=float(sum(p.device_ms for p in psts)),
+                               cross_ms=float(sum(p.cross_ms for p in psts)), sweep_ms=float(sum(p.sweep_ms for p in psts)),
+                               prune_ms=float(sum(p.prune_ms for p in psts)),
                                host_threads=int(os.environ.get("MRP_HOST_THREADS", "0")) or min(16, os.cpu_count() or 1))
-        for d_ in pdch:
-            d_.close()
+        for grp in pdch:
+            for d_ in grp:
+                d_.close()
+        for c_ in gctx:
+            c_.close()
 
     if rank == 0 and not args.no_cpu_baseline and n_gpus == 1:
         # CPU baseline: the oracle (C restatement of the reference's linked-list/hash implementation, -O3 -mpopcnt)
