@@ -171,3 +171,30 @@ def test_bubbles_to_haplotype_tags_end_to_end(gpu_ctx, orc):
     tagged = int(((hap == 1) | (hap == 2)).sum())
     assert max(agree, tagged - agree) >= 0.85 * tagged
     dchunk.close()
+
+
+@pytest.mark.parametrize("seed,maxp", [(21, 50), (22, 20), (23, 128)])
+def test_resident_unit_test_shape_max_mode(gpu_ctx, orc, seed, maxp):
+    """tests/stRPHmmTest.c-shaped input (1..9 alleles per site, so columns mix allele counts and take the general
+    emission path) in max-plus mode with the unit tests' trimming (min 0, max N): resident merge == oracle."""
+    chunk = synth.make_unit_test_chunk(seed=seed, ref_length=150, coverage=12, min_read=10, max_read=60, error_rate=0.05)
+    pd = synth.unit_test_params(max_partitions=maxp, max_not_sum=1)
+    oc = orc.OracleChunk(chunk)
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    params = capi.Params.from_reference_names(pd)
+    ref = oc.get_rp_hmms(orc.make_params(pd))
+    got = capi.get_rp_hmms_resident(gpu_ctx, dchunk, chunk, params)
+    assert len(ref) == len(got)
+    for hr, hg in zip(ref, got):
+        assert_same_hmm(orc.flatten(hr, oc.pool_off), capi.hmm_to_flat(hg), values=False)
+        capi.hmm_destroy(hg)
+    # and the whole driver (ancestor model in the final sweep: sites with up to 9 alleles)
+    pd2 = dict(pd, includeAncestorSubProb=1, roundsOfIterativeRefinement=3)
+    refp = oc.phase(pd2)
+    (gotp,), st = capi.phase_reads_many(gpu_ctx, [dchunk], [chunk], capi.Params.from_reference_names(pd2))
+    assert st.resident == 1
+    for k in PHASE_KEYS:
+        assert (np.asarray(gotp[k]) == np.asarray(refp[k])).all(), k
+    assert gotp["reads1"] == refp["reads1"] and gotp["reads2"] == refp["reads2"]
+    dchunk.close()
+    oc.close()
