@@ -1509,7 +1509,7 @@ static void r_free_tree(rnode_vec *t) {
 }
 
 /* run every merge node, level by level */
-static double g_t_prepare, g_t_level; /* MRP_TIMING diagnostics (single caller at a time) */
+static __thread double g_t_prepare, g_t_level; /* MRP_TIMING diagnostics of the calling thread */
 typedef struct {
     rnode_vec *t;
     int64_t node;
