@@ -13,7 +13,7 @@ from typing import Dict, List, Optional, Sequence
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libmargin_rphmm.so")
+LIB_PATH = os.environ.get("MRP_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libmargin_rphmm.so")
 
 MRP_OK = 0
 MRP_ERR_ARG, MRP_ERR_NO_DEVICE, MRP_ERR_HIP, MRP_ERR_NOMEM, MRP_ERR_UNSUPPORTED, MRP_ERR_LOOKUP = 1, 2, 3, 4, 5, 6

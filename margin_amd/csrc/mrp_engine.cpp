@@ -154,6 +154,7 @@ struct mrp_engine_level_state {
     uint64_t *path_part = nullptr; /* final level */
     double *fb = nullptr;
     bool final_level = false;
+    unsigned long long clk[12] = {0};
     mrp_xhmm *x = nullptr;
     int64_t n = 0, total_cols = 0, level_cells = 0, level_merge = 0;
     double t_begin = 0, t_launched = 0;
@@ -292,8 +293,8 @@ static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         ENG_TRY(L->d_nkept.alloc((size_t) total_cols));
         ENG_TRY(L->d_nkeptm.alloc((size_t) total_cols));
     }
-    ENG_TRY(L->d_err.alloc(4));
-    ENG_TRY(hipMemsetAsync(L->d_err.p, 0, 16, s));
+    ENG_TRY(L->d_err.alloc(64));
+    ENG_TRY(hipMemsetAsync(L->d_err.p, 0, 256, s));
     PruneScratch sc{};
     sc.kept = L->d_kept.p; sc.kept_np = L->d_kept_np.p; sc.keptm = L->d_keptm.p; sc.n_kept = L->d_nkept.p; sc.n_keptm = L->d_nkeptm.p;
     sc.err = L->d_err.p;
@@ -333,6 +334,9 @@ static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         ENG_TRY(hipMemcpyAsync(L->nm, seg->n_merge.p, sizeof(int32_t) * (size_t) total_cols, hipMemcpyDeviceToHost, s));
     }
     ENG_TRY(hipMemcpyAsync(L->err, L->d_err.p, 16, hipMemcpyDeviceToHost, s));
+#ifdef PRUNE_EXP_CLOCK
+    ENG_TRY(hipMemcpyAsync(L->clk, L->d_err.p + 4, 96, hipMemcpyDeviceToHost, s));
+#endif
     L->t_launched = eng_now();
     if (getenv("MRP_TIMING"))
         fprintf(stderr, "    begin: checks+segment %.1f ms, bulk add %.1f, cross descriptors %.1f, batch upload %.1f, engine upload %.1f, launches %.1f\n",
@@ -352,6 +356,11 @@ int mrp_engine_level_end(mrp_engine *e) {
     if (getenv("MRP_TIMING"))
         fprintf(stderr, "  level: %lld hmms %lld cols %lld cells: host build + upload %.1f ms, kernels (after launch) %.1f ms\n",
                 (long long) L->n, (long long) L->total_cols, (long long) L->level_cells, L->t_launched - L->t_begin, eng_now() - L->t_launched);
+#ifdef PRUNE_EXP_CLOCK
+    fprintf(stderr, "  prune clocks (wave 0 of every hmm, shader cycles):");
+    for (int i = 0; i < 12; i++) fprintf(stderr, " %llu", L->clk[i]);
+    fprintf(stderr, "\n");
+#endif
     if (L->err[0] & MRP_ENGINE_ERR_POSTERIOR) return mrp_set_error(MRP_ERR_ARG, "ERROR: invalid prob (f + b exceeds the column total)");
     if (L->err[0] & MRP_ENGINE_ERR_RANGE) return mrp_set_error(MRP_ERR_LOOKUP, "device-resident merge: transition index out of range");
     if (L->err[0] & MRP_ENGINE_ERR_STRUCTURE)

@@ -164,6 +164,13 @@ hipError_t mrp_launch_cross(const CrossCol *cols_dev, int64_t n_cols, uint64_t *
 /* ------------------------------------------------------------------------------------------ */
 /* prune                                                                                       */
 /* ------------------------------------------------------------------------------------------ */
+/* profiling aid: build with -DPRUNE_EXP_CLOCK to sum the shader cycles wave 0 spends in each section of a column
+ * (read back and printed by mrp_engine.cpp; profiles/r01/prune_sections_v3.txt) */
+#ifdef PRUNE_EXP_CLOCK
+#define CLK(slot) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (wave == 0) clk[slot] += t_ - tlast; tlast = t_; } while (0)
+#else
+#define CLK(slot) do { } while (0)
+#endif
 #define PRUNE_CPT 16 /* cells per lane held in registers: a column has at most 16 * (threads of the workgroup) cells */
 
 /* n kept of n_link candidates whose first g pass the posterior threshold: the loop of hmm.c:1073-1079 /
@@ -239,6 +246,10 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
     int errbits = 0;
+#ifdef PRUNE_EXP_CLOCK
+    uint64_t clk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tlast = __builtin_amdgcn_s_memtime();
+#endif
 
     for (int64_t hi_ = blockIdx.x; hi_ < n_hmms; hi_ += gridDim.x) {
         const PruneHmm h = k_load(hmms + hi_);
@@ -277,6 +288,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
         /* ---- stRPHmm_pruneForwards hmm.c:1049-1109 ---- */
         for (int k = 0; k < K; k++) {
             uint32_t *hk = hist + (k & 1) * nb_r;
+            CLK(0);
             PRUNE_SHARE(col, lo, hi, nj)
             /* [A] linked cells (getLinkedCells :1021-1047) in list order, posterior bins, histogram */
             int cnt = 0;
@@ -304,6 +316,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
                 }
             }
             if (lane == 0) sh[wave] = (uint32_t) cnt;
+            CLK(1);
             /* the next column's cells are requested now and consumed after the two barriers below */
             const SweepCol cur = col;
             if (k + 1 < K) {
@@ -311,7 +324,9 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
                 PRUNE_SHARE(col, lo1, hi1, nj1)
                 PRUNE_LOAD(col, lo1, hi1, nj1)
             }
+            CLK(2);
             lds_barrier();
+            CLK(3);
             if (wave != 0) {
                 uint32_t *hn = hist + ((k + 1) & 1) * nb_r;
                 for (int i = tid - WAVE; i < nb_r; i += T - WAVE) hn[i] = 0;
@@ -353,6 +368,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
                 const int B = om ? __shfl(myB, src, WAVE) : -1;
                 const int quota = om ? __shfl(myQ, src, WAVE) : 0;
                 const int nG = n - quota;
+                CLK(4);
                 /* ordered selection over the wave segments (list order) */
                 {
                     int gc = 0, ec = 0;
@@ -381,6 +397,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
                         }
                     }
                 }
+                CLK(5);
                 /* stable descending sort of the kept cells (stList_sort :1071): smaller bin = larger posterior; the key
                  * bin | list position | cell is unique, so a bitonic sort in registers is stable by construction */
                 const int64_t lcol = h.col0 + k;
@@ -402,6 +419,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
                         sc.kept_np[lcol * S + i] = my_np[u];
                     }
                 }
+                CLK(6);
                 if (lane == 0) sc.n_kept[lcol] = n;
                 /* the kept flags of the previous merge column are no longer needed */
                 for (int i = lane; i < n_old; i += WAVE) flags[oldm[i]] = 0;
@@ -440,6 +458,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
                             mkey[u] = ((uint32_t) bin << 21) | ((uint32_t) pos << 14) | m;
                         }
                     }
+                    CLK(7);
                     const int gm = __popcll(__ballot(pass_thr[0] != 0)) + __popcll(__ballot(pass_thr[1] != 0));
                     mn = kept_count(mnl, gm, p.min_p, p.max_p);
                     /* stable descending sort by posterior (:1090), the first mn stay */
@@ -455,10 +474,12 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
                         }
                     }
                 }
+                CLK(8);
                 if (lane == 0) sc.n_keptm[lcol] = mn;
                 n_old = mn;
             }
             lds_barrier();
+            CLK(9);
         }
         /* clear the flags left by the last merge column (n_old is only maintained by wave 0) */
         if (wave == 0)
@@ -550,6 +571,11 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
     }
 #undef PRUNE_SHARE
 #undef PRUNE_LOAD
+#ifdef PRUNE_EXP_CLOCK
+    CLK(10);
+    if (wave == 0 && lane == 0 && T == 1024)
+        for (int i = 0; i < 12; i++) atomicAdd((unsigned long long *) (sc.err + 4) + i, (unsigned long long) clk[i]);
+#endif
     if (errbits) atomicOr(sc.err, errbits);
 }
 
