@@ -188,26 +188,64 @@ static __device__ __forceinline__ int posterior_bin(int32_t f, int32_t b, int64_
     return s < n_bins - 1 ? (int) s : n_bins - 1;
 }
 
+/* Cross-lane primitives of the single-wave section, on the DPP path where gfx950 has one (tools/ubench/dpp_prims.hip
+ * checks them against the __shfl versions and times them: bitonic128 0.58 us vs 1.10 us, scan 0.07 vs 0.20 us). */
+template <int CTRL, int ROWMASK = 0xf>
+static __device__ __forceinline__ uint32_t dpp_mov(uint32_t x) {
+    return (uint32_t) __builtin_amdgcn_update_dpp(0, (int) x, CTRL, ROWMASK, 0xf, false);
+}
+static __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
+    int t;
+    t = (int) dpp_mov<0x111>((uint32_t) v) + v; if ((lane & 15) >= 1) v = t;       /* row_shr:1 */
+    t = (int) dpp_mov<0x112>((uint32_t) v) + v; if ((lane & 15) >= 2) v = t;
+    t = (int) dpp_mov<0x114>((uint32_t) v) + v; if ((lane & 15) >= 4) v = t;
+    t = (int) dpp_mov<0x118>((uint32_t) v) + v; if ((lane & 15) >= 8) v = t;
+    t = (int) dpp_mov<0x142, 0xa>((uint32_t) v) + v; if ((lane & 31) >= 16) v = t; /* row_bcast:15 */
+    t = (int) dpp_mov<0x143, 0xc>((uint32_t) v) + v; if (lane >= 32) v = t;        /* row_bcast:31 */
+    return v;
+}
+template <int J>
+static __device__ __forceinline__ uint32_t lane_xor(uint32_t x, int lane) {
+    if (J == 1) return dpp_mov<0xB1>(x); /* quad_perm [1,0,3,2] */
+    if (J == 2) return dpp_mov<0x4E>(x); /* quad_perm [2,3,0,1] */
+    if (J == 4) { const uint32_t a = dpp_mov<0x104>(x), b = dpp_mov<0x114>(x); return (lane & 4) ? b : a; } /* row_shl:4 / row_shr:4 */
+    if (J == 8) { const uint32_t a = dpp_mov<0x108>(x), b = dpp_mov<0x118>(x); return (lane & 8) ? b : a; }
+    return (uint32_t) __shfl_xor((int) x, J, WAVE);
+}
 /* Ascending bitonic sort of 128 distinct keys held two per lane (index lane and lane + 64) by one wave. */
-static __device__ __forceinline__ void wave_bitonic_sort128(uint32_t &k0, uint32_t &k1, int lane) {
-#pragma unroll
-    for (int k = 2; k <= 128; k <<= 1) {
-#pragma unroll
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            if (j == 64) { /* k == 128: the partner is the lane's other key */
-                const uint32_t lo = k0 < k1 ? k0 : k1, hi = k0 < k1 ? k1 : k0;
-                k0 = lo; k1 = hi;
-            } else {
-                const uint32_t p0 = __shfl_xor(k0, j, WAVE), p1 = __shfl_xor(k1, j, WAVE);
-                const bool lower = (lane & j) == 0;
-                const bool asc0 = (lane & k) == 0, asc1 = ((lane + 64) & k) == 0;
-                const uint32_t mn0 = k0 < p0 ? k0 : p0, mx0 = k0 < p0 ? p0 : k0;
-                const uint32_t mn1 = k1 < p1 ? k1 : p1, mx1 = k1 < p1 ? p1 : k1;
-                k0 = (lower == asc0) ? mn0 : mx0;
-                k1 = (lower == asc1) ? mn1 : mx1;
-            }
-        }
+template <int K, int J>
+static __device__ __forceinline__ void bitonic_step(uint32_t &k0, uint32_t &k1, int lane) {
+    if (J == 64) { /* K == 128: the partner is the lane's other key */
+        const uint32_t lo = k0 < k1 ? k0 : k1, hi = k0 < k1 ? k1 : k0;
+        k0 = lo; k1 = hi;
+    } else {
+        const uint32_t p0 = lane_xor<J>(k0, lane), p1 = lane_xor<J>(k1, lane);
+        const bool lower = (lane & J) == 0;
+        const bool asc0 = (lane & K) == 0, asc1 = ((lane + 64) & K) == 0;
+        const uint32_t mn0 = k0 < p0 ? k0 : p0, mx0 = k0 < p0 ? p0 : k0;
+        const uint32_t mn1 = k1 < p1 ? k1 : p1, mx1 = k1 < p1 ? p1 : k1;
+        k0 = (lower == asc0) ? mn0 : mx0;
+        k1 = (lower == asc1) ? mn1 : mx1;
     }
+}
+template <int K>
+static __device__ __forceinline__ void bitonic_merge(uint32_t &k0, uint32_t &k1, int lane) {
+    if (K >= 128) bitonic_step<K, 64>(k0, k1, lane);
+    if (K >= 64) bitonic_step<K, 32>(k0, k1, lane);
+    if (K >= 32) bitonic_step<K, 16>(k0, k1, lane);
+    if (K >= 16) bitonic_step<K, 8>(k0, k1, lane);
+    if (K >= 8) bitonic_step<K, 4>(k0, k1, lane);
+    if (K >= 4) bitonic_step<K, 2>(k0, k1, lane);
+    bitonic_step<K, 1>(k0, k1, lane);
+}
+static __device__ __forceinline__ void wave_bitonic_sort128(uint32_t &k0, uint32_t &k1, int lane) {
+    bitonic_merge<2>(k0, k1, lane);
+    bitonic_merge<4>(k0, k1, lane);
+    bitonic_merge<8>(k0, k1, lane);
+    bitonic_merge<16>(k0, k1, lane);
+    bitonic_merge<32>(k0, k1, lane);
+    bitonic_merge<64>(k0, k1, lane);
+    bitonic_merge<128>(k0, k1, lane);
 }
 
 /* One workgroup per hmm.  Per column there are two phases separated by a barrier each:
@@ -262,6 +300,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
         uint32_t r_np[PRUNE_CPT];
         int32_t r_f[PRUNE_CPT], r_b[PRUNE_CPT];
         SweepCol col = k_load(d.scols + h.col0);
+        SweepCol col_next = K > 1 ? k_load(d.scols + h.col0 + 1) : col;
         /* this wave's share of the column: [lo, hi), 64 cells per step */
 #define PRUNE_SHARE(colv, lo_, hi_v, nj_)                                                     \
         const int per_##nj_ = (((colv).n_cells + W - 1) / W + 63) & ~63;                      \
@@ -320,7 +359,8 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
             /* the next column's cells are requested now and consumed after the two barriers below */
             const SweepCol cur = col;
             if (k + 1 < K) {
-                col = k_load(d.scols + h.col0 + k + 1);
+                col = col_next; /* its descriptor was requested one column ago */
+                if (k + 2 < K) col_next = k_load(d.scols + h.col0 + k + 2);
                 PRUNE_SHARE(col, lo1, hi1, nj1)
                 PRUNE_LOAD(col, lo1, hi1, nj1)
             }
@@ -334,39 +374,54 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
                 /* [B] cutoff bin and quota */
                 int n_link = 0;
                 for (int w = 0; w < W; w++) n_link += (int) sh[w];
-                const int bpl = nb_r / WAVE;
-                int tot = 0, pass = 0;
-                for (int q = 0; q < bpl; q++) {
-                    const int bb = lane * bpl + q;
-                    const int v = bb < nb ? (int) hk[bb] : 0;
-                    tot += v;
-                    if (bb <= p.thr_bin) pass += v;
-                }
-                int incl = tot, g = pass;
-#pragma unroll
-                for (int o = 1; o < WAVE; o <<= 1) {
-                    const int t = __shfl_up(incl, o, WAVE);
-                    if (lane >= o) incl += t;
-                }
-#pragma unroll
-                for (int o = 32; o > 0; o >>= 1) g += __shfl_xor(g, o, WAVE);
-                const int n = kept_count(n_link, g, p.min_p, p.max_p);
-                const int ex = incl - tot;
-                int myB = -1, myQ = 0;
-                const bool owner = n > 0 && ex < n && n <= incl;
-                if (owner) {
-                    int cum = ex;
+                int n, B = -1, quota = 0;
+                if (p.thr_bin >= nb - 1) {
+                    /* no posterior threshold in force (shipped parameters): every linked cell passes it, and the cutoff is
+                     * found by walking the histogram 64 bins at a time -- it almost always lies in the first few chunks */
+                    n = kept_count(n_link, n_link, p.min_p, p.max_p);
+                    int cum = 0;
+                    for (int c0 = 0; n > 0 && c0 < nb_r; c0 += WAVE) {
+                        const int v = (int) hk[c0 + lane];
+                        const int incl = wave_incl_scan(v, lane);
+                        const uint64_t hit = __ballot(cum + incl >= n);
+                        if (hit) {
+                            const int src = __ffsll((unsigned long long) hit) - 1;
+                            const int before = cum + __shfl(incl - v, src, WAVE);
+                            B = c0 + src;
+                            quota = n - before;
+                            break;
+                        }
+                        cum += __shfl(incl, WAVE - 1, WAVE);
+                    }
+                } else {
+                    const int bpl = nb_r / WAVE;
+                    int tot = 0, pass = 0;
                     for (int q = 0; q < bpl; q++) {
                         const int bb = lane * bpl + q;
                         const int v = bb < nb ? (int) hk[bb] : 0;
-                        if (cum + v >= n) { myB = bb; myQ = n - cum; break; }
-                        cum += v;
+                        tot += v;
+                        if (bb <= p.thr_bin) pass += v;
                     }
+                    const int incl = wave_incl_scan(tot, lane);
+                    const int g = __shfl(wave_incl_scan(pass, lane), WAVE - 1, WAVE);
+                    n = kept_count(n_link, g, p.min_p, p.max_p);
+                    const int ex = incl - tot;
+                    int myB = -1, myQ = 0;
+                    const bool owner = n > 0 && ex < n && n <= incl;
+                    if (owner) {
+                        int cum = ex;
+                        for (int q = 0; q < bpl; q++) {
+                            const int bb = lane * bpl + q;
+                            const int v = bb < nb ? (int) hk[bb] : 0;
+                            if (cum + v >= n) { myB = bb; myQ = n - cum; break; }
+                            cum += v;
+                        }
+                    }
+                    const uint64_t om = __ballot(owner);
+                    const int src = om ? __ffsll((unsigned long long) om) - 1 : 0;
+                    B = om ? __shfl(myB, src, WAVE) : -1;
+                    quota = om ? __shfl(myQ, src, WAVE) : 0;
                 }
-                const uint64_t om = __ballot(owner);
-                const int src = om ? __ffsll((unsigned long long) om) - 1 : 0;
-                const int B = om ? __shfl(myB, src, WAVE) : -1;
-                const int quota = om ? __shfl(myQ, src, WAVE) : 0;
                 const int nG = n - quota;
                 CLK(4);
                 /* ordered selection over the wave segments (list order) */
@@ -401,19 +456,34 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
                 /* stable descending sort of the kept cells (stList_sort :1071): smaller bin = larger posterior; the key
                  * bin | list position | cell is unique, so a bitonic sort in registers is stable by construction */
                 const int64_t lcol = h.col0 + k;
-                uint32_t key[2], my_np[2], my_c[2];
+                uint32_t key[2], my_np[2], my_c[2], my_src[2];
+                int32_t pre_mf[2] = {0, 0}, pre_mb[2] = {0, 0};
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const int i = lane + u * WAVE;
                     key[u] = i < nG ? ((gsel[i] >> 16) << 21) | ((uint32_t) i << 14) | (gsel[i] & 0x3FFFu) : 0xFFFFFFFFu;
+                    /* the posteriors of the merge cells the selected cells lead to are requested now, for the selection in
+                     * its unsorted order, and consumed after the sort (slot i of the selection = um[i] below) */
+                    if (k + 1 < K && i < n) {
+                        const uint32_t m = (i < nG ? gnp[i] : enp[i - nG]) & 0xFFFFu;
+                        pre_mf[u] = d.merge_f32[cur.mcell_off + m];
+                        pre_mb[u] = d.merge_b32[cur.mcell_off + m];
+                    }
                 }
                 wave_bitonic_sort128(key[0], key[1], lane);
+                if (k + 1 < K) {
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int i = lane + u * WAVE;
+                        if (i < n) um[i] = (uint32_t) posterior_bin(pre_mf[u], pre_mb[u], total, nb, &errbits);
+                    }
+                }
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const int i = lane + u * WAVE;
-                    if (i < nG) { my_c[u] = key[u] & 0x3FFFu; my_np[u] = gnp[(key[u] >> 14) & 0x7Fu]; }
-                    else if (i < n) { my_c[u] = esel[i - nG]; my_np[u] = enp[i - nG]; }
-                    else { my_c[u] = 0u; my_np[u] = 0u; }
+                    if (i < nG) { my_c[u] = key[u] & 0x3FFFu; my_np[u] = gnp[(key[u] >> 14) & 0x7Fu]; my_src[u] = (key[u] >> 14) & 0x7Fu; }
+                    else if (i < n) { my_c[u] = esel[i - nG]; my_np[u] = enp[i - nG]; my_src[u] = (uint32_t) i; }
+                    else { my_c[u] = 0u; my_np[u] = 0u; my_src[u] = 0u; }
                     if (i < n) {
                         sc.kept[lcol * S + i] = (uint16_t) my_c[u];
                         sc.kept_np[lcol * S + i] = my_np[u];
@@ -453,7 +523,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
                         if (first[u]) {
                             const int pos = u == 0 ? (int) lanemask_lt_count(f0, lane) : __popcll(f0) + (int) lanemask_lt_count(f1, lane);
                             const uint32_t m = my_np[u] & 0xFFFFu;
-                            const int bin = posterior_bin(d.merge_f32[cur.mcell_off + m], d.merge_b32[cur.mcell_off + m], total, nb, &errbits);
+                            const int bin = (int) um[my_src[u]]; /* gathered before the sort */
                             pass_thr[u] = bin <= p.thr_bin ? 1 : 0;
                             mkey[u] = ((uint32_t) bin << 21) | ((uint32_t) pos << 14) | m;
                         }
@@ -595,6 +665,8 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const PruneHmm *hmms_dev, int6
     }
     if (lds > (size_t) MRP_LDS_BUDGET) return hipErrorInvalidValue;
     const dim3 grid((unsigned) (n_hmms < 65536 ? n_hmms : 65536));
+    /* 1 024 threads for the big columns even when fewer would hold them: the per-wave share of phase [A] is what the
+     * column's critical path waits for (640 threads measured 8 % slower) */
     if (p.max_cells <= 256 * PRUNE_CPT)
         hipLaunchKernelGGL(mrp_prune_kernel<256>, grid, dim3(256), lds, stream, d, hmms_dev, n_hmms, p, s);
     else
