@@ -198,3 +198,28 @@ def test_resident_unit_test_shape_max_mode(gpu_ctx, orc, seed, maxp):
     assert gotp["reads1"] == refp["reads1"] and gotp["reads2"] == refp["reads2"]
     dchunk.close()
     oc.close()
+
+
+def test_resident_full_size_config2_chunk(gpu_ctx, orc):
+    """BASELINE.json configs[1] at full size (1 Mb, 2 000 het sites, 30x): the resident pipeline's haplotypes, genotype
+    calls and read bipartition against the oracle, next to a second full-size chunk sharing the launches."""
+    chunks = [synth.make_ont_chunk(seed=s, region_bp=1_000_000, n_sites=2000, coverage=30.0) for s in (1, 2)]
+    pd = _params()
+    params = capi.Params.from_reference_names(pd)
+    dchunks = [capi.DeviceChunk.from_chunk(gpu_ctx, c) for c in chunks]
+    got, st = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
+    assert st.resident == 1 and st.cells > 10_000_000
+    oc = orc.OracleChunk(chunks[0])
+    ref = oc.phase(pd)
+    oc.close()
+    for k in PHASE_KEYS:
+        assert (np.asarray(got[0][k]) == np.asarray(ref[k])).all(), k
+    assert got[0]["reads1"] == ref["reads1"] and got[0]["reads2"] == ref["reads2"]
+    assert got[0]["n_sweeps"] == ref["fb_calls"]
+    # size-independent property on the second chunk: hap2 is the complement call wherever the genotype is heterozygous
+    g = got[1]
+    het = np.asarray(g["hap1"]) != np.asarray(g["hap2"])
+    assert het.mean() > 0.9 and len(set(g["reads1"]) & set(g["reads2"])) == 0
+    assert len(g["reads1"]) + len(g["reads2"]) == len(chunks[1].reads)
+    for d in dchunks:
+        d.close()
