@@ -270,11 +270,8 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
     uint32_t *gnp = gsel + S;         /* [S] their next | prev << 16 */
     uint32_t *esel = gnp + S;         /* [S] selected candidates in the cutoff bin: cell */
     uint32_t *enp = esel + S;         /* [S] */
-    uint32_t *ksort = enp + S;        /* [S] kept cells in kept order */
-    uint32_t *knp = ksort + S;        /* [S] their next | prev << 16 */
-    uint32_t *um = knp + S;           /* [S] linked merge cells in first-occurrence order */
-    uint32_t *umbin = um + S;         /* [S] their posterior bins */
-    uint32_t *oldm = umbin + S;       /* [S] kept merge cells of the previous merge column (flag owners) */
+    uint32_t *um = enp + S;           /* [S] posterior bin of the merge cell each selected cell leads to (selection order) */
+    uint32_t *oldm = um + S;          /* [S] kept merge cells of the previous merge column (flag owners) */
     uint32_t *sh = oldm + S;          /* [64] per-wave counters */
     uint32_t *hist = sh + 64;         /* [2][nb_r] */
     uint32_t *cand = hist + 2 * nb_r; /* [cap_c] linked cells of the column, list order per wave segment: bin << 16 | cell */
@@ -653,7 +650,7 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const PruneHmm *hmms_dev, int6
                             hipStream_t stream) {
     if (n_hmms <= 0) return hipSuccess;
     if (p.S > MRP_PRUNE_MAX_S || p.max_cells > MRP_PRUNE_MAX_CELLS || p.max_merge > MRP_PRUNE_MAX_CELLS || p.n_bins > 1024) return hipErrorInvalidValue;
-    const size_t lds = (size_t) (9 * p.S + 64 + 2 * ((p.n_bins + 63) & ~63) + 2 * ((std::max(p.max_cells, p.max_merge) + 3) & ~3)) * 4 +
+    const size_t lds = (size_t) (6 * p.S + 64 + 2 * ((p.n_bins + 63) & ~63) + 2 * ((std::max(p.max_cells, p.max_merge) + 3) & ~3)) * 4 +
                        (size_t) ((p.max_merge + 3) & ~3) + 16;
     static bool configured = false;
     if (!configured) {
