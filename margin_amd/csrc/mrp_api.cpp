@@ -478,7 +478,7 @@ int mrp_batch_add_resident_bulk(mrp_batch *b, int64_t n, const mrp_xhmm *x, int6
     /* pass 1: sizes per hmm */
     struct Sz { int64_t cells, merge, cols, reads, slots, tiles; int bad; };
     std::vector<Sz> sz((size_t) n);
-    mrp_parallel_for(n, 64, [&](int64_t i) {
+    mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
         const mrp_xhmm &h = x[i];
         const mrp_chunk *ch = h.chunk;
         Sz s{0, 0, h.n_cols, 0, 0, 0, 0};
@@ -516,7 +516,7 @@ int mrp_batch_add_resident_bulk(mrp_batch *b, int64_t n, const mrp_xhmm *x, int6
     std::vector<int> unsupported((size_t) n, 0);
     std::vector<int64_t> alg((size_t) n, 0), prof((size_t) n, 0), pops((size_t) n, 0);
     /* pass 2: descriptors */
-    mrp_parallel_for(n, 64, [&](int64_t i) {
+    mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
         const mrp_xhmm &xh = x[i];
         const mrp_chunk *ch = xh.chunk;
         const int K = xh.n_cols;
@@ -528,6 +528,8 @@ int mrp_batch_add_resident_bulk(mrp_batch *b, int64_t n, const mrp_xhmm *x, int6
         h.max_merge = 1;
         h.max_cells = 1;
         int64_t c_off = cell0[(size_t) i], m_off = mcell0[(size_t) i], s_off = slot0[(size_t) i], t_off = tile0[(size_t) i];
+        int64_t l_prof = 0, l_alg = 0, l_pops = 0;
+        int l_unsupported = 0;
         for (int k = 0; k < K; k++) {
             const int64_t col = col0[(size_t) i] + k;
             DevCol c{};
@@ -548,7 +550,7 @@ int mrp_batch_add_resident_bulk(mrp_batch *b, int64_t n, const mrp_xhmm *x, int6
                 if ((int32_t) ch->allele_number[c.site_start + s2] != uniform) uniform = 0;
             if (ancestor)
                 for (int s2 = 0; s2 < c.n_sites; s2++)
-                    if (ch->allele_number[c.site_start + s2] > MRP_MAX_ALLELES) unsupported[(size_t) i] = 1;
+                    if (ch->allele_number[c.site_start + s2] > MRP_MAX_ALLELES) l_unsupported = 1;
             for (int t0 = 0; t0 < c.n_cells; t0 += MRP_EMIT_TILE) {
                 EmitTile t{};
                 t.cell_off = c.cell_off + t0;
@@ -574,15 +576,17 @@ int mrp_batch_add_resident_bulk(mrp_batch *b, int64_t n, const mrp_xhmm *x, int6
             int64_t per_site = 255ll * c.depth;
             if (ancestor) per_site += 2ll * ch->max_sub + ch->max_prior;
             h.cost_bound += per_site * c.n_sites;
-            prof[(size_t) i] += (int64_t) c.depth * c.n_slots;
-            alg[(size_t) i] += 24ll * c.n_cells + 32ll * c.n_merge + (int64_t) c.depth * c.n_slots + 8;
-            pops[(size_t) i] += (int64_t) c.n_cells * 2 * c.n_slots * 8;
+            l_prof += (int64_t) c.depth * c.n_slots; /* (locals: neighbouring hmms are built by different threads) */
+            l_alg += 24ll * c.n_cells + 32ll * c.n_merge + (int64_t) c.depth * c.n_slots + 8;
+            l_pops += (int64_t) c.n_cells * 2 * c.n_slots * 8;
             c_off += c.n_cells; m_off += c.n_merge; s_off += c.n_slots;
         }
         h.n_cells = sz[(size_t) i].cells;
         h.n_merge = sz[(size_t) i].merge;
         h.wide_idx = h.max_merge > 65535 ? 1 : 0;
-        if (h.wide_idx) unsupported[(size_t) i] = 1;
+        if (h.wide_idx) l_unsupported = 1;
+        unsupported[(size_t) i] = l_unsupported;
+        prof[(size_t) i] = l_prof; alg[(size_t) i] = l_alg; pops[(size_t) i] = l_pops;
         b->hmms[(size_t) i] = h;
         if (sz[(size_t) i].reads > 0)
             memcpy(&b->read_byte_off[(size_t) read0[(size_t) i]], xh.read_byte_off, sizeof(int64_t) * (size_t) sz[(size_t) i].reads);
@@ -741,11 +745,11 @@ int mrp_batch_upload(mrp_batch *b) {
     d.n_merge = b->n_merge;
     d.n_slots = b->n_slots;
     /* host copies of the bulky inputs are no longer needed */
-    std::vector<uint64_t>().swap(b->partition);
-    std::vector<uint32_t>().swap(b->cell_next);
-    std::vector<uint32_t>().swap(b->cell_prev);
-    std::vector<uint32_t>().swap(b->cell_np);
-    std::vector<int64_t>().swap(b->read_byte_off);
+    HostVec<uint64_t>().swap(b->partition);
+    HostVec<uint32_t>().swap(b->cell_next);
+    HostVec<uint32_t>().swap(b->cell_prev);
+    HostVec<uint32_t>().swap(b->cell_np);
+    HostVec<int64_t>().swap(b->read_byte_off);
     b->uploaded = true;
     return MRP_OK;
 }

@@ -225,10 +225,10 @@ static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     rc = mrp_batch_add_resident_bulk(b, n, x, cell0.data(), col0.data());
     if (rc != MRP_OK) return rc;
     const double tB = eng_now();
-    std::vector<CrossCol> cc((size_t) total_cols);
-    std::vector<PruneHmm> ph((size_t) n);
-    std::vector<int32_t> col_hmm((size_t) total_cols);
-    mrp_parallel_for(n, 64, [&](int64_t i) {
+    HostVec<CrossCol> cc((size_t) total_cols); /* filled entirely below */
+    HostVec<PruneHmm> ph((size_t) n);
+    HostVec<int32_t> col_hmm((size_t) total_cols);
+    mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
         mrp_xhmm &h = x[i];
         const int K = h.n_cols;
         const int64_t colbase = col0[(size_t) i];

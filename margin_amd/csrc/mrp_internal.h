@@ -10,6 +10,9 @@
 #include <algorithm>
 #include <iterator>
 #include <map>
+#include <memory>
+#include <new>
+#include <type_traits>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -18,6 +21,17 @@
 #include "mrp_device.h"
 #include "mrp_kernels.h"
 #include "rphmm_host.h"
+
+/* std::vector whose resize() leaves trivially constructible elements uninitialised: the descriptor arrays of a level
+ * are tens of megabytes that the filling threads overwrite entirely; zero-filling them first is a serial pass. */
+template <class T>
+struct DefaultInitAllocator : std::allocator<T> {
+    template <class U> struct rebind { using other = DefaultInitAllocator<U>; };
+    using std::allocator<T>::allocator;
+    template <class U> void construct(U *p) noexcept(std::is_nothrow_default_constructible<U>::value) { ::new (static_cast<void *>(p)) U; }
+    template <class U, class... Args> void construct(U *p, Args &&...args) { ::new (static_cast<void *>(p)) U(std::forward<Args>(args)...); }
+};
+template <class T> using HostVec = std::vector<T, DefaultInitAllocator<T>>;
 
 /* Caching device allocator of a context.  hipMalloc / hipFree of multi-GB arrays cost hundreds of
  * milliseconds and hipFree synchronizes the device, so blocks are kept and handed out again by size
@@ -108,7 +122,8 @@ struct DevBuf {
         if (pool) return pool->alloc((void **) &p, bytes, &cls);
         return hipMalloc((void **) &p, bytes);
     }
-    hipError_t upload(const std::vector<T> &h, hipStream_t s) {
+    template <class A>
+    hipError_t upload(const std::vector<T, A> &h, hipStream_t s) {
         hipError_t e = alloc(h.size());
         if (e != hipSuccess || h.empty()) return e;
         return hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, s);
@@ -160,14 +175,14 @@ struct mrp_batch {
     mrp_context *ctx = nullptr;
     std::mutex mu; /* mrp_batch_add may be called from several host threads (recording) */
     std::vector<const mrp_chunk *> chunks;
-    std::vector<DevHmm> hmms;
-    std::vector<DevCol> cols;
-    std::vector<int64_t> read_byte_off;
-    std::vector<uint64_t> partition;
-    std::vector<SweepCol> scols;
-    std::vector<PlaneCol> pcols;
-    std::vector<uint32_t> cell_next, cell_prev, cell_np;
-    std::vector<EmitTile> tiles;
+    HostVec<DevHmm> hmms;
+    HostVec<DevCol> cols;
+    HostVec<int64_t> read_byte_off;
+    HostVec<uint64_t> partition;
+    HostVec<SweepCol> scols;
+    HostVec<PlaneCol> pcols;
+    HostVec<uint32_t> cell_next, cell_prev, cell_np;
+    HostVec<EmitTile> tiles;
     int64_t n_fast_tiles = 0;
     bool need_wide = false;
     std::vector<JobOut> outs;
