@@ -744,12 +744,12 @@ int mrp_batch_upload(mrp_batch *b) {
     d.n_cells = (int64_t) nC;
     d.n_merge = b->n_merge;
     d.n_slots = b->n_slots;
-    /* host copies of the bulky inputs are no longer needed */
+    /* host copies of the bulky inputs are no longer needed (a resident batch keeps its arrays' capacity for the next level) */
+    if (!b->resident) HostVec<int64_t>().swap(b->read_byte_off);
     HostVec<uint64_t>().swap(b->partition);
     HostVec<uint32_t>().swap(b->cell_next);
     HostVec<uint32_t>().swap(b->cell_prev);
     HostVec<uint32_t>().swap(b->cell_np);
-    HostVec<int64_t>().swap(b->read_byte_off);
     b->uploaded = true;
     return MRP_OK;
 }

@@ -49,6 +49,7 @@ struct mrp_engine {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     mrp_engine_stats stats{};
     struct mrp_engine_level_state *cur = nullptr; /* a level between begin and end */
+    mrp_batch *spare = nullptr;                   /* the batch object of the previous level, emptied */
 };
 
 static void mrp_engine_level_abandon(mrp_engine *e);
@@ -112,6 +113,7 @@ void mrp_engine_destroy(mrp_engine *e) {
         if (ev) (void) hipEventDestroy(ev);
     mrp_context *ctx = e->ctx;
     mrp_engine_level_abandon(e);
+    if (e->spare) mrp_batch_destroy(e->spare);
     delete e;
     ctx->pool.reclaim();
 }
@@ -158,8 +160,19 @@ struct mrp_engine_level_state {
     mrp_xhmm *x = nullptr;
     int64_t n = 0, total_cols = 0, level_cells = 0, level_merge = 0;
     double t_begin = 0, t_launched = 0;
+    mrp_engine *owner = nullptr;
     ~mrp_engine_level_state() {
-        if (b) mrp_batch_destroy(b); /* synchronizes the stream before the buffers go back to the pool */
+        if (!b) return;
+        mrp_context *ctx = b->ctx;
+        (void) hipSetDevice(ctx->device);
+        (void) hipStreamSynchronize(ctx->stream); /* before the buffers go back to the pool */
+        if (owner && !owner->spare) {
+            b->recycle();
+            owner->spare = b;
+        } else {
+            mrp_batch_destroy(b);
+        }
+        ctx->pool.reclaim();
     }
 };
 
@@ -218,7 +231,10 @@ static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     ENG_TRY(seg->n_merge.alloc((size_t) total_cols));
 
     const double tA = eng_now();
-    int rc = mrp_batch_create(ctx, &L->b);
+    int rc = MRP_OK;
+    L->owner = e;
+    if (e->spare) { L->b = e->spare; e->spare = nullptr; }
+    else rc = mrp_batch_create(ctx, &L->b);
     if (rc != MRP_OK) return rc;
     mrp_batch *b = L->b;
     std::vector<int64_t> cell0((size_t) n), col0((size_t) n);

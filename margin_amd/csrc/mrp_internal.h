@@ -208,6 +208,23 @@ struct mrp_batch {
     DevBuf<int32_t> d_order_wide, d_order_mid, d_order_narrow, d_order_f64, d_pack_list, d_plane_list;
     DevBuf<EmitTile> d_tiles;
     MrpBatchDev dev{};
+    /* back to the empty state, keeping the capacity of the host arrays (the resident engine reuses one batch object for
+     * all levels of a run: their descriptor arrays are tens of megabytes).  Only after the stream was synchronized. */
+    void recycle() {
+        d_hmms.release(); d_cols.release(); d_chunks.release(); d_read_byte_off.release(); d_partition.release(); d_planes.release();
+        d_scols.release(); d_pcols.release(); d_next.release(); d_prev.release(); d_np.release(); d_slot_total.release();
+        d_slot_bytes.release(); d_cost.release(); d_f.release(); d_b.release(); d_mf.release(); d_mb.release(); d_total.release();
+        d_hmm_fb.release(); d_f32.release(); d_b32.release(); d_mf32.release(); d_mb32.release(); d_order_wide.release();
+        d_order_mid.release(); d_order_narrow.release(); d_order_f64.release(); d_tiles.release(); d_pack_list.release(); d_plane_list.release();
+        chunks.clear(); hmms.clear(); cols.clear(); read_byte_off.clear(); partition.clear(); scols.clear(); pcols.clear();
+        cell_next.clear(); cell_prev.clear(); cell_np.clear(); tiles.clear(); outs.clear();
+        order_wide.clear(); order_mid.clear(); order_narrow.clear(); order_f64.clear();
+        n_fast_tiles = 0; need_wide = false; n_merge = 0; n_slots = 0; n_cells_total = 0; resident = false;
+        stats = mrp_launch_stats{};
+        max_merge_wide = max_merge_mid = max_merge_narrow = 1;
+        uploaded = launched = false;
+        dev = MrpBatchDev{};
+    }
     void bind_pool(DevPool *pl) {
         d_hmms.pool = pl; d_cols.pool = pl; d_chunks.pool = pl; d_read_byte_off.pool = pl; d_partition.pool = pl; d_planes.pool = pl;
         d_scols.pool = pl; d_pcols.pool = pl; d_next.pool = pl; d_prev.pool = pl; d_np.pool = pl; d_slot_total.pool = pl;
