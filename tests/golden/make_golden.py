@@ -52,5 +52,38 @@ def main():
         print(name, len(jobs), "jobs", sum(len(j["partition"]) for j in jobs), "cells")
 
 
+PHASE_CASES = {
+    # whole phasing runs (bubbleGraph.c:2673 driver): inputs incl. the read table, and every output of the driver
+    "phase_ont": (lambda: synth.make_ont_chunk(seed=43, region_bp=40_000, n_sites=80, coverage=24), synth.shipped_phase_params()),
+    "phase_unit_max": (lambda: synth.make_unit_test_chunk(seed=44, ref_length=60, coverage=10, min_read=8, max_read=30, error_rate=0.05),
+                       dict(synth.unit_test_params(max_partitions=40, max_not_sum=1), includeAncestorSubProb=1,
+                            roundsOfIterativeRefinement=2)),
+}
+PHASE_OUT = ["hap1", "hap2", "genotype", "ancestor", "genotype_probs", "hap_probs1", "hap_probs2", "support1", "support2"]
+
+
+def main_phase():
+    import json
+    for name, (factory, pd) in PHASE_CASES.items():
+        chunk = factory()
+        oc = orc.OracleChunk(chunk)
+        res = oc.phase(pd)
+        oc.close()
+        out = dict(allele_number=chunk.allele_number, sub=chunk.sub, prior=chunk.prior, pool=chunk.pool,
+                   read_ref_start=np.array([r.ref_start for r in chunk.reads], dtype=np.int32),
+                   read_length=np.array([r.length for r in chunk.reads], dtype=np.int32),
+                   read_strand=np.array([r.strand for r in chunk.reads], dtype=np.int32),
+                   read_pool_off=np.array([r.pool_off for r in chunk.reads], dtype=np.int64),
+                   read_names=np.array([r.name for r in chunk.reads]), params=np.array(json.dumps(pd)),
+                   ref_start=np.int64(res["ref_start"]), length=np.int64(res["length"]),
+                   reads1=np.array(res["reads1"], dtype=np.int64), reads2=np.array(res["reads2"], dtype=np.int64),
+                   fb_calls=np.int64(res["fb_calls"]))
+        for k in PHASE_OUT:
+            out[k] = np.asarray(res[k])
+        np.savez_compressed(os.path.join(HERE, f"{name}.npz"), **out)
+        print(name, len(chunk.reads), "reads", int(res["length"]), "sites", int(res["fb_calls"]), "sweeps")
+
+
 if __name__ == "__main__":
     main()
+    main_phase()
