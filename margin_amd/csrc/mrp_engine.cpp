@@ -284,6 +284,17 @@ static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     });
     L->level_cells = b->stats.n_cells;
     L->level_merge = b->stats.n_merge_cells;
+    /* the prune kernel walks one hmm per workgroup and its columns one after the other: longest hmms first, so that the
+     * launch does not end with a long chain that started late */
+    {
+        std::vector<int32_t> perm((size_t) n), pos((size_t) n);
+        for (int64_t i = 0; i < n; i++) perm[(size_t) i] = (int32_t) i;
+        std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t c) { return ph[(size_t) a].n_cols > ph[(size_t) c].n_cols; });
+        HostVec<PruneHmm> sorted((size_t) n);
+        for (int64_t j = 0; j < n; j++) { sorted[(size_t) j] = ph[(size_t) perm[(size_t) j]]; pos[(size_t) perm[(size_t) j]] = (int32_t) j; }
+        ph.swap(sorted);
+        mrp_parallel_for(total_cols, 65536, [&](int64_t c) { col_hmm[(size_t) c] = pos[(size_t) col_hmm[(size_t) c]]; });
+    }
 
     const double tC = eng_now();
     rc = mrp_batch_upload(b);
