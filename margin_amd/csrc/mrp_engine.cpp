@@ -307,6 +307,15 @@ static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         pp.max_cells = std::max(pp.max_cells, b->hmms[i].max_cells);
         pp.max_merge = std::max(pp.max_merge, b->hmms[i].max_merge);
     }
+    if (getenv("MRP_TIMING")) {
+        int64_t ns = 0, cs = 0, nb2 = 0, cb = 0, longest_s = 0, longest_b = 0;
+        for (size_t i = 0; i < b->hmms.size(); i++) {
+            if (b->hmms[i].max_cells <= 4096) { ns++; cs += b->hmms[i].n_cols; longest_s = std::max<int64_t>(longest_s, b->hmms[i].n_cols); }
+            else { nb2++; cb += b->hmms[i].n_cols; longest_b = std::max<int64_t>(longest_b, b->hmms[i].n_cols); }
+        }
+        fprintf(stderr, "    prune classes: <=4096 cells/column: %lld hmms %lld cols (longest %lld); larger: %lld hmms %lld cols (longest %lld)\n",
+                (long long) ns, (long long) cs, (long long) longest_s, (long long) nb2, (long long) cb, (long long) longest_b);
+    }
     DevPool *pl = &ctx->pool;
     L->d_cc.pool = pl; L->d_ph.pool = pl; L->d_col_hmm.pool = L->d_nkept.pool = L->d_nkeptm.pool = L->d_err.pool = pl;
     L->d_kept.pool = L->d_keptm.pool = pl; L->d_kept_np.pool = pl;

@@ -324,6 +324,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
         /* ---- stRPHmm_pruneForwards hmm.c:1049-1109 ---- */
         for (int k = 0; k < K; k++) {
             uint32_t *hk = hist + (k & 1) * nb_r;
+            const int bpl = nb_r / WAVE; /* bins per lane of the cutoff search */
             CLK(0);
             PRUNE_SHARE(col, lo, hi, nj)
             /* [A] linked cells (getLinkedCells :1021-1047) in list order, posterior bins, histogram */
@@ -339,7 +340,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
                         if (linked) {
                             const int bin = posterior_bin(r_f[j], r_b[j], total, nb, &errbits);
                             entry = ((uint32_t) bin << 16) | (uint32_t) c;
-                            atomicAdd(&hk[bin], 1u);
+                            atomicAdd(&hk[(bin % bpl) * WAVE + bin / bpl], 1u); /* lane-major: bin b lives at (b % bpl) * 64 + b / bpl */
                         }
                     }
                     const uint64_t m = __ballot(linked);
@@ -371,54 +372,35 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
                 /* [B] cutoff bin and quota */
                 int n_link = 0;
                 for (int w = 0; w < W; w++) n_link += (int) sh[w];
-                int n, B = -1, quota = 0;
-                if (p.thr_bin >= nb - 1) {
-                    /* no posterior threshold in force (shipped parameters): every linked cell passes it, and the cutoff is
-                     * found by walking the histogram 64 bins at a time -- it almost always lies in the first few chunks */
-                    n = kept_count(n_link, n_link, p.min_p, p.max_p);
-                    int cum = 0;
-                    for (int c0 = 0; n > 0 && c0 < nb_r; c0 += WAVE) {
-                        const int v = (int) hk[c0 + lane];
-                        const int incl = wave_incl_scan(v, lane);
-                        const uint64_t hit = __ballot(cum + incl >= n);
-                        if (hit) {
-                            const int src = __ffsll((unsigned long long) hit) - 1;
-                            const int before = cum + __shfl(incl - v, src, WAVE);
-                            B = c0 + src;
-                            quota = n - before;
-                            break;
-                        }
-                        cum += __shfl(incl, WAVE - 1, WAVE);
-                    }
-                } else {
-                    const int bpl = nb_r / WAVE;
-                    int tot = 0, pass = 0;
-                    for (int q = 0; q < bpl; q++) {
-                        const int bb = lane * bpl + q;
-                        const int v = bb < nb ? (int) hk[bb] : 0;
-                        tot += v;
-                        if (bb <= p.thr_bin) pass += v;
-                    }
-                    const int incl = wave_incl_scan(tot, lane);
-                    const int g = __shfl(wave_incl_scan(pass, lane), WAVE - 1, WAVE);
-                    n = kept_count(n_link, g, p.min_p, p.max_p);
-                    const int ex = incl - tot;
-                    int myB = -1, myQ = 0;
-                    const bool owner = n > 0 && ex < n && n <= incl;
-                    if (owner) {
-                        int cum = ex;
-                        for (int q = 0; q < bpl; q++) {
-                            const int bb = lane * bpl + q;
-                            const int v = bb < nb ? (int) hk[bb] : 0;
-                            if (cum + v >= n) { myB = bb; myQ = n - cum; break; }
-                            cum += v;
-                        }
-                    }
-                    const uint64_t om = __ballot(owner);
-                    const int src = om ? __ffsll((unsigned long long) om) - 1 : 0;
-                    B = om ? __shfl(myB, src, WAVE) : -1;
-                    quota = om ? __shfl(myQ, src, WAVE) : 0;
+                /* lane l owns the bpl consecutive bins [l * bpl, (l + 1) * bpl); the histogram is stored lane-major, so these
+                 * reads are conflict-free and the search has a fixed, short cost wherever the cutoff lies (the posteriors of
+                 * the linked cells spread over hundreds of bins) */
+                int v[16];
+                int tot = 0, pass = 0;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    v[q] = q < bpl ? (int) hk[q * WAVE + lane] : 0;
+                    tot += v[q];
+                    if (lane * bpl + q <= p.thr_bin) pass += v[q];
                 }
+                const int incl = wave_incl_scan(tot, lane);
+                const int g = p.thr_bin >= nb - 1 ? n_link : __shfl(wave_incl_scan(pass, lane), WAVE - 1, WAVE);
+                const int n = kept_count(n_link, g, p.min_p, p.max_p);
+                const int ex = incl - tot;
+                int myB = -1, myQ = 0;
+                const bool owner_lane = n > 0 && ex < n && n <= incl;
+                if (owner_lane) {
+                    int cum = ex;
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        if (myB < 0 && cum + v[q] >= n) { myB = lane * bpl + q; myQ = n - cum; }
+                        cum += v[q];
+                    }
+                }
+                const uint64_t om = __ballot(owner_lane);
+                const int src = om ? __ffsll((unsigned long long) om) - 1 : 0;
+                const int B = om ? __shfl(myB, src, WAVE) : -1;
+                const int quota = om ? __shfl(myQ, src, WAVE) : 0;
                 const int nG = n - quota;
                 CLK(4);
                 /* ordered selection over the wave segments (list order) */
