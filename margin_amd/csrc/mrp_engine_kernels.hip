@@ -540,35 +540,38 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
         if (wave == 0) {
             uint32_t pm[2] = {0u, 0u}; /* kept merge cells of the merge column after column k: they own the flags */
             bool pmk[2] = {false, false};
-            int nk = sc.n_kept[h.col0 + K - 1];
-            uint32_t cc[2], cn[2];
+            /* the lists of a column are requested two columns before they are used */
+            struct Lists { int nk, nm; uint32_t cc[2], cn[2], mm[2]; };
+            auto fetch = [&](int k) {
+                Lists L;
+                L.nk = 0; L.nm = 0;
 #pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int i = lane + u * WAVE;
-                cc[u] = i < nk ? sc.kept[(h.col0 + K - 1) * S + i] : 0u;
-                cn[u] = i < nk ? sc.kept_np[(h.col0 + K - 1) * S + i] : 0u;
-            }
-            for (int k = K - 1; k >= 0; k--) {
-                const int64_t lcol = h.col0 + k;
-                /* prefetch: the lists of column k - 1 and of the merge column between */
-                int nk_p = 0, nmp = 0;
-                uint32_t cc_p[2] = {0u, 0u}, cn_p[2] = {0u, 0u}, mm[2] = {0u, 0u};
-                if (k > 0) {
-                    nk_p = sc.n_kept[lcol - 1];
-                    nmp = sc.n_keptm[lcol - 1];
+                for (int u = 0; u < 2; u++) { L.cc[u] = 0u; L.cn[u] = 0u; L.mm[u] = 0u; }
+                if (k >= 0) {
+                    const int64_t lc = h.col0 + k;
+                    L.nk = sc.n_kept[lc];
+                    L.nm = sc.n_keptm[lc];
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         const int i = lane + u * WAVE;
-                        cc_p[u] = i < nk_p ? sc.kept[(lcol - 1) * S + i] : 0u;
-                        cn_p[u] = i < nk_p ? sc.kept_np[(lcol - 1) * S + i] : 0u;
-                        mm[u] = i < nmp ? sc.keptm[(lcol - 1) * S + i] : 0u;
+                        /* (the counts are not known yet when the lists are requested: every slot below S is read) */
+                        L.cc[u] = i < S ? sc.kept[lc * S + i] : 0u;
+                        L.cn[u] = i < S ? sc.kept_np[lc * S + i] : 0u;
+                        L.mm[u] = i < S ? sc.keptm[lc * S + i] : 0u;
                     }
                 }
+                return L;
+            };
+            Lists cur = fetch(K - 1), nx1 = fetch(K - 2);
+            for (int k = K - 1; k >= 0; k--) {
+                const int64_t lcol = h.col0 + k;
+                const Lists nx2 = fetch(k - 2);
+                const int nk = cur.nk;
                 bool keep[2];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const int i = lane + u * WAVE;
-                    keep[u] = i < nk && (k + 1 == K || flags[cn[u] & 0xFFFFu] != 0);
+                    keep[u] = i < nk && (k + 1 == K || flags[cur.cn[u] & 0xFFFFu] != 0);
                 }
                 const uint64_t m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
                 const int ns = __popcll(m0) + __popcll(m1);
@@ -577,43 +580,43 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
                 if (ns != nk) {
                     if (keep[0]) {
                         const int pos = (int) lanemask_lt_count(m0, lane);
-                        sc.kept[lcol * S + pos] = (uint16_t) cc[0];
-                        sc.kept_np[lcol * S + pos] = cn[0];
+                        sc.kept[lcol * S + pos] = (uint16_t) cur.cc[0];
+                        sc.kept_np[lcol * S + pos] = cur.cn[0];
                     }
                     if (keep[1]) {
                         const int pos = __popcll(m0) + (int) lanemask_lt_count(m1, lane);
-                        sc.kept[lcol * S + pos] = (uint16_t) cc[1];
-                        sc.kept_np[lcol * S + pos] = cn[1];
+                        sc.kept[lcol * S + pos] = (uint16_t) cur.cc[1];
+                        sc.kept_np[lcol * S + pos] = cur.cn[1];
                     }
                     if (lane == 0) sc.n_kept[lcol] = ns;
                 }
                 if (k == 0) break;
                 /* merge column k - 1 keeps the merge cells some surviving cell comes from (:1141-1155) */
-                if (keep[0]) flags[cn[0] >> 16] = 1;
-                if (keep[1]) flags[cn[1] >> 16] = 1;
+                if (keep[0]) flags[cur.cn[0] >> 16] = 1;
+                if (keep[1]) flags[cur.cn[1] >> 16] = 1;
+                const int nmp = nx1.nm;
                 bool mk[2];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const int i = lane + u * WAVE;
-                    mk[u] = i < nmp && flags[mm[u]] != 0;
+                    mk[u] = i < nmp && flags[nx1.mm[u]] != 0;
                 }
                 const uint64_t q0 = __ballot(mk[0]), q1 = __ballot(mk[1]);
                 const int nms = __popcll(q0) + __popcll(q1);
                 if (nms != nmp) {
-                    if (mk[0]) sc.keptm[(lcol - 1) * S + (int) lanemask_lt_count(q0, lane)] = (uint16_t) mm[0];
-                    if (mk[1]) sc.keptm[(lcol - 1) * S + __popcll(q0) + (int) lanemask_lt_count(q1, lane)] = (uint16_t) mm[1];
+                    if (mk[0]) sc.keptm[(lcol - 1) * S + (int) lanemask_lt_count(q0, lane)] = (uint16_t) nx1.mm[0];
+                    if (mk[1]) sc.keptm[(lcol - 1) * S + __popcll(q0) + (int) lanemask_lt_count(q1, lane)] = (uint16_t) nx1.mm[1];
                     if (lane == 0) sc.n_keptm[lcol - 1] = nms;
                 }
                 /* leave flagged exactly the surviving merge cells of column k - 1 */
-                if (keep[0]) flags[cn[0] >> 16] = 0;
-                if (keep[1]) flags[cn[1] >> 16] = 0;
-                if (mk[0]) flags[mm[0]] = 1;
-                if (mk[1]) flags[mm[1]] = 1;
-                pm[0] = mm[0]; pm[1] = mm[1];
+                if (keep[0]) flags[cur.cn[0] >> 16] = 0;
+                if (keep[1]) flags[cur.cn[1] >> 16] = 0;
+                if (mk[0]) flags[nx1.mm[0]] = 1;
+                if (mk[1]) flags[nx1.mm[1]] = 1;
+                pm[0] = nx1.mm[0]; pm[1] = nx1.mm[1];
                 pmk[0] = mk[0]; pmk[1] = mk[1];
-                nk = nk_p;
-                cc[0] = cc_p[0]; cc[1] = cc_p[1];
-                cn[0] = cn_p[0]; cn[1] = cn_p[1];
+                cur = nx1;
+                nx1 = nx2;
             }
         }
         __syncthreads();
