@@ -256,8 +256,16 @@ static __device__ __forceinline__ void wave_bitonic_sort128(uint32_t &k0, uint32
  *       rank sort of the <= S kept cells, their distinct next merge cells, the merge cells' posteriors,
  *       rank sort, new kept flags.  Meanwhile the other waves only wait; the loads of the next column are
  *       already in flight. */
+/* the few arrays of the level's batch the prune kernel reads (the whole MrpBatchDev by value costs ~60 SGPRs) */
+struct PruneIn {
+    const SweepCol *scols;
+    const uint32_t *cell_np;
+    const int32_t *cell_f32, *cell_b32, *merge_f32, *merge_b32;
+    const double *hmm_fb;
+};
+
 template <int T>
-__global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
+__global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
                                                       PruneParams p, PruneScratch sc) {
     constexpr int W = T / WAVE;
     extern __shared__ uint32_t lds[];
@@ -305,18 +313,24 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
         const int hi_v = lo_ + per_##nj_ < (colv).n_cells ? lo_ + per_##nj_ : (colv).n_cells; \
         const int nj_ = (hi_v - lo_ + 63) >> 6;
 #define PRUNE_LOAD(colv, lo_, hi_v, nj_)                                                      \
-        _Pragma("unroll") for (int j = 0; j < PRUNE_CPT; j++) {                               \
-            if (j < nj_) {                                                                    \
-                const int c = lo_ + j * WAVE + lane;                                          \
-                if (c < hi_v) {                                                               \
-                    r_np[j] = d.cell_np[(colv).cell_off + c];                                 \
-                    r_f[j] = d.cell_f32[(colv).cell_off + c];                                 \
-                    r_b[j] = d.cell_b32[(colv).cell_off + c];                                 \
+        {                                                                                     \
+            /* one base address per array, constant strides: the loads take immediate offsets */ \
+            const int64_t first_ = (colv).cell_off + lo_ + lane;                              \
+            const uint32_t *__restrict__ pn_ = d.cell_np + first_;                            \
+            const int32_t *__restrict__ pf_ = d.cell_f32 + first_;                            \
+            const int32_t *__restrict__ pb_ = d.cell_b32 + first_;                            \
+            const int left_ = hi_v - lo_ - lane; /* cells of this lane's stride that exist */ \
+            _Pragma("unroll") for (int j = 0; j < PRUNE_CPT; j++) {                           \
+                if (j * WAVE < left_) {                                                       \
+                    r_np[j] = pn_[j * WAVE];                                                  \
+                    r_f[j] = pf_[j * WAVE];                                                   \
+                    r_b[j] = pb_[j * WAVE];                                                   \
                 }                                                                             \
             }                                                                                 \
         }
         {
             PRUNE_SHARE(col, lo0, hi0, nj0)
+            (void) nj0;
             PRUNE_LOAD(col, lo0, hi0, nj0)
         }
         __syncthreads();
@@ -360,6 +374,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(MrpBatchDev d, const Prune
                 col = col_next; /* its descriptor was requested one column ago */
                 if (k + 2 < K) col_next = k_load(d.scols + h.col0 + k + 2);
                 PRUNE_SHARE(col, lo1, hi1, nj1)
+                (void) nj1;
                 PRUNE_LOAD(col, lo1, hi1, nj1)
             }
             CLK(2);
@@ -647,12 +662,13 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const PruneHmm *hmms_dev, int6
     }
     if (lds > (size_t) MRP_LDS_BUDGET) return hipErrorInvalidValue;
     const dim3 grid((unsigned) (n_hmms < 65536 ? n_hmms : 65536));
+    const PruneIn in{d.scols, d.cell_np, d.cell_f32, d.cell_b32, d.merge_f32, d.merge_b32, d.hmm_fb};
     /* 1 024 threads for the big columns even when fewer would hold them: the per-wave share of phase [A] is what the
      * column's critical path waits for (640 threads measured 8 % slower) */
     if (p.max_cells <= 256 * PRUNE_CPT)
-        hipLaunchKernelGGL(mrp_prune_kernel<256>, grid, dim3(256), lds, stream, d, hmms_dev, n_hmms, p, s);
+        hipLaunchKernelGGL(mrp_prune_kernel<256>, grid, dim3(256), lds, stream, in, hmms_dev, n_hmms, p, s);
     else
-        hipLaunchKernelGGL(mrp_prune_kernel<1024>, grid, dim3(1024), lds, stream, d, hmms_dev, n_hmms, p, s);
+        hipLaunchKernelGGL(mrp_prune_kernel<1024>, grid, dim3(1024), lds, stream, in, hmms_dev, n_hmms, p, s);
     return hipGetLastError();
 }
 
