@@ -45,9 +45,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the end-to-end device-resident phasing leg")
     ap.add_argument("--pipeline-runs", type=int, default=3)
-    ap.add_argument("--pipeline-groups", type=int, default=2,
-                    help="phase the chunks as this many concurrent batches (one host thread + context each): the host work "
-                         "of one batch overlaps the device work of the other")
+    ap.add_argument("--pipeline-groups", type=int, default=1,
+                    help="additional caller-side split of the chunks into concurrent mrp_phase_reads_many calls (the call itself "
+                         "already runs two interleaved halves on sibling contexts, MRP_PHASE_GROUPS)")
     ap.add_argument("--split", type=int, default=int(os.environ.get("MRP_BENCH_SPLIT", "1")),
                     help="record the chunks into this many device batches launched on separate streams (their kernels overlap)")
     return ap.parse_args()
@@ -224,7 +224,7 @@ def main():
         out["pipeline"] = dict(what="mrp_phase_reads_many: profile sequences -> haplotypes, all merge levels resident on the device",
                                value=p_units * args.pipeline_runs / p_el, unit="het-site-reads/s",
                                ms_per_batch=1e3 * p_el / args.pipeline_runs, chunks_per_gpu=n_chunks, runs=args.pipeline_runs,
-                               concurrent_batches=G, resident=int(all(p.resident for p in psts)), levels=int(psts[0].levels),
+                               concurrent_batches=G * int(os.environ.get("MRP_PHASE_GROUPS", "2")), resident=int(all(p.resident for p in psts)), levels=int(psts[0].levels),
                                hmms=int(sum(p.hmms for p in psts)), columns=int(sum(p.columns for p in psts)),
                                cells=int(sum(p.cells for p in psts)), device_ms=float(sum(p.device_ms for p in psts)),
                                cross_ms=float(sum(p.cross_ms for p in psts)), sweep_ms=float(sum(p.sweep_ms for p in psts)),

@@ -54,6 +54,16 @@ void mrp_chunk_host_view(const mrp_chunk *chunk, mrp_chunk_host *out) {
     out->pool_bytes = chunk->pool_bytes;
 }
 mrp_context *mrp_chunk_context(const mrp_chunk *chunk) { return chunk->ctx; }
+int mrp_context_device(const mrp_context *ctx) { return ctx->device; }
+mrp_context *mrp_context_sibling(mrp_context *ctx, int i) {
+    std::lock_guard<std::mutex> lock(ctx->sibling_mu);
+    while ((int) ctx->siblings.size() <= i) {
+        mrp_context *s = nullptr;
+        if (mrp_context_create(ctx->device, &s) != MRP_OK) return nullptr;
+        ctx->siblings.push_back(s);
+    }
+    return ctx->siblings[(size_t) i];
+}
 int mrp_set_error(int code, const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
@@ -96,6 +106,8 @@ int mrp_context_create(int device, mrp_context **out) {
 
 void mrp_context_destroy(mrp_context *ctx) {
     if (!ctx) return;
+    for (mrp_context *s : ctx->siblings) mrp_context_destroy(s);
+    ctx->siblings.clear();
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     ctx->pool.destroy();

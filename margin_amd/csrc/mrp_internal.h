@@ -137,6 +137,8 @@ struct mrp_context {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
     DevPool pool;
+    std::vector<mrp_context *> siblings; /* further contexts on the same device (concurrent batches of mrp_phase_reads_many) */
+    std::mutex sibling_mu;
     /* page-locked host staging for the small per-level results of the resident engine (grow-only) */
     void *pinned = nullptr;
     size_t pinned_bytes = 0;

@@ -920,7 +920,7 @@ static int check_reads(const world *w, const mrp_read *reads, int64_t n) {
 static int world_init(world *w, mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *reads, int64_t n_reads,
                       mrp_batch *record) {
     if (!ctx || !chunk || (n_reads > 0 && !reads)) return mrp_set_error(MRP_ERR_ARG, "NULL argument");
-    if (mrp_chunk_context(chunk) != ctx) return mrp_set_error(MRP_ERR_ARG, "chunk belongs to a different context");
+    if (mrp_context_device(mrp_chunk_context(chunk)) != mrp_context_device(ctx)) return mrp_set_error(MRP_ERR_ARG, "chunk lives on a different device");
     memset(w, 0, sizeof(*w));
     w->chunk = chunk; w->reads = reads; w->n_reads = n_reads; w->ctx = ctx; w->record = record;
     mrp_chunk_host_view(chunk, &w->ch);
@@ -1867,6 +1867,26 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
     return rc;
 }
 
+/* one concurrent batch of mrp_phase_reads_many: while its levels wait for the device, the other batch's host work runs */
+typedef struct {
+    mrp_context *ctx;
+    int64_t n;
+    const mrp_chunk **chunks;
+    const mrp_read **reads;
+    int64_t *n_reads;
+    const mrp_params *params;
+    mrp_phase_result **out;
+    mrp_phase_many_stats stats;
+    int rc;
+    char err[256];
+} phase_group;
+static void *phase_group_main(void *p) {
+    phase_group *g = p;
+    g->rc = phase_many_resident(g->ctx, g->n, g->chunks, g->reads, g->n_reads, g->params, g->out, &g->stats);
+    if (g->rc != MRP_OK) snprintf(g->err, sizeof(g->err), "%s", mrp_last_error());
+    return NULL;
+}
+
 int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *const *chunks, const mrp_read *const *reads,
                          const int64_t *n_reads, const mrp_params *params, mrp_phase_result **out,
                          mrp_phase_many_stats *stats) {
@@ -1874,7 +1894,53 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
         return mrp_set_error(MRP_ERR_ARG, "mrp_phase_reads_many: bad arguments");
     if (stats) memset(stats, 0, sizeof(*stats));
     for (int64_t c = 0; c < n_chunks; c++) out[c] = NULL;
-    int rc = phase_many_resident(ctx, n_chunks, chunks, reads, n_reads, params, out, stats);
+    /* the levels of a batch alternate host work (structure, descriptors) and device work; two interleaved halves of the
+     * chunks, each with its own context and host thread, keep both busy (MRP_PHASE_GROUPS, default 2) */
+    int G = getenv("MRP_PHASE_GROUPS") ? atoi(getenv("MRP_PHASE_GROUPS")) : 2;
+    if (G < 1) G = 1;
+    if (G > 8) G = 8;
+    if (n_chunks < 4 * G) G = 1;
+    int rc = MRP_OK;
+    if (G == 1) {
+        rc = phase_many_resident(ctx, n_chunks, chunks, reads, n_reads, params, out, stats);
+    } else {
+        phase_group *grp = xcalloc((size_t) G, sizeof(*grp));
+        pthread_t th[8];
+        int started[8] = {0};
+        for (int g = 0; g < G; g++) {
+            phase_group *q = &grp[g];
+            q->ctx = g == 0 ? ctx : mrp_context_sibling(ctx, g - 1);
+            q->params = params;
+            q->n = (n_chunks - g + G - 1) / G;
+            q->chunks = xmalloc(sizeof(*q->chunks) * (size_t) q->n);
+            q->reads = xmalloc(sizeof(*q->reads) * (size_t) q->n);
+            q->n_reads = xmalloc(sizeof(*q->n_reads) * (size_t) q->n);
+            q->out = xcalloc((size_t) q->n, sizeof(*q->out));
+            for (int64_t i = 0; i < q->n; i++) { q->chunks[i] = chunks[g + i * G]; q->reads[i] = reads[g + i * G]; q->n_reads[i] = n_reads[g + i * G]; }
+            if (!q->ctx) { q->rc = MRP_ERR_HIP; snprintf(q->err, sizeof(q->err), "%s", mrp_last_error()); continue; }
+            if (g > 0 && pthread_create(&th[g], NULL, phase_group_main, q) == 0) started[g] = 1;
+        }
+        phase_group_main(&grp[0]);
+        for (int g = 1; g < G; g++) {
+            if (started[g]) pthread_join(th[g], NULL);
+            else if (grp[g].ctx) phase_group_main(&grp[g]); /* thread creation failed: run it here */
+        }
+        for (int g = 0; g < G; g++) {
+            phase_group *q = &grp[g];
+            if (q->rc != MRP_OK && (rc == MRP_OK || rc == MRP_ERR_UNSUPPORTED)) rc = mrp_set_error(q->rc, "%s", q->err);
+            for (int64_t i = 0; i < q->n; i++) out[g + i * G] = q->out[i];
+            if (stats && q->rc == MRP_OK) {
+                stats->resident = 1;
+                stats->levels = q->stats.levels > stats->levels ? q->stats.levels : stats->levels;
+                stats->hmms += q->stats.hmms; stats->columns += q->stats.columns; stats->cells += q->stats.cells;
+                stats->merge_cells += q->stats.merge_cells;
+                stats->device_ms += q->stats.device_ms; stats->cross_ms += q->stats.cross_ms; stats->sweep_ms += q->stats.sweep_ms;
+                stats->prune_ms += q->stats.prune_ms;
+            }
+            free(q->chunks); free(q->reads); free(q->n_reads); free(q->out);
+        }
+        free(grp);
+    }
     if (rc == MRP_ERR_UNSUPPORTED) {
         /* parameters or hmm shapes outside the resident path: the hashing path, chunk by chunk */
         if (stats) memset(stats, 0, sizeof(*stats));

@@ -27,6 +27,9 @@ typedef struct mrp_chunk_host {
 
 void mrp_chunk_host_view(const mrp_chunk *chunk, mrp_chunk_host *out);
 mrp_context *mrp_chunk_context(const mrp_chunk *chunk);
+int mrp_context_device(const mrp_context *ctx);
+/* a further context (stream, allocator cache) on the same device, owned by ctx and destroyed with it; i = 0, 1, ... */
+mrp_context *mrp_context_sibling(mrp_context *ctx, int i);
 int mrp_set_error(int code, const char *fmt, ...);
 /* host worker threads for structural code and descriptor building (MRP_HOST_THREADS, default min(16, cores)) */
 int mrp_host_threads(void);
