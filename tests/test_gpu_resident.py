@@ -225,3 +225,28 @@ def test_resident_full_size_config2_chunk(gpu_ctx, orc):
     assert len(g["reads1"]) + len(g["reads2"]) == len(chunks[1].reads)
     for d in dchunks:
         d.close()
+
+
+def test_resident_hifi_shape_multiallelic(gpu_ctx, orc):
+    """BASELINE.json configs[4] shape: 35x reads of ~18 kb, 1 % allele error, sites with 2, 3 or 4 alleles
+    (indel-like variants of phase_vcf mode) -- columns mix allele counts, so merge levels take the general emission path
+    and the final sweep the ancestor model over up to 4 alleles.  Resident pipeline == oracle."""
+    chunk = synth.make_ont_chunk(seed=51, region_bp=150_000, n_sites=300, coverage=35.0, median_len=18_000.0, allele_error=0.01,
+                                 allele_choices=(2, 3, 4), allele_probs=(0.85, 0.1, 0.05), length_model="normal", normal_sd=3000.0)
+    assert set(np.unique(chunk.allele_number)) == {2, 3, 4}
+    pd = _params()
+    oc = orc.OracleChunk(chunk)
+    ref = oc.phase(pd)
+    oc.close()
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    (got,), st = capi.phase_reads_many(gpu_ctx, [dchunk], [chunk], capi.Params.from_reference_names(pd))
+    assert st.resident == 1
+    for k in PHASE_KEYS:
+        assert (np.asarray(got[k]) == np.asarray(ref[k])).all(), k
+    assert got["reads1"] == ref["reads1"] and got["reads2"] == ref["reads2"]
+    assert got["n_sweeps"] == ref["fb_calls"]
+    # the phasing recovers the simulated haplotypes up to the global label
+    h1, t1, t2 = np.asarray(got["hap1"]).astype(np.int64), chunk.hap1[got["ref_start"]:got["ref_start"] + got["length"]], \
+        chunk.hap2[got["ref_start"]:got["ref_start"] + got["length"]]
+    assert max((h1 == t1).mean(), (h1 == t2).mean()) > 0.95
+    dchunk.close()
