@@ -241,7 +241,7 @@ void mrp_phase_result_destroy(mrp_phase_result *r);
  *   -> stRPHmm_prune (hmm.c:1160)
  * of every merge level (coordination.c:263-409); only per-column cell counts return to the host between
  * levels and only the final, pruned hmms are copied back.  Max-plus mode (maxNotSumTransitions, every
- * shipped parameter file) with at most 128 partitions per column; otherwise MRP_ERR_UNSUPPORTED
+ * shipped parameter file) with at most 120 partitions per column; otherwise MRP_ERR_UNSUPPORTED
  * (mrp_get_rp_hmms_resident) or the per-chunk path is taken (mrp_phase_reads_many, stats->resident = 0). */
 int mrp_get_rp_hmms_resident(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *reads, const int32_t *read_index,
                              int64_t n, const mrp_params *params, mrp_hmm ***hmms_out, int64_t *n_out);

@@ -77,8 +77,8 @@ struct PruneScratch {
 #define MRP_ENGINE_ERR_RANGE 4     /* index out of range */
 
 /* largest column the prune kernel handles (LDS candidate list) */
-#define MRP_PRUNE_MAX_CELLS 16384
-#define MRP_PRUNE_MAX_S 128
+#define MRP_PRUNE_MAX_CELLS 14400
+#define MRP_PRUNE_MAX_S 120 /* with 120 * 120 candidate cells the prune kernel's LDS (157 KB) still fits a CU */
 
 hipError_t mrp_launch_cross(const CrossCol *cols_dev, int64_t n_cols, uint64_t *partition, uint32_t *cell_np, int32_t *err,
                             hipStream_t stream);

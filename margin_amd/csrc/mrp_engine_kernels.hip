@@ -271,7 +271,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
     extern __shared__ uint32_t lds[];
     const int S = p.S;
     const int nb = p.n_bins;
-    const int nb_r = (nb + 63) & ~63;
+    const int nb_r = 1024; /* 16 bins per lane of the cutoff search: bin b lives at (b & 15) * 64 + (b >> 4) */
     const int cap_c = ((p.max_cells > p.max_merge ? p.max_cells : p.max_merge) + 3) & ~3;
     /* LDS layout (dwords) */
     uint32_t *gsel = lds;             /* [S] selected candidates above the cutoff bin: bin << 16 | cell */
@@ -281,7 +281,8 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
     uint32_t *um = enp + S;           /* [S] posterior bin of the merge cell each selected cell leads to (selection order) */
     uint32_t *oldm = um + S;          /* [S] kept merge cells of the previous merge column (flag owners) */
     uint32_t *sh = oldm + S;          /* [64] per-wave counters */
-    uint32_t *hist = sh + 64;         /* [2][nb_r] */
+    uint32_t *stg = sh + 64;          /* [W][4][64] staging of linked cells: cell, transitions, f, b */
+    uint32_t *hist = stg + W * 4 * WAVE; /* [2][nb_r] */
     uint32_t *cand = hist + 2 * nb_r; /* [cap_c] linked cells of the column, list order per wave segment: bin << 16 | cell */
     uint32_t *cand_np = cand + cap_c; /* [cap_c] */
     uint8_t *flags = reinterpret_cast<uint8_t *>(cand_np + cap_c); /* [max_merge] kept flag per merge cell */
@@ -338,34 +339,47 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
         /* ---- stRPHmm_pruneForwards hmm.c:1049-1109 ---- */
         for (int k = 0; k < K; k++) {
             uint32_t *hk = hist + (k & 1) * nb_r;
-            const int bpl = nb_r / WAVE; /* bins per lane of the cutoff search */
+            const int bpl = 16; /* bins per lane of the cutoff search */
             CLK(0);
             PRUNE_SHARE(col, lo, hi, nj)
-            /* [A] linked cells (getLinkedCells :1021-1047) in list order, posterior bins, histogram */
-            int cnt = 0;
+            /* [A] linked cells (getLinkedCells :1021-1047) in list order.  Few cells are linked (a hundred or so kept
+             * merge cells lead into the column), so the loop over the cells only tests and stages them; posterior bin,
+             * candidate list and histogram are done for 64 staged cells at a time with all lanes busy. */
+            uint32_t *sg = stg + wave * 4 * WAVE;
+            int cnt = 0, staged = 0;
+#define PRUNE_FLUSH(count_)                                                                       \
+            {                                                                                     \
+                if (lane < (count_)) {                                                            \
+                    const uint32_t c_ = sg[lane], np_ = sg[WAVE + lane];                          \
+                    const int bin_ = posterior_bin((int32_t) sg[2 * WAVE + lane], (int32_t) sg[3 * WAVE + lane], total, nb, &errbits); \
+                    cand[lo + cnt + lane] = ((uint32_t) bin_ << 16) | c_;                         \
+                    cand_np[lo + cnt + lane] = np_;                                               \
+                    atomicAdd(&hk[(bin_ & 15) * WAVE + (bin_ >> 4)], 1u);                         \
+                }                                                                                 \
+                cnt += (count_);                                                                  \
+            }
 #pragma unroll
             for (int j = 0; j < PRUNE_CPT; j++) {
                 if (j < nj) {
                     const int c = lo + j * WAVE + lane;
-                    bool linked = false;
-                    uint32_t entry = 0;
-                    if (c < hi) {
-                        linked = k == 0 || flags[r_np[j] >> 16] != 0;
-                        if (linked) {
-                            const int bin = posterior_bin(r_f[j], r_b[j], total, nb, &errbits);
-                            entry = ((uint32_t) bin << 16) | (uint32_t) c;
-                            atomicAdd(&hk[(bin % bpl) * WAVE + bin / bpl], 1u); /* lane-major: bin b lives at (b % bpl) * 64 + b / bpl */
+                    const bool linked = c < hi && (k == 0 || flags[r_np[j] >> 16] != 0);
+                    const uint64_t m = __ballot(linked);
+                    if (m) { /* wave-uniform */
+                        const int nl = __popcll(m);
+                        const int pos = staged + (int) lanemask_lt_count(m, lane);
+                        if (linked && pos < WAVE) { sg[pos] = (uint32_t) c; sg[WAVE + pos] = r_np[j]; sg[2 * WAVE + pos] = (uint32_t) r_f[j]; sg[3 * WAVE + pos] = (uint32_t) r_b[j]; }
+                        if (staged + nl >= WAVE) {
+                            PRUNE_FLUSH(WAVE)
+                            if (linked && pos >= WAVE) { sg[pos - WAVE] = (uint32_t) c; sg[pos] = r_np[j]; sg[WAVE + pos] = (uint32_t) r_f[j]; sg[2 * WAVE + pos] = (uint32_t) r_b[j]; }
+                            staged = staged + nl - WAVE;
+                        } else {
+                            staged += nl;
                         }
                     }
-                    const uint64_t m = __ballot(linked);
-                    if (linked) {
-                        const int pos = lo + cnt + (int) lanemask_lt_count(m, lane);
-                        cand[pos] = entry;
-                        cand_np[pos] = r_np[j];
-                    }
-                    cnt += __popcll(m);
                 }
             }
+            if (staged > 0) PRUNE_FLUSH(staged)
+#undef PRUNE_FLUSH
             if (lane == 0) sh[wave] = (uint32_t) cnt;
             CLK(1);
             /* the next column's cells are requested now and consumed after the two barriers below */
@@ -650,8 +664,8 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const PruneHmm *hmms_dev, int6
                             hipStream_t stream) {
     if (n_hmms <= 0) return hipSuccess;
     if (p.S > MRP_PRUNE_MAX_S || p.max_cells > MRP_PRUNE_MAX_CELLS || p.max_merge > MRP_PRUNE_MAX_CELLS || p.n_bins > 1024) return hipErrorInvalidValue;
-    const size_t lds = (size_t) (6 * p.S + 64 + 2 * ((p.n_bins + 63) & ~63) + 2 * ((std::max(p.max_cells, p.max_merge) + 3) & ~3)) * 4 +
-                       (size_t) ((p.max_merge + 3) & ~3) + 16;
+    const size_t cap = (size_t) ((std::max(p.max_cells, p.max_merge) + 3) & ~3);
+    auto lds_for = [&](int threads) { return (size_t) (6 * p.S + 64 + (threads / 64) * 4 * 64 + 2 * 1024 + 2 * cap) * 4 + (size_t) ((p.max_merge + 3) & ~3) + 16; };
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void *) mrp_prune_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -660,15 +674,15 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const PruneHmm *hmms_dev, int6
         if (e != hipSuccess) return e;
         configured = true;
     }
-    if (lds > (size_t) MRP_LDS_BUDGET) return hipErrorInvalidValue;
+    if (lds_for(1024) > (size_t) MRP_LDS_BUDGET) return hipErrorInvalidValue;
     const dim3 grid((unsigned) (n_hmms < 65536 ? n_hmms : 65536));
     const PruneIn in{d.scols, d.cell_np, d.cell_f32, d.cell_b32, d.merge_f32, d.merge_b32, d.hmm_fb};
     /* 1 024 threads for the big columns even when fewer would hold them: the per-wave share of phase [A] is what the
      * column's critical path waits for (640 threads measured 8 % slower) */
     if (p.max_cells <= 256 * PRUNE_CPT)
-        hipLaunchKernelGGL(mrp_prune_kernel<256>, grid, dim3(256), lds, stream, in, hmms_dev, n_hmms, p, s);
+        hipLaunchKernelGGL(mrp_prune_kernel<256>, grid, dim3(256), lds_for(256), stream, in, hmms_dev, n_hmms, p, s);
     else
-        hipLaunchKernelGGL(mrp_prune_kernel<1024>, grid, dim3(1024), lds, stream, in, hmms_dev, n_hmms, p, s);
+        hipLaunchKernelGGL(mrp_prune_kernel<1024>, grid, dim3(1024), lds_for(1024), stream, in, hmms_dev, n_hmms, p, s);
     return hipGetLastError();
 }
 

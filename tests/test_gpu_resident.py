@@ -175,7 +175,7 @@ def test_bubbles_to_haplotype_tags_end_to_end(gpu_ctx, orc):
     dchunk.close()
 
 
-@pytest.mark.parametrize("seed,maxp", [(21, 50), (22, 20), (23, 128)])
+@pytest.mark.parametrize("seed,maxp", [(21, 50), (22, 20), (23, 120)])
 def test_resident_unit_test_shape_max_mode(gpu_ctx, orc, seed, maxp):
     """tests/stRPHmmTest.c-shaped input (1..9 alleles per site, so columns mix allele counts and take the general
     emission path) in max-plus mode with the unit tests' trimming (min 0, max N): resident merge == oracle."""
