@@ -796,11 +796,9 @@ int mrp_batch_launch(mrp_batch *b) {
     static const int t_wide = getenv("MRP_T_WIDE") ? atoi(getenv("MRP_T_WIDE")) : 512;   /* tuning knobs */
     static const int t_mid = getenv("MRP_T_MID") ? atoi(getenv("MRP_T_MID")) : 512;
     static const int t_narrow = getenv("MRP_T_NARROW") ? atoi(getenv("MRP_T_NARROW")) : 64;
-    static const int skip_env = getenv("MRP_SKIP") ? atoi(getenv("MRP_SKIP")) : 0; /* experiment only: bit0 wide, bit1 mid, bit2 narrow */
-    const int skip = b->hmms.size() > 2000 ? skip_env : 0;
-    if (!(skip & 1)) HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_wide.p, (int64_t) b->order_wide.size(), t_wide, b->max_merge_wide, s));
-    if (!(skip & 2)) HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_mid.p, (int64_t) b->order_mid.size(), t_mid, b->max_merge_mid, ctx->aux[0]));
-    if (!(skip & 4)) HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), t_narrow, b->max_merge_narrow, ctx->aux[1]));
+    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_wide.p, (int64_t) b->order_wide.size(), t_wide, b->max_merge_wide, s));
+    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_mid.p, (int64_t) b->order_mid.size(), t_mid, b->max_merge_mid, ctx->aux[0]));
+    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), t_narrow, b->max_merge_narrow, ctx->aux[1]));
     HIP_TRY(mrp_launch_sweep_f64(d, b->d_order_f64.p, (int64_t) b->order_f64.size(), 256, s));
     HIP_TRY(hipEventRecord(ctx->join[0], ctx->aux[0]));
     HIP_TRY(hipEventRecord(ctx->join[1], ctx->aux[1]));
