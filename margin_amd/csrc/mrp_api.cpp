@@ -329,8 +329,7 @@ int mrp_batch_add_impl(mrp_batch *b, const mrp_hmm_job *job, bool resident, int6
         b->n_cells_total++;
         if (!resident) {
             b->partition.push_back(0);
-            b->cell_next.push_back(0);
-            b->cell_prev.push_back(0);
+            if (b->need_wide) { b->cell_next.push_back(0); b->cell_prev.push_back(0); }
             b->cell_np.push_back(0);
         }
     }
@@ -433,14 +432,26 @@ int mrp_batch_add_impl(mrp_batch *b, const mrp_hmm_job *job, bool resident, int6
     h.n_cells = n_cells;
     h.n_merge = n_merge;
     h.wide_idx = h.max_merge > 65535 ? 1 : 0;
-    if (h.wide_idx) b->need_wide = true;
+    if (h.wide_idx && !b->need_wide) {
+        /* the first hmm whose transitions do not fit 16 bits: from now on the full indices are kept too; those of the
+         * hmms added so far are recovered from their packed form (they fit) */
+        b->need_wide = true;
+        if (!resident) {
+            const size_t have = b->cell_np.size();
+            b->cell_next.resize(have);
+            b->cell_prev.resize(have);
+            for (size_t c = 0; c < have; c++) { b->cell_next[c] = b->cell_np[c] & 0xFFFFu; b->cell_prev[c] = b->cell_np[c] >> 16; }
+        }
+    }
     b->hmms.push_back(h);
     b->n_cells_total += n_cells;
     if (resident && h.wide_idx) return fail(MRP_ERR_UNSUPPORTED, "device-resident hmm with more than 65535 merge cells in a column");
     if (!resident) {
         b->partition.insert(b->partition.end(), job->partition, job->partition + n_cells);
-        b->cell_next.insert(b->cell_next.end(), nxt.begin(), nxt.end());
-        b->cell_prev.insert(b->cell_prev.end(), prv.begin(), prv.end());
+        if (b->need_wide) {
+            b->cell_next.insert(b->cell_next.end(), nxt.begin(), nxt.end());
+            b->cell_prev.insert(b->cell_prev.end(), prv.begin(), prv.end());
+        }
         const size_t base = b->cell_np.size();
         b->cell_np.resize(base + (size_t) n_cells);
         for (int64_t c = 0; c < n_cells; c++) b->cell_np[base + c] = (nxt[c] & 0xFFFFu) | (prv[c] << 16);

@@ -135,3 +135,53 @@ def test_malformed_jobs_are_rejected(gpu_ctx, small_ont):
         capi.fb_run(gpu_ctx, [capi.Job(dchunk, bad2, int(flat["flags"]))])
     assert e.value.code == capi.MRP_ERR_ARG
     dchunk.close()
+
+
+def test_merge_column_beyond_16_bit_indices(gpu_ctx, small_ont):
+    """A merge column with 70 000 cells: transitions no longer fit the packed 16-bit form, the hmm is routed to the fp64
+    kernel with full 32-bit indices.  It is batched AFTER an ordinary hmm (whose indices were kept packed only) to cover
+    the switch-over in mrp_batch_add.  Expectation computed independently with numpy: the merge column is the identity
+    (one cell in, one cell out per merge cell), so f1 = e0 + e1, b0 = e1, and every total is max(e0 + e1)."""
+    chunk, res = small_ont
+    jobs = res["jobs"]
+    rng = np.random.default_rng(77)
+    depth, C = 17, 70_000
+    reads = [i for i, r in enumerate(chunk.reads) if r.length >= 2][:depth]
+    assert len(reads) == depth
+    site_of = [chunk.reads[i].ref_start for i in reads]
+    # one-site columns at each read's own first two sites would differ per read; use per-read byte offsets of any two
+    # consecutive sites of the read (the kernel only needs "where do this read's bytes for the column start")
+    rbo0 = np.array([chunk.reads[i].pool_off for i in reads], dtype=np.int64)
+    rbo1 = rbo0 + np.array([int(chunk.allele_number[s]) for s in site_of], dtype=np.int64)
+    # all sites biallelic in the ONT generator: a column = 1 site = 2 allele slots, read i's bytes at offset rbo[i] + a
+    P = rng.choice(1 << depth, size=C, replace=False).astype(np.uint64)
+    mask = np.uint64((1 << depth) - 1)
+    flat = dict(n_columns=2, col_ref_start=np.array([0, 1], dtype=np.int32), col_length=np.array([1, 1], dtype=np.int32),
+                col_depth=np.array([depth, depth], dtype=np.int32), col_cell_off=np.array([0, C, 2 * C], dtype=np.int64),
+                col_read_off=np.array([0, depth, 2 * depth], dtype=np.int64), read_byte_off=np.concatenate([rbo0, rbo1]),
+                partition=np.concatenate([P, P]), mask_from=np.array([mask], dtype=np.uint64), mask_to=np.array([mask], dtype=np.uint64),
+                mcol_cell_off=np.array([0, C], dtype=np.int64), merge_from=P.copy(), merge_to=P.copy(),
+                cell_next=np.concatenate([np.arange(C), np.zeros(C)]).astype(np.uint32),
+                cell_prev=np.concatenate([np.zeros(C), np.arange(C)]).astype(np.uint32), flags=1)
+    assert int(chunk.allele_number[0]) == 2 and int(chunk.allele_number[1]) == 2
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    small = capi.Job(dchunk, jobs[0], int(jobs[0]["flags"]))
+    wide = capi.Job(dchunk, flat, 1)
+    capi.fb_run(gpu_ctx, [small, wide])
+    assert_job_equal(jobs[0], small.results(), exact=True)
+    bits = ((P[:, None] >> np.arange(depth, dtype=np.uint64)[None, :]) & np.uint64(1)).astype(np.int64)  # [C, depth]
+
+    def cost(rbo):
+        by = np.stack([chunk.pool[rbo + a].astype(np.int64) for a in range(2)], axis=1)  # [depth, 2]
+        h1 = bits @ by
+        h2 = by.sum(axis=0)[None, :] - h1
+        return -(h1.min(axis=1) + h2.min(axis=1)).astype(np.float64)
+
+    e0, e1 = cost(rbo0), cost(rbo1)
+    r = wide.results()
+    best = (e0 + e1).max()
+    assert (r["cell_forward"][:C] == e0).all() and (r["cell_forward"][C:] == e0 + e1).all()
+    assert (r["cell_backward"][:C] == e1).all() and (r["cell_backward"][C:] == 0).all()
+    assert (r["merge_forward"] == e0).all() and (r["merge_backward"] == e1).all()
+    assert (r["col_total"] == best).all() and r["hmm_forward"][0] == best and r["hmm_backward"][0] == best
+    dchunk.close()
