@@ -250,3 +250,29 @@ def test_resident_hifi_shape_multiallelic(gpu_ctx, orc):
         chunk.hap2[got["ref_start"]:got["ref_start"] + got["length"]]
     assert max((h1 == t1).mean(), (h1 == t2).mean()) > 0.95
     dchunk.close()
+
+
+def test_resident_depth_64_columns(gpu_ctx, orc):
+    """Coverage beyond maxCoverageDepth = 64: reads are filtered down to 64 tiling paths (coordination.c:443-488) and the
+    top merge levels reach columns with 49..64 reads -- the widest emission variants (16 words per partition), 64-bit
+    partitions with the top bit in use, accept masks of depth 64."""
+    chunk = synth.make_ont_chunk(seed=61, region_bp=30_000, n_sites=60, coverage=95.0, median_len=9_000.0, sigma=0.3)
+    pd = _params(maxCoverageDepth=64)
+    oc = orc.OracleChunk(chunk)
+    ref = oc.phase(pd, capture_jobs=True)
+    oc.close()
+    deepest = max(int(np.max(j["col_depth"])) for j in ref["jobs"])
+    assert deepest > 48, deepest
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    params = capi.Params.from_reference_names(pd)
+    (got,), st = capi.phase_reads_many(gpu_ctx, [dchunk], [chunk], params)
+    assert st.resident == 1
+    for k in PHASE_KEYS:
+        assert (np.asarray(got[k]) == np.asarray(ref[k])).all(), k
+    assert got["reads1"] == ref["reads1"] and got["reads2"] == ref["reads2"]
+    # and the same sweeps through the forward/backward seam (the oracle's own jobs)
+    from tests.helpers import assert_job_equal, run_jobs_on_gpu
+    deep = [j for j in ref["jobs"] if int(np.max(j["col_depth"])) > 48][:4]
+    for f, r in zip(deep, run_jobs_on_gpu(gpu_ctx, dchunk, deep)):
+        assert_job_equal(f, r, exact=True)
+    dchunk.close()
