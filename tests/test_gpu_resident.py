@@ -276,3 +276,39 @@ def test_resident_depth_64_columns(gpu_ctx, orc):
     for f, r in zip(deep, run_jobs_on_gpu(gpu_ctx, dchunk, deep)):
         assert_job_equal(f, r, exact=True)
     dchunk.close()
+
+
+def _subset_chunk(chunk, keep):
+    """the same sites and pool with a subset of the reads (pool offsets stay valid)"""
+    return synth.Chunk(allele_number=chunk.allele_number, allele_offset=chunk.allele_offset, sub=chunk.sub, prior=chunk.prior,
+                       pool=chunk.pool, reads=[chunk.reads[i] for i in keep])
+
+
+def test_resident_ragged_inputs(gpu_ctx, orc):
+    """Edge shapes in one call: a single read, one strand only, two reads that do not overlap (gap columns of
+    stRPHmm_fuse, hmm.c:335-359), reads of one site, and a dense chunk next to them."""
+    base = synth.make_ont_chunk(seed=71, region_bp=60_000, n_sites=120, coverage=25)
+    reads = base.reads
+    fwd = [i for i, r in enumerate(reads) if r.strand == 1]
+    far = sorted(range(len(reads)), key=lambda i: reads[i].ref_start)
+    a = far[0]
+    b = next(i for i in far if reads[i].ref_start >= reads[a].ref_start + reads[a].length + 3)
+    one_site = [i for i, r in enumerate(reads) if r.length == 1][:3]
+    cases = [_subset_chunk(base, [0]), _subset_chunk(base, fwd), _subset_chunk(base, [a, b]),
+             _subset_chunk(base, one_site + [a]) if one_site else _subset_chunk(base, [a]), base]
+    pd = _params()
+    params = capi.Params.from_reference_names(pd)
+    dchunks = [capi.DeviceChunk.from_chunk(gpu_ctx, c) for c in cases]
+    got, st = capi.phase_reads_many(gpu_ctx, dchunks, cases, params)
+    assert st.resident == 1
+    for c, g in zip(cases, got):
+        oc = orc.OracleChunk(c)
+        ref = oc.phase(pd)
+        oc.close()
+        assert g["ref_start"] == ref["ref_start"] and g["length"] == ref["length"]
+        for k in PHASE_KEYS:
+            assert (np.asarray(g[k]) == np.asarray(ref[k])).all(), (len(c.reads), k)
+        assert g["reads1"] == ref["reads1"] and g["reads2"] == ref["reads2"], len(c.reads)
+        assert g["n_sweeps"] == ref["fb_calls"]
+    for d in dchunks:
+        d.close()
