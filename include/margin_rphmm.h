@@ -315,6 +315,57 @@ int mrp_phase_sets(int64_t n_variants, const mrp_variant *v, int64_t min_spannin
                    double max_discordant_ratio, int32_t *phase_set_out, int32_t *reason_out);
 double mrp_binomial_p_value(int64_t n, int64_t k); /* bubbleGraph.c:2876-2883 */
 
+/* ---------------------------------------------------------------------------------------------------------------
+ * Read x allele alignment likelihoods: the banded pair-HMM forward probability that fills
+ * Bubble.alleleReadSupports (bubbleGraph.c:1421-1464 -> computeForwardProbability, pairwiseAligner.c:849-903).
+ * Device work: one kernel with a pair per lane for short x strings, one with a pair per wave for everything else.
+ * The arithmetic is the reference's: fp64 + and * only (logAdd is a cubic interpolation, pairwiseAligner.c:279-299),
+ * evaluated without fused multiply-add, so results are bit-identical to a strict IEEE build of the reference.
+ * Symbols: 0..3 = A C G T, >= 4 = N (convertNucleotideCharToSymbol, stateMachine.c:25-42).  Nucleotide emissions
+ * only; the run-length (repeat count) emissions of margin polish (stateMachine.c:722-753) are out of scope.
+ * ------------------------------------------------------------------------------------------------------------- */
+typedef struct mrp_pair_hmm { /* struct _StateMachine3 (stateMachine.c:507-519) + NucleotideEmissions, all in log space */
+    double match_continue, match_from_gap_x, match_from_gap_y, gap_open_x, gap_open_y, gap_extend_x, gap_extend_y,
+            gap_switch_to_x, gap_switch_to_y;
+    double e_match[16]; /* [x * 4 + y] */
+    double e_gap_x[4], e_gap_y[4];
+} mrp_pair_hmm;
+
+typedef struct mrp_pairhmm_stats {
+    int64_t pairs_lane, pairs_wave; /* pairs handled by the pair-per-lane / pair-per-wave kernel */
+    int64_t cells;                  /* dp cells inside the bands, (0,0) included */
+    double kernel_ms;               /* HIP events around the launches */
+    double total_ms;                /* host wall time of the call */
+} mrp_pairhmm_stats;
+
+/* symbol_convertStringToSymbols (stateMachine.c:84-92) with the nucleotide alphabet */
+void mrp_symbols_from_chars(const char *s, int64_t n, uint8_t *out);
+/* nucleotideEmissions_reverseComplement (stateMachine.c:457-473): the state machine of reverse strand reads (parser.c:356) */
+void mrp_pair_hmm_reverse_complement(mrp_pair_hmm *m);
+/* band_construct (pairwiseAligner.c:175-226): xmy_l / xmy_r of the lx + ly + 1 diagonals; anchors = n_anchors (x, y)
+ * sequence coordinates, strictly increasing in both.  MRP_ERR_ARG where the reference asserts / throws. */
+int mrp_band_diagonals(const int64_t *anchors, int64_t n_anchors, int64_t lx, int64_t ly, int64_t expansion, int32_t *xmy_l,
+                       int32_t *xmy_r);
+/* computeForwardProbability for n_pairs (x, y) string pairs stored in one pool of symbols.  model_index (NULL: all 0)
+ * selects models[i] per pair; anchor_off (NULL: no anchors anywhere) holds n_pairs + 1 offsets into anchors (pairs of
+ * int64).  A pair without anchors covers its whole matrix, as in the reference.  out[i] = log probability (0.0 for two
+ * empty strings, :860-862).  Limits: a diagonal of at most 2 048 cells for pairs that go to the pair-per-wave kernel
+ * (x longer than 104 symbols, or anchored); beyond that MRP_ERR_UNSUPPORTED.  stats may be NULL. */
+int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int32_t n_models, int64_t n_pairs, const uint8_t *pool,
+                              int64_t pool_bytes, const int64_t *x_off, const int32_t *x_len, const int64_t *y_off,
+                              const int32_t *y_len, const uint8_t *model_index, const int64_t *anchor_off, const int64_t *anchors,
+                              int64_t expansion, int ragged_left, int ragged_right, double *out, mrp_pairhmm_stats *stats);
+/* The alleleReadSupports loop of bubbleGraph.c:1421-1464 for n_bubbles bubbles.  Bubble b owns alleles
+ * [allele_first[b], allele_first[b+1]) and read substrings [read_first[b], read_first[b+1]); x = allele, y = read
+ * substring, the read's strand picks the state machine -- except that, as in the reference (cachedScores is keyed by the
+ * substring alone), a read whose substring equals that of an earlier read of the bubble copies that read's scores.
+ * support is the concatenation over bubbles of float[alleleNo * readNo], entry j * readNo + k.  No anchors (the
+ * reference anchors only strings longer than referenceExpansionForStructuralVariants). */
+int mrp_allele_read_supports(mrp_context *ctx, const mrp_pair_hmm *forward_model, const mrp_pair_hmm *reverse_model, int64_t n_bubbles,
+                             const int64_t *allele_first, const int64_t *read_first, const uint8_t *pool, int64_t pool_bytes,
+                             const int64_t *allele_off, const int32_t *allele_len, const int64_t *read_off, const int32_t *read_len,
+                             const uint8_t *read_forward_strand, int64_t expansion, float *support, mrp_pairhmm_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

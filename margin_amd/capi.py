@@ -30,6 +30,8 @@ EXPORTED_SYMBOLS = [
     "mrp_phase_result_destroy", "mrp_get_rp_hmms_resident", "mrp_phase_reads_many", "mrp_reference_from_bubbles",
     "mrp_profile_seqs_from_bubbles", "mrp_assign_reads_to_haplotypes", "mrp_stitch_create", "mrp_stitch_destroy",
     "mrp_stitch_chunk", "mrp_stitch_size", "mrp_stitch_lookup", "mrp_phase_sets", "mrp_binomial_p_value",
+    "mrp_symbols_from_chars", "mrp_pair_hmm_reverse_complement", "mrp_band_diagonals", "mrp_forward_probabilities",
+    "mrp_allele_read_supports",
 ]
 
 
@@ -121,6 +123,61 @@ class Variant(C.Structure):
 _lib = None
 
 
+class PairHmm(C.Structure):
+    """mrp_pair_hmm: struct _StateMachine3 (impl/stateMachine.c:507-519) + NucleotideEmissions, log space."""
+    _TRANSITIONS = ("match_continue", "match_from_gap_x", "match_from_gap_y", "gap_open_x", "gap_open_y", "gap_extend_x", "gap_extend_y",
+                    "gap_switch_to_x", "gap_switch_to_y")
+    _fields_ = [(n, C.c_double) for n in _TRANSITIONS] + [("e_match", C.c_double * 16), ("e_gap_x", C.c_double * 4), ("e_gap_y", C.c_double * 4)]
+
+    @classmethod
+    def default_nucleotide(cls) -> "PairHmm":
+        """stateMachine3_constructNucleotide (impl/stateMachine.c:612-644, :409-432): the literals of the reference."""
+        m = cls(-0.030064059121770816, -1.272871422049609, -1.272871422049609, -4.21256642, -4.21256642, -0.3388262689231553,
+                -0.3388262689231553, -4.910694825551255, -4.910694825551255)
+        ma, tv, ti = -1.8917761142, -4.3459578861, -3.760242452
+        m.e_match[:] = [ma, tv, ti, tv, tv, ma, tv, ti, ti, tv, ma, tv, tv, ti, tv, ma]
+        m.e_gap_x[:] = [-1.3862943611] * 4
+        m.e_gap_y[:] = [-1.3862943611] * 4
+        return m
+
+    @classmethod
+    def from_margin_hmm(cls, hmm_type: int, transitions, emissions) -> "PairHmm":
+        """hmm_getStateMachine (impl/stateMachine.c:690-703) for the "type" / "transitions" / "emissions" arrays of a margin
+        parameter file: type 2 = threeState (symmetric, :663-682), 3 = threeStateAsymmetric (:646-661); emissions =
+        16 match + 4 gap-x + 4 gap-y probabilities (:481-488).  log(0) = -inf, as in C."""
+        t = np.asarray(transitions, dtype=np.float64).reshape(3, 3)
+        e = np.asarray(emissions, dtype=np.float64)
+        assert hmm_type in (2, 3) and e.shape == (24,)
+        M, X, Y = 0, 1, 2
+        with np.errstate(divide="ignore"):
+            lg = lambda v: float(np.log(np.float64(v)))
+            if hmm_type == 3:
+                vals = [lg(t[M, M]), lg(t[X, M]), lg(t[Y, M]), lg(t[M, X]), lg(t[M, Y]), lg(t[X, X]), lg(t[Y, Y]), lg(t[Y, X]), lg(t[X, Y])]
+            else:
+                fg, go, ge, gs = lg((t[X, M] + t[Y, M]) / 2.0), lg((t[M, X] + t[M, Y]) / 2.0), lg((t[X, X] + t[Y, Y]) / 2.0), lg((t[Y, X] + t[X, Y]) / 2.0)
+                vals = [lg(t[M, M]), fg, fg, go, go, ge, ge, gs, gs]
+            m = cls(*vals)
+            m.e_match[:] = [lg(v) for v in e[:16]]
+            m.e_gap_x[:] = [lg(v) for v in e[16:20]]
+            m.e_gap_y[:] = [lg(v) for v in e[20:24]]
+        return m
+
+    def copy(self) -> "PairHmm":
+        m = PairHmm()
+        C.memmove(C.byref(m), C.byref(self), C.sizeof(PairHmm))
+        return m
+
+    def reverse_complement(self) -> "PairHmm":
+        """the state machine of reverse strand reads (impl/parser.c:356-358)"""
+        m = self.copy()
+        load().mrp_pair_hmm_reverse_complement(C.byref(m))
+        return m
+
+
+class PairHmmStats(C.Structure):
+    _fields_ = [("pairs_lane", C.c_int64), ("pairs_wave", C.c_int64), ("cells", C.c_int64), ("kernel_ms", C.c_double), ("total_ms", C.c_double)]
+
+
 def load():
     """dlopen the in-tree library; raises if it has not been built (no fallback)."""
     global _lib
@@ -179,6 +236,13 @@ def load():
     L.mrp_phase_sets.argtypes = [i64, P(Variant), i64, C.c_double, C.c_double, vp, vp]
     L.mrp_binomial_p_value.argtypes = [i64, i64]
     L.mrp_binomial_p_value.restype = C.c_double
+    L.mrp_symbols_from_chars.argtypes = [C.c_char_p, i64, vp]
+    L.mrp_symbols_from_chars.restype = None
+    L.mrp_pair_hmm_reverse_complement.argtypes = [P(PairHmm)]
+    L.mrp_pair_hmm_reverse_complement.restype = None
+    L.mrp_band_diagonals.argtypes = [vp, i64, i64, i64, i64, vp, vp]
+    L.mrp_forward_probabilities.argtypes = [vp, vp, i32, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, C.c_int, C.c_int, vp, P(PairHmmStats)]
+    L.mrp_allele_read_supports.argtypes = [vp, P(PairHmm), P(PairHmm), i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp, P(PairHmmStats)]
     _lib = L
     return L
 
@@ -610,3 +674,73 @@ def phase_sets(variants, min_spanning, min_binomial, max_discordant):
     rs = np.zeros(n, dtype=np.int32)
     _check(L.mrp_phase_sets(n, arr, int(min_spanning), float(min_binomial), float(max_discordant), ps.ctypes.data, rs.ctypes.data))
     return [(int(ps[i]), int(rs[i])) for i in range(n)]
+
+
+# ---- read x allele alignment likelihoods (pair-HMM forward probability) ----
+
+def symbols_from_chars(seq) -> np.ndarray:
+    b = seq.encode() if isinstance(seq, str) else bytes(seq)
+    out = np.zeros(len(b), dtype=np.uint8)
+    load().mrp_symbols_from_chars(b, len(b), out.ctypes.data)
+    return out
+
+
+def band_diagonals(anchors, lx: int, ly: int, expansion: int):
+    a = np.ascontiguousarray(np.asarray(anchors, dtype=np.int64).reshape(-1, 2))
+    lo, hi = np.zeros(lx + ly + 1, dtype=np.int32), np.zeros(lx + ly + 1, dtype=np.int32)
+    _check(load().mrp_band_diagonals(a.ctypes.data if len(a) else None, len(a), lx, ly, expansion, lo.ctypes.data, hi.ctypes.data))
+    return lo, hi
+
+
+def _opt(a, dtype):
+    return None if a is None else np.ascontiguousarray(a, dtype=dtype)
+
+
+def forward_probabilities(ctx: Context, models, pool, x_off, x_len, y_off, y_len, model_index=None, anchor_off=None, anchors=None,
+                          expansion: int = 4, ragged_left: bool = False, ragged_right: bool = False):
+    """computeForwardProbability for a batch of pairs -> (float64 [n_pairs], PairHmmStats)"""
+    arr = (PairHmm * len(models))(*models)
+    pool = np.ascontiguousarray(pool, dtype=np.uint8)
+    xo, xl, yo, yl = _opt(x_off, np.int64), _opt(x_len, np.int32), _opt(y_off, np.int64), _opt(y_len, np.int32)
+    mi, ao, an = _opt(model_index, np.uint8), _opt(anchor_off, np.int64), _opt(anchors, np.int64)
+    n = len(xo)
+    out = np.zeros(n, dtype=np.float64)
+    st = PairHmmStats()
+    ptr = lambda a: None if a is None or a.size == 0 else a.ctypes.data
+    _check(load().mrp_forward_probabilities(ctx.h, C.cast(arr, C.c_void_p), len(models), n, ptr(pool), pool.size, ptr(xo), ptr(xl), ptr(yo), ptr(yl),
+                                            ptr(mi), None if ao is None else ao.ctypes.data, ptr(an), int(expansion), int(ragged_left),
+                                            int(ragged_right), ptr(out), C.byref(st)))
+    return out, st
+
+
+def allele_read_supports(ctx: Context, forward_model: PairHmm, reverse_model: PairHmm, bubbles, expansion: int = 4):
+    """bubbles: list of (alleles, reads, read_forward_strand) with alleles / reads lists of uint8 symbol arrays.
+    Returns ([float32 array [n_alleles, n_reads] per bubble], PairHmmStats): Bubble.alleleReadSupports (bubbleGraph.c:1421-1464)."""
+    strings, a_first, r_first, a_len, r_len, strand = [], [0], [0], [], [], []
+    a_off, r_off, pos = [], [], 0
+    for alleles, reads, fwd in bubbles:
+        for a in alleles:
+            a = np.ascontiguousarray(a, dtype=np.uint8)
+            strings.append(a); a_off.append(pos); a_len.append(len(a)); pos += len(a)
+        for r in reads:
+            r = np.ascontiguousarray(r, dtype=np.uint8)
+            strings.append(r); r_off.append(pos); r_len.append(len(r)); pos += len(r)
+        strand.extend(int(bool(x)) for x in fwd)
+        a_first.append(len(a_off))
+        r_first.append(len(r_off))
+    pool = np.concatenate(strings) if strings else np.zeros(0, dtype=np.uint8)
+    af, rf = np.array(a_first, dtype=np.int64), np.array(r_first, dtype=np.int64)
+    ao, al = np.array(a_off, dtype=np.int64), np.array(a_len, dtype=np.int32)
+    ro, rl = np.array(r_off, dtype=np.int64), np.array(r_len, dtype=np.int32)
+    sd = np.array(strand, dtype=np.uint8)
+    sizes = [(af[b + 1] - af[b]) * (rf[b + 1] - rf[b]) for b in range(len(bubbles))]
+    sup = np.zeros(int(sum(sizes)), dtype=np.float32)
+    st = PairHmmStats()
+    ptr = lambda a: None if a.size == 0 else a.ctypes.data
+    _check(load().mrp_allele_read_supports(ctx.h, C.byref(forward_model), C.byref(reverse_model), len(bubbles), af.ctypes.data, rf.ctypes.data,
+                                           ptr(pool), pool.size, ptr(ao), ptr(al), ptr(ro), ptr(rl), ptr(sd), int(expansion), ptr(sup), C.byref(st)))
+    out, p = [], 0
+    for b, sz in enumerate(sizes):
+        out.append(sup[p:p + int(sz)].reshape(int(af[b + 1] - af[b]), int(rf[b + 1] - rf[b])))
+        p += int(sz)
+    return out, st

@@ -1,0 +1,572 @@
+/*
+ * mrp_pairhmm.hip -- read x allele alignment likelihoods: the banded pair-HMM forward probability of the reference
+ * (computeForwardProbability, impl/pairwiseAligner.c:849-903) for batches of string pairs, and the alleleReadSupports
+ * loop around it (impl/bubbleGraph.c:1421-1464).  gfx950 only; compiled with -ffp-contract=off.
+ *
+ * The recursion (stateMachine3_cellCalculate, impl/stateMachine.c:562-586) gives every dp cell (x, y) three states from
+ * its neighbours (x-1, y), (x-1, y-1), (x, y-1); a neighbour outside the band contributes nothing, which is what a
+ * neighbour holding LOG_ZERO contributes, so the kernels keep -inf where the reference keeps NULL.  Each state is a
+ * chain of three logAdd (pairwiseAligner.c:279-299: cubic interpolation in fp64, float literals, no exp / log) in the
+ * reference's order.  Two mappings:
+ *
+ *   phm_lane_kernel   a pair per LANE, for pairs whose x string has at most 104 symbols and no anchors (their band is
+ *                     the whole matrix): the lane walks its matrix row by row, the previous row lives in LDS as
+ *                     row[x][state][lane] (conflict-free), the column x = 0 in registers.  All 64 lanes do useful
+ *                     work in every step when the pairs of a wave have similar shapes (the host sorts them), which
+ *                     is the case that matters: margin phase aligns ~25-symbol alleles to ~25-symbol read substrings,
+ *                     10^5 pairs per 1 Mb chunk.  LDS per wave = 1 536 B x (longest x string of the launch class):
+ *                     25 symbols -> 4 waves per CU, one per SIMD.
+ *   phm_wave_kernel   a pair per WAVE for everything else (long strings, anchored bands): x+y diagonal by diagonal, a
+ *                     lane per cell of the diagonal, the last two diagonals in LDS.
+ *
+ * Bound: fp64 VALU issue (~45 instructions per logAdd, six logAdd per cell); the kernels move ~0.1 B per flop.
+ */
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+#include "../../include/margin_rphmm.h"
+#include "mrp_internal.h"
+#include "rphmm_host.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+constexpr int PHM_WAVE = 64;
+constexpr int PHM_LANE_MAX_X = 104;    /* 104 * 1 536 B = 156 KB of the 160 KB */
+constexpr int PHM_WAVE_MAX_WIDTH = 2048; /* 3 diagonals * 2 048 cells * 3 states * 8 B = 144 KB */
+
+struct PhmModelDev {
+    double t[9];     /* order of mrp_pair_hmm */
+    double em[25];   /* [cx * 5 + cy], N rows / columns hold log(0.25^2) as written in stateMachine.c:380 */
+    double ex[5], ey[5];
+    double start[3]; /* stateMachine3_startStateProb / raggedStartStateProb */
+    double end[3];   /* stateMachine3_endStateProb / raggedEndStateProb */
+};
+
+struct PhmPair {
+    int64_t x_off, y_off;
+    int64_t band_off; /* first diagonal in the band array, -1: whole matrix */
+    int32_t lx, ly, model, out;
+};
+
+struct St {
+    double m, x, y;
+};
+
+#define PHM_NEG (-__builtin_inf())
+
+/* lookup(), pairwiseAligner.c:282-293: the float literals are rounded to float first, as the C compiler does */
+static __device__ __forceinline__ double phm_lookup(double x) {
+    const bool a = x <= 1.0, b = x <= 2.5, c = x <= 4.5;
+    const double c3 = a ? (double) -0.009350833524763f : b ? (double) -0.014532321752540f : c ? (double) -0.004605031767994f : (double) -0.000458661602210f;
+    const double c2 = a ? (double) 0.130659527668286f : b ? (double) 0.139942324101744f : c ? (double) 0.063427417320019f : (double) 0.009695946122598f;
+    const double c1 = a ? (double) 0.498799810682272f : b ? (double) 0.495635523139337f : c ? (double) 0.695956496475118f : (double) 0.930734667215156f;
+    const double c0 = a ? (double) 0.693203116424741f : b ? (double) 0.692140569840976f : c ? (double) 0.514272634594009f : (double) 0.168037164329057f;
+    return ((c3 * x + c2) * x + c1) * x + c0;
+}
+/* logAdd(), pairwiseAligner.c:295-299 */
+static __device__ __forceinline__ double phm_log_add(double x, double y) {
+    const bool lt = x < y;
+    const double hi = lt ? y : x, lo = lt ? x : y;
+    const double d = hi - lo; /* NaN for two LOG_ZEROs: not used, lo == LOG_ZERO decides first */
+    return (lo == PHM_NEG || d >= 7.5) ? hi : phm_lookup(d) + lo;
+}
+/* toCells[to] = logAdd(toCells[to], from + (eP + tP)) three times, starting from LOG_ZERO (logAdd(LOG_ZERO, a) == a) */
+static __device__ __forceinline__ double phm_chain(double a, double b, double c) { return phm_log_add(phm_log_add(a, b), c); }
+
+struct PhmRowT { /* eP + tP of the gap-y transitions of a row (y fixed) */
+    double open, extend, sw;
+};
+static __device__ __forceinline__ St phm_cell(const St &lower, const St &middle, const St &upper, const double *t, double eX, double eM,
+                                              const PhmRowT &ty) {
+    St cur;
+    cur.x = phm_chain(lower.m + (eX + t[3]), lower.x + (eX + t[5]), lower.y + (eX + t[7]));
+    cur.m = phm_chain(middle.m + (eM + t[0]), middle.x + (eM + t[1]), middle.y + (eM + t[2]));
+    cur.y = phm_chain(upper.m + ty.open, upper.y + ty.extend, upper.x + ty.sw);
+    return cur;
+}
+/* cell_dotProduct, pairwiseAligner.c:333-339 */
+static __device__ __forceinline__ double phm_dot(const St &f, const double *e) {
+    double tot = f.m + e[0];
+    tot = phm_log_add(tot, f.x + e[1]);
+    return phm_log_add(tot, f.y + e[2]);
+}
+static __device__ __forceinline__ int phm_wave_max(int v) {
+    for (int o = 32; o >= 1; o >>= 1) {
+        const int w = __shfl_xor(v, o, PHM_WAVE);
+        v = w > v ? w : v;
+    }
+    return v;
+}
+
+__global__ void __launch_bounds__(PHM_WAVE) phm_lane_kernel(const PhmPair *__restrict__ pairs, int64_t n_pairs, const uint8_t *__restrict__ pool,
+                                                              const PhmModelDev *__restrict__ models, double *__restrict__ out) {
+    extern __shared__ double phm_row[]; /* [x - 1][state][lane] */
+    const int lane = threadIdx.x;
+    const int64_t pi = (int64_t) blockIdx.x * PHM_WAVE + lane;
+    const bool have = pi < n_pairs;
+    PhmPair p;
+    if (have) p = pairs[pi];
+    else { p.x_off = 0; p.y_off = 0; p.band_off = -1; p.lx = -1; p.ly = -1; p.model = 0; p.out = 0; }
+    const int lx = p.lx, ly = p.ly;
+    const int mx = phm_wave_max(lx), my = phm_wave_max(ly);
+    const PhmModelDev *__restrict__ M = models + p.model;
+    double t[9], e_end[3];
+#pragma unroll
+    for (int i = 0; i < 9; i++) t[i] = M->t[i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) e_end[i] = M->end[i];
+    for (int x = 1; x <= mx; x++)
+#pragma unroll
+        for (int s = 0; s < 3; s++) phm_row[((x - 1) * 3 + s) * PHM_WAVE + lane] = PHM_NEG;
+    St b0{M->start[0], M->start[1], M->start[2]}; /* cell (0, y) */
+    St b0_old{PHM_NEG, PHM_NEG, PHM_NEG};
+    double result = PHM_NEG;
+    const uint8_t *__restrict__ sx = pool + p.x_off;
+    const uint8_t *__restrict__ sy = pool + p.y_off;
+    for (int y = 0; y <= my; y++) {
+        int cy = 4;
+        if (y >= 1 && y <= ly) { cy = sy[y - 1]; cy = cy > 4 ? 4 : cy; }
+        const double eY = M->ey[cy];
+        const PhmRowT ty{eY + t[4], eY + t[6], eY + t[8]};
+        if (y >= 1) {
+            b0_old = b0;
+            b0.m = PHM_NEG;
+            b0.x = PHM_NEG;
+            b0.y = phm_chain(b0_old.m + ty.open, b0_old.y + ty.extend, b0_old.x + ty.sw);
+        }
+        if (lx == 0 && y == ly) result = phm_dot(b0, e_end);
+        St left = b0, diag = b0_old;
+        const double *__restrict__ em_row = M->em + cy;
+        int cx_next = 4;
+        if (1 <= lx) { cx_next = sx[0]; cx_next = cx_next > 4 ? 4 : cx_next; }
+        for (int x = 1; x <= mx; x++) {
+            const int cx = cx_next;
+            cx_next = 4;
+            if (x + 1 <= lx) { cx_next = sx[x]; cx_next = cx_next > 4 ? 4 : cx_next; }
+            const double eX = M->ex[cx], eM = em_row[cx * 5];
+            double *__restrict__ r = phm_row + (size_t) (x - 1) * 3 * PHM_WAVE + lane;
+            const St up{r[0], r[PHM_WAVE], r[2 * PHM_WAVE]};
+            const St cur = phm_cell(left, diag, up, t, eX, eM, ty);
+            if (x <= lx && y <= ly) {
+                r[0] = cur.m;
+                r[PHM_WAVE] = cur.x;
+                r[2 * PHM_WAVE] = cur.y;
+            }
+            if (x == lx && y == ly) result = phm_dot(cur, e_end);
+            diag = up;
+            left = cur;
+        }
+    }
+    if (have) out[p.out] = (lx == 0 && ly == 0) ? 0.0 : result; /* :860-862 */
+}
+
+__global__ void __launch_bounds__(PHM_WAVE) phm_wave_kernel(const PhmPair *__restrict__ pairs, int64_t n_pairs, const uint8_t *__restrict__ pool,
+                                                              const PhmModelDev *__restrict__ models, const int32_t *__restrict__ band, int W,
+                                                              double *__restrict__ out) {
+    extern __shared__ double phm_diag[]; /* 3 diagonals x W cells x 3 states */
+    const int lane = threadIdx.x;
+    for (int64_t pi = blockIdx.x; pi < n_pairs; pi += gridDim.x) {
+        const PhmPair p = pairs[pi];
+        const int lx = p.lx, ly = p.ly, n = lx + ly;
+        if (n == 0) {
+            if (lane == 0) out[p.out] = 0.0;
+            continue;
+        }
+        const PhmModelDev *__restrict__ M = models + p.model;
+        double t[9];
+#pragma unroll
+        for (int i = 0; i < 9; i++) t[i] = M->t[i];
+        const uint8_t *__restrict__ sx = pool + p.x_off;
+        const uint8_t *__restrict__ sy = pool + p.y_off;
+        double *d0 = phm_diag, *d1 = phm_diag + 3 * W, *d2 = phm_diag + 6 * W; /* being written, xay - 1, xay - 2 */
+        auto limits = [&](int d, int &l, int &r) {
+            if (p.band_off >= 0) {
+                l = band[2 * (p.band_off + d)];
+                r = band[2 * (p.band_off + d) + 1];
+            } else {
+                const int xlo = d - ly > 0 ? d - ly : 0, xhi = d < lx ? d : lx;
+                l = 2 * xlo - d;
+                r = 2 * xhi - d;
+            }
+        };
+        int l1, r1, l2 = 1, r2 = 0;
+        limits(0, l1, r1);
+        for (int i = lane; i <= (r1 - l1) / 2; i += PHM_WAVE) {
+            d1[3 * i] = M->start[0];
+            d1[3 * i + 1] = M->start[1];
+            d1[3 * i + 2] = M->start[2];
+        }
+        __syncthreads();
+        for (int d = 1; d <= n; d++) {
+            int l, r;
+            limits(d, l, r);
+            const int width = (r - l) / 2 + 1;
+            for (int i = lane; i < width; i += PHM_WAVE) {
+                const int xmy = l + 2 * i;
+                const int x = (d + xmy) >> 1, y = (d - xmy) >> 1;
+                St lower{PHM_NEG, PHM_NEG, PHM_NEG}, middle = lower, upper = lower;
+                if (xmy - 1 >= l1 && xmy - 1 <= r1) { const double *c = d1 + 3 * ((xmy - 1 - l1) >> 1); lower = St{c[0], c[1], c[2]}; }
+                if (xmy + 1 >= l1 && xmy + 1 <= r1) { const double *c = d1 + 3 * ((xmy + 1 - l1) >> 1); upper = St{c[0], c[1], c[2]}; }
+                if (xmy >= l2 && xmy <= r2) { const double *c = d2 + 3 * ((xmy - l2) >> 1); middle = St{c[0], c[1], c[2]}; }
+                int cx = 4, cy = 4;
+                if (x > 0) { cx = sx[x - 1]; cx = cx > 4 ? 4 : cx; }
+                if (y > 0) { cy = sy[y - 1]; cy = cy > 4 ? 4 : cy; }
+                const double eY = M->ey[cy];
+                const PhmRowT ty{eY + t[4], eY + t[6], eY + t[8]};
+                const St cur = phm_cell(lower, middle, upper, t, M->ex[cx], M->em[cx * 5 + cy], ty);
+                d0[3 * i] = cur.m;
+                d0[3 * i + 1] = cur.x;
+                d0[3 * i + 2] = cur.y;
+            }
+            __syncthreads();
+            double *tmp = d2;
+            d2 = d1; d1 = d0; d0 = tmp;
+            l2 = l1; r2 = r1; l1 = l; r1 = r;
+        }
+        /* diagonalCalculationTotalProbability on the last diagonal (:578-596, no diagonal beyond it): dpDiagonal_dotProduct */
+        if (lane == 0) {
+            const double e_end[3] = {M->end[0], M->end[1], M->end[2]};
+            double tot = PHM_NEG;
+            for (int i = 0; i <= (r1 - l1) / 2; i++) tot = phm_log_add(tot, phm_dot(St{d1[3 * i], d1[3 * i + 1], d1[3 * i + 2]}, e_end));
+            out[p.out] = tot;
+        }
+        __syncthreads();
+    }
+}
+
+/* ---------------- host ---------------- */
+
+int fail(int code, const char *msg) { return mrp_set_error(code, "%s", msg); }
+
+#define PHM_HIP(expr)                                                                                                  \
+    do {                                                                                                               \
+        hipError_t e_ = (expr);                                                                                        \
+        if (e_ != hipSuccess) return mrp_set_error(MRP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e_));       \
+    } while (0)
+
+/* band_construct in closed form.  Between two consecutive anchor points P = (px, py) and N = (nx, ny) (matrix
+ * coordinates; the first P is (0, 0), the last N is (lx, ly)) the reference bounds the diagonals xay in (px + py,
+ * nx + ny] by xL = px - e/2, yL = ny + e/2, xU = nx + e/2, yU = py - e/2 (clamped to the matrix), :218-221; on such a
+ * diagonal band_setCurrentDiagonal (:96-114) yields the smallest xmy of the right parity with xmy >= xL - yL, x >= xL,
+ * y <= yL and the largest with xmy <= (xU - yU rounded UP to the parity), x <= xU, y >= yU. */
+int band_closed_form(const int64_t *anchors, int64_t n_anchors, int64_t lx, int64_t ly, int64_t expansion, int32_t *L, int32_t *R,
+                     int64_t *cells, int *max_width) {
+    if (lx < 0 || ly < 0 || expansion < 0 || expansion % 2 != 0) return MRP_ERR_ARG;
+    const int64_t e2 = expansion / 2;
+    auto clamp = [](int64_t z, int64_t hi) { return z < 0 ? (int64_t) 0 : (z > hi ? hi : z); };
+    L[0] = 0;
+    R[0] = 0;
+    int64_t total = 1;
+    int mw = 1;
+    int64_t px = 0, py = 0, ai = 0;
+    while (px + py < lx + ly) {
+        int64_t nx = lx, ny = ly;
+        if (ai < n_anchors) {
+            nx = anchors[2 * ai] + 1;
+            ny = anchors[2 * ai + 1] + 1;
+            ai++;
+            if (!(nx > px && ny > py && nx <= lx && ny <= ly)) return MRP_ERR_ARG; /* asserts :206-211 */
+        }
+        const int64_t xL = clamp(px - e2, lx), yL = clamp(ny + e2, ly), xU = clamp(nx + e2, lx), yU = clamp(py - e2, ly);
+        for (int64_t d = px + py + 1; d <= nx + ny; d++) {
+            int64_t l = xL - yL, r = xU - yU;
+            if ((d + l) % 2 != 0) l++;
+            if ((d + r) % 2 != 0) r++;
+            l = std::max(l, std::max(2 * xL - d, d - 2 * yL));
+            r = std::min(r, std::min(2 * xU - d, d - 2 * yU));
+            if (l > r) return MRP_ERR_ARG; /* diagonal_construct :22-27 throws */
+            L[d] = (int32_t) l;
+            R[d] = (int32_t) r;
+            const int64_t w = (r - l) / 2 + 1;
+            total += w;
+            if (w > mw) mw = (int) w;
+        }
+        px = nx;
+        py = ny;
+    }
+    /* the reference ignores anchors left over once (lx, ly) has been reached only if there are none: an anchor list that
+     * runs past the end fails its asserts, an anchor exactly at (lx - 1, ly - 1) followed by nothing is fine */
+    if (ai < n_anchors) return MRP_ERR_ARG;
+    if (cells) *cells = total;
+    if (max_width) *max_width = mw;
+    return MRP_OK;
+}
+
+void model_to_device(const mrp_pair_hmm &m, int ragged_left, int ragged_right, PhmModelDev &d) {
+    const double *t = &m.match_continue;
+    for (int i = 0; i < 9; i++) d.t[i] = t[i];
+    for (int x = 0; x < 5; x++)
+        for (int y = 0; y < 5; y++) d.em[x * 5 + y] = (x >= 4 || y >= 4) ? -2.772588722 : m.e_match[x * 4 + y]; /* stateMachine.c:378-383 */
+    for (int s = 0; s < 5; s++) {
+        d.ex[s] = s >= 4 ? -1.386294361 : m.e_gap_x[s]; /* :363-368 */
+        d.ey[s] = s >= 4 ? -1.386294361 : m.e_gap_y[s];
+    }
+    const double ninf = -INFINITY;
+    /* stateMachine.c:521-560 */
+    d.start[0] = ragged_left ? ninf : 0.0;
+    d.start[1] = ragged_left ? 0.0 : ninf;
+    d.start[2] = ragged_left ? 0.0 : ninf;
+    if (ragged_right) {
+        d.end[0] = (m.gap_open_x + m.gap_open_y) / 2.0;
+        d.end[1] = m.gap_extend_x;
+        d.end[2] = m.gap_extend_y;
+    } else {
+        d.end[0] = m.match_continue;
+        d.end[1] = m.match_from_gap_x;
+        d.end[2] = m.match_from_gap_y;
+    }
+}
+
+double now_ms() {
+    return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+const int LANE_CLASS_CAP[4] = {25, 33, 51, PHM_LANE_MAX_X}; /* 4, 3, 2, 1 waves per CU */
+const int WAVE_CLASS_CAP[4] = {64, 256, 1024, PHM_WAVE_MAX_WIDTH};
+
+}  // namespace
+
+extern "C" {
+
+void mrp_symbols_from_chars(const char *s, int64_t n, uint8_t *out) {
+    for (int64_t i = 0; i < n; i++) {
+        switch (s[i]) {
+            case 'A': case 'a': out[i] = 0; break;
+            case 'C': case 'c': out[i] = 1; break;
+            case 'G': case 'g': out[i] = 2; break;
+            case 'T': case 't': out[i] = 3; break;
+            default: out[i] = 4;
+        }
+    }
+}
+
+void mrp_pair_hmm_reverse_complement(mrp_pair_hmm *m) {
+    for (int i = 0; i < 4; i++)
+        for (int j = i + 1; j < 4; j++) std::swap(m->e_match[i * 4 + j], m->e_match[(3 - i) * 4 + (3 - j)]);
+    std::swap(m->e_match[0], m->e_match[15]);
+    std::swap(m->e_match[5], m->e_match[10]);
+    for (int i = 0; i < 2; i++) {
+        std::swap(m->e_gap_x[i], m->e_gap_x[3 - i]);
+        std::swap(m->e_gap_y[i], m->e_gap_y[3 - i]);
+    }
+}
+
+int mrp_band_diagonals(const int64_t *anchors, int64_t n_anchors, int64_t lx, int64_t ly, int64_t expansion, int32_t *xmy_l, int32_t *xmy_r) {
+    if (!xmy_l || !xmy_r || (n_anchors > 0 && !anchors) || n_anchors < 0) return fail(MRP_ERR_ARG, "mrp_band_diagonals: null argument");
+    if (lx + ly >= (1ll << 30)) return fail(MRP_ERR_ARG, "mrp_band_diagonals: strings too long");
+    const int rc = band_closed_form(anchors, n_anchors, lx, ly, expansion, xmy_l, xmy_r, nullptr, nullptr);
+    return rc == MRP_OK ? rc : fail(rc, "mrp_band_diagonals: invalid anchors or expansion (pairwiseAligner.c:179,206-211)");
+}
+
+int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int32_t n_models, int64_t n_pairs, const uint8_t *pool,
+                              int64_t pool_bytes, const int64_t *x_off, const int32_t *x_len, const int64_t *y_off, const int32_t *y_len,
+                              const uint8_t *model_index, const int64_t *anchor_off, const int64_t *anchors, int64_t expansion, int ragged_left,
+                              int ragged_right, double *out, mrp_pairhmm_stats *stats) {
+    const double t_begin = now_ms();
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!ctx) return fail(MRP_ERR_NO_DEVICE, "mrp_forward_probabilities: no context (the pair-HMM path has no CPU fallback)");
+    if (n_pairs < 0 || n_models <= 0 || !models || pool_bytes < 0) return fail(MRP_ERR_ARG, "mrp_forward_probabilities: bad sizes");
+    if (n_pairs == 0) return MRP_OK;
+    if (!x_off || !x_len || !y_off || !y_len || !out || (pool_bytes > 0 && !pool)) return fail(MRP_ERR_ARG, "mrp_forward_probabilities: null argument");
+    if (n_pairs >= (1ll << 31)) return fail(MRP_ERR_ARG, "mrp_forward_probabilities: more than 2^31 pairs in one call");
+    if (expansion < 0 || expansion % 2 != 0) return fail(MRP_ERR_ARG, "mrp_forward_probabilities: diagonalExpansion must be even (pairwiseAligner.c:855)");
+
+    /* classify */
+    HostVec<PhmPair> lane_pairs[4], wave_pairs[4];
+    HostVec<int32_t> band;
+    int64_t cells = 0;
+    std::vector<int32_t> L, R;
+    for (int64_t i = 0; i < n_pairs; i++) {
+        const int64_t lx = x_len[i], ly = y_len[i];
+        if (lx < 0 || ly < 0 || x_off[i] < 0 || y_off[i] < 0 || x_off[i] + lx > pool_bytes || y_off[i] + ly > pool_bytes)
+            return mrp_set_error(MRP_ERR_ARG, "mrp_forward_probabilities: pair %lld lies outside the symbol pool", (long long) i);
+        const int mi = model_index ? model_index[i] : 0;
+        if (mi >= n_models) return mrp_set_error(MRP_ERR_ARG, "mrp_forward_probabilities: pair %lld uses model %d of %d", (long long) i, mi, n_models);
+        const int64_t na = anchor_off ? anchor_off[i + 1] - anchor_off[i] : 0;
+        if (na < 0 || (na > 0 && !anchors)) return fail(MRP_ERR_ARG, "mrp_forward_probabilities: bad anchor offsets");
+        PhmPair p;
+        p.x_off = x_off[i];
+        p.y_off = y_off[i];
+        p.band_off = -1;
+        p.lx = (int32_t) lx;
+        p.ly = (int32_t) ly;
+        p.model = mi;
+        p.out = (int32_t) i;
+        if (na == 0 && lx <= PHM_LANE_MAX_X) {
+            int c = 0;
+            while (lx > LANE_CLASS_CAP[c]) c++;
+            lane_pairs[c].push_back(p);
+            cells += (lx + 1) * (ly + 1);
+            continue;
+        }
+        int width;
+        if (na == 0) {
+            width = (int) std::min(lx, ly) + 1;
+            cells += (lx + 1) * (ly + 1);
+        } else {
+            if (lx + ly >= (1ll << 30)) return fail(MRP_ERR_ARG, "mrp_forward_probabilities: strings too long");
+            L.resize((size_t) (lx + ly + 1));
+            R.resize((size_t) (lx + ly + 1));
+            int64_t c = 0;
+            const int rc = band_closed_form(anchors + 2 * anchor_off[i], na, lx, ly, expansion, L.data(), R.data(), &c, &width);
+            if (rc != MRP_OK) return mrp_set_error(rc, "mrp_forward_probabilities: pair %lld has invalid anchors (pairwiseAligner.c:206-211)", (long long) i);
+            cells += c;
+            p.band_off = (int64_t) band.size() / 2;
+            for (int64_t d = 0; d <= lx + ly; d++) { band.push_back(L[(size_t) d]); band.push_back(R[(size_t) d]); }
+        }
+        if (width > PHM_WAVE_MAX_WIDTH)
+            return mrp_set_error(MRP_ERR_UNSUPPORTED, "mrp_forward_probabilities: pair %lld has a diagonal of %d cells (limit %d)", (long long) i, width, PHM_WAVE_MAX_WIDTH);
+        int c = 0;
+        while (width > WAVE_CLASS_CAP[c]) c++;
+        wave_pairs[c].push_back(p);
+    }
+    /* pairs of similar shape share a wave: longest first, so the tail of the launch is made of the cheap ones */
+    for (auto &v : lane_pairs)
+        std::sort(v.begin(), v.end(), [](const PhmPair &a, const PhmPair &b) { return a.ly != b.ly ? a.ly > b.ly : (a.lx != b.lx ? a.lx > b.lx : a.out < b.out); });
+    for (auto &v : wave_pairs)
+        std::sort(v.begin(), v.end(), [](const PhmPair &a, const PhmPair &b) {
+            const int64_t ca = (int64_t) a.lx * a.ly, cb = (int64_t) b.lx * b.ly;
+            return ca != cb ? ca > cb : a.out < b.out;
+        });
+
+    PHM_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    std::vector<PhmModelDev> hm((size_t) n_models);
+    for (int i = 0; i < n_models; i++) model_to_device(models[i], ragged_left, ragged_right, hm[(size_t) i]);
+    DevBuf<PhmModelDev> d_models;
+    DevBuf<uint8_t> d_pool;
+    DevBuf<int32_t> d_band;
+    DevBuf<double> d_out;
+    DevBuf<PhmPair> d_pairs[8];
+    d_models.pool = d_pool.pool = d_band.pool = d_out.pool = &ctx->pool;
+    PHM_HIP(d_models.upload(hm, s));
+    PHM_HIP(d_pool.alloc((size_t) pool_bytes));
+    if (pool_bytes) PHM_HIP(hipMemcpyAsync(d_pool.p, pool, (size_t) pool_bytes, hipMemcpyHostToDevice, s));
+    PHM_HIP(d_band.upload(band, s));
+    PHM_HIP(d_out.alloc((size_t) n_pairs));
+    for (int c = 0; c < 4; c++) {
+        d_pairs[c].pool = d_pairs[4 + c].pool = &ctx->pool;
+        PHM_HIP(d_pairs[c].upload(lane_pairs[c], s));
+        PHM_HIP(d_pairs[4 + c].upload(wave_pairs[c], s));
+    }
+    static bool configured = false;
+    if (!configured) {
+        PHM_HIP(hipFuncSetAttribute((const void *) phm_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PHM_HIP(hipFuncSetAttribute((const void *) phm_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        configured = true;
+    }
+    PHM_HIP(hipEventRecord(ctx->ev[0], s));
+    for (int c = 0; c < 4; c++) {
+        const int64_t n = (int64_t) lane_pairs[c].size();
+        if (n == 0) continue;
+        int cap = 1;
+        for (const PhmPair &p : lane_pairs[c]) cap = std::max(cap, (int) p.lx);
+        const size_t lds = (size_t) cap * 3 * PHM_WAVE * sizeof(double);
+        hipLaunchKernelGGL(phm_lane_kernel, dim3((unsigned) ((n + PHM_WAVE - 1) / PHM_WAVE)), dim3(PHM_WAVE), lds, s, d_pairs[c].p, n, d_pool.p,
+                           d_models.p, d_out.p);
+        PHM_HIP(hipGetLastError());
+        if (stats) stats->pairs_lane += n;
+    }
+    for (int c = 0; c < 4; c++) {
+        const int64_t n = (int64_t) wave_pairs[c].size();
+        if (n == 0) continue;
+        const int W = WAVE_CLASS_CAP[c];
+        const size_t lds = (size_t) 9 * W * sizeof(double);
+        hipLaunchKernelGGL(phm_wave_kernel, dim3((unsigned) std::min<int64_t>(n, 16384)), dim3(PHM_WAVE), lds, s, d_pairs[4 + c].p, n, d_pool.p,
+                           d_models.p, d_band.p, W, d_out.p);
+        PHM_HIP(hipGetLastError());
+        if (stats) stats->pairs_wave += n;
+    }
+    PHM_HIP(hipEventRecord(ctx->ev[1], s));
+    PHM_HIP(hipMemcpyAsync(out, d_out.p, (size_t) n_pairs * sizeof(double), hipMemcpyDeviceToHost, s));
+    PHM_HIP(hipStreamSynchronize(s));
+    if (stats) {
+        float ms = 0.f;
+        PHM_HIP(hipEventElapsedTime(&ms, ctx->ev[0], ctx->ev[1]));
+        stats->kernel_ms = ms;
+        stats->cells = cells;
+    }
+    d_models.release(); d_pool.release(); d_band.release(); d_out.release();
+    for (auto &b : d_pairs) b.release();
+    ctx->pool.reclaim();
+    if (stats) stats->total_ms = now_ms() - t_begin;
+    return MRP_OK;
+}
+
+int mrp_allele_read_supports(mrp_context *ctx, const mrp_pair_hmm *forward_model, const mrp_pair_hmm *reverse_model, int64_t n_bubbles,
+                             const int64_t *allele_first, const int64_t *read_first, const uint8_t *pool, int64_t pool_bytes,
+                             const int64_t *allele_off, const int32_t *allele_len, const int64_t *read_off, const int32_t *read_len,
+                             const uint8_t *read_forward_strand, int64_t expansion, float *support, mrp_pairhmm_stats *stats) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    if (!ctx) return fail(MRP_ERR_NO_DEVICE, "mrp_allele_read_supports: no context (the pair-HMM path has no CPU fallback)");
+    if (n_bubbles < 0) return fail(MRP_ERR_ARG, "mrp_allele_read_supports: bad sizes");
+    if (n_bubbles == 0) return MRP_OK;
+    if (!forward_model || !reverse_model || !allele_first || !read_first || !allele_off || !allele_len || !read_off || !read_len ||
+        !read_forward_strand || !support || (pool_bytes > 0 && !pool))
+        return fail(MRP_ERR_ARG, "mrp_allele_read_supports: null argument");
+    const int64_t n_reads_total = read_first[n_bubbles];
+    for (int64_t k = 0; k < n_reads_total; k++)
+        if (read_len[k] < 0 || read_off[k] < 0 || read_off[k] + read_len[k] > pool_bytes) return fail(MRP_ERR_ARG, "mrp_allele_read_supports: read substring outside the pool");
+    /* cachedScores (bubbleGraph.c:1418,1431-1441): the first read of the bubble with a given substring owns the scores */
+    std::vector<int64_t> owner((size_t) n_reads_total);
+    mrp_parallel_for(n_bubbles, 64, [&](int64_t b) {
+        const int64_t r0 = read_first[b], r1 = read_first[b + 1];
+        std::vector<int64_t> order((size_t) (r1 - r0));
+        for (int64_t k = r0; k < r1; k++) order[(size_t) (k - r0)] = k;
+        auto less = [&](int64_t a, int64_t c) {
+            if (read_len[a] != read_len[c]) return read_len[a] < read_len[c];
+            const int cmp = memcmp(pool + read_off[a], pool + read_off[c], (size_t) read_len[a]);
+            return cmp != 0 ? cmp < 0 : a < c;
+        };
+        std::sort(order.begin(), order.end(), less);
+        for (size_t i = 0; i < order.size(); i++) {
+            const int64_t k = order[i];
+            const bool same = i > 0 && read_len[order[i - 1]] == read_len[k] && memcmp(pool + read_off[order[i - 1]], pool + read_off[k], (size_t) read_len[k]) == 0;
+            owner[(size_t) k] = same ? owner[(size_t) order[i - 1]] : k;
+        }
+    });
+    const mrp_pair_hmm models[2] = {*forward_model, *reverse_model};
+    std::vector<int64_t> xo, yo, where;
+    std::vector<int32_t> xl, yl;
+    std::vector<uint8_t> mi;
+    std::vector<int64_t> support_first((size_t) n_bubbles + 1, 0);
+    for (int64_t b = 0; b < n_bubbles; b++) {
+        const int64_t na = allele_first[b + 1] - allele_first[b], nr = read_first[b + 1] - read_first[b];
+        if (na < 0 || nr < 0) return fail(MRP_ERR_ARG, "mrp_allele_read_supports: offsets not ascending");
+        support_first[(size_t) b + 1] = support_first[(size_t) b] + na * nr;
+        for (int64_t k = read_first[b]; k < read_first[b + 1]; k++) {
+            if (owner[(size_t) k] != k) continue;
+            for (int64_t j = allele_first[b]; j < allele_first[b + 1]; j++) {
+                xo.push_back(allele_off[j]);
+                xl.push_back(allele_len[j]);
+                yo.push_back(read_off[k]);
+                yl.push_back(read_len[k]);
+                mi.push_back(read_forward_strand[k] ? 0 : 1);
+                where.push_back(support_first[(size_t) b] + (j - allele_first[b]) * nr + (k - read_first[b]));
+            }
+        }
+    }
+    std::vector<double> lp(xo.size());
+    const int rc = mrp_forward_probabilities(ctx, models, 2, (int64_t) xo.size(), pool, pool_bytes, xo.data(), xl.data(), yo.data(), yl.data(), mi.data(),
+                                             nullptr, nullptr, expansion, 0, 0, lp.data(), stats);
+    if (rc != MRP_OK) return rc;
+    for (size_t i = 0; i < lp.size(); i++) support[where[i]] = (float) lp[i];
+    for (int64_t b = 0; b < n_bubbles; b++) {
+        const int64_t na = allele_first[b + 1] - allele_first[b], nr = read_first[b + 1] - read_first[b];
+        for (int64_t k = 0; k < nr; k++) {
+            const int64_t o = owner[(size_t) (read_first[b] + k)] - read_first[b];
+            if (o == k) continue;
+            for (int64_t j = 0; j < na; j++) support[support_first[(size_t) b] + j * nr + k] = support[support_first[(size_t) b] + j * nr + o];
+        }
+    }
+    return MRP_OK;
+}
+
+}  // extern "C"

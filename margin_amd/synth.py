@@ -157,3 +157,75 @@ def unit_test_params(max_partitions: int = 50, max_not_sum: int = 0, min_cov: in
                 minPosteriorProbabilityForPartition=0.0, maxCoverageDepth=64,
                 minReadCoverageToSupportPhasingBetweenHeterozygousSites=min_cov, includeInvertedPartitions=1,
                 roundsOfIterativeRefinement=0, includeAncestorSubProb=0)
+
+
+# ---- read x allele alignment pairs (pair-HMM forward probability) ----
+
+def random_sequence(rng, length: int, n_rate: float = 0.0) -> np.ndarray:
+    """uint8 symbols 0..3 (ACGT), 4 = N with probability n_rate"""
+    s = rng.integers(0, 4, size=length).astype(np.uint8)
+    if n_rate > 0:
+        s[rng.random(length) < n_rate] = 4
+    return s
+
+
+def evolve_sequence(rng, s: np.ndarray, sub: float = 0.05, ins: float = 0.03, dele: float = 0.03) -> np.ndarray:
+    """substitutions, insertions and deletions at ONT-like rates (the role of evolveSequence in tests/pairwiseAlignerTest.c)"""
+    out = []
+    for c in s:
+        r = rng.random()
+        if r < dele:
+            continue
+        out.append(int(rng.integers(0, 4)) if r < dele + sub else int(c))
+        while rng.random() < ins:
+            out.append(int(rng.integers(0, 4)))
+    return np.array(out, dtype=np.uint8)
+
+
+def margin_phase_pair_hmm_arrays():
+    """"hmmForwardStrandReadGivenReference" of the reference's params/base_params.json (type, transitions, emissions)"""
+    transitions = [0.8, 0.1, 0.1, 0.5, 0.5, 0.0, 0.5, 0.0, 0.5]
+    emissions = [0.969, 0.005, 0.017, 0.009, 0.008, 0.973, 0.007, 0.012, 0.021, 0.007, 0.967, 0.006, 0.008, 0.008, 0.004, 0.98,
+                 1.0, 1.0, 1.0, 1.0, 0.25, 0.25, 0.25, 0.25]
+    return 2, transitions, emissions
+
+
+def make_bubble_strings(seed: int = 1, n_sites: int = 2000, coverage: int = 30, expansion: int = 12, allele_error=(0.05, 0.03, 0.03),
+                        duplicate_rate: float = 0.0):
+    """The strings margin phase aligns for one chunk of config 2: per het SNP site two alleles (the reference window of
+    referenceExpansionForSmallVariants = 12 either side, the site substituted) and ~coverage read substrings, each a noisy
+    copy of one allele, strand Bernoulli(0.5).  Returns a list of (alleles, reads, forward_strand) bubbles."""
+    rng = np.random.default_rng(seed)
+    bubbles = []
+    for _ in range(n_sites):
+        ref = random_sequence(rng, 2 * expansion + 1)
+        alt = ref.copy()
+        alt[expansion] = (alt[expansion] + 1 + rng.integers(0, 3)) % 4
+        n = max(1, int(rng.poisson(coverage)))
+        reads, strands = [], []
+        for _k in range(n):
+            if reads and rng.random() < duplicate_rate:
+                reads.append(reads[int(rng.integers(0, len(reads)))].copy())
+            else:
+                reads.append(evolve_sequence(rng, ref if rng.random() < 0.5 else alt, *allele_error))
+            strands.append(bool(rng.random() < 0.5))
+        bubbles.append(([ref, alt], reads, strands))
+    return bubbles
+
+
+def pairs_from_bubbles(bubbles):
+    """flatten bubbles into (pool, x_off, x_len, y_off, y_len, model_index): every allele x read pair, model 0 = forward strand"""
+    strings, xo, xl, yo, yl, mi = [], [], [], [], [], []
+    pos = 0
+    for alleles, reads, fwd in bubbles:
+        a_at = []
+        for a in alleles:
+            strings.append(a); a_at.append((pos, len(a))); pos += len(a)
+        for r, f in zip(reads, fwd):
+            strings.append(r)
+            for (ao, al) in a_at:
+                xo.append(ao); xl.append(al); yo.append(pos); yl.append(len(r)); mi.append(0 if f else 1)
+            pos += len(r)
+    pool = np.concatenate(strings) if strings else np.zeros(0, dtype=np.uint8)
+    return (pool, np.array(xo, dtype=np.int64), np.array(xl, dtype=np.int32), np.array(yo, dtype=np.int64), np.array(yl, dtype=np.int32),
+            np.array(mi, dtype=np.uint8))

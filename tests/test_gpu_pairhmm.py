@@ -1,0 +1,137 @@
+"""GPU parity of the pair-HMM forward probability (mrp_forward_probabilities / mrp_allele_read_supports) through the C-ABI:
+bit-exact fp64 against the CPU oracle (the arithmetic is + and * only; neither side may fuse them)."""
+import os
+
+import numpy as np
+import pytest
+
+from margin_amd import capi, synth
+from oracle import pairhmm as ph
+from tests.test_pairhmm import GOLDEN, omodel, random_anchors
+
+pytestmark = pytest.mark.gpu
+
+
+def models3():
+    t, tr, em = synth.margin_phase_pair_hmm_arrays()
+    f = capi.PairHmm.from_margin_hmm(t, tr, em)
+    return [f, f.reverse_complement(), capi.PairHmm.default_nucleotide()]
+
+
+def pack(pairs):
+    strings, xo, xl, yo, yl, pos = [], [], [], [], [], 0
+    for a, b in pairs:
+        strings += [a, b]
+        xo.append(pos); xl.append(len(a)); pos += len(a)
+        yo.append(pos); yl.append(len(b)); pos += len(b)
+    pool = np.concatenate(strings) if pos else np.zeros(0, np.uint8)
+    return pool, np.array(xo, np.int64), np.array(xl, np.int32), np.array(yo, np.int64), np.array(yl, np.int32)
+
+
+def test_golden_vectors(gpu_ctx):
+    g = np.load(GOLDEN)
+    models = [capi.PairHmm.from_buffer_copy(g["models"][i].tobytes()) for i in range(len(g["models"]))]
+    for tag in ("short", "long"):
+        out, st = capi.forward_probabilities(gpu_ctx, models, g["pool"], g[f"{tag}_x_off"], g[f"{tag}_x_len"], g[f"{tag}_y_off"], g[f"{tag}_y_len"],
+                                             g[f"{tag}_model"], g[f"{tag}_anchor_off"], g[f"{tag}_anchors"], int(g["expansion"]),
+                                             bool(g[f"{tag}_ragged"][0]), bool(g[f"{tag}_ragged"][1]))
+        assert (out == g[f"{tag}_out"]).all()
+        assert (st.pairs_wave > 0) == (tag == "long")
+
+
+@pytest.mark.parametrize("ragged", [(False, False), (True, False), (False, True), (True, True)])
+def test_pair_per_lane_kernel_bit_exact(gpu_ctx, ragged):
+    """every launch class of the pair-per-lane kernel (x up to 25 / 33 / 51 / 104 symbols), empty strings, Ns, three models"""
+    rng = np.random.default_rng(100 + 2 * ragged[0] + ragged[1])
+    pairs = []
+    for _ in range(700):
+        lx = int(rng.choice([0, 1, 2, 24, 25, 26, 33, 34, 51, 52, 104])) if rng.random() < 0.4 else int(rng.integers(0, 105))
+        a = synth.random_sequence(rng, lx, n_rate=0.03)
+        b = synth.evolve_sequence(rng, a) if rng.random() < 0.8 else synth.random_sequence(rng, int(rng.integers(0, 160)), n_rate=0.03)
+        pairs.append((a, b))
+    pairs += [(np.zeros(0, np.uint8), np.zeros(0, np.uint8)), (np.zeros(0, np.uint8), synth.random_sequence(rng, 9)), (synth.random_sequence(rng, 9), np.zeros(0, np.uint8))]
+    pool, xo, xl, yo, yl = pack(pairs)
+    mi = rng.integers(0, 3, size=len(pairs)).astype(np.uint8)
+    ms = models3()
+    out, st = capi.forward_probabilities(gpu_ctx, ms, pool, xo, xl, yo, yl, mi, expansion=4, ragged_left=ragged[0], ragged_right=ragged[1])
+    ref = ph.forward_batch([omodel(m) for m in ms], pool, xo, xl, yo, yl, mi, expansion=4, ragged_left=ragged[0], ragged_right=ragged[1])
+    assert st.pairs_lane == len(pairs) and st.pairs_wave == 0
+    assert st.cells == int(((xl.astype(np.int64) + 1) * (yl.astype(np.int64) + 1)).sum())
+    assert (out == ref).all()
+    assert out[len(pairs) - 3] == 0.0  # two empty strings: LOG_ONE, pairwiseAligner.c:860-862
+
+
+def test_pair_per_wave_kernel_bit_exact(gpu_ctx):
+    """long strings without anchors (whole matrix, diagonals wider than a wave) and anchored bands of several expansions"""
+    rng = np.random.default_rng(7)
+    ms = models3()
+    oms = [omodel(m) for m in ms]
+    for expansion in (0, 4, 20):
+        pairs, aoff, anc = [], [0], []
+        for i in range(40):
+            lx = int(rng.integers(105, 700)) if i % 4 else int(rng.integers(0, 60))
+            a = synth.random_sequence(rng, lx, n_rate=0.01)
+            b = synth.evolve_sequence(rng, a)
+            pairs.append((a, b))
+            if i % 3:
+                anc += random_anchors(rng, len(a), len(b))
+            aoff.append(len(anc))
+        pool, xo, xl, yo, yl = pack(pairs)
+        mi = rng.integers(0, 3, size=len(pairs)).astype(np.uint8)
+        an = np.array(anc, np.int64).reshape(-1, 2)
+        out, st = capi.forward_probabilities(gpu_ctx, ms, pool, xo, xl, yo, yl, mi, np.array(aoff, np.int64), an, expansion=expansion, ragged_left=True)
+        ref = ph.forward_batch(oms, pool, xo, xl, yo, yl, mi, np.array(aoff, np.int64), an, expansion=expansion, ragged_left=True)
+        assert st.pairs_wave > 0 and np.isfinite(ref).all()
+        assert (out == ref).all()
+
+
+def test_allele_read_supports_like_the_bubble_loop(gpu_ctx):
+    """mrp_allele_read_supports = the loop of bubbleGraph.c:1421-1464, duplicates and strands included, float32 results"""
+    t, tr, em = synth.margin_phase_pair_hmm_arrays()
+    f = capi.PairHmm.from_margin_hmm(t, tr, em)
+    r = f.reverse_complement()
+    bubbles = synth.make_bubble_strings(seed=11, n_sites=60, coverage=20, duplicate_rate=0.3)
+    bubbles.append(([synth.random_sequence(np.random.default_rng(1), 25)], [], []))  # a bubble without reads
+    got, st = capi.allele_read_supports(gpu_ctx, f, r, bubbles)
+    n_dup = 0
+    for (alleles, reads, fwd), sup in zip(bubbles, got):
+        ref = ph.allele_read_supports(omodel(f), omodel(r), alleles, reads, fwd) if reads else np.zeros((len(alleles), 0), np.float32)
+        assert sup.shape == ref.shape and (sup == ref).all()
+        n_dup += len(reads) - len({bytes(x) for x in reads})
+    assert n_dup > 50 and st.pairs_lane == sum(2 * len({bytes(x) for x in b[1]}) for b in bubbles)
+
+
+def test_config2_chunk_of_alignments(gpu_ctx):
+    """one 1 Mb chunk of config 2 (2 000 sites x ~30 reads x 2 alleles = ~1.2e5 pairs): a sample against the oracle, and the
+    size-independent property that a pair's result does not depend on the batch it travels in"""
+    ms = models3()[:2]
+    bubbles = synth.make_bubble_strings(seed=2, n_sites=2000, coverage=30)
+    pool, xo, xl, yo, yl, mi = synth.pairs_from_bubbles(bubbles)
+    out, st = capi.forward_probabilities(gpu_ctx, ms, pool, xo, xl, yo, yl, mi)
+    assert len(out) > 100_000 and np.isfinite(out).all() and (out <= 0).all()
+    rng = np.random.default_rng(0)
+    pick = np.sort(rng.choice(len(out), size=3000, replace=False))
+    ref = ph.forward_batch([omodel(m) for m in ms], pool, xo[pick], xl[pick], yo[pick], yl[pick], mi[pick])
+    assert (out[pick] == ref).all()
+    sub, _ = capi.forward_probabilities(gpu_ctx, ms, pool, xo[pick], xl[pick], yo[pick], yl[pick], mi[pick])
+    assert (sub == out[pick]).all()
+
+
+def test_errors(gpu_ctx):
+    ms = models3()
+    a = np.zeros(10, np.uint8)
+    with pytest.raises(capi.MrpError) as e:  # anchors not increasing
+        capi.forward_probabilities(gpu_ctx, ms, a, [0], [5], [5], [5], None, [0, 2], [[2, 2], [2, 3]])
+    assert e.value.code == capi.MRP_ERR_ARG
+    with pytest.raises(capi.MrpError) as e:  # string outside the pool
+        capi.forward_probabilities(gpu_ctx, ms, a, [0], [5], [6], [5])
+    assert e.value.code == capi.MRP_ERR_ARG
+    with pytest.raises(capi.MrpError) as e:  # model index
+        capi.forward_probabilities(gpu_ctx, ms, a, [0], [5], [5], [5], [3])
+    assert e.value.code == capi.MRP_ERR_ARG
+    big = np.zeros(2 * 2100, np.uint8)
+    with pytest.raises(capi.MrpError) as e:  # a 2 101-cell diagonal
+        capi.forward_probabilities(gpu_ctx, ms, big, [0], [2100], [2100], [2100])
+    assert e.value.code == capi.MRP_ERR_UNSUPPORTED
+    out, _ = capi.forward_probabilities(gpu_ctx, ms, a, np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros(0, np.int32))
+    assert len(out) == 0
