@@ -350,7 +350,7 @@ int mrp_band_diagonals(const int64_t *anchors, int64_t n_anchors, int64_t lx, in
  * selects models[i] per pair; anchor_off (NULL: no anchors anywhere) holds n_pairs + 1 offsets into anchors (pairs of
  * int64).  A pair without anchors covers its whole matrix, as in the reference.  out[i] = log probability (0.0 for two
  * empty strings, :860-862).  Limits: a diagonal of at most 2 048 cells for pairs that go to the pair-per-wave kernel
- * (x longer than 104 symbols, or anchored); beyond that MRP_ERR_UNSUPPORTED.  stats may be NULL. */
+ * (x longer than 100 symbols, or anchored); beyond that MRP_ERR_UNSUPPORTED.  stats may be NULL. */
 int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int32_t n_models, int64_t n_pairs, const uint8_t *pool,
                               int64_t pool_bytes, const int64_t *x_off, const int32_t *x_len, const int64_t *y_off,
                               const int32_t *y_len, const uint8_t *model_index, const int64_t *anchor_off, const int64_t *anchors,

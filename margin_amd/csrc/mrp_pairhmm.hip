@@ -9,7 +9,7 @@
  * chain of three logAdd (pairwiseAligner.c:279-299: cubic interpolation in fp64, float literals, no exp / log) in the
  * reference's order.  Two mappings:
  *
- *   phm_lane_kernel   a pair per LANE, for pairs whose x string has at most 104 symbols and no anchors (their band is
+ *   phm_lane_kernel   a pair per LANE, for pairs whose x string has at most 100 symbols and no anchors (their band is
  *                     the whole matrix): the lane walks its matrix row by row, the previous row lives in LDS as
  *                     row[x][state][lane] (conflict-free), the column x = 0 in registers.  All 64 lanes do useful
  *                     work in every step when the pairs of a wave have similar shapes (the host sorts them), which
@@ -19,7 +19,7 @@
  *   phm_wave_kernel   a pair per WAVE for everything else (long strings, anchored bands): x+y diagonal by diagonal, a
  *                     lane per cell of the diagonal, the last two diagonals in LDS.
  *
- * Bound: fp64 VALU issue (~45 instructions per logAdd, six logAdd per cell); the kernels move ~0.1 B per flop.
+ * Bound: fp64 VALU issue (six logAdd per cell); the kernels move ~0.1 B per flop.
  */
 #include <hip/hip_runtime.h>
 
@@ -38,7 +38,13 @@
 namespace {
 
 constexpr int PHM_WAVE = 64;
-constexpr int PHM_LANE_MAX_X = 104;    /* 104 * 1 536 B = 156 KB of the 160 KB */
+constexpr int PHM_LANE_MAX_X = 100;    /* 100 * 1 600 B = 156 KB of the 160 KB, the rest holds the tables */
+constexpr int PHM_LDS_BYTES = 160 * 1024;
+#ifndef PHM_ROWS
+#define PHM_ROWS 4 /* rows a lane of the pair-per-lane kernel advances together */
+#endif
+constexpr int PHM_LANE_BYTES_PER_X = 3 * 64 * 8 + 64; /* LDS per wave and x position: three states per lane + the lane's symbol */
+constexpr int PHM_ETAB = 25 * 6;       /* doubles per model in the emission + transition table */
 constexpr int PHM_WAVE_MAX_WIDTH = 2048; /* 3 diagonals * 2 048 cells * 3 states * 8 B = 144 KB */
 
 struct PhmModelDev {
@@ -52,6 +58,11 @@ struct PhmModelDev {
 struct PhmPair {
     int64_t x_off, y_off;
     int64_t band_off; /* first diagonal in the band array, -1: whole matrix */
+    int32_t lx, ly, model, out;
+};
+
+struct PhmLanePair { /* pair-per-lane kernel: no band */
+    int64_t x_off, y_off;
     int32_t lx, ly, model, out;
 };
 
@@ -77,6 +88,56 @@ static __device__ __forceinline__ double phm_log_add(double x, double y) {
     const double d = hi - lo; /* NaN for two LOG_ZEROs: not used, lo == LOG_ZERO decides first */
     return (lo == PHM_NEG || d >= 7.5) ? hi : phm_lookup(d) + lo;
 }
+/* The same two functions with the coefficients of the interval read from LDS (coef[interval][c3, c2, c1, c0]) instead
+ * of selected with 24 v_cndmask: the pair-per-lane kernel is bound by VALU issue, its LDS pipe is mostly idle */
+__device__ const float PHM_COEF[16] = {-0.009350833524763f, 0.130659527668286f, 0.498799810682272f, 0.693203116424741f,
+                                       -0.014532321752540f, 0.139942324101744f, 0.495635523139337f, 0.692140569840976f,
+                                       -0.004605031767994f, 0.063427417320019f, 0.695956496475118f, 0.514272634594009f,
+                                       -0.000458661602210f, 0.009695946122598f, 0.930734667215156f, 0.168037164329057f};
+/* -DPHM_COEF_SELECT: the coefficients are float literals, select the float's bits (3 v_cndmask each) and widen */
+static __device__ __forceinline__ double phm_lookup_t(double x, const double *coef) {
+#ifdef PHM_COEF_SELECT
+    const bool a = x <= 1.0, b = x <= 2.5, c = x <= 4.5;
+    auto sel = [&](float f0, float f1, float f2, float f3) {
+        uint32_t v = c ? __float_as_uint(f2) : __float_as_uint(f3);
+        v = b ? __float_as_uint(f1) : v;
+        v = a ? __float_as_uint(f0) : v;
+        double d;
+        asm("v_cvt_f64_f32 %0, %1" : "=v"(d) : "v"(v));
+        return d;
+    };
+    const double c3 = sel(-0.009350833524763f, -0.014532321752540f, -0.004605031767994f, -0.000458661602210f);
+    const double c2 = sel(0.130659527668286f, 0.139942324101744f, 0.063427417320019f, 0.009695946122598f);
+    const double c1 = sel(0.498799810682272f, 0.495635523139337f, 0.695956496475118f, 0.930734667215156f);
+    const double c0 = sel(0.693203116424741f, 0.692140569840976f, 0.514272634594009f, 0.168037164329057f);
+    return ((c3 * x + c2) * x + c1) * x + c0;
+#else
+    const int idx = (x > 1.0 ? 1 : 0) + (x > 2.5 ? 1 : 0) + (x > 4.5 ? 1 : 0);
+    const double2 a = *reinterpret_cast<const double2 *>(coef + idx * 4);
+    const double2 b = *reinterpret_cast<const double2 *>(coef + idx * 4 + 2);
+    return ((a.x * x + a.y) * x + b.x) * x + b.y;
+#endif
+}
+/* Branch-free on purpose: the interpolation is evaluated for every lane and thrown away where logAdd returns the larger
+ * operand (d = inf or NaN then selects a valid table row and produces a value nobody reads).  With the conditional
+ * written around the interpolation the compiler emits one basic block per logAdd, each waiting for its own LDS read, and
+ * the single wave of a SIMD sits idle for the latency six times per cell; as straight-line code the three state chains
+ * of a cell interleave. */
+static __device__ __forceinline__ double phm_log_add_t(double x, double y, const double *coef) {
+    /* the larger and the smaller operand (for x == y the reference takes hi = x, lo = y: the same two numbers) */
+    const double hi = __builtin_fmax(x, y), lo = __builtin_fmin(x, y);
+    const double d = hi - lo; /* inf if lo is LOG_ZERO, NaN if both are */
+    const double v = phm_lookup_t(d, coef) + lo;
+    return !(d < 7.5) ? hi : v; /* lo == LOG_ZERO || d >= 7.5 */
+}
+/* HAS_SWITCH = false: every model has TRANSITION_GAP_SWITCH_TO_X / _Y = log(0) (the shipped margin parameters), the
+ * third term of the gap chains is LOG_ZERO and logAdd(a, LOG_ZERO) == a */
+template <bool THIRD>
+static __device__ __forceinline__ double phm_chain_t(double a, double b, double c, const double *coef) {
+    const double ab = phm_log_add_t(a, b, coef);
+    return THIRD ? phm_log_add_t(ab, c, coef) : ab;
+}
+
 /* toCells[to] = logAdd(toCells[to], from + (eP + tP)) three times, starting from LOG_ZERO (logAdd(LOG_ZERO, a) == a) */
 static __device__ __forceinline__ double phm_chain(double a, double b, double c) { return phm_log_add(phm_log_add(a, b), c); }
 
@@ -105,66 +166,142 @@ static __device__ __forceinline__ int phm_wave_max(int v) {
     return v;
 }
 
-__global__ void __launch_bounds__(PHM_WAVE) phm_lane_kernel(const PhmPair *__restrict__ pairs, int64_t n_pairs, const uint8_t *__restrict__ pool,
-                                                              const PhmModelDev *__restrict__ models, double *__restrict__ out) {
-    extern __shared__ double phm_row[]; /* [x - 1][state][lane] */
-    const int lane = threadIdx.x;
-    const int64_t pi = (int64_t) blockIdx.x * PHM_WAVE + lane;
+/* LDS: coef[16] | etab[n_models][cx][cy][6] = eX + {open, extend, switch to x}, eM + {continue, from x, from y} |
+ * rows[wave][x - 1][state][lane].  The waves of a workgroup share the tables and nothing else.
+ *
+ * A lane walks its matrix R rows at a time, row r one column behind row r - 1 (x_r = k - r in step k), so the R cells
+ * of a step depend only on cells of earlier steps: left = the row's own cell of step k - 1, up / diagonal = the cells
+ * of the row above from steps k - 1 / k - 2, all in registers.  Only the first row of a pass reads the LDS row (the last
+ * row of the previous pass) and only the last row writes it.  With one wave per SIMD this is what hides the latency of
+ * the dependent fp64 chains and of the table reads: R * 3 independent chains per step instead of 3.
+ * Cells beyond a lane's own strings are computed and ignored: nothing flows from larger x or y to smaller. */
+template <int R, bool HAS_SWITCH>
+__global__ void __launch_bounds__(256) phm_lane_kernel(const PhmLanePair *__restrict__ pairs, int64_t n_pairs, const uint8_t *__restrict__ pool,
+                                                       const PhmModelDev *__restrict__ models, int n_models, int cap, double *__restrict__ out) {
+    extern __shared__ double phm_lds[];
+    double *coef = phm_lds;
+    double *etab = phm_lds + 16;
+    const int lane = threadIdx.x & (PHM_WAVE - 1), wave = threadIdx.x / PHM_WAVE, n_waves = blockDim.x / PHM_WAVE;
+    uint8_t *wave_base = reinterpret_cast<uint8_t *>(etab + (size_t) n_models * PHM_ETAB) + (size_t) wave * cap * PHM_LANE_BYTES_PER_X;
+    double *row = reinterpret_cast<double *>(wave_base) + lane;          /* [x - 1][state][lane] */
+    uint8_t *symx = wave_base + (size_t) cap * 3 * PHM_WAVE * sizeof(double) + lane; /* [x - 1][lane]: the lane's x string */
+    if (threadIdx.x < 16) coef[threadIdx.x] = (double) PHM_COEF[threadIdx.x];
+    for (int i = threadIdx.x; i < n_models * 25; i += blockDim.x) {
+        const PhmModelDev *__restrict__ Mi = models + i / 25;
+        const int c = i % 25;
+        const double eX = Mi->ex[c / 5], eM = Mi->em[c];
+        double *e = etab + (size_t) i * 6;
+        e[0] = eX + Mi->t[3];
+        e[1] = eX + Mi->t[5];
+        e[2] = eX + Mi->t[7];
+        e[3] = eM + Mi->t[0];
+        e[4] = eM + Mi->t[1];
+        e[5] = eM + Mi->t[2];
+    }
+    __syncthreads();
+    const int64_t pi = ((int64_t) blockIdx.x * n_waves + wave) * PHM_WAVE + lane;
     const bool have = pi < n_pairs;
-    PhmPair p;
+    PhmLanePair p;
     if (have) p = pairs[pi];
-    else { p.x_off = 0; p.y_off = 0; p.band_off = -1; p.lx = -1; p.ly = -1; p.model = 0; p.out = 0; }
+    else { p.x_off = 0; p.y_off = 0; p.lx = -1; p.ly = -1; p.model = 0; p.out = 0; }
     const int lx = p.lx, ly = p.ly;
     const int mx = phm_wave_max(lx), my = phm_wave_max(ly);
+    const int mx1 = mx > 1 ? mx : 1;
     const PhmModelDev *__restrict__ M = models + p.model;
-    double t[9], e_end[3];
-#pragma unroll
-    for (int i = 0; i < 9; i++) t[i] = M->t[i];
-#pragma unroll
-    for (int i = 0; i < 3; i++) e_end[i] = M->end[i];
-    for (int x = 1; x <= mx; x++)
-#pragma unroll
-        for (int s = 0; s < 3; s++) phm_row[((x - 1) * 3 + s) * PHM_WAVE + lane] = PHM_NEG;
-    St b0{M->start[0], M->start[1], M->start[2]}; /* cell (0, y) */
-    St b0_old{PHM_NEG, PHM_NEG, PHM_NEG};
-    double result = PHM_NEG;
+    const double t_open_y = M->t[4], t_extend_y = M->t[6], t_switch_y = M->t[8];
     const uint8_t *__restrict__ sx = pool + p.x_off;
     const uint8_t *__restrict__ sy = pool + p.y_off;
-    for (int y = 0; y <= my; y++) {
-        int cy = 4;
-        if (y >= 1 && y <= ly) { cy = sy[y - 1]; cy = cy > 4 ? 4 : cy; }
-        const double eY = M->ey[cy];
-        const PhmRowT ty{eY + t[4], eY + t[6], eY + t[8]};
-        if (y >= 1) {
-            b0_old = b0;
-            b0.m = PHM_NEG;
-            b0.x = PHM_NEG;
-            b0.y = phm_chain(b0_old.m + ty.open, b0_old.y + ty.extend, b0_old.x + ty.sw);
-        }
-        if (lx == 0 && y == ly) result = phm_dot(b0, e_end);
-        St left = b0, diag = b0_old;
-        const double *__restrict__ em_row = M->em + cy;
-        int cx_next = 4;
-        if (1 <= lx) { cx_next = sx[0]; cx_next = cx_next > 4 ? 4 : cx_next; }
-        for (int x = 1; x <= mx; x++) {
-            const int cx = cx_next;
-            cx_next = 4;
-            if (x + 1 <= lx) { cx_next = sx[x]; cx_next = cx_next > 4 ? 4 : cx_next; }
-            const double eX = M->ex[cx], eM = em_row[cx * 5];
-            double *__restrict__ r = phm_row + (size_t) (x - 1) * 3 * PHM_WAVE + lane;
-            const St up{r[0], r[PHM_WAVE], r[2 * PHM_WAVE]};
-            const St cur = phm_cell(left, diag, up, t, eX, eM, ty);
-            if (x <= lx && y <= ly) {
-                r[0] = cur.m;
-                r[PHM_WAVE] = cur.x;
-                r[2 * PHM_WAVE] = cur.y;
-            }
-            if (x == lx && y == ly) result = phm_dot(cur, e_end);
-            diag = up;
-            left = cur;
-        }
+    /* no global loads inside the step loop (the compiler waits for each one on the spot): the x string goes to LDS */
+    for (int x = 1; x <= mx1; x++) {
+        int c = 4;
+        if (x <= lx) { c = sx[x - 1]; c = c > 4 ? 4 : c; }
+        symx[(x - 1) * PHM_WAVE] = (uint8_t) c;
+#pragma unroll
+        for (int s = 0; s < 3; s++) row[((x - 1) * 3 + s) * PHM_WAVE] = PHM_NEG;
     }
-    if (have) out[p.out] = (lx == 0 && ly == 0) ? 0.0 : result; /* :860-862 */
+    const St neg{PHM_NEG, PHM_NEG, PHM_NEG};
+    St b_prev = neg; /* cell (0, y0 - 1) */
+    St fin = neg;    /* cell (lx, ly) */
+    const double *__restrict__ etab_m = etab + (size_t) p.model * PHM_ETAB;
+    int cy_next[R];
+#pragma unroll
+    for (int r = 0; r < R; r++) {
+        cy_next[r] = 4;
+        if (r >= 1 && r <= ly) { cy_next[r] = sy[r - 1]; cy_next[r] = cy_next[r] > 4 ? 4 : cy_next[r]; }
+    }
+    for (int y0 = 0; y0 <= my; y0 += R) {
+        const double *etab_r[R];
+        double ty_open[R], ty_extend[R], ty_switch[R];
+        St b0[R]; /* cell (0, y0 + r): only the gap-y state can be reached */
+#pragma unroll
+        for (int r = 0; r < R; r++) {
+            const int y = y0 + r;
+            const int cy = cy_next[r];
+            /* the y symbols of the next pass are requested now and waited for after the step loop */
+            cy_next[r] = 4;
+            if (y + R <= ly) { cy_next[r] = sy[y + R - 1]; cy_next[r] = cy_next[r] > 4 ? 4 : cy_next[r]; }
+            const double eY = M->ey[cy];
+            ty_open[r] = eY + t_open_y;
+            ty_extend[r] = eY + t_extend_y;
+            ty_switch[r] = eY + t_switch_y;
+            etab_r[r] = etab_m + cy * 6;
+            const St above = r == 0 ? b_prev : b0[r > 0 ? r - 1 : 0];
+            if (y == 0) b0[r] = St{M->start[0], M->start[1], M->start[2]};
+            else b0[r] = St{PHM_NEG, PHM_NEG, phm_chain_t<HAS_SWITCH>(above.m + ty_open[r], above.y + ty_extend[r], above.x + ty_switch[r], coef)};
+            if (lx == 0 && y == ly) fin = b0[r];
+        }
+        St c1[R], c2[R]; /* the row's cells of the last two steps */
+        int cxs[R];
+#pragma unroll
+        for (int r = 0; r < R; r++) { c1[r] = neg; c2[r] = neg; cxs[r] = 4; }
+        St up0_prev = b_prev;
+        for (int k = 0; k <= mx + R - 1; k++) {
+            /* one basic block: no branch between the R cells, so that their chains interleave */
+            const int kc = (k < 1 ? 1 : (k > mx1 ? mx1 : k)) - 1; /* steps 0 and > mx read a valid slot and ignore it */
+            const double *r0 = row + (size_t) kc * 3 * PHM_WAVE;
+            const St up0{r0[0], r0[PHM_WAVE], r0[2 * PHM_WAVE]};
+            const int c0 = symx[kc * PHM_WAVE];
+#pragma unroll
+            for (int r = R - 1; r >= 1; r--) cxs[r] = cxs[r - 1];
+            cxs[0] = (k >= 1 && k <= lx) ? c0 : 4;
+            St nw[R];
+#pragma unroll
+            for (int r = 0; r < R; r++) {
+                const int x = k - r;
+                const St left = c1[r];
+                const St up = r == 0 ? up0 : c1[r > 0 ? r - 1 : 0];
+                const St diag = r == 0 ? up0_prev : c2[r > 0 ? r - 1 : 0];
+                const double2 *__restrict__ e = reinterpret_cast<const double2 *>(etab_r[r] + cxs[r] * 30);
+                const double2 e01 = e[0], e23 = e[1], e45 = e[2];
+                St cur;
+                cur.x = phm_chain_t<HAS_SWITCH>(left.m + e01.x, left.x + e01.y, left.y + e23.x, coef);
+                cur.m = phm_chain_t<true>(diag.m + e23.y, diag.x + e45.x, diag.y + e45.y, coef);
+                cur.y = phm_chain_t<HAS_SWITCH>(up.m + ty_open[r], up.y + ty_extend[r], up.x + ty_switch[r], coef);
+                const bool last = x == lx && y0 + r == ly && lx >= 1;
+                fin.m = last ? cur.m : fin.m;
+                fin.x = last ? cur.x : fin.x;
+                fin.y = last ? cur.y : fin.y;
+                nw[r].m = x == 0 ? b0[r].m : cur.m;
+                nw[r].x = x == 0 ? b0[r].x : cur.x;
+                nw[r].y = x == 0 ? b0[r].y : cur.y;
+            }
+            const int xl = k - (R - 1);
+            if (xl >= 1 && xl <= mx) {
+                double *rl = row + (size_t) (xl - 1) * 3 * PHM_WAVE;
+                rl[0] = nw[R - 1].m;
+                rl[PHM_WAVE] = nw[R - 1].x;
+                rl[2 * PHM_WAVE] = nw[R - 1].y;
+            }
+#pragma unroll
+            for (int r = 0; r < R; r++) { c2[r] = c1[r]; c1[r] = nw[r]; }
+            up0_prev = k == 0 ? b_prev : up0;
+        }
+        b_prev = b0[R - 1];
+    }
+    if (have) {
+        const double e_end[3] = {M->end[0], M->end[1], M->end[2]};
+        out[p.out] = (lx == 0 && ly == 0) ? 0.0 : phm_dot(fin, e_end); /* :860-862; the last diagonal holds one cell */
+    }
 }
 
 __global__ void __launch_bounds__(PHM_WAVE) phm_wave_kernel(const PhmPair *__restrict__ pairs, int64_t n_pairs, const uint8_t *__restrict__ pool,
@@ -328,7 +465,6 @@ double now_ms() {
     return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-const int LANE_CLASS_CAP[4] = {25, 33, 51, PHM_LANE_MAX_X}; /* 4, 3, 2, 1 waves per CU */
 const int WAVE_CLASS_CAP[4] = {64, 256, 1024, PHM_WAVE_MAX_WIDTH};
 
 }  // namespace
@@ -378,34 +514,91 @@ int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int3
     if (n_pairs >= (1ll << 31)) return fail(MRP_ERR_ARG, "mrp_forward_probabilities: more than 2^31 pairs in one call");
     if (expansion < 0 || expansion % 2 != 0) return fail(MRP_ERR_ARG, "mrp_forward_probabilities: diagonalExpansion must be even (pairwiseAligner.c:855)");
 
-    /* classify */
-    HostVec<PhmPair> lane_pairs[4], wave_pairs[4];
+    /* classify.  The pair-per-lane kernel takes the unanchored pairs whose x string fits its LDS row next to the tables;
+     * launch classes by x length (4, 3, 2, 1 waves per workgroup = per CU). */
+    const int table_bytes = (16 + n_models * PHM_ETAB) * (int) sizeof(double);
+    const int lane_max_x = std::max(0, std::min(PHM_LANE_MAX_X, (PHM_LDS_BYTES - table_bytes) / PHM_LANE_BYTES_PER_X));
+    int lane_cap[4];
+    for (int c = 0; c < 4; c++) lane_cap[c] = std::min(lane_max_x, (PHM_LDS_BYTES - table_bytes) / ((4 - c) * PHM_LANE_BYTES_PER_X));
+    constexpr uint32_t WAVE_KEY = 0xFFFFFFFFu;
+    constexpr int LY_CLIP = 4095;
+    HostVec<uint32_t> key((size_t) n_pairs);
+    std::atomic<int64_t> bad{-1}, cells_atomic{0};
+    mrp_parallel_for((n_pairs + 16383) / 16384, 1, [&](int64_t blk) {
+        int64_t c_local = 0;
+        for (int64_t i = blk * 16384; i < std::min(n_pairs, (blk + 1) * 16384); i++) {
+            const int64_t lx = x_len[i], ly = y_len[i];
+            const int mi = model_index ? model_index[i] : 0;
+            const int64_t na = anchor_off ? anchor_off[i + 1] - anchor_off[i] : 0;
+            if (lx < 0 || ly < 0 || x_off[i] < 0 || y_off[i] < 0 || x_off[i] + lx > pool_bytes || y_off[i] + ly > pool_bytes || mi >= n_models || na < 0 ||
+                (na > 0 && !anchors)) {
+                int64_t expect = -1;
+                bad.compare_exchange_strong(expect, i);
+                key[(size_t) i] = WAVE_KEY;
+                continue;
+            }
+            if (na == 0 && lx <= lane_max_x) {
+                key[(size_t) i] = (uint32_t) (std::min<int64_t>(ly, LY_CLIP) << 7 | lx);
+                c_local += (lx + 1) * (ly + 1);
+            } else {
+                key[(size_t) i] = WAVE_KEY;
+            }
+        }
+        cells_atomic += c_local;
+    });
+    if (bad.load() >= 0)
+        return mrp_set_error(MRP_ERR_ARG, "mrp_forward_probabilities: pair %lld lies outside the symbol pool, names a model >= %d or has bad anchor offsets",
+                             (long long) bad.load(), n_models);
+    int64_t cells = cells_atomic.load();
+    /* pairs of similar shape share a wave (counting sort on (y length, x length), longest first so that the tail of a
+     * launch is made of the cheap ones) */
+    HostVec<PhmLanePair> lane_pairs[4];
+    int64_t lane_n[4] = {0, 0, 0, 0};
+    {
+        std::vector<int32_t> hist((size_t) (LY_CLIP + 1) << 7, 0);
+        for (int64_t i = 0; i < n_pairs; i++)
+            if (key[(size_t) i] != WAVE_KEY) hist[key[(size_t) i]]++;
+        int cls_of[128];
+        for (int lx = 0; lx < 128; lx++) {
+            int c = 0;
+            while (c < 3 && lx > lane_cap[c]) c++;
+            cls_of[lx] = c;
+        }
+        for (int64_t b = (int64_t) hist.size() - 1; b >= 0; b--) {
+            const int32_t h = hist[(size_t) b];
+            if (!h) continue;
+            const int c = cls_of[b & 127];
+            hist[(size_t) b] = (int32_t) lane_n[c];
+            lane_n[c] += h;
+        }
+        for (int c = 0; c < 4; c++) lane_pairs[c].resize((size_t) lane_n[c]);
+        for (int64_t i = 0; i < n_pairs; i++) {
+            const uint32_t k = key[(size_t) i];
+            if (k == WAVE_KEY) continue;
+            PhmLanePair &q = lane_pairs[cls_of[k & 127]][(size_t) hist[k]++];
+            q.x_off = x_off[i];
+            q.y_off = y_off[i];
+            q.lx = x_len[i];
+            q.ly = y_len[i];
+            q.model = model_index ? model_index[i] : 0;
+            q.out = (int32_t) i;
+        }
+    }
+    HostVec<PhmPair> wave_pairs[4];
     HostVec<int32_t> band;
-    int64_t cells = 0;
     std::vector<int32_t> L, R;
     for (int64_t i = 0; i < n_pairs; i++) {
+        if (key[(size_t) i] != WAVE_KEY) continue;
         const int64_t lx = x_len[i], ly = y_len[i];
-        if (lx < 0 || ly < 0 || x_off[i] < 0 || y_off[i] < 0 || x_off[i] + lx > pool_bytes || y_off[i] + ly > pool_bytes)
-            return mrp_set_error(MRP_ERR_ARG, "mrp_forward_probabilities: pair %lld lies outside the symbol pool", (long long) i);
-        const int mi = model_index ? model_index[i] : 0;
-        if (mi >= n_models) return mrp_set_error(MRP_ERR_ARG, "mrp_forward_probabilities: pair %lld uses model %d of %d", (long long) i, mi, n_models);
         const int64_t na = anchor_off ? anchor_off[i + 1] - anchor_off[i] : 0;
-        if (na < 0 || (na > 0 && !anchors)) return fail(MRP_ERR_ARG, "mrp_forward_probabilities: bad anchor offsets");
         PhmPair p;
         p.x_off = x_off[i];
         p.y_off = y_off[i];
         p.band_off = -1;
         p.lx = (int32_t) lx;
         p.ly = (int32_t) ly;
-        p.model = mi;
+        p.model = model_index ? model_index[i] : 0;
         p.out = (int32_t) i;
-        if (na == 0 && lx <= PHM_LANE_MAX_X) {
-            int c = 0;
-            while (lx > LANE_CLASS_CAP[c]) c++;
-            lane_pairs[c].push_back(p);
-            cells += (lx + 1) * (ly + 1);
-            continue;
-        }
         int width;
         if (na == 0) {
             width = (int) std::min(lx, ly) + 1;
@@ -427,9 +620,6 @@ int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int3
         while (width > WAVE_CLASS_CAP[c]) c++;
         wave_pairs[c].push_back(p);
     }
-    /* pairs of similar shape share a wave: longest first, so the tail of the launch is made of the cheap ones */
-    for (auto &v : lane_pairs)
-        std::sort(v.begin(), v.end(), [](const PhmPair &a, const PhmPair &b) { return a.ly != b.ly ? a.ly > b.ly : (a.lx != b.lx ? a.lx > b.lx : a.out < b.out); });
     for (auto &v : wave_pairs)
         std::sort(v.begin(), v.end(), [](const PhmPair &a, const PhmPair &b) {
             const int64_t ca = (int64_t) a.lx * a.ly, cb = (int64_t) b.lx * b.ly;
@@ -439,12 +629,17 @@ int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int3
     PHM_HIP(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     std::vector<PhmModelDev> hm((size_t) n_models);
-    for (int i = 0; i < n_models; i++) model_to_device(models[i], ragged_left, ragged_right, hm[(size_t) i]);
+    bool has_switch = false;
+    for (int i = 0; i < n_models; i++) {
+        model_to_device(models[i], ragged_left, ragged_right, hm[(size_t) i]);
+        if (!(models[i].gap_switch_to_x == -INFINITY && models[i].gap_switch_to_y == -INFINITY)) has_switch = true;
+    }
     DevBuf<PhmModelDev> d_models;
     DevBuf<uint8_t> d_pool;
     DevBuf<int32_t> d_band;
     DevBuf<double> d_out;
-    DevBuf<PhmPair> d_pairs[8];
+    DevBuf<PhmLanePair> d_lane[4];
+    DevBuf<PhmPair> d_wave[4];
     d_models.pool = d_pool.pool = d_band.pool = d_out.pool = &ctx->pool;
     PHM_HIP(d_models.upload(hm, s));
     PHM_HIP(d_pool.alloc((size_t) pool_bytes));
@@ -452,13 +647,14 @@ int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int3
     PHM_HIP(d_band.upload(band, s));
     PHM_HIP(d_out.alloc((size_t) n_pairs));
     for (int c = 0; c < 4; c++) {
-        d_pairs[c].pool = d_pairs[4 + c].pool = &ctx->pool;
-        PHM_HIP(d_pairs[c].upload(lane_pairs[c], s));
-        PHM_HIP(d_pairs[4 + c].upload(wave_pairs[c], s));
+        d_lane[c].pool = d_wave[c].pool = &ctx->pool;
+        PHM_HIP(d_lane[c].upload(lane_pairs[c], s));
+        PHM_HIP(d_wave[c].upload(wave_pairs[c], s));
     }
     static bool configured = false;
     if (!configured) {
-        PHM_HIP(hipFuncSetAttribute((const void *) phm_lane_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PHM_HIP(hipFuncSetAttribute((const void *) phm_lane_kernel<PHM_ROWS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        PHM_HIP(hipFuncSetAttribute((const void *) phm_lane_kernel<PHM_ROWS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         PHM_HIP(hipFuncSetAttribute((const void *) phm_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
@@ -467,10 +663,17 @@ int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int3
         const int64_t n = (int64_t) lane_pairs[c].size();
         if (n == 0) continue;
         int cap = 1;
-        for (const PhmPair &p : lane_pairs[c]) cap = std::max(cap, (int) p.lx);
-        const size_t lds = (size_t) cap * 3 * PHM_WAVE * sizeof(double);
-        hipLaunchKernelGGL(phm_lane_kernel, dim3((unsigned) ((n + PHM_WAVE - 1) / PHM_WAVE)), dim3(PHM_WAVE), lds, s, d_pairs[c].p, n, d_pool.p,
-                           d_models.p, d_out.p);
+        for (const PhmLanePair &p : lane_pairs[c]) cap = std::max(cap, (int) p.lx);
+        const int row_bytes = cap * PHM_LANE_BYTES_PER_X;
+        const int nw = std::max(1, std::min(4, (PHM_LDS_BYTES - table_bytes) / row_bytes));
+        const size_t lds = (size_t) table_bytes + (size_t) nw * row_bytes;
+        const int64_t per_wg = (int64_t) nw * PHM_WAVE;
+        if (has_switch)
+            hipLaunchKernelGGL((phm_lane_kernel<PHM_ROWS, true>), dim3((unsigned) ((n + per_wg - 1) / per_wg)), dim3((unsigned) per_wg), lds, s, d_lane[c].p, n, d_pool.p,
+                               d_models.p, (int) n_models, cap, d_out.p);
+        else
+            hipLaunchKernelGGL((phm_lane_kernel<PHM_ROWS, false>), dim3((unsigned) ((n + per_wg - 1) / per_wg)), dim3((unsigned) per_wg), lds, s, d_lane[c].p, n, d_pool.p,
+                               d_models.p, (int) n_models, cap, d_out.p);
         PHM_HIP(hipGetLastError());
         if (stats) stats->pairs_lane += n;
     }
@@ -479,7 +682,7 @@ int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int3
         if (n == 0) continue;
         const int W = WAVE_CLASS_CAP[c];
         const size_t lds = (size_t) 9 * W * sizeof(double);
-        hipLaunchKernelGGL(phm_wave_kernel, dim3((unsigned) std::min<int64_t>(n, 16384)), dim3(PHM_WAVE), lds, s, d_pairs[4 + c].p, n, d_pool.p,
+        hipLaunchKernelGGL(phm_wave_kernel, dim3((unsigned) std::min<int64_t>(n, 16384)), dim3(PHM_WAVE), lds, s, d_wave[c].p, n, d_pool.p,
                            d_models.p, d_band.p, W, d_out.p);
         PHM_HIP(hipGetLastError());
         if (stats) stats->pairs_wave += n;
@@ -494,7 +697,8 @@ int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int3
         stats->cells = cells;
     }
     d_models.release(); d_pool.release(); d_band.release(); d_out.release();
-    for (auto &b : d_pairs) b.release();
+    for (auto &b : d_lane) b.release();
+    for (auto &b : d_wave) b.release();
     ctx->pool.reclaim();
     if (stats) stats->total_ms = now_ms() - t_begin;
     return MRP_OK;

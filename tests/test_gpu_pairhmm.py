@@ -41,11 +41,11 @@ def test_golden_vectors(gpu_ctx):
 
 @pytest.mark.parametrize("ragged", [(False, False), (True, False), (False, True), (True, True)])
 def test_pair_per_lane_kernel_bit_exact(gpu_ctx, ragged):
-    """every launch class of the pair-per-lane kernel (x up to 25 / 33 / 51 / 104 symbols), empty strings, Ns, three models"""
+    """every launch class of the pair-per-lane kernel (x up to 26 / 34 / 52 / 100 symbols with three models), empty strings, Ns, three models"""
     rng = np.random.default_rng(100 + 2 * ragged[0] + ragged[1])
     pairs = []
     for _ in range(700):
-        lx = int(rng.choice([0, 1, 2, 24, 25, 26, 33, 34, 51, 52, 104])) if rng.random() < 0.4 else int(rng.integers(0, 105))
+        lx = int(rng.choice([0, 1, 2, 25, 26, 27, 34, 35, 52, 53, 100])) if rng.random() < 0.4 else int(rng.integers(0, 101))
         a = synth.random_sequence(rng, lx, n_rate=0.03)
         b = synth.evolve_sequence(rng, a) if rng.random() < 0.8 else synth.random_sequence(rng, int(rng.integers(0, 160)), n_rate=0.03)
         pairs.append((a, b))
@@ -69,7 +69,7 @@ def test_pair_per_wave_kernel_bit_exact(gpu_ctx):
     for expansion in (0, 4, 20):
         pairs, aoff, anc = [], [0], []
         for i in range(40):
-            lx = int(rng.integers(105, 700)) if i % 4 else int(rng.integers(0, 60))
+            lx = int(rng.integers(101, 700)) if i % 4 else int(rng.integers(0, 60))
             a = synth.random_sequence(rng, lx, n_rate=0.01)
             b = synth.evolve_sequence(rng, a)
             pairs.append((a, b))
