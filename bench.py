@@ -45,6 +45,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pipeline", action="store_true", help="skip the end-to-end device-resident phasing leg")
     ap.add_argument("--pipeline-runs", type=int, default=3)
+    ap.add_argument("--align-chunks", type=int, default=4, help="chunks whose read x allele pairs the alignment leg scores (0: skip)")
+    ap.add_argument("--align-runs", type=int, default=3)
     ap.add_argument("--pipeline-groups", type=int, default=1,
                     help="additional caller-side split of the chunks into concurrent mrp_phase_reads_many calls (the call itself "
                          "already runs two interleaved halves on sibling contexts, MRP_PHASE_GROUPS)")
@@ -235,6 +237,60 @@ def main():
                 d_.close()
         for c_ in gctx:
             c_.close()
+
+    if args.align_chunks > 0:
+        # Alignment leg: the banded pair-HMM forward probability of every read substring against every
+        # allele of every site (bubbleGraph.c:1421-1464), the numbers that become the profile bytes the sweep above reads.
+        # value = pairs / kernel time (HIP events inside the library, strings already on the device); the rate of the
+        # whole call (classification, upload, download) is given beside it.
+        t_hmm, t_tr, t_em = synth.margin_phase_pair_hmm_arrays()
+        fwd = capi.PairHmm.from_margin_hmm(t_hmm, t_tr, t_em)
+        a_models = [fwd, fwd.reverse_complement()]
+        bubbles = []
+        for c in range(args.align_chunks):
+            bubbles += synth.make_bubble_strings(seed=1000 * rank + c + 1, n_sites=args.sites, coverage=int(args.coverage))
+        a_in = synth.pairs_from_bubbles(bubbles)
+        actx = capi.Context(local_rank)
+        capi.forward_probabilities(actx, a_models, *a_in)  # warm-up
+        barrier()
+        t0 = time.perf_counter()
+        k_ms, cells = 0.0, 0
+        for _ in range(args.align_runs):
+            a_out, a_st = capi.forward_probabilities(actx, a_models, *a_in)
+            k_ms += a_st.kernel_ms
+            cells = a_st.cells
+        barrier()
+        a_el = time.perf_counter() - t0
+        n_pairs = len(a_in[1])
+        k_s, _ = sharding.reduce_elapsed_and_units(dist, k_ms / 1e3, float(n_pairs), device=reduce_dev)
+        a_el, a_pairs = sharding.reduce_elapsed_and_units(dist, a_el, float(n_pairs), device=reduce_dev)
+        out["alignment"] = dict(what="mrp_forward_probabilities: banded pair-HMM forward log probability, read substring x allele",
+                                value=a_pairs * args.align_runs / k_s, unit="pairs/s", cells_per_s=cells * world * args.align_runs / k_s,
+                                kernel_ms=1e3 * k_s / args.align_runs, call_value=a_pairs * args.align_runs / a_el,
+                                call_ms=1e3 * a_el / args.align_runs, pairs_per_gpu=n_pairs, cells_per_gpu=int(cells), chunks_per_gpu=args.align_chunks,
+                                dtype="f64", parity="bit-exact vs oracle/pairhmm_oracle.c (no fused multiply-add on either side)",
+                                bound="fp64 VALU issue", runs=args.align_runs)
+        if rank == 0 and not args.no_cpu_baseline and n_gpus == 1:
+            from oracle import pairhmm as ph
+            om = [ph.Model.from_buffer_copy(bytes(m)) for m in a_models]
+            n_thr = max(1, min(16, os.cpu_count() or 1))
+            per = 8000
+            pool_, xo, xl, yo, yl, mi = a_in
+            parts = [slice(t * per, (t + 1) * per) for t in range(n_thr) if t * per < n_pairs]
+
+            def cpu_align(sl):
+                t1 = time.perf_counter()
+                r = ph.forward_batch(om, pool_, xo[sl], xl[sl], yo[sl], yl[sl], mi[sl])
+                return time.perf_counter() - t1, r
+
+            with ThreadPoolExecutor(max_workers=len(parts)) as ex:
+                res_a = list(ex.map(cpu_align, parts))
+            same = all((r[1] == a_out[sl]).all() for r, sl in zip(res_a, parts))
+            n_s = sum(len(r[1]) for r in res_a)
+            out["alignment"]["cpu_baseline"] = dict(value=n_s / max(r[0] for r in res_a), unit="pairs/s", cores=len(parts), kind="port",
+                                                    sample=f"{n_s} of {n_pairs} pairs, {per} per thread", per_core=len(res_a[0][1]) / res_a[0][0],
+                                                    identical_to_gpu=bool(same))
+        actx.close()
 
     if rank == 0 and not args.no_cpu_baseline and n_gpus == 1:
         # CPU baseline: the oracle (C restatement of the reference's linked-list/hash implementation, -O3 -mpopcnt)

@@ -41,7 +41,7 @@ constexpr int PHM_WAVE = 64;
 constexpr int PHM_LANE_MAX_X = 100;    /* 100 * 1 600 B = 156 KB of the 160 KB, the rest holds the tables */
 constexpr int PHM_LDS_BYTES = 160 * 1024;
 #ifndef PHM_ROWS
-#define PHM_ROWS 4 /* rows a lane of the pair-per-lane kernel advances together */
+#define PHM_ROWS 2 /* rows a lane of the pair-per-lane kernel advances together (measured: 1 -> 2.49 ms, 2 -> 2.11, 3 -> 2.75, 4 -> 2.61, 6 -> 3.23 for 4.8e5 pairs) */
 #endif
 constexpr int PHM_LANE_BYTES_PER_X = 3 * 64 * 8 + 64; /* LDS per wave and x position: three states per lane + the lane's symbol */
 constexpr int PHM_ETAB = 25 * 6;       /* doubles per model in the emission + transition table */
@@ -658,6 +658,8 @@ int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int3
         PHM_HIP(hipFuncSetAttribute((const void *) phm_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
         configured = true;
     }
+    /* kernel_ms must not contain the tail of the uploads (the copy engine finishes them behind the event otherwise) */
+    if (stats) PHM_HIP(hipStreamSynchronize(s));
     PHM_HIP(hipEventRecord(ctx->ev[0], s));
     for (int c = 0; c < 4; c++) {
         const int64_t n = (int64_t) lane_pairs[c].size();
