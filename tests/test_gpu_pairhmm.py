@@ -135,3 +135,60 @@ def test_errors(gpu_ctx):
     assert e.value.code == capi.MRP_ERR_UNSUPPORTED
     out, _ = capi.forward_probabilities(gpu_ctx, ms, a, np.zeros(0, np.int64), np.zeros(0, np.int32), np.zeros(0, np.int64), np.zeros(0, np.int32))
     assert len(out) == 0
+
+
+def test_strings_to_haplotype_tags(gpu_ctx, orc):
+    """From the aligned strings to the HP tags with nothing but the product in the chain: read substrings x alleles ->
+    mrp_allele_read_supports (pair-HMM, device) -> profile bytes and site tables (rphmm_frame.c) -> device-resident phasing ->
+    read-to-haplotype assignment; against the same chain built from the oracles."""
+    from oracle import frame_oracle as fo
+    rng = np.random.default_rng(77)
+    n_sites, n_reads = 150, 110
+    t, tr, em = synth.margin_phase_pair_hmm_arrays()
+    fwd = capi.PairHmm.from_margin_hmm(t, tr, em)
+    rev = fwd.reverse_complement()
+    truth = rng.integers(0, 2, size=n_sites)
+    haps, strands = rng.integers(0, 2, size=n_reads), rng.integers(0, 2, size=n_reads)
+    spans = []
+    for r in range(n_reads):
+        a = int(rng.integers(0, n_sites - 5))
+        spans.append((a, int(min(n_sites - 1, a + rng.integers(4, 40)))))
+    bubbles, br = [], []
+    for i in range(n_sites):
+        ref = synth.random_sequence(rng, 25)
+        alt = ref.copy()
+        alt[12] = (alt[12] + 1 + rng.integers(0, 3)) % 4
+        rs = [r for r, (a, b) in enumerate(spans) if a <= i <= b]
+        reads = []
+        for r in rs:
+            allele = truth[i] if haps[r] == 0 else 1 - truth[i]
+            reads.append(synth.evolve_sequence(rng, alt if allele else ref, 0.04, 0.02, 0.02))
+        bubbles.append(([ref, alt], reads, [bool(strands[r]) for r in rs]))
+        br.append(rs)
+    sup, st = capi.allele_read_supports(gpu_ctx, fwd, rev, bubbles)
+    for (alleles, reads, fs), s_ in zip(bubbles, sup):
+        assert (s_ == ph.allele_read_supports(omodel(fwd), omodel(rev), alleles, reads, fs)).all()
+    an = [2] * n_sites
+    seqs, pool = capi.profile_seqs_from_bubbles(an, br, sup, n_reads)
+    ref_seqs = fo.get_profile_seqs([fo.Bubble(2, rs, np.asarray(s_).reshape(-1).tolist()) for rs, s_ in zip(br, sup)])
+    assert (np.array([b for p in ref_seqs.values() for b in p["probs"]], dtype=np.uint8) == pool).all()
+    a_num, sub, prior = capi.reference_from_bubbles(an, br, sup, 0.0)
+    off = np.concatenate([[0], np.cumsum(a_num)]).astype(np.int64)
+    reads = [synth.Read(name=f"r{q['read']:04d}", ref_start=q["ref_start"], length=q["length"], strand=int(strands[q["read"]]), hap=int(haps[q["read"]]),
+                        pool_off=q["pool_offset"], nbytes=int(off[q["ref_start"] + q["length"]] - off[q["ref_start"]])) for q in seqs]
+    chunk = synth.Chunk(allele_number=a_num, allele_offset=off, sub=sub, prior=prior, pool=pool, reads=reads)
+    pd = synth.shipped_phase_params()
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    (got,), pst = capi.phase_reads_many(gpu_ctx, [dchunk], [chunk], capi.Params.from_reference_names(pd))
+    oc = orc.OracleChunk(chunk)
+    ref = oc.phase(pd)
+    oc.close()
+    for k in ("hap1", "hap2", "genotype", "ancestor"):
+        assert (np.asarray(got[k]) == np.asarray(ref[k])).all(), k
+    assert got["reads1"] == ref["reads1"] and got["reads2"] == ref["reads2"]
+    recs, _ = capi.read_records(chunk)
+    hap, _phred = capi.assign_reads_to_haplotypes(a_num, pool, recs, len(reads), got, min_phred=0)
+    agree = sum(1 for i, r in enumerate(reads) if hap[i] in (1, 2) and (hap[i] - 1) == r.hap)
+    tagged = int(((hap == 1) | (hap == 2)).sum())
+    assert tagged >= 0.9 * len(reads) and max(agree, tagged - agree) >= 0.9 * tagged
+    dchunk.close()
