@@ -399,6 +399,8 @@ int mrp_engine_level_end(mrp_engine *e) {
 #endif
     if (L->err[0] & MRP_ENGINE_ERR_POSTERIOR) return mrp_set_error(MRP_ERR_ARG, "ERROR: invalid prob (f + b exceeds the column total)");
     if (L->err[0] & MRP_ENGINE_ERR_RANGE) return mrp_set_error(MRP_ERR_LOOKUP, "device-resident merge: transition index out of range");
+    if (L->err[0] & MRP_ENGINE_ERR_MERGE)
+        return mrp_set_error(MRP_ERR_UNSUPPORTED, "device-resident merge: a merge cell reached from the kept cells falls below the posterior threshold");
     if (L->err[0] & MRP_ENGINE_ERR_STRUCTURE)
         return mrp_set_error(MRP_ERR_UNSUPPORTED, "device-resident merge: a parent hmm is not in complement-pair order");
     int64_t colbase = 0;

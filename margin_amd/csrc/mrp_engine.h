@@ -75,6 +75,7 @@ struct PruneScratch {
 #define MRP_ENGINE_ERR_STRUCTURE 1 /* a parent is not in complement-pair order: closed-form cross product not valid */
 #define MRP_ENGINE_ERR_POSTERIOR 2 /* f + b > total (column.c:183 "invalid prob") */
 #define MRP_ENGINE_ERR_RANGE 4     /* index out of range */
+#define MRP_ENGINE_ERR_MERGE 8     /* a next merge cell of the kept cells would itself be pruned (hmm.c:1090-1100): not handled on the device */
 
 /* largest column the prune kernel handles (LDS candidate list) */
 #define MRP_PRUNE_MAX_CELLS 14400

@@ -252,10 +252,11 @@ static __device__ __forceinline__ void wave_bitonic_sort128(uint32_t &k0, uint32
  *   [A] all waves: the column's cells (np, f, b were loaded into registers while the previous column was
  *       processed) are tested against the kept flags of the previous merge column, binned by posterior and
  *       appended, in list order, to the candidate list in LDS;
- *   [B] wave 0 alone, without further barriers: cutoff bin from the histogram, ordered selection, stable
- *       rank sort of the <= S kept cells, their distinct next merge cells, the merge cells' posteriors,
- *       rank sort, new kept flags.  Meanwhile the other waves only wait; the loads of the next column are
- *       already in flight. */
+ *   [B] wave 0 alone, without further barriers: cutoff bin from the histogram, ordered selection of the <= S kept
+ *       cells, kept flags of their next merge cells -- all the next column's [A] needs.  Everything else a column
+ *       produces (stable sort of the kept cells, distinct next merge cells in order of first use, their posteriors,
+ *       stable sort, lists to HBM) is done one and two columns later by waves 1 and 2, beside wave 0's [B] of the
+ *       columns that follow, from double-buffered copies of the selection.  The loads of the next column are already in flight. */
 /* the few arrays of the level's batch the prune kernel reads (the whole MrpBatchDev by value costs ~60 SGPRs) */
 struct PruneIn {
     const SweepCol *scols;
@@ -274,18 +275,19 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
     const int nb_r = 1024; /* 16 bins per lane of the cutoff search: bin b lives at (b & 15) * 64 + (b >> 4) */
     const int cap_c = ((p.max_cells > p.max_merge ? p.max_cells : p.max_merge) + 3) & ~3;
     /* LDS layout (dwords) */
-    uint32_t *gsel = lds;             /* [S] selected candidates above the cutoff bin: bin << 16 | cell */
-    uint32_t *gnp = gsel + S;         /* [S] their next | prev << 16 */
-    uint32_t *esel = gnp + S;         /* [S] selected candidates in the cutoff bin: cell */
-    uint32_t *enp = esel + S;         /* [S] */
-    uint32_t *um = enp + S;           /* [S] posterior bin of the merge cell each selected cell leads to (selection order) */
-    uint32_t *oldm = um + S;          /* [S] kept merge cells of the previous merge column (flag owners) */
-    uint32_t *sh = oldm + S;          /* [64] per-wave counters */
+    /* the selection of a column lives in one of two buffers: wave 0 fills buffer k & 1 while wave 1 turns buffer (k - 1) & 1
+     * into the sorted lists of column k - 1 */
+    uint32_t *sel = lds;              /* [2][4][S]: gsel (bin << 16 | cell, above the cutoff bin), gnp (next | prev << 16), esel (cell, in the cutoff bin), enp */
+    uint32_t *um = sel + 8 * S;       /* [S] posterior bin of the merge cell each selected cell leads to (selection order); wave 1 */
+    uint32_t *s1 = um + S;            /* [2][2][S] stage 1 -> stage 2: next | prev and merge posterior bin per sorted kept cell */
+    uint32_t *sh = s1 + 4 * S;        /* [64] per-wave counters [0, W); n, nG of the two selection buffers at [32, 36); n of the stage-1 buffers at [36, 38) */
     uint32_t *stg = sh + 64;          /* [W][4][64] staging of linked cells: cell, transitions, f, b */
     uint32_t *hist = stg + W * 4 * WAVE; /* [2][nb_r] */
     uint32_t *cand = hist + 2 * nb_r; /* [cap_c] linked cells of the column, list order per wave segment: bin << 16 | cell */
     uint32_t *cand_np = cand + cap_c; /* [cap_c] */
-    uint8_t *flags = reinterpret_cast<uint8_t *>(cand_np + cap_c); /* [max_merge] kept flag per merge cell */
+    uint32_t *htab_key = cand_np + cap_c; /* [256] merge cell -> first kept cell that uses it (open addressing); wave 1 */
+    uint32_t *htab_val = htab_key + 256;  /* [256] */
+    uint8_t *flags = reinterpret_cast<uint8_t *>(htab_val + 256); /* [max_merge] kept flag per merge cell */
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
@@ -301,7 +303,8 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
         const int64_t total = (int64_t) d.hmm_fb[2 * h.hmm_index]; /* max mode: the same integer for every column */
         for (int i = tid; i < 2 * nb_r; i += T) hist[i] = 0;
         for (int i = tid; i < (p.max_merge + 3) / 4; i += T) reinterpret_cast<uint32_t *>(flags)[i] = 0;
-        int n_old = 0;
+        int n_prev = 0, nG_prev = 0; /* wave 0: the selection whose next merge cells own the kept flags */
+        int64_t mcell_prev = 0;       /* first merge cell of the merge column after the previous column */
 
         uint32_t r_np[PRUNE_CPT];
         int32_t r_f[PRUNE_CPT], r_b[PRUNE_CPT];
@@ -336,6 +339,123 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
         }
         __syncthreads();
 
+        /* The sorted lists of a finished selection, in two stages one column apart, so that neither is longer than wave 0's
+         * part of a column.  Nothing later in the forward pass reads them: the kept flags were already set by wave 0 from
+         * the unsorted selection.
+         * Stage 1 (wave 1, column kk from selection buffer kk & 1): stable sort of the kept cells, kept lists to HBM, the
+         * posterior bins of the merge cells they lead to; leaves next | prev and that bin per sorted kept cell in LDS. */
+        auto lists_stage1 = [&](int kk, int64_t mcell_off) {
+            const int b = kk & 1;
+            const uint32_t *gsel = sel + b * 4 * S, *gnp = gsel + S, *esel = gnp + S, *enp = esel + S;
+            uint32_t *snp = s1 + b * 2 * S, *sbin = snp + S;
+            const int n = (int) sh[32 + 2 * b], nG = (int) sh[33 + 2 * b];
+            const int64_t lcol = h.col0 + kk;
+            const bool has_merge = kk + 1 < K;
+            uint32_t key[2], my_np[2], my_c[2], my_src[2];
+            int32_t pre_mf[2] = {0, 0}, pre_mb[2] = {0, 0};
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = lane + u * WAVE;
+                /* stable descending sort of the kept cells (stList_sort :1071): smaller bin = larger posterior; the key
+                 * bin | list position | cell is unique, so a bitonic sort in registers is stable by construction */
+                key[u] = i < nG ? ((gsel[i] >> 16) << 21) | ((uint32_t) i << 14) | (gsel[i] & 0x3FFFu) : 0xFFFFFFFFu;
+                /* the posteriors of the merge cells the selected cells lead to are requested now, for the selection in
+                 * its unsorted order, and consumed after the sort (slot i of the selection = um[i] below) */
+                if (has_merge && i < n) {
+                    const uint32_t m = (i < nG ? gnp[i] : enp[i - nG]) & 0xFFFFu;
+                    pre_mf[u] = d.merge_f32[mcell_off + m];
+                    pre_mb[u] = d.merge_b32[mcell_off + m];
+                }
+            }
+            wave_bitonic_sort128(key[0], key[1], lane);
+            if (has_merge) {
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int i = lane + u * WAVE;
+                    if (i < n) um[i] = (uint32_t) posterior_bin(pre_mf[u], pre_mb[u], total, nb, &errbits);
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = lane + u * WAVE;
+                if (i < nG) { my_c[u] = key[u] & 0x3FFFu; my_np[u] = gnp[(key[u] >> 14) & 0x7Fu]; my_src[u] = (key[u] >> 14) & 0x7Fu; }
+                else if (i < n) { my_c[u] = esel[i - nG]; my_np[u] = enp[i - nG]; my_src[u] = (uint32_t) i; }
+                else { my_c[u] = 0u; my_np[u] = 0u; my_src[u] = 0u; }
+                if (i < n) {
+                    sc.kept[lcol * S + i] = (uint16_t) my_c[u];
+                    sc.kept_np[lcol * S + i] = my_np[u];
+                    snp[i] = my_np[u];
+                    if (has_merge) sbin[i] = um[my_src[u]];
+                }
+            }
+            if (lane == 0) { sc.n_kept[lcol] = n; sh[36 + b] = (uint32_t) n; }
+        };
+        /* Stage 2 (wave 2, one column later): distinct next merge cells in order of first use, stable sort by posterior,
+         * kept merge list to HBM. */
+        auto lists_stage2 = [&](int kk) {
+            const int b = kk & 1;
+            const uint32_t *snp = s1 + b * 2 * S, *sbin = snp + S;
+            const int n = (int) sh[36 + b];
+            const int64_t lcol = h.col0 + kk;
+            int mn = 0;
+            if (kk + 1 < K) {
+                /* getLinkedMergeCells :989-1004: distinct next merge cells in order of first use (sorted order of the
+                 * kept cells): a 256-slot open-addressing table, merge cell -> smallest sorted index that uses it */
+                for (int i = lane; i < 256; i += WAVE) { htab_key[i] = 0xFFFFFFFFu; htab_val[i] = 0xFFFFFFFFu; }
+                uint32_t my_m[2] = {0u, 0u};
+                int slot[2] = {0, 0};
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int i = lane + u * WAVE;
+                    if (i < n) {
+                        const uint32_t m = snp[i] & 0xFFFFu;
+                        my_m[u] = m;
+                        int q = (int) ((m * 2654435761u) >> 24);
+                        for (;;) {
+                            const uint32_t prev = atomicCAS(&htab_key[q], 0xFFFFFFFFu, m);
+                            if (prev == 0xFFFFFFFFu || prev == m) break;
+                            q = (q + 1) & 255;
+                        }
+                        slot[u] = q;
+                        atomicMin(&htab_val[q], (uint32_t) i);
+                    }
+                }
+                bool first[2];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int i = lane + u * WAVE;
+                    first[u] = i < n && htab_val[slot[u]] == (uint32_t) i;
+                }
+                const uint64_t f0 = __ballot(first[0]), f1 = __ballot(first[1]);
+                const int mnl = __popcll(f0) + __popcll(f1);
+                uint32_t mkey[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
+                int pass_thr[2] = {0, 0};
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    if (first[u]) {
+                        const int pos = u == 0 ? (int) lanemask_lt_count(f0, lane) : __popcll(f0) + (int) lanemask_lt_count(f1, lane);
+                        const int bin = (int) sbin[lane + u * WAVE];
+                        pass_thr[u] = bin <= p.thr_bin ? 1 : 0;
+                        mkey[u] = ((uint32_t) bin << 21) | ((uint32_t) pos << 14) | my_m[u];
+                    }
+                }
+                const int gm = __popcll(__ballot(pass_thr[0] != 0)) + __popcll(__ballot(pass_thr[1] != 0));
+                mn = kept_count(mnl, gm, p.min_p, p.max_p);
+                /* Wave 0 has flagged EVERY distinct next merge cell.  That is what :1090-1100 keeps: a merge cell's
+                 * posterior is at least that of any cell leading to it (max mode, exact integers), so whenever more
+                 * than min_p cells were kept they all pass the threshold, and so do their merge cells.  Checked, not
+                 * assumed: a violation discards the level (the host falls back to the per-chunk path). */
+                if (mn != mnl) errbits |= MRP_ENGINE_ERR_MERGE;
+                /* stable descending sort by posterior (:1090) */
+                wave_bitonic_sort128(mkey[0], mkey[1], lane);
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int r = lane + u * WAVE;
+                    if (r < mn) sc.keptm[lcol * S + r] = (uint16_t) (mkey[u] & 0x3FFFu);
+                }
+            }
+            if (lane == 0) sc.n_keptm[lcol] = mn;
+        };
         /* ---- stRPHmm_pruneForwards hmm.c:1049-1109 ---- */
         for (int k = 0; k < K; k++) {
             uint32_t *hk = hist + (k & 1) * nb_r;
@@ -394,10 +514,16 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
             CLK(2);
             lds_barrier();
             CLK(3);
-            if (wave != 0) {
+            if (wave == 1) {
+                if (k > 0) lists_stage1(k - 1, mcell_prev);
+            } else if (wave == 2) {
+                if (k > 1) lists_stage2(k - 2);
+            } else if (wave > 2) {
                 uint32_t *hn = hist + ((k + 1) & 1) * nb_r;
-                for (int i = tid - WAVE; i < nb_r; i += T - WAVE) hn[i] = 0;
-            } else {
+                for (int i = lane + (wave - 3) * WAVE; i < nb_r; i += T - 3 * WAVE) hn[i] = 0;
+            }
+            if (wave == 0) {
+                uint32_t *gsel = sel + (k & 1) * 4 * S, *gnp = gsel + S, *esel = gnp + S, *enp = esel + S;
                 /* [B] cutoff bin and quota */
                 int n_link = 0;
                 for (int w = 0; w < W; w++) n_link += (int) sh[w];
@@ -461,107 +587,28 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
                     }
                 }
                 CLK(5);
-                /* stable descending sort of the kept cells (stList_sort :1071): smaller bin = larger posterior; the key
-                 * bin | list position | cell is unique, so a bitonic sort in registers is stable by construction */
-                const int64_t lcol = h.col0 + k;
-                uint32_t key[2], my_np[2], my_c[2], my_src[2];
-                int32_t pre_mf[2] = {0, 0}, pre_mb[2] = {0, 0};
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const int i = lane + u * WAVE;
-                    key[u] = i < nG ? ((gsel[i] >> 16) << 21) | ((uint32_t) i << 14) | (gsel[i] & 0x3FFFu) : 0xFFFFFFFFu;
-                    /* the posteriors of the merge cells the selected cells lead to are requested now, for the selection in
-                     * its unsorted order, and consumed after the sort (slot i of the selection = um[i] below) */
-                    if (k + 1 < K && i < n) {
-                        const uint32_t m = (i < nG ? gnp[i] : enp[i - nG]) & 0xFFFFu;
-                        pre_mf[u] = d.merge_f32[cur.mcell_off + m];
-                        pre_mb[u] = d.merge_b32[cur.mcell_off + m];
-                    }
+                if (lane == 0) { sh[32 + 2 * (k & 1)] = (uint32_t) n; sh[33 + 2 * (k & 1)] = (uint32_t) nG; }
+                /* the kept flags: those of the previous merge column go (its selection still sits in the other buffer),
+                 * those of the merge column after this one are the next merge cells of the selection */
+                {
+                    const uint32_t *pg = sel + ((k + 1) & 1) * 4 * S + S, *pe = pg + 2 * S;
+                    for (int i = lane; i < n_prev; i += WAVE) flags[(i < nG_prev ? pg[i] : pe[i - nG_prev]) & 0xFFFFu] = 0;
+                    if (k + 1 < K)
+                        for (int i = lane; i < n; i += WAVE) flags[(i < nG ? gnp[i] : enp[i - nG]) & 0xFFFFu] = 1;
                 }
-                wave_bitonic_sort128(key[0], key[1], lane);
-                if (k + 1 < K) {
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int i = lane + u * WAVE;
-                        if (i < n) um[i] = (uint32_t) posterior_bin(pre_mf[u], pre_mb[u], total, nb, &errbits);
-                    }
-                }
-#pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const int i = lane + u * WAVE;
-                    if (i < nG) { my_c[u] = key[u] & 0x3FFFu; my_np[u] = gnp[(key[u] >> 14) & 0x7Fu]; my_src[u] = (key[u] >> 14) & 0x7Fu; }
-                    else if (i < n) { my_c[u] = esel[i - nG]; my_np[u] = enp[i - nG]; my_src[u] = (uint32_t) i; }
-                    else { my_c[u] = 0u; my_np[u] = 0u; my_src[u] = 0u; }
-                    if (i < n) {
-                        sc.kept[lcol * S + i] = (uint16_t) my_c[u];
-                        sc.kept_np[lcol * S + i] = my_np[u];
-                    }
-                }
-                CLK(6);
-                if (lane == 0) sc.n_kept[lcol] = n;
-                /* the kept flags of the previous merge column are no longer needed */
-                for (int i = lane; i < n_old; i += WAVE) flags[oldm[i]] = 0;
-                int mn = 0;
-                if (k + 1 < K) {
-                    /* getLinkedMergeCells :989-1004: distinct next merge cells in order of first use.  The candidate
-                     * list is consumed, its storage serves as "first kept cell that uses merge cell m" */
-                    uint32_t *owner = cand;
-                    bool first[2];
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int i = lane + u * WAVE;
-                        if (i < n) owner[my_np[u] & 0xFFFFu] = 0xFFFFFFFFu;
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int i = lane + u * WAVE;
-                        if (i < n) atomicMin(&owner[my_np[u] & 0xFFFFu], (uint32_t) i);
-                    }
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int i = lane + u * WAVE;
-                        first[u] = i < n && owner[my_np[u] & 0xFFFFu] == (uint32_t) i;
-                    }
-                    const uint64_t f0 = __ballot(first[0]), f1 = __ballot(first[1]);
-                    const int mnl = __popcll(f0) + __popcll(f1);
-                    uint32_t mkey[2] = {0xFFFFFFFFu, 0xFFFFFFFFu};
-                    int pass_thr[2] = {0, 0};
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        if (first[u]) {
-                            const int pos = u == 0 ? (int) lanemask_lt_count(f0, lane) : __popcll(f0) + (int) lanemask_lt_count(f1, lane);
-                            const uint32_t m = my_np[u] & 0xFFFFu;
-                            const int bin = (int) um[my_src[u]]; /* gathered before the sort */
-                            pass_thr[u] = bin <= p.thr_bin ? 1 : 0;
-                            mkey[u] = ((uint32_t) bin << 21) | ((uint32_t) pos << 14) | m;
-                        }
-                    }
-                    CLK(7);
-                    const int gm = __popcll(__ballot(pass_thr[0] != 0)) + __popcll(__ballot(pass_thr[1] != 0));
-                    mn = kept_count(mnl, gm, p.min_p, p.max_p);
-                    /* stable descending sort by posterior (:1090), the first mn stay */
-                    wave_bitonic_sort128(mkey[0], mkey[1], lane);
-#pragma unroll
-                    for (int u = 0; u < 2; u++) {
-                        const int r = lane + u * WAVE;
-                        if (r < mn) {
-                            const uint32_t m = mkey[u] & 0x3FFFu;
-                            flags[m] = 1;
-                            oldm[r] = m;
-                            sc.keptm[lcol * S + r] = (uint16_t) m;
-                        }
-                    }
-                }
+                n_prev = k + 1 < K ? n : 0;
+                nG_prev = nG;
                 CLK(8);
-                if (lane == 0) sc.n_keptm[lcol] = mn;
-                n_old = mn;
             }
+            mcell_prev = cur.mcell_off;
             lds_barrier();
             CLK(9);
         }
-        /* clear the flags left by the last merge column (n_old is only maintained by wave 0) */
-        if (wave == 0)
-            for (int i = lane; i < n_old; i += WAVE) flags[oldm[i]] = 0;
+        /* the lists of the last two columns */
+        if (wave == 1) lists_stage1(K - 1, mcell_prev);
+        if (wave == 2 && K > 1) lists_stage2(K - 2);
+        lds_barrier();
+        if (wave == 2) lists_stage2(K - 1);
         __syncthreads(); /* also makes the lists above visible in global memory */
 
         /* ---- stRPHmm_pruneBackwards hmm.c:1111-1158: lists of at most S entries, one wave; the lists of
@@ -665,7 +712,7 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const PruneHmm *hmms_dev, int6
     if (n_hmms <= 0) return hipSuccess;
     if (p.S > MRP_PRUNE_MAX_S || p.max_cells > MRP_PRUNE_MAX_CELLS || p.max_merge > MRP_PRUNE_MAX_CELLS || p.n_bins > 1024) return hipErrorInvalidValue;
     const size_t cap = (size_t) ((std::max(p.max_cells, p.max_merge) + 3) & ~3);
-    auto lds_for = [&](int threads) { return (size_t) (6 * p.S + 64 + (threads / 64) * 4 * 64 + 2 * 1024 + 2 * cap) * 4 + (size_t) ((p.max_merge + 3) & ~3) + 16; };
+    auto lds_for = [&](int threads) { return (size_t) (13 * p.S + 64 + (threads / 64) * 4 * 64 + 2 * 1024 + 2 * cap + 512) * 4 + (size_t) ((p.max_merge + 3) & ~3) + 16; };
     static bool configured = false;
     if (!configured) {
         hipError_t e = hipFuncSetAttribute((const void *) mrp_prune_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
