@@ -265,6 +265,13 @@ struct PruneIn {
     const double *hmm_fb;
 };
 
+/* buffer descriptor over [p, p + bytes): both made wave-uniform for the compiler (cdna_hip_programming.md T8 / T20) */
+static __device__ __forceinline__ __amdgpu_buffer_rsrc_t prune_rsrc(const void *p, int bytes) {
+    const uint64_t a = (uint64_t) p;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t) a), hi = __builtin_amdgcn_readfirstlane((uint32_t) (a >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc((void *) (((uint64_t) hi << 32) | lo), 0, bytes, 0x00020000);
+}
+
 template <int T>
 __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
                                                       PruneParams p, PruneScratch sc) {
@@ -318,17 +325,18 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
         const int nj_ = (hi_v - lo_ + 63) >> 6;
 #define PRUNE_LOAD(colv, lo_, hi_v, nj_)                                                      \
         {                                                                                     \
-            /* one base address per array, constant strides: the loads take immediate offsets */ \
-            const int64_t first_ = (colv).cell_off + lo_ + lane;                              \
-            const uint32_t *__restrict__ pn_ = d.cell_np + first_;                            \
-            const int32_t *__restrict__ pf_ = d.cell_f32 + first_;                            \
-            const int32_t *__restrict__ pb_ = d.cell_b32 + first_;                            \
-            const int left_ = hi_v - lo_ - lane; /* cells of this lane's stride that exist */ \
+            /* buffer loads: one descriptor per array over this wave's share, the hardware's range check instead of an \
+             * exec mask per load (out of range reads 0 and is never looked at), immediate offsets */ \
+            const int64_t first_ = (colv).cell_off + lo_;                                     \
+            const int bytes_ = __builtin_amdgcn_readfirstlane((hi_v - lo_) * 4);              \
+            const auto rn_ = prune_rsrc(d.cell_np + first_, bytes_);                          \
+            const auto rf_ = prune_rsrc(d.cell_f32 + first_, bytes_);                         \
+            const auto rb_ = prune_rsrc(d.cell_b32 + first_, bytes_);                         \
             _Pragma("unroll") for (int j = 0; j < PRUNE_CPT; j++) {                           \
-                if (j * WAVE < left_) {                                                       \
-                    r_np[j] = pn_[j * WAVE];                                                  \
-                    r_f[j] = pf_[j * WAVE];                                                   \
-                    r_b[j] = pb_[j * WAVE];                                                   \
+                if (j < nj_) { /* wave-uniform */                                              \
+                    r_np[j] = (uint32_t) __builtin_amdgcn_raw_buffer_load_b32(rn_, lane * 4 + j * WAVE * 4, 0, 0); \
+                    r_f[j] = (int32_t) __builtin_amdgcn_raw_buffer_load_b32(rf_, lane * 4 + j * WAVE * 4, 0, 0);   \
+                    r_b[j] = (int32_t) __builtin_amdgcn_raw_buffer_load_b32(rb_, lane * 4 + j * WAVE * 4, 0, 0);   \
                 }                                                                             \
             }                                                                                 \
         }
