@@ -1536,15 +1536,26 @@ static void level_finish(int64_t i, void *arg) {
 static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params) {
     int max_h = 0;
     for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > max_h) max_h = t->a[i].height;
+    /* Level of a merge node = as late as its parent allows (every root at the last level), not its height: the merges
+     * near the roots are the expensive ones (a workgroup walks ~10^3 columns of ~10^4 cells one after the other) and a
+     * level costs what its longest hmm costs, so they should share their levels -- a problem one merge deeper than the
+     * others then adds a level of small leaf merges instead of a level with a single large hmm on an idle device. */
+    int *lvl = xmalloc(sizeof(int) * (size_t) (t->n + 1));
+    for (int64_t i = 0; i < t->n; i++) lvl[i] = -1;
+    for (int64_t i = t->n - 1; i >= 0; i--) { /* children precede their parent */
+        if (lvl[i] < 0) lvl[i] = max_h;
+        if (t->a[i].left >= 0) { lvl[t->a[i].left] = lvl[i] - 1; lvl[t->a[i].right] = lvl[i] - 1; }
+    }
     const uint32_t flags = sweep_flags(params);
     int rc = MRP_OK;
     for (int h = 1; h <= max_h && rc == MRP_OK; h++) {
         const double t0 = now_ms();
         int64_t n_items = 0;
-        for (int64_t i = 0; i < t->n; i++) if (t->a[i].height == h) n_items++;
+        for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > 0 && lvl[i] == h) n_items++;
+        if (n_items == 0) continue;
         level_item *items = xcalloc((size_t) n_items + 1, sizeof(*items));
         n_items = 0;
-        for (int64_t i = 0; i < t->n; i++) if (t->a[i].height == h) { items[n_items].t = t; items[n_items].node = i; n_items++; }
+        for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > 0 && lvl[i] == h) { items[n_items].t = t; items[n_items].node = i; n_items++; }
         /* the merges of a level touch disjoint nodes: structure in parallel, device work as one batch */
         parallel_for(n_items, level_prepare, items);
         int64_t n_x = 0;
@@ -1593,6 +1604,7 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params) {
         for (int64_t i = 0; i < n_items; i++) t->a[items[i].node].path = items[i].res;
         free(items);
     }
+    free(lvl);
     return rc;
 }
 
