@@ -145,3 +145,21 @@ def test_oracle_reproduces_golden_vectors():
         out = ph.forward_batch(models, g["pool"], g[f"{tag}_x_off"], g[f"{tag}_x_len"], g[f"{tag}_y_off"], g[f"{tag}_y_len"], g[f"{tag}_model"],
                                g[f"{tag}_anchor_off"], g[f"{tag}_anchors"], int(g["expansion"]), bool(g[f"{tag}_ragged"][0]), bool(g[f"{tag}_ragged"][1]))
         assert (out == g[f"{tag}_out"]).all()
+
+
+def test_pairhmm_entry_points_fail_loudly_without_a_context():
+    """no CPU fallback: without a device context the product returns MRP_ERR_NO_DEVICE, it does not compute"""
+    L = capi.load()
+    m = capi.PairHmm.default_nucleotide()
+    out = np.zeros(1)
+    z64, z32 = np.zeros(1, np.int64), np.array([3], np.int32)
+    pool = np.zeros(6, np.uint8)
+    y_off = np.array([3], np.int64)
+    rc = L.mrp_forward_probabilities(None, C.byref(m), 1, 1, pool.ctypes.data, 6, z64.ctypes.data, z32.ctypes.data, y_off.ctypes.data, z32.ctypes.data,
+                                     None, None, None, 4, 0, 0, out.ctypes.data, None)
+    assert rc == capi.MRP_ERR_NO_DEVICE and b"no CPU fallback" in L.mrp_last_error()
+    first = np.array([0, 1], np.int64)
+    sup = np.zeros(1, np.float32)
+    rc = L.mrp_allele_read_supports(None, C.byref(m), C.byref(m), 1, first.ctypes.data, first.ctypes.data, pool.ctypes.data, 6, z64.ctypes.data,
+                                    z32.ctypes.data, y_off.ctypes.data, z32.ctypes.data, np.ones(1, np.uint8).ctypes.data, 4, sup.ctypes.data, None)
+    assert rc == capi.MRP_ERR_NO_DEVICE
