@@ -264,8 +264,9 @@ def main():
         n_pairs = len(a_in[1])
         k_s, _ = sharding.reduce_elapsed_and_units(dist, k_ms / 1e3, float(n_pairs), device=reduce_dev)
         a_el, a_pairs = sharding.reduce_elapsed_and_units(dist, a_el, float(n_pairs), device=reduce_dev)
+        _, cells_all = sharding.reduce_elapsed_and_units(dist, 0.0, float(cells), device=reduce_dev)
         out["alignment"] = dict(what="mrp_forward_probabilities: banded pair-HMM forward log probability, read substring x allele",
-                                value=a_pairs * args.align_runs / k_s, unit="pairs/s", cells_per_s=cells * world * args.align_runs / k_s,
+                                value=a_pairs * args.align_runs / k_s, unit="pairs/s", cells_per_s=cells_all * args.align_runs / k_s,
                                 kernel_ms=1e3 * k_s / args.align_runs, call_value=a_pairs * args.align_runs / a_el,
                                 call_ms=1e3 * a_el / args.align_runs, pairs_per_gpu=n_pairs, cells_per_gpu=int(cells), chunks_per_gpu=args.align_chunks,
                                 dtype="f64", parity="bit-exact vs oracle/pairhmm_oracle.c (no fused multiply-add on either side)",
