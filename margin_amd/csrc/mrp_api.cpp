@@ -10,6 +10,8 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
@@ -470,6 +472,95 @@ int mrp_batch_add_impl(mrp_batch *b, const mrp_hmm_job *job, bool resident, int6
     if (mcell0_out) *mcell0_out = mcell0;
     if (col0_out) *col0_out = col0;
     return MRP_OK;
+}
+
+/* ---- persistent host worker pool ----------------------------------------------------------------------------
+ * mrp_pool_run(n, grain, fn, arg) calls fn(i, arg) for every i in [0, n) on the calling thread and the pool's workers and
+ * returns when all are done.  The resident pipeline issues ~50 short parallel loops per call; creating and joining 15
+ * threads for each of them cost more than many of the loops.  Several callers may be inside at once (the concurrent
+ * halves of mrp_phase_reads_many): jobs queue up, a worker serves the oldest job that still has indices to hand out. */
+namespace {
+struct PoolJob {
+    void (*fn)(int64_t, void *);
+    void *arg;
+    int64_t n, grain;
+    std::atomic<int64_t> next{0}, done{0};
+    int active = 0; /* workers currently holding the pointer (under Pool::mu) */
+};
+struct Pool {
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    std::vector<PoolJob *> jobs;
+    std::vector<std::thread> workers;
+    bool stop = false;
+    static void run_chunks(PoolJob *j) {
+        for (;;) {
+            const int64_t lo = j->next.fetch_add(j->grain);
+            if (lo >= j->n) return;
+            const int64_t hi = std::min(j->n, lo + j->grain);
+            for (int64_t i = lo; i < hi; i++) j->fn(i, j->arg);
+            j->done.fetch_add(hi - lo);
+        }
+    }
+    void worker() {
+        std::unique_lock<std::mutex> lk(mu);
+        for (;;) {
+            PoolJob *j = nullptr;
+            for (PoolJob *q : jobs)
+                if (q->next.load() < q->n) { j = q; break; }
+            if (!j) {
+                if (stop) return;
+                cv_work.wait(lk);
+                continue;
+            }
+            j->active++;
+            lk.unlock();
+            run_chunks(j);
+            lk.lock();
+            j->active--;
+            cv_done.notify_all();
+        }
+    }
+    void ensure(int n_workers) {
+        std::lock_guard<std::mutex> lk(mu);
+        while ((int) workers.size() < n_workers) workers.emplace_back([this] { worker(); });
+    }
+    ~Pool() {
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_work.notify_all();
+        for (auto &t : workers) t.join();
+    }
+};
+Pool &pool() {
+    static Pool *p = new Pool(); /* never destroyed: worker threads must not be joined from a static destructor at exit */
+    return *p;
+}
+}  // namespace
+
+extern "C" void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void *), void *arg) {
+    if (n <= 0) return;
+    if (grain < 1) grain = 1;
+    const int nt = (int) std::min<int64_t>(mrp_host_threads(), (n + grain - 1) / grain);
+    if (nt <= 1) {
+        for (int64_t i = 0; i < n; i++) fn(i, arg);
+        return;
+    }
+    Pool &P = pool();
+    P.ensure(mrp_host_threads() - 1);
+    PoolJob j;
+    j.fn = fn; j.arg = arg; j.n = n; j.grain = grain;
+    {
+        std::lock_guard<std::mutex> lk(P.mu);
+        P.jobs.push_back(&j);
+    }
+    P.cv_work.notify_all();
+    Pool::run_chunks(&j);
+    std::unique_lock<std::mutex> lk(P.mu);
+    P.cv_done.wait(lk, [&] { return j.done.load() >= j.n && j.active == 0; });
+    P.jobs.erase(std::find(P.jobs.begin(), P.jobs.end(), &j));
 }
 
 int mrp_host_threads(void) {

@@ -250,26 +250,10 @@ int mrp_batch_add_resident_bulk(mrp_batch *b, int64_t n, const mrp_xhmm *x, int6
 
 #include <atomic>
 #include <thread>
+extern "C" void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void *), void *arg);
 template <class F>
 static inline void mrp_parallel_for(int64_t n, int64_t grain, F f) {
-    const int nt = (int) std::min<int64_t>(mrp_host_threads(), (n + grain - 1) / std::max<int64_t>(grain, 1));
-    if (nt <= 1) {
-        for (int64_t i = 0; i < n; i++) f(i);
-        return;
-    }
-    std::atomic<int64_t> next{0};
-    auto work = [&]() {
-        for (;;) {
-            const int64_t lo = next.fetch_add(grain);
-            if (lo >= n) break;
-            const int64_t hi = std::min(n, lo + grain);
-            for (int64_t i = lo; i < hi; i++) f(i);
-        }
-    };
-    std::vector<std::thread> th;
-    for (int t = 1; t < nt; t++) th.emplace_back(work);
-    work();
-    for (auto &t : th) t.join();
+    mrp_pool_run(n, grain, [](int64_t i, void *a) { (*static_cast<F *>(a))(i); }, &f);
 }
 
 #endif

@@ -31,30 +31,7 @@ static double now_ms(void) {
 /* host worker threads: the structural code is independent per chunk / per merge node */
 #include <pthread.h>
 typedef void (*par_fn)(int64_t i, void *arg);
-typedef struct { par_fn fn; void *arg; int64_t n; int64_t next; pthread_mutex_t mu; } par_ctl;
-static void *par_worker(void *p) {
-    par_ctl *c = p;
-    for (;;) {
-        pthread_mutex_lock(&c->mu);
-        const int64_t i = c->next++;
-        pthread_mutex_unlock(&c->mu);
-        if (i >= c->n) break;
-        c->fn(i, c->arg);
-    }
-    return NULL;
-}
-static void parallel_for(int64_t n, par_fn fn, void *arg) {
-    int nt = mrp_host_threads();
-    if (nt > n) nt = (int) n;
-    if (nt <= 1) { for (int64_t i = 0; i < n; i++) fn(i, arg); return; }
-    par_ctl c = {fn, arg, n, 0, PTHREAD_MUTEX_INITIALIZER};
-    pthread_t th[64];
-    if (nt > 64) nt = 64;
-    int started = 0;
-    for (int t = 1; t < nt; t++) if (pthread_create(&th[started], NULL, par_worker, &c) == 0) started++;
-    par_worker(&c);
-    for (int t = 0; t < started; t++) pthread_join(th[t], NULL);
-}
+static void parallel_for(int64_t n, par_fn fn, void *arg) { mrp_pool_run(n, 1, fn, arg); } /* persistent pool, mrp_api.cpp */
 
 /* ------------------------------------------------------------------------------------------ */
 /* helpers                                                                                     */

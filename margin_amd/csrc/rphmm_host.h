@@ -33,6 +33,8 @@ mrp_context *mrp_context_sibling(mrp_context *ctx, int i);
 int mrp_set_error(int code, const char *fmt, ...);
 /* host worker threads for structural code and descriptor building (MRP_HOST_THREADS, default min(16, cores)) */
 int mrp_host_threads(void);
+/* fn(i, arg) for every i in [0, n), grain indices at a time, on the caller and the persistent worker pool (mrp_api.cpp) */
+void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void *), void *arg);
 
 /* ---- device-resident merge levels (mrp_engine.cpp), driven by the structural code of rphmm_host.c ---- */
 typedef struct mrp_engine mrp_engine;
