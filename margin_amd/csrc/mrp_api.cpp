@@ -110,6 +110,7 @@ void mrp_context_destroy(mrp_context *ctx) {
     if (!ctx) return;
     for (mrp_context *s : ctx->siblings) mrp_context_destroy(s);
     ctx->siblings.clear();
+    if (ctx->spare_batch) { mrp_batch_destroy(ctx->spare_batch); ctx->spare_batch = nullptr; }
     (void) hipSetDevice(ctx->device);
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     ctx->pool.destroy();

@@ -52,6 +52,12 @@ struct mrp_engine {
     mrp_batch *spare = nullptr;                   /* the batch object of the previous level, emptied */
 };
 
+static double eng_now() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return 1e3 * ts.tv_sec + 1e-6 * ts.tv_nsec;
+}
+
 static void mrp_engine_level_abandon(mrp_engine *e);
 
 extern "C" {
@@ -90,6 +96,13 @@ int mrp_engine_create(mrp_context *ctx, const mrp_params *params, mrp_engine **o
         const double post = std::min(1.0, exp(-(double) b2)); /* exactly 0.0 in the last bin */
         if (!(post < params->min_posterior_probability_for_partition)) pp.thr_bin = b2;
     }
+    e->leaf_part.pool = &ctx->pool;
+    e->leaf_np.pool = &ctx->pool;
+    {
+        std::lock_guard<std::mutex> lock(ctx->sibling_mu);
+        e->spare = ctx->spare_batch;
+        ctx->spare_batch = nullptr;
+    }
     hipError_t he = e->leaf_part.alloc(4);
     if (he == hipSuccess) he = e->leaf_np.alloc(4);
     const uint64_t lp[4] = {1, 0, 0, 0}; /* stRPHmm_construct hmm.c:97-133 */
@@ -108,14 +121,26 @@ int mrp_engine_create(mrp_context *ctx, const mrp_params *params, mrp_engine **o
 void mrp_engine_destroy(mrp_engine *e) {
     if (!e) return;
     (void) hipSetDevice(e->ctx->device);
+    const double t0 = eng_now();
     (void) hipStreamSynchronize(e->ctx->stream);
+    const double t1 = eng_now();
     for (auto &ev : e->ev)
         if (ev) (void) hipEventDestroy(ev);
     mrp_context *ctx = e->ctx;
     mrp_engine_level_abandon(e);
+    const double t2 = eng_now();
+    if (e->spare) { /* kept for the next engine of this context */
+        std::lock_guard<std::mutex> lock(ctx->sibling_mu);
+        if (!ctx->spare_batch) { ctx->spare_batch = e->spare; e->spare = nullptr; }
+    }
     if (e->spare) mrp_batch_destroy(e->spare);
+    const double t3 = eng_now();
     delete e;
+    const double t4 = eng_now();
     ctx->pool.reclaim();
+    if (getenv("MRP_TIMING"))
+        fprintf(stderr, "  engine destroy: sync %.1f ms, events %.1f, spare batch %.1f, segments %.1f, reclaim %.1f\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3,
+                eng_now() - t4);
 }
 
 int32_t mrp_engine_stride(const mrp_engine *e) { return e->pp.S; }
@@ -183,11 +208,6 @@ static void mrp_engine_level_abandon(mrp_engine *e) {
 
 extern "C" {
 
-static double eng_now() {
-    timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return 1e3 * ts.tv_sec + 1e-6 * ts.tv_nsec;
-}
 
 static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) {
     if (!e || n < 0 || (n > 0 && !x)) return mrp_set_error(MRP_ERR_ARG, "mrp_engine_level: bad arguments");

@@ -139,6 +139,9 @@ struct mrp_context {
     DevPool pool;
     std::vector<mrp_context *> siblings; /* further contexts on the same device (concurrent batches of mrp_phase_reads_many) */
     std::mutex sibling_mu;
+    /* the emptied batch object of the last resident engine on this context: its host arrays keep their capacity (and their
+     * mapped pages) from one mrp_phase_reads_many call to the next */
+    struct mrp_batch *spare_batch = nullptr;
     /* page-locked host staging for the small per-level results of the resident engine (grow-only) */
     void *pinned = nullptr;
     size_t pinned_bytes = 0;

@@ -1778,6 +1778,7 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
     mrp_params pc = *params;
     pc.include_ancestor_sub_prob = 0; /* bubbleGraph.c:2733 */
     mrp_engine *e = NULL;
+    const double t_enter = now_ms();
     int rc = mrp_engine_create(ctx, &pc, &e);
     if (rc != MRP_OK) return rc;
     many_state *st = xcalloc((size_t) n_chunks + 1, sizeof(*st));
@@ -1848,11 +1849,16 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
         stats->merge_cells = es.merge_cells;
         stats->device_ms = es.device_ms; stats->cross_ms = es.cross_ms; stats->sweep_ms = es.sweep_ms; stats->prune_ms = es.prune_ms;
     }
+    const double t_clean = now_ms();
     for (int64_t c = 0; c < n_chunks; c++) { mrp_hmm_destroy(st[c].hmm); free(st[c].discarded); free(st[c].tree.a); free(st[c].path); free(st[c].chosen); }
     r_free_tree(&tree);
     for (int64_t c = 0; c < n_chunks; c++) { for (int64_t i = 0; i < st[c].blocks.n; i++) free(st[c].blocks.a[i]); free(st[c].blocks.a); }
     free(st);
+    const double t_eng = now_ms();
     mrp_engine_destroy(e);
+    if (timing)
+        fprintf(stderr, "  engine create %.1f ms, host clean-up %.1f, engine destroy %.1f, whole call %.1f\n", tt[0] - t_enter, t_eng - t_clean,
+                now_ms() - t_eng, now_ms() - t_enter);
     return rc;
 }
 
