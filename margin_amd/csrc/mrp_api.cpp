@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <ctime>
 #include <mutex>
 #include <new>
 #include <thread>
@@ -738,6 +739,9 @@ int mrp_batch_upload(mrp_batch *b) {
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
 
+    const bool timing_ = getenv("MRP_TIMING") != nullptr;
+    auto now_ = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return 1e3 * ts.tv_sec + 1e-6 * ts.tv_nsec; };
+    const double u0 = now_();
     /* launch plan: int32/LDS path for max-plus HMMs that fit, fp64 path otherwise.  The int32 path is
      * split into size classes (LDS per workgroup = 2 * largest merge column * 4 B) that are launched
      * on separate streams so that small hmms do not inherit the residency of the largest one. */
@@ -771,6 +775,7 @@ int mrp_batch_upload(mrp_batch *b) {
     plan(narrow, b->order_narrow, &b->max_merge_narrow);
     plan(generic, b->order_f64, nullptr);
 
+    const double u1 = now_();
     std::vector<DevChunk> chunks;
     for (auto *c : b->chunks) chunks.push_back(c->dev);
 
@@ -795,6 +800,7 @@ int mrp_batch_upload(mrp_batch *b) {
     HIP_TRY(b->d_order_mid.upload(b->order_mid, s));
     HIP_TRY(b->d_order_narrow.upload(b->order_narrow, s));
     HIP_TRY(b->d_order_f64.upload(b->order_f64, s));
+    const double u2 = now_();
     {   /* fast tiles first */
         auto is_fast = [](const EmitTile &t) { return t.uniform_alleles != 0 && !(t.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB); };
         auto mid_it = std::stable_partition(b->tiles.begin(), b->tiles.end(), is_fast);
@@ -806,6 +812,7 @@ int mrp_batch_upload(mrp_batch *b) {
     for (size_t i = 0; i < b->pcols.size(); i++) (b->pcols[i].need_planes ? plane_list : pack_list).push_back((int32_t) i);
     HIP_TRY(b->d_pack_list.upload(pack_list, s));
     HIP_TRY(b->d_plane_list.upload(plane_list, s));
+    const double u3 = now_();
     const size_t nC = (size_t) b->n_cells_total;
     HIP_TRY(b->d_planes.alloc((size_t) b->n_slots * 8));
     HIP_TRY(b->d_slot_total.alloc((size_t) b->n_slots));
@@ -823,7 +830,10 @@ int mrp_batch_upload(mrp_batch *b) {
     }
     HIP_TRY(b->d_total.alloc(b->cols.size()));
     HIP_TRY(b->d_hmm_fb.alloc(2 * b->hmms.size()));
+    const double u4 = now_();
     HIP_TRY(hipStreamSynchronize(s));
+    if (timing_)
+        fprintf(stderr, "      upload: plan %.2f ms, arrays %.2f, tiles+lists %.2f, allocs %.2f, sync %.2f\n", u1 - u0, u2 - u1, u3 - u2, u4 - u3, now_() - u4);
 
     MrpBatchDev &d = b->dev;
     d.hmms = b->d_hmms.p;
