@@ -517,7 +517,8 @@ int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int3
     /* classify.  The pair-per-lane kernel takes the unanchored pairs whose x string fits its LDS row next to the tables;
      * launch classes by x length (4, 3, 2, 1 waves per workgroup = per CU). */
     const int table_bytes = (16 + n_models * PHM_ETAB) * (int) sizeof(double);
-    const int lane_max_x = std::max(0, std::min(PHM_LANE_MAX_X, (PHM_LDS_BYTES - table_bytes) / PHM_LANE_BYTES_PER_X));
+    /* (-1: the tables of this many models leave no room for a row, every pair goes to the pair-per-wave kernel) */
+    const int lane_max_x = PHM_LDS_BYTES - table_bytes < PHM_LANE_BYTES_PER_X ? -1 : std::min(PHM_LANE_MAX_X, (PHM_LDS_BYTES - table_bytes) / PHM_LANE_BYTES_PER_X);
     int lane_cap[4];
     for (int c = 0; c < 4; c++) lane_cap[c] = std::min(lane_max_x, (PHM_LDS_BYTES - table_bytes) / ((4 - c) * PHM_LANE_BYTES_PER_X));
     constexpr uint32_t WAVE_KEY = 0xFFFFFFFFu;

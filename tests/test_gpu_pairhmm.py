@@ -192,3 +192,24 @@ def test_strings_to_haplotype_tags(gpu_ctx, orc):
     tagged = int(((hap == 1) | (hap == 2)).sum())
     assert tagged >= 0.9 * len(reads) and max(agree, tagged - agree) >= 0.9 * tagged
     dchunk.close()
+
+
+def test_many_models(gpu_ctx):
+    """the emission tables of the pair-per-lane kernel live in LDS next to the rows: 40 models shrink the rows it can hold,
+    200 models leave no room at all (every pair then takes the pair-per-wave kernel); results do not change"""
+    rng = np.random.default_rng(5)
+    base = models3()
+    pairs = [(synth.random_sequence(rng, int(rng.integers(0, 60))), synth.random_sequence(rng, int(rng.integers(0, 60)))) for _ in range(300)]
+    pool, xo, xl, yo, yl = pack(pairs)
+    for n_models in (40, 200):
+        ms = []
+        for i in range(n_models):
+            m = base[i % 3].copy()
+            m.gap_open_x -= 0.01 * i
+            m.e_match[5] -= 0.003 * i
+            ms.append(m)
+        mi = rng.integers(0, n_models, size=len(pairs)).astype(np.uint8)
+        out, st = capi.forward_probabilities(gpu_ctx, ms, pool, xo, xl, yo, yl, mi)
+        ref = ph.forward_batch([omodel(m) for m in ms], pool, xo, xl, yo, yl, mi)
+        assert (out == ref).all()
+        assert (st.pairs_lane == 0) == (n_models == 200)
