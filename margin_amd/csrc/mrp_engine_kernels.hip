@@ -309,6 +309,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
         const int K = h.n_cols;
         const int64_t total = (int64_t) d.hmm_fb[2 * h.hmm_index]; /* max mode: the same integer for every column */
         for (int i = tid; i < 2 * nb_r; i += T) hist[i] = 0;
+        if (tid < 2) sh[40 + tid] = 0u;
         for (int i = tid; i < (p.max_merge + 3) / 4; i += T) reinterpret_cast<uint32_t *>(flags)[i] = 0;
         int n_prev = 0, nG_prev = 0; /* wave 0: the selection whose next merge cells own the kept flags */
         int64_t mcell_prev = 0;       /* first merge cell of the merge column after the previous column */
@@ -508,7 +509,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
             }
             if (staged > 0) PRUNE_FLUSH(staged)
 #undef PRUNE_FLUSH
-            if (lane == 0) sh[wave] = (uint32_t) cnt;
+            if (lane == 0) { sh[wave] = (uint32_t) cnt; atomicAdd(&sh[40 + (k & 1)], (uint32_t) cnt); }
             CLK(1);
             /* the next column's cells are requested now and consumed after the two barriers below */
             const SweepCol cur = col;
@@ -533,8 +534,8 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
             if (wave == 0) {
                 uint32_t *gsel = sel + (k & 1) * 4 * S, *gnp = gsel + S, *esel = gnp + S, *enp = esel + S;
                 /* [B] cutoff bin and quota */
-                int n_link = 0;
-                for (int w = 0; w < W; w++) n_link += (int) sh[w];
+                const int n_link = (int) sh[40 + (k & 1)]; /* summed by the waves at the end of [A] */
+                if (lane == 0) sh[40 + ((k + 1) & 1)] = 0u;
                 /* lane l owns the bpl consecutive bins [l * bpl, (l + 1) * bpl); the histogram is stored lane-major, so these
                  * reads are conflict-free and the search has a fixed, short cost wherever the cutoff lies (the posteriors of
                  * the linked cells spread over hundreds of bins) */
@@ -562,8 +563,9 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
                 }
                 const uint64_t om = __ballot(owner_lane);
                 const int src = om ? __ffsll((unsigned long long) om) - 1 : 0;
-                const int B = om ? __shfl(myB, src, WAVE) : -1;
-                const int quota = om ? __shfl(myQ, src, WAVE) : 0;
+                const int srcu = __builtin_amdgcn_readfirstlane(src); /* wave-uniform: v_readlane instead of ds_bpermute */
+                const int B = om ? __builtin_amdgcn_readlane(myB, srcu) : -1;
+                const int quota = om ? __builtin_amdgcn_readlane(myQ, srcu) : 0;
                 const int nG = n - quota;
                 CLK(4);
                 /* ordered selection over the wave segments (list order) */
