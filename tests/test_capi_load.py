@@ -59,3 +59,34 @@ def test_product_package_does_not_touch_the_oracle():
     import subprocess
     out = subprocess.run(["ldd", capi.LIB_PATH], capture_output=True, text=True).stdout
     assert "liborc" not in out
+
+
+def test_host_worker_pool_runs_every_index_once():
+    """mrp_pool_run (the persistent pool behind the host-side parallel loops): concurrent callers, grains, nesting."""
+    import threading
+    lib = capi.load()
+    CB = C.CFUNCTYPE(None, C.c_int64, C.c_void_p)
+    lib.mrp_pool_run.argtypes = [C.c_int64, C.c_int64, CB, C.c_void_p]
+    lib.mrp_pool_run.restype = None
+    errors = []
+
+    def caller(seed):
+        for r in range(30):
+            n = 1 + (seed * 31 + r * 17) % 200
+            hits = [0] * n
+            lock = threading.Lock()
+
+            def body(i, _arg):
+                with lock:
+                    hits[i] += 1
+            cb = CB(body)
+            lib.mrp_pool_run(n, 1 + r % 4, cb, None)
+            if hits != [1] * n:
+                errors.append((seed, r, n))
+
+    threads = [threading.Thread(target=caller, args=(s,)) for s in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors

@@ -312,3 +312,40 @@ def test_resident_ragged_inputs(gpu_ctx, orc):
         assert g["n_sweeps"] == ref["fb_calls"]
     for d in dchunks:
         d.close()
+
+
+def test_resident_many_small_chunks_do_not_depend_on_their_batch(gpu_ctx, orc):
+    """Config-3 shape (chr20 cut into 100 kb chunks of ~130 sites): 150 chunks in one call.  The merge trees have different
+    heights, so the level schedule (every root at the last level) mixes leaf merges of deep problems with larger merges of
+    shallow ones.  Size-independent property: a chunk's result does not depend on what else is in the call -- the whole
+    batch against the same chunks phased in three smaller calls in another order; a sample against the oracle."""
+    rng = np.random.default_rng(3)
+    chunks = []
+    for s in range(150):
+        n = int(rng.integers(60, 200))
+        chunks.append(synth.make_ont_chunk(seed=1000 + s, region_bp=100_000, n_sites=n, coverage=float(rng.integers(12, 45))))
+    pd = _params()
+    params = capi.Params.from_reference_names(pd)
+    dchunks = [capi.DeviceChunk.from_chunk(gpu_ctx, c) for c in chunks]
+    got, st = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
+    assert st.resident == 1 and len(got) == 150
+    order = rng.permutation(150)
+    again = [None] * 150
+    for part in (order[:40], order[40:110], order[110:]):
+        res, st2 = capi.phase_reads_many(gpu_ctx, [dchunks[i] for i in part], [chunks[i] for i in part], params)
+        assert st2.resident == 1
+        for i, r in zip(part, res):
+            again[i] = r
+    for a, b in zip(got, again):
+        for k in PHASE_KEYS:
+            assert (np.asarray(a[k]) == np.asarray(b[k])).all(), k
+        assert a["reads1"] == b["reads1"] and a["reads2"] == b["reads2"] and a["n_sweeps"] == b["n_sweeps"]
+    for i in order[:6]:
+        oc = orc.OracleChunk(chunks[i])
+        ref = oc.phase(pd)
+        oc.close()
+        for k in PHASE_KEYS:
+            assert (np.asarray(got[i][k]) == np.asarray(ref[k])).all(), k
+        assert got[i]["reads1"] == ref["reads1"] and got[i]["reads2"] == ref["reads2"]
+    for d in dchunks:
+        d.close()
