@@ -723,14 +723,13 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const PruneHmm *hmms_dev, int6
     if (p.S > MRP_PRUNE_MAX_S || p.max_cells > MRP_PRUNE_MAX_CELLS || p.max_merge > MRP_PRUNE_MAX_CELLS || p.n_bins > 1024) return hipErrorInvalidValue;
     const size_t cap = (size_t) ((std::max(p.max_cells, p.max_merge) + 3) & ~3);
     auto lds_for = [&](int threads) { return (size_t) (13 * p.S + 64 + (threads / 64) * 4 * 64 + 2 * 1024 + 2 * cap + 512) * 4 + (size_t) ((p.max_merge + 3) & ~3) + 16; };
-    static bool configured = false;
-    if (!configured) {
+    /* once per process (thread-safe static initialisation: the concurrent halves of a call launch from two host threads) */
+    static const hipError_t configured = [] {
         hipError_t e = hipFuncSetAttribute((const void *) mrp_prune_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess)
-            e = hipFuncSetAttribute((const void *) mrp_prune_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return e;
-        configured = true;
-    }
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *) mrp_prune_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return e;
+    }();
+    if (configured != hipSuccess) return configured;
     if (lds_for(1024) > (size_t) MRP_LDS_BUDGET) return hipErrorInvalidValue;
     const dim3 grid((unsigned) (n_hmms < 65536 ? n_hmms : 65536));
     const PruneIn in{d.scols, d.cell_np, d.cell_f32, d.cell_b32, d.merge_f32, d.merge_b32, d.hmm_fb};

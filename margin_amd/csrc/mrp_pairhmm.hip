@@ -652,13 +652,14 @@ int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int3
         PHM_HIP(d_lane[c].upload(lane_pairs[c], s));
         PHM_HIP(d_wave[c].upload(wave_pairs[c], s));
     }
-    static bool configured = false;
-    if (!configured) {
-        PHM_HIP(hipFuncSetAttribute((const void *) phm_lane_kernel<PHM_ROWS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PHM_HIP(hipFuncSetAttribute((const void *) phm_lane_kernel<PHM_ROWS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        PHM_HIP(hipFuncSetAttribute((const void *) phm_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-        configured = true;
-    }
+    /* once per process (thread-safe static initialisation; contexts of several host threads may call concurrently) */
+    static const hipError_t configured = [] {
+        hipError_t e = hipFuncSetAttribute((const void *) phm_lane_kernel<PHM_ROWS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PHM_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *) phm_lane_kernel<PHM_ROWS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PHM_LDS_BYTES);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *) phm_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PHM_LDS_BYTES);
+        return e;
+    }();
+    PHM_HIP(configured);
     /* kernel_ms must not contain the tail of the uploads (the copy engine finishes them behind the event otherwise) */
     if (stats) PHM_HIP(hipStreamSynchronize(s));
     PHM_HIP(hipEventRecord(ctx->ev[0], s));
