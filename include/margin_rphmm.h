@@ -346,6 +346,9 @@ void mrp_pair_hmm_reverse_complement(mrp_pair_hmm *m);
  * sequence coordinates, strictly increasing in both.  MRP_ERR_ARG where the reference asserts / throws. */
 int mrp_band_diagonals(const int64_t *anchors, int64_t n_anchors, int64_t lx, int64_t ly, int64_t expansion, int32_t *xmy_l,
                        int32_t *xmy_r);
+/* getKmerAlignmentAnchors (pairwiseAligner.c:1519-1627, KMER_SIZE = 20): the chain of shared 20-mers the reference anchors
+ * long (structural variant) alleles with; out receives at most ly - 19 (x, y) pairs, the count is returned (host only) */
+int64_t mrp_kmer_alignment_anchors(const uint8_t *x, int64_t lx, const uint8_t *y, int64_t ly, int64_t *out);
 /* computeForwardProbability for n_pairs (x, y) string pairs stored in one pool of symbols.  model_index (NULL: all 0)
  * selects models[i] per pair; anchor_off (NULL: no anchors anywhere) holds n_pairs + 1 offsets into anchors (pairs of
  * int64).  A pair without anchors covers its whole matrix, as in the reference.  out[i] = log probability (0.0 for two
@@ -359,12 +362,14 @@ int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int3
  * [allele_first[b], allele_first[b+1]) and read substrings [read_first[b], read_first[b+1]); x = allele, y = read
  * substring, the read's strand picks the state machine -- except that, as in the reference (cachedScores is keyed by the
  * substring alone), a read whose substring equals that of an earlier read of the bubble copies that read's scores.
- * support is the concatenation over bubbles of float[alleleNo * readNo], entry j * readNo + k.  No anchors (the
- * reference anchors only strings longer than referenceExpansionForStructuralVariants). */
+ * support is the concatenation over bubbles of float[alleleNo * readNo], entry j * readNo + k.  A pair whose allele or
+ * read substring is longer than sv_threshold (referenceExpansionForStructuralVariants, 512 in the shipped parameters) is
+ * banded around its k-mer anchors (:1448-1451), every other pair covers its whole matrix. */
 int mrp_allele_read_supports(mrp_context *ctx, const mrp_pair_hmm *forward_model, const mrp_pair_hmm *reverse_model, int64_t n_bubbles,
                              const int64_t *allele_first, const int64_t *read_first, const uint8_t *pool, int64_t pool_bytes,
                              const int64_t *allele_off, const int32_t *allele_len, const int64_t *read_off, const int32_t *read_len,
-                             const uint8_t *read_forward_strand, int64_t expansion, float *support, mrp_pairhmm_stats *stats);
+                             const uint8_t *read_forward_strand, int64_t expansion, int64_t sv_threshold, float *support,
+                             mrp_pairhmm_stats *stats);
 
 #ifdef __cplusplus
 }

@@ -31,7 +31,7 @@ EXPORTED_SYMBOLS = [
     "mrp_profile_seqs_from_bubbles", "mrp_assign_reads_to_haplotypes", "mrp_stitch_create", "mrp_stitch_destroy",
     "mrp_stitch_chunk", "mrp_stitch_size", "mrp_stitch_lookup", "mrp_phase_sets", "mrp_binomial_p_value",
     "mrp_symbols_from_chars", "mrp_pair_hmm_reverse_complement", "mrp_band_diagonals", "mrp_forward_probabilities",
-    "mrp_allele_read_supports",
+    "mrp_allele_read_supports", "mrp_kmer_alignment_anchors",
 ]
 
 
@@ -242,7 +242,9 @@ def load():
     L.mrp_pair_hmm_reverse_complement.restype = None
     L.mrp_band_diagonals.argtypes = [vp, i64, i64, i64, i64, vp, vp]
     L.mrp_forward_probabilities.argtypes = [vp, vp, i32, i64, vp, i64, vp, vp, vp, vp, vp, vp, vp, i64, C.c_int, C.c_int, vp, P(PairHmmStats)]
-    L.mrp_allele_read_supports.argtypes = [vp, P(PairHmm), P(PairHmm), i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, vp, P(PairHmmStats)]
+    L.mrp_allele_read_supports.argtypes = [vp, P(PairHmm), P(PairHmm), i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, i64, vp, P(PairHmmStats)]
+    L.mrp_kmer_alignment_anchors.argtypes = [vp, i64, vp, i64, vp]
+    L.mrp_kmer_alignment_anchors.restype = i64
     _lib = L
     return L
 
@@ -713,7 +715,16 @@ def forward_probabilities(ctx: Context, models, pool, x_off, x_len, y_off, y_len
     return out, st
 
 
-def allele_read_supports(ctx: Context, forward_model: PairHmm, reverse_model: PairHmm, bubbles, expansion: int = 4):
+def kmer_alignment_anchors(sx, sy) -> np.ndarray:
+    """getKmerAlignmentAnchors (impl/pairwiseAligner.c:1563-1627): int64 [n, 2] (x, y) sequence coordinates"""
+    sx = np.ascontiguousarray(sx, dtype=np.uint8)
+    sy = np.ascontiguousarray(sy, dtype=np.uint8)
+    out = np.zeros((max(len(sy), 1), 2), dtype=np.int64)
+    n = load().mrp_kmer_alignment_anchors(sx.ctypes.data if sx.size else None, sx.size, sy.ctypes.data if sy.size else None, sy.size, out.ctypes.data)
+    return out[:n].copy()
+
+
+def allele_read_supports(ctx: Context, forward_model: PairHmm, reverse_model: PairHmm, bubbles, expansion: int = 4, sv_threshold: int = 512):
     """bubbles: list of (alleles, reads, read_forward_strand) with alleles / reads lists of uint8 symbol arrays.
     Returns ([float32 array [n_alleles, n_reads] per bubble], PairHmmStats): Bubble.alleleReadSupports (bubbleGraph.c:1421-1464)."""
     strings, a_first, r_first, a_len, r_len, strand = [], [0], [0], [], [], []
@@ -738,7 +749,7 @@ def allele_read_supports(ctx: Context, forward_model: PairHmm, reverse_model: Pa
     st = PairHmmStats()
     ptr = lambda a: None if a.size == 0 else a.ctypes.data
     _check(load().mrp_allele_read_supports(ctx.h, C.byref(forward_model), C.byref(reverse_model), len(bubbles), af.ctypes.data, rf.ctypes.data,
-                                           ptr(pool), pool.size, ptr(ao), ptr(al), ptr(ro), ptr(rl), ptr(sd), int(expansion), ptr(sup), C.byref(st)))
+                                           ptr(pool), pool.size, ptr(ao), ptr(al), ptr(ro), ptr(rl), ptr(sd), int(expansion), int(sv_threshold), ptr(sup), C.byref(st)))
     out, p = [], 0
     for b, sz in enumerate(sizes):
         out.append(sup[p:p + int(sz)].reshape(int(af[b + 1] - af[b]), int(rf[b + 1] - rf[b])))

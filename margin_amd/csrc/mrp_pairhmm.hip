@@ -27,6 +27,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <string_view>
+#include <unordered_map>
 #include <vector>
 
 #include "../../include/margin_rphmm.h"
@@ -467,6 +469,44 @@ double now_ms() {
 
 const int WAVE_CLASS_CAP[4] = {64, 256, 1024, PHM_WAVE_MAX_WIDTH};
 
+/* getKmerAlignmentAnchors (pairwiseAligner.c:1563-1627) with KMER_SIZE = 20 (:1519): first occurrence of every k-mer of x
+ * (getKmers :1543-1555), then over the k-mers of y found among them, in order of y, the best chain with increasing x; the
+ * walk back over earlier pairs stops at the first chainable one that was a running maximum (:1592).  Appends (x, y). */
+constexpr int64_t PHM_KMER = 20;
+int64_t kmer_anchors(const uint8_t *sx, int64_t lx, const uint8_t *sy, int64_t ly, std::vector<int64_t> &out) {
+    if (PHM_KMER > lx || PHM_KMER > ly) return 0;
+    std::unordered_map<std::string_view, int64_t> first;
+    first.reserve((size_t) (lx - PHM_KMER + 1) * 2);
+    for (int64_t i = 0; i + PHM_KMER <= lx; i++) first.emplace(std::string_view((const char *) sx + i, (size_t) PHM_KMER), i);
+    struct ChainPair { int64_t x, y, score, back; bool high; };
+    std::vector<ChainPair> cp;
+    int64_t max_score = 0, max_pair = -1;
+    for (int64_t y = 0; y + PHM_KMER <= ly; y++) {
+        auto it = first.find(std::string_view((const char *) sy + y, (size_t) PHM_KMER));
+        if (it == first.end()) continue;
+        ChainPair c{it->second, y, 1, -1, false};
+        for (int64_t j = (int64_t) cp.size() - 1; j >= 0; j--) {
+            if (cp[(size_t) j].x < c.x) {
+                if (cp[(size_t) j].score + 1 > c.score) { c.score = cp[(size_t) j].score + 1; c.back = j; }
+                if (cp[(size_t) j].high) break;
+            }
+        }
+        if (c.score >= max_score) { c.high = true; max_score = c.score; max_pair = (int64_t) cp.size(); }
+        cp.push_back(c);
+    }
+    int64_t n = 0;
+    for (int64_t q = max_pair; q != -1; q = cp[(size_t) q].back) n++;
+    const size_t base = out.size();
+    out.resize(base + 2 * (size_t) n);
+    int64_t w = n;
+    for (int64_t q = max_pair; q != -1; q = cp[(size_t) q].back) {
+        w--;
+        out[base + 2 * (size_t) w] = cp[(size_t) q].x + PHM_KMER / 2;
+        out[base + 2 * (size_t) w + 1] = cp[(size_t) q].y + PHM_KMER / 2;
+    }
+    return n;
+}
+
 }  // namespace
 
 extern "C" {
@@ -492,6 +532,14 @@ void mrp_pair_hmm_reverse_complement(mrp_pair_hmm *m) {
         std::swap(m->e_gap_x[i], m->e_gap_x[3 - i]);
         std::swap(m->e_gap_y[i], m->e_gap_y[3 - i]);
     }
+}
+
+int64_t mrp_kmer_alignment_anchors(const uint8_t *x, int64_t lx, const uint8_t *y, int64_t ly, int64_t *out) {
+    if (!out || lx < 0 || ly < 0 || (lx > 0 && !x) || (ly > 0 && !y)) return 0;
+    std::vector<int64_t> v;
+    const int64_t n = kmer_anchors(x, lx, y, ly, v);
+    if (n > 0) memcpy(out, v.data(), sizeof(int64_t) * 2 * (size_t) n);
+    return n;
 }
 
 int mrp_band_diagonals(const int64_t *anchors, int64_t n_anchors, int64_t lx, int64_t ly, int64_t expansion, int32_t *xmy_l, int32_t *xmy_r) {
@@ -711,7 +759,8 @@ int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int3
 int mrp_allele_read_supports(mrp_context *ctx, const mrp_pair_hmm *forward_model, const mrp_pair_hmm *reverse_model, int64_t n_bubbles,
                              const int64_t *allele_first, const int64_t *read_first, const uint8_t *pool, int64_t pool_bytes,
                              const int64_t *allele_off, const int32_t *allele_len, const int64_t *read_off, const int32_t *read_len,
-                             const uint8_t *read_forward_strand, int64_t expansion, float *support, mrp_pairhmm_stats *stats) {
+                             const uint8_t *read_forward_strand, int64_t expansion, int64_t sv_threshold, float *support,
+                             mrp_pairhmm_stats *stats) {
     if (stats) memset(stats, 0, sizeof(*stats));
     if (!ctx) return fail(MRP_ERR_NO_DEVICE, "mrp_allele_read_supports: no context (the pair-HMM path has no CPU fallback)");
     if (n_bubbles < 0) return fail(MRP_ERR_ARG, "mrp_allele_read_supports: bad sizes");
@@ -741,9 +790,10 @@ int mrp_allele_read_supports(mrp_context *ctx, const mrp_pair_hmm *forward_model
         }
     });
     const mrp_pair_hmm models[2] = {*forward_model, *reverse_model};
-    std::vector<int64_t> xo, yo, where;
+    std::vector<int64_t> xo, yo, where, anchor_off, anchors;
     std::vector<int32_t> xl, yl;
     std::vector<uint8_t> mi;
+    anchor_off.push_back(0);
     std::vector<int64_t> support_first((size_t) n_bubbles + 1, 0);
     for (int64_t b = 0; b < n_bubbles; b++) {
         const int64_t na = allele_first[b + 1] - allele_first[b], nr = read_first[b + 1] - read_first[b];
@@ -758,12 +808,18 @@ int mrp_allele_read_supports(mrp_context *ctx, const mrp_pair_hmm *forward_model
                 yl.push_back(read_len[k]);
                 mi.push_back(read_forward_strand[k] ? 0 : 1);
                 where.push_back(support_first[(size_t) b] + (j - allele_first[b]) * nr + (k - read_first[b]));
+                if (read_len[k] > sv_threshold || allele_len[j] > sv_threshold) { /* bubbleGraph.c:1448-1451 */
+                    if (allele_len[j] < 0 || allele_off[j] < 0 || allele_off[j] + allele_len[j] > pool_bytes)
+                        return fail(MRP_ERR_ARG, "mrp_allele_read_supports: allele outside the pool");
+                    kmer_anchors(pool + allele_off[j], allele_len[j], pool + read_off[k], read_len[k], anchors);
+                }
+                anchor_off.push_back((int64_t) anchors.size() / 2);
             }
         }
     }
     std::vector<double> lp(xo.size());
     const int rc = mrp_forward_probabilities(ctx, models, 2, (int64_t) xo.size(), pool, pool_bytes, xo.data(), xl.data(), yo.data(), yl.data(), mi.data(),
-                                             nullptr, nullptr, expansion, 0, 0, lp.data(), stats);
+                                             anchors.empty() ? nullptr : anchor_off.data(), anchors.empty() ? nullptr : anchors.data(), expansion, 0, 0, lp.data(), stats);
     if (rc != MRP_OK) return rc;
     for (size_t i = 0; i < lp.size(); i++) support[where[i]] = (float) lp[i];
     for (int64_t b = 0; b < n_bubbles; b++) {

@@ -49,7 +49,9 @@ def lib():
         L.pho_forward_batch.restype = None
         L.pho_forward_batch.argtypes = [vp, i64, vp, vp, vp, vp, vp, vp, vp, vp, i64, C.c_int, C.c_int, vp]
         L.pho_allele_read_supports.restype = None
-        L.pho_allele_read_supports.argtypes = [C.POINTER(Model), C.POINTER(Model), i64, vp, vp, i64, vp, vp, vp, i64, vp]
+        L.pho_allele_read_supports.argtypes = [C.POINTER(Model), C.POINTER(Model), i64, vp, vp, i64, vp, vp, vp, i64, i64, vp]
+        L.pho_kmer_anchors.restype = i64
+        L.pho_kmer_anchors.argtypes = [vp, i64, vp, i64, i64, vp]
         _lib = L
     return _lib
 
@@ -111,7 +113,17 @@ def forward_batch(models, pool, x_off, x_len, y_off, y_len, model_index=None, an
     return out
 
 
-def allele_read_supports(forward_model: Model, reverse_model: Model, alleles, reads, read_forward_strand, expansion: int = 4) -> np.ndarray:
+def kmer_anchors(sx, sy, k: int = 20) -> np.ndarray:
+    """getKmerAlignmentAnchors (impl/pairwiseAligner.c:1563-1627): int64 [n, 2] (x, y)"""
+    sx = np.ascontiguousarray(sx, dtype=np.uint8)
+    sy = np.ascontiguousarray(sy, dtype=np.uint8)
+    out = np.zeros((max(len(sy), 1), 2), dtype=np.int64)
+    n = lib().pho_kmer_anchors(_p(sx), len(sx), _p(sy), len(sy), k, _p(out))
+    return out[:n].copy()
+
+
+def allele_read_supports(forward_model: Model, reverse_model: Model, alleles, reads, read_forward_strand, expansion: int = 4,
+                         sv_threshold: int = 512) -> np.ndarray:
     """alleles / reads: lists of uint8 symbol arrays of one bubble; returns float32 [n_alleles, n_reads] (bubbleGraph.c:1421-1464)."""
     al = [np.ascontiguousarray(a, dtype=np.uint8) for a in alleles]
     rd = [np.ascontiguousarray(r, dtype=np.uint8) for r in reads]
@@ -122,5 +134,5 @@ def allele_read_supports(forward_model: Model, reverse_model: Model, alleles, re
     st = np.ascontiguousarray(read_forward_strand, dtype=np.uint8)
     out = np.zeros((len(al), len(rd)), dtype=np.float32)
     lib().pho_allele_read_supports(C.byref(forward_model), C.byref(reverse_model), len(al), C.cast(ap, C.c_void_p), _p(alen), len(rd),
-                                   C.cast(rp, C.c_void_p), _p(rlen), _p(st), expansion, _p(out))
+                                   C.cast(rp, C.c_void_p), _p(rlen), _p(st), expansion, sv_threshold, _p(out))
     return out

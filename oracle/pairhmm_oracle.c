@@ -16,6 +16,8 @@
  *   total           impl/pairwiseAligner.c:333-339,450-461,578-596
  *   driver          impl/pairwiseAligner.c:849-903 (computeForwardProbability)
  *   bubble loop     impl/bubbleGraph.c:1421-1464 (cachedScores keyed by the read substring alone)
+ *   k-mer anchors   impl/pairwiseAligner.c:1519-1627 (getKmerAlignmentAnchors, for strings longer than
+ *                   referenceExpansionForStructuralVariants)
  *
  * Parity pins available from the reference's own tests (tests/pairwiseAlignerTest.c): test_bands :64-127 (exact
  * diagonals), test_logAdd :129-139 (0.001), test_cell :168-197, test_diagonalDPCalculations :257-340 (forward ==
@@ -245,14 +247,66 @@ void pho_test_cell(const pho_model *m, int cX, int cY, double *total_forward, do
     *total_backward = tb;
 }
 
+/* getKmerAlignmentAnchors, impl/pairwiseAligner.c:1519-1627: the first occurrence of every k-mer of x in a hash (getKmers
+ * :1543-1555, kmerKey :1524-1531), then for the k-mers of y found there, in order of y, the longest chain with increasing
+ * x (the inner walk stops at the first chainable pair that was a running maximum, :1592).  Anchors are the k-mer centres.
+ * out: at most ly - k + 1 pairs (x, y); returns their number. */
+static uint64_t kmer_key(const uint8_t *c, int64_t k) {
+    uint64_t h = 0;
+    for (int64_t i = 0; i < k; i++) h = c[i] + (h << 6) + (h << 16) - h;
+    return h;
+}
+int64_t pho_kmer_anchors(const uint8_t *sx, int64_t lX, const uint8_t *sy, int64_t lY, int64_t k, int64_t *out) {
+    if (k > lX || k > lY) return 0;
+    const int64_t nx = lX - k + 1, ny = lY - k + 1;
+    int64_t cap = 16;
+    while (cap < 2 * nx) cap *= 2;
+    int64_t *tab = malloc(sizeof(int64_t) * (size_t) cap);
+    for (int64_t i = 0; i < cap; i++) tab[i] = -1;
+    for (int64_t i = 0; i < nx; i++) { /* first hit counts */
+        uint64_t h = kmer_key(sx + i, k) & (uint64_t) (cap - 1);
+        while (tab[h] >= 0 && memcmp(sx + tab[h], sx + i, (size_t) k) != 0) h = (h + 1) & (uint64_t) (cap - 1);
+        if (tab[h] < 0) tab[h] = i;
+    }
+    typedef struct { uint64_t x, y, score; int64_t back; int high; } chain_pair;
+    chain_pair *cp = malloc(sizeof(chain_pair) * (size_t) (ny > 0 ? ny : 1));
+    int64_t n = 0, max_pair = -1;
+    uint64_t max_score = 0;
+    for (int64_t y = 0; y < ny; y++) {
+        uint64_t h = kmer_key(sy + y, k) & (uint64_t) (cap - 1);
+        while (tab[h] >= 0 && memcmp(sx + tab[h], sy + y, (size_t) k) != 0) h = (h + 1) & (uint64_t) (cap - 1);
+        if (tab[h] < 0) continue;
+        cp[n].x = (uint64_t) tab[h]; cp[n].y = (uint64_t) y; cp[n].score = 1; cp[n].back = -1;
+        for (int64_t j = n - 1; j >= 0; j--) {
+            if (cp[j].x < cp[n].x) {
+                if (cp[j].score + 1 > cp[n].score) { cp[n].score = cp[j].score + 1; cp[n].back = j; }
+                if (cp[j].high) break;
+            }
+        }
+        if (cp[n].score >= max_score) { cp[n].high = 1; max_score = cp[n].score; max_pair = n; }
+        else cp[n].high = 0;
+        n++;
+    }
+    int64_t m = 0;
+    for (int64_t q = max_pair; q != -1; q = cp[q].back) m++;
+    int64_t w = m;
+    for (int64_t q = max_pair; q != -1; q = cp[q].back) { /* stList_reverse: ascending */
+        w--;
+        out[2 * w] = (int64_t) cp[q].x + k / 2;
+        out[2 * w + 1] = (int64_t) cp[q].y + k / 2;
+    }
+    free(cp); free(tab);
+    return m;
+}
+
 /* The alleleReadSupports loop of bubbleGraph.c:1421-1464 for one bubble: support[j * n_reads + k] = (float) forward
  * probability of read substring k given allele j, with the state machine of the read's strand -- except that a read
  * whose substring equals that of an earlier read of the bubble copies that read's row (cachedScores is keyed by the
- * substring alone, so the earlier read's strand decides).  No anchors (strings longer than
- * referenceExpansionForStructuralVariants take anchors; not restated). */
+ * substring alone, so the earlier read's strand decides).  Strings longer than sv_threshold
+ * (referenceExpansionForStructuralVariants) are anchored on shared 20-mers (:1448-1451). */
 void pho_allele_read_supports(const pho_model *forward_model, const pho_model *reverse_model, int64_t n_alleles, const uint8_t *const *alleles,
                               const int64_t *allele_len, int64_t n_reads, const uint8_t *const *reads, const int64_t *read_len,
-                              const uint8_t *read_forward_strand, int64_t expansion, float *support) {
+                              const uint8_t *read_forward_strand, int64_t expansion, int64_t sv_threshold, float *support) {
     for (int64_t k = 0; k < n_reads; k++) {
         int64_t first = -1;
         for (int64_t q = 0; q < k && first < 0; q++)
@@ -262,8 +316,15 @@ void pho_allele_read_supports(const pho_model *forward_model, const pho_model *r
             continue;
         }
         const pho_model *m = read_forward_strand[k] ? forward_model : reverse_model;
-        for (int64_t j = 0; j < n_alleles; j++)
-            support[j * n_reads + k] = (float) pho_forward_probability(m, alleles[j], allele_len[j], reads[k], read_len[k], NULL, 0, expansion, 0, 0);
+        for (int64_t j = 0; j < n_alleles; j++) {
+            int64_t *anchors = NULL, na = 0;
+            if (read_len[k] > sv_threshold || allele_len[j] > sv_threshold) {
+                anchors = malloc(sizeof(int64_t) * 2 * (size_t) (read_len[k] + 1));
+                na = pho_kmer_anchors(alleles[j], allele_len[j], reads[k], read_len[k], 20, anchors);
+            }
+            support[j * n_reads + k] = (float) pho_forward_probability(m, alleles[j], allele_len[j], reads[k], read_len[k], anchors, na, expansion, 0, 0);
+            free(anchors);
+        }
     }
 }
 

@@ -213,3 +213,34 @@ def test_many_models(gpu_ctx):
         ref = ph.forward_batch([omodel(m) for m in ms], pool, xo, xl, yo, yl, mi)
         assert (out == ref).all()
         assert (st.pairs_lane == 0) == (n_models == 200)
+
+
+def test_structural_variant_alleles_are_anchored(gpu_ctx):
+    """bubbleGraph.c:1448-1451: strings longer than referenceExpansionForStructuralVariants are banded around their shared
+    20-mers.  Bubbles with an insertion allele of several hundred bases next to ordinary SNP bubbles, through
+    mrp_allele_read_supports and through the oracle's loop."""
+    rng = np.random.default_rng(21)
+    t, tr, em = synth.margin_phase_pair_hmm_arrays()
+    f = capi.PairHmm.from_margin_hmm(t, tr, em)
+    r = f.reverse_complement()
+    bubbles = synth.make_bubble_strings(seed=4, n_sites=6, coverage=12)
+    for _ in range(4):
+        flank = synth.random_sequence(rng, 560)
+        ins = synth.random_sequence(rng, int(rng.integers(80, 400)))
+        ref = flank
+        alt = np.concatenate([flank[:280], ins, flank[280:]])
+        reads, strands = [], []
+        for _k in range(10):
+            reads.append(synth.evolve_sequence(rng, alt if rng.random() < 0.5 else ref, 0.03, 0.01, 0.01))
+            strands.append(bool(rng.random() < 0.5))
+        reads.append(reads[0].copy())
+        strands.append(not strands[0])
+        bubbles.append(([ref, alt], reads, strands))
+    got, st = capi.allele_read_supports(gpu_ctx, f, r, bubbles, expansion=4, sv_threshold=512)
+    assert st.pairs_wave > 0 and st.pairs_lane > 0
+    for (alleles, reads, fs), s_ in zip(bubbles, got):
+        ref_s = ph.allele_read_supports(omodel(f), omodel(r), alleles, reads, fs, expansion=4, sv_threshold=512)
+        assert np.isfinite(ref_s).all() and (s_ == ref_s).all()
+    # without the threshold the same pairs take their whole matrix: other numbers (the band cuts probability mass away)
+    full, _ = capi.allele_read_supports(gpu_ctx, f, r, bubbles[-1:], expansion=4, sv_threshold=10 ** 9)
+    assert (full[0] >= got[-1]).all() and (full[0] != got[-1]).any()

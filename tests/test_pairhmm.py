@@ -161,5 +161,29 @@ def test_pairhmm_entry_points_fail_loudly_without_a_context():
     first = np.array([0, 1], np.int64)
     sup = np.zeros(1, np.float32)
     rc = L.mrp_allele_read_supports(None, C.byref(m), C.byref(m), 1, first.ctypes.data, first.ctypes.data, pool.ctypes.data, 6, z64.ctypes.data,
-                                    z32.ctypes.data, y_off.ctypes.data, z32.ctypes.data, np.ones(1, np.uint8).ctypes.data, 4, sup.ctypes.data, None)
+                                    z32.ctypes.data, y_off.ctypes.data, z32.ctypes.data, np.ones(1, np.uint8).ctypes.data, 4, 512, sup.ctypes.data, None)
     assert rc == capi.MRP_ERR_NO_DEVICE
+
+
+def test_kmer_alignment_anchors():
+    """test_getKmerAlignmentAnchors, tests/pairwiseAlignerTest.c:1191-1230 (anchors strictly increasing, inside both strings),
+    and the product's function against the oracle's restatement (repeats included: only the first occurrence of a k-mer of
+    x counts, pairwiseAligner.c:1547-1551)."""
+    rng = np.random.default_rng(8)
+    for t in range(200):
+        a = synth.random_sequence(rng, int(rng.integers(1, 1000)), n_rate=0.005)
+        b = synth.evolve_sequence(rng, a, 0.02, 0.01, 0.01)
+        if t % 5 == 0 and len(a) > 120:
+            b = np.concatenate([b[:len(b) // 2], a[40:100], b[len(b) // 2:]])
+        ref = ph.kmer_anchors(a, b)
+        got = capi.kmer_alignment_anchors(a, b)
+        assert ref.shape == got.shape and (ref == got).all()
+        px = py = -1
+        for x, y in got:
+            assert px < x < len(a) and py < y < len(b)
+            px, py = x, y
+        if len(got):
+            capi.band_diagonals(got, len(a), len(b), 4)  # valid anchors for band_construct
+    assert len(capi.kmer_alignment_anchors(synth.random_sequence(rng, 19), synth.random_sequence(rng, 300))) == 0
+    same = synth.random_sequence(rng, 64)
+    assert capi.kmer_alignment_anchors(same, same).tolist() == [[i + 10, i + 10] for i in range(45)]
