@@ -592,12 +592,13 @@ int mrp_batch_add_resident_bulk(mrp_batch *b, int64_t n, const mrp_xhmm *x, int6
         chunk_index[(size_t) i] = idx;
     }
     /* pass 1: sizes per hmm */
-    struct Sz { int64_t cells, merge, cols, reads, slots, tiles; int bad; };
+    struct Sz { int64_t cells, merge, cols, reads, slots, tiles, tiles_fast; int bad; };
     std::vector<Sz> sz((size_t) n);
     mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
         const mrp_xhmm &h = x[i];
         const mrp_chunk *ch = h.chunk;
-        Sz s{0, 0, h.n_cols, 0, 0, 0, 0};
+        Sz s{0, 0, h.n_cols, 0, 0, 0, 0, 0};
+        const bool anc1 = (h.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
         if (h.n_cols < 1 || !h.cols || !h.col_ref_start || !h.col_length || !h.col_depth || !h.col_read_off) s.bad = 1;
         for (int k = 0; k < h.n_cols && !s.bad; k++) {
             const int64_t C = (int64_t) h.cols[k].C1 * h.cols[k].C2;
@@ -608,26 +609,33 @@ int mrp_batch_add_resident_bulk(mrp_batch *b, int64_t n, const mrp_xhmm *x, int6
             if (k + 1 < h.n_cols) s.merge += (int64_t) h.cols[k].Ma * h.cols[k].Mb;
             s.slots += ch->allele_offset[st + ln] - ch->allele_offset[st];
             s.tiles += (C + MRP_EMIT_TILE - 1) / MRP_EMIT_TILE;
+            bool uni = !anc1;
+            for (int s2 = 1; s2 < ln && uni; s2++) uni = ch->allele_number[st + s2] == ch->allele_number[st];
+            if (uni) s.tiles_fast += (C + MRP_EMIT_TILE - 1) / MRP_EMIT_TILE;
         }
         s.reads = s.bad ? 0 : h.col_read_off[h.n_cols];
         sz[(size_t) i] = s;
     });
-    std::vector<int64_t> cell0((size_t) n), mcell0((size_t) n), col0((size_t) n), read0((size_t) n), slot0((size_t) n), tile0((size_t) n);
-    int64_t cells = 0, merge = 0, cols = 0, reads = 0, slots = 0, tiles = 0;
+    std::vector<int64_t> cell0((size_t) n), mcell0((size_t) n), col0((size_t) n), read0((size_t) n), slot0((size_t) n), tile0((size_t) n), tilef0((size_t) n);
+    int64_t cells = 0, merge = 0, cols = 0, reads = 0, slots = 0, tiles = 0, tiles_fast = 0;
     for (int64_t i = 0; i < n; i++) {
         if (sz[(size_t) i].bad) return fail(MRP_ERR_ARG, "device-resident hmm %lld: inconsistent column description", (long long) i);
         cells = (cells + 3) & ~3ll; /* every hmm starts at a multiple of 4 cells */
         cell0[(size_t) i] = cells; mcell0[(size_t) i] = merge; col0[(size_t) i] = cols; read0[(size_t) i] = reads;
-        slot0[(size_t) i] = slots; tile0[(size_t) i] = tiles;
+        slot0[(size_t) i] = slots; tile0[(size_t) i] = tiles - tiles_fast; /* general tiles before this hmm */
+        tilef0[(size_t) i] = tiles_fast;
         cells += sz[(size_t) i].cells; merge += sz[(size_t) i].merge; cols += sz[(size_t) i].cols; reads += sz[(size_t) i].reads;
-        slots += sz[(size_t) i].slots; tiles += sz[(size_t) i].tiles;
+        slots += sz[(size_t) i].slots; tiles += sz[(size_t) i].tiles; tiles_fast += sz[(size_t) i].tiles_fast;
     }
     b->hmms.resize((size_t) n);
     b->outs.resize((size_t) n);
     b->cols.resize((size_t) cols);
     b->scols.resize((size_t) cols);
     b->pcols.resize((size_t) cols);
-    b->tiles.resize((size_t) tiles);
+    b->tiles.clear(); /* written on the device (mrp_tiles_kernel): fast tiles first, then the general ones */
+    b->tilecols.resize((size_t) cols);
+    b->n_tiles_dev = tiles;
+    b->n_fast_tiles = tiles_fast;
     b->read_byte_off.resize((size_t) reads);
     std::vector<int> unsupported((size_t) n, 0);
     std::vector<int64_t> alg((size_t) n, 0), prof((size_t) n, 0), pops((size_t) n, 0);
@@ -643,7 +651,8 @@ int mrp_batch_add_resident_bulk(mrp_batch *b, int64_t n, const mrp_xhmm *x, int6
         h.flags = xh.flags;
         h.max_merge = 1;
         h.max_cells = 1;
-        int64_t c_off = cell0[(size_t) i], m_off = mcell0[(size_t) i], s_off = slot0[(size_t) i], t_off = tile0[(size_t) i];
+        int64_t c_off = cell0[(size_t) i], m_off = mcell0[(size_t) i], s_off = slot0[(size_t) i];
+        int64_t t_gen = tiles_fast + tile0[(size_t) i], t_fast = tilef0[(size_t) i];
         int64_t l_prof = 0, l_alg = 0, l_pops = 0;
         int l_unsupported = 0;
         for (int k = 0; k < K; k++) {
@@ -667,17 +676,14 @@ int mrp_batch_add_resident_bulk(mrp_batch *b, int64_t n, const mrp_xhmm *x, int6
             if (ancestor)
                 for (int s2 = 0; s2 < c.n_sites; s2++)
                     if (ch->allele_number[c.site_start + s2] > MRP_MAX_ALLELES) l_unsupported = 1;
-            for (int t0 = 0; t0 < c.n_cells; t0 += MRP_EMIT_TILE) {
-                EmitTile t{};
-                t.cell_off = c.cell_off + t0;
-                t.slot_off = c.slot_off;
-                t.n = std::min<int32_t>(MRP_EMIT_TILE, c.n_cells - t0);
-                t.col = (int32_t) col;
-                t.n_sites = c.n_sites;
-                t.uniform_alleles = uniform;
-                t.depth = c.depth;
-                t.flags = xh.flags;
-                b->tiles[(size_t) t_off++] = t;
+            {
+                const int64_t nt = ((int64_t) c.n_cells + MRP_EMIT_TILE - 1) / MRP_EMIT_TILE;
+                const bool fast = uniform != 0 && !ancestor;
+                TileCol tc{};
+                tc.first = fast ? t_fast : t_gen;
+                tc.uniform_alleles = uniform;
+                (fast ? t_fast : t_gen) += nt;
+                b->tilecols[(size_t) col] = tc;
             }
             SweepCol sc{};
             sc.cell_off = c.cell_off; sc.mcell_off = c.mcell_off; sc.n_cells = c.n_cells; sc.n_merge = c.n_merge;
@@ -801,12 +807,19 @@ int mrp_batch_upload(mrp_batch *b) {
     HIP_TRY(b->d_order_narrow.upload(b->order_narrow, s));
     HIP_TRY(b->d_order_f64.upload(b->order_f64, s));
     const double u2 = now_();
-    {   /* fast tiles first */
-        auto is_fast = [](const EmitTile &t) { return t.uniform_alleles != 0 && !(t.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB); };
-        auto mid_it = std::stable_partition(b->tiles.begin(), b->tiles.end(), is_fast);
-        b->n_fast_tiles = mid_it - b->tiles.begin();
+    if (!b->tilecols.empty()) { /* resident batch: the tiles are written on the device */
+        HIP_TRY(b->d_tilecols.upload(b->tilecols, s));
+        HIP_TRY(b->d_tiles.alloc((size_t) b->n_tiles_dev));
+        HIP_TRY(mrp_launch_tiles(b->d_cols.p, b->d_tilecols.p, (int64_t) b->cols.size(), b->d_tiles.p, s));
+    } else {
+        {   /* fast tiles first */
+            auto is_fast = [](const EmitTile &t) { return t.uniform_alleles != 0 && !(t.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB); };
+            auto mid_it = std::stable_partition(b->tiles.begin(), b->tiles.end(), is_fast);
+            b->n_fast_tiles = mid_it - b->tiles.begin();
+        }
+        b->n_tiles_dev = (int64_t) b->tiles.size();
+        HIP_TRY(b->d_tiles.upload(b->tiles, s));
     }
-    HIP_TRY(b->d_tiles.upload(b->tiles, s));
     std::vector<int32_t> pack_list, plane_list;
     pack_list.reserve(b->pcols.size());
     for (size_t i = 0; i < b->pcols.size(); i++) (b->pcols[i].need_planes ? plane_list : pack_list).push_back((int32_t) i);
@@ -892,7 +905,7 @@ int mrp_batch_launch(mrp_batch *b) {
     HIP_TRY(hipEventRecord(ctx->ev[0], s));
     HIP_TRY(mrp_launch_planes(d, s));
     HIP_TRY(hipEventRecord(ctx->ev[1], s));
-    HIP_TRY(mrp_launch_emission(d, b->d_tiles.p, b->n_fast_tiles, (int64_t) b->tiles.size() - b->n_fast_tiles, s));
+    HIP_TRY(mrp_launch_emission(d, b->d_tiles.p, b->n_fast_tiles, b->n_tiles_dev - b->n_fast_tiles, s));
     HIP_TRY(hipEventRecord(ctx->ev[3], s));
     if (!b->order_f64.empty()) {
         /* stRPHmm_initialiseProbs (hmm.c:752-789) for the accumulate-in-place fp64 path */

@@ -39,6 +39,13 @@ struct DevCol {
     uint32_t flags;     /* MRP_FLAG_* of the owning hmm */
 };
 
+/* resident batches: where a column's emission tiles go in the tile array (written on the device, mrp_tiles_kernel) */
+struct TileCol {
+    int64_t first;           /* index of the column's first tile */
+    int32_t uniform_alleles; /* EmitTile.uniform_alleles of the column */
+    int32_t pad;
+};
+
 /* what the bit-plane kernel needs of a column (read through the scalar cache) */
 struct PlaneCol {
     const uint8_t *pool; /* profile pool of the column's chunk */

@@ -189,6 +189,9 @@ struct mrp_batch {
     HostVec<uint32_t> cell_next, cell_prev, cell_np;
     HostVec<EmitTile> tiles;
     int64_t n_fast_tiles = 0;
+    HostVec<TileCol> tilecols; /* resident batches: the tiles are written on the device from these */
+    int64_t n_tiles_dev = 0;   /* their number (tiles stays empty) */
+    DevBuf<TileCol> d_tilecols;
     bool need_wide = false;
     std::vector<JobOut> outs;
     int64_t n_merge = 0, n_slots = 0;
@@ -220,11 +223,11 @@ struct mrp_batch {
         d_scols.release(); d_pcols.release(); d_next.release(); d_prev.release(); d_np.release(); d_slot_total.release();
         d_slot_bytes.release(); d_cost.release(); d_f.release(); d_b.release(); d_mf.release(); d_mb.release(); d_total.release();
         d_hmm_fb.release(); d_f32.release(); d_b32.release(); d_mf32.release(); d_mb32.release(); d_order_wide.release();
-        d_order_mid.release(); d_order_narrow.release(); d_order_f64.release(); d_tiles.release(); d_pack_list.release(); d_plane_list.release();
+        d_order_mid.release(); d_order_narrow.release(); d_order_f64.release(); d_tiles.release(); d_pack_list.release(); d_plane_list.release(); d_tilecols.release();
         chunks.clear(); hmms.clear(); cols.clear(); read_byte_off.clear(); partition.clear(); scols.clear(); pcols.clear();
-        cell_next.clear(); cell_prev.clear(); cell_np.clear(); tiles.clear(); outs.clear();
+        cell_next.clear(); cell_prev.clear(); cell_np.clear(); tiles.clear(); tilecols.clear(); outs.clear();
         order_wide.clear(); order_mid.clear(); order_narrow.clear(); order_f64.clear();
-        n_fast_tiles = 0; need_wide = false; n_merge = 0; n_slots = 0; n_cells_total = 0; resident = false;
+        n_fast_tiles = 0; n_tiles_dev = 0; need_wide = false; n_merge = 0; n_slots = 0; n_cells_total = 0; resident = false;
         stats = mrp_launch_stats{};
         max_merge_wide = max_merge_mid = max_merge_narrow = 1;
         uploaded = launched = false;
@@ -235,7 +238,7 @@ struct mrp_batch {
         d_scols.pool = pl; d_pcols.pool = pl; d_next.pool = pl; d_prev.pool = pl; d_np.pool = pl; d_slot_total.pool = pl;
         d_slot_bytes.pool = pl; d_cost.pool = pl; d_f.pool = pl; d_b.pool = pl; d_mf.pool = pl; d_mb.pool = pl; d_total.pool = pl;
         d_hmm_fb.pool = pl; d_f32.pool = pl; d_b32.pool = pl; d_mf32.pool = pl; d_mb32.pool = pl; d_order_wide.pool = pl;
-        d_order_mid.pool = pl; d_order_narrow.pool = pl; d_order_f64.pool = pl; d_tiles.pool = pl; d_pack_list.pool = pl; d_plane_list.pool = pl;
+        d_order_mid.pool = pl; d_order_narrow.pool = pl; d_order_f64.pool = pl; d_tiles.pool = pl; d_pack_list.pool = pl; d_plane_list.pool = pl; d_tilecols.pool = pl;
     }
 };
 

@@ -50,6 +50,8 @@ hipError_t mrp_launch_planes(const MrpBatchDev &d, hipStream_t stream);
 /* workgroups of the grid-striding kernels: 256 CUs x 8 workgroups of 256 threads */
 #define MRP_PERSISTENT_GRID 2048
 /* tiles_dev[0..n_fast) take the uniform-allele fast path, the next n_general the general path */
+/* the EmitTile array of a resident batch from its column descriptors (one thread per column) */
+hipError_t mrp_launch_tiles(const DevCol *cols_dev, const TileCol *tilecols_dev, int64_t n_cols, EmitTile *tiles_dev, hipStream_t stream);
 hipError_t mrp_launch_emission(const MrpBatchDev &d, const EmitTile *tiles_dev, int64_t n_fast, int64_t n_general,
                                hipStream_t stream);
 /* order[0..n) = indices into d.hmms handled by this launch, one workgroup each */

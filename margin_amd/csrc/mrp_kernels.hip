@@ -431,6 +431,37 @@ __global__ void __launch_bounds__(256) mrp_emission_general_kernel(MrpBatchDev d
     }
 }
 
+/* Resident batches: the host describes columns only; their tiles (48 B per 512 cells, tens of MB at the large levels) are
+ * written here instead of being filled by host threads, partitioned and uploaded. */
+__global__ void __launch_bounds__(256) mrp_tiles_kernel(const DevCol *__restrict__ cols, const TileCol *__restrict__ tc, int64_t n_cols,
+                                                        EmitTile *__restrict__ tiles) {
+    const int64_t col = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= n_cols) return;
+    const DevCol c = cols[col];
+    const TileCol t0 = tc[col];
+    int64_t at = t0.first;
+    for (int32_t off = 0; off < c.n_cells; off += MRP_EMIT_TILE, at++) {
+        EmitTile t;
+        t.cell_off = c.cell_off + off;
+        t.slot_off = c.slot_off;
+        t.n = c.n_cells - off < MRP_EMIT_TILE ? c.n_cells - off : MRP_EMIT_TILE;
+        t.col = (int32_t) col;
+        t.n_sites = c.n_sites;
+        t.uniform_alleles = t0.uniform_alleles;
+        t.depth = c.depth;
+        t.flags = c.flags;
+        t.pad[0] = 0;
+        t.pad[1] = 0;
+        tiles[at] = t;
+    }
+}
+
+hipError_t mrp_launch_tiles(const DevCol *cols_dev, const TileCol *tilecols_dev, int64_t n_cols, EmitTile *tiles_dev, hipStream_t stream) {
+    if (n_cols <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mrp_tiles_kernel, dim3((unsigned) ((n_cols + 255) / 256)), dim3(256), 0, stream, cols_dev, tilecols_dev, n_cols, tiles_dev);
+    return hipGetLastError();
+}
+
 hipError_t mrp_launch_emission(const MrpBatchDev &d, const EmitTile *tiles_dev, int64_t n_fast, int64_t n_general,
                                hipStream_t stream) {
     const int waves = 4;
