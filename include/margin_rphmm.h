@@ -142,6 +142,10 @@ typedef struct mrp_launch_stats {
     int64_t algorithmic_bytes;  /* sum_k 24*C_k + 32*M_k + depth_k*alleles_k + 8 */
     int64_t popcount_ops;       /* sum_k C_k * L_k * 2 * A * 8 popcount64 of the CPU formulation */
     int64_t units;              /* not known to the library; 0 */
+    /* the same three durations averaged over the batch's launches since the previous mrp_batch_stats call (at most the 32
+     * most recent): launches may be queued back to back without waiting for each other, every one keeps its own events */
+    double avg_planes_ms, avg_emission_ms, avg_sweep_ms;
+    int64_t launches_averaged;
 } mrp_launch_stats;
 /* Waits for the launch to finish, then fills stats. */
 int mrp_batch_stats(mrp_batch *batch, mrp_launch_stats *out);

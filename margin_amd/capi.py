@@ -57,7 +57,8 @@ class LaunchStats(C.Structure):
     _fields_ = [("planes_ms", C.c_double), ("emission_ms", C.c_double), ("sweep_ms", C.c_double), ("n_hmms", C.c_int64),
                 ("n_columns", C.c_int64), ("n_cells", C.c_int64), ("n_merge_cells", C.c_int64),
                 ("profile_bytes", C.c_int64), ("algorithmic_bytes", C.c_int64), ("popcount_ops", C.c_int64),
-                ("units", C.c_int64)]
+                ("units", C.c_int64), ("avg_planes_ms", C.c_double), ("avg_emission_ms", C.c_double), ("avg_sweep_ms", C.c_double),
+                ("launches_averaged", C.c_int64)]
 
 
 class Params(C.Structure):

@@ -96,6 +96,7 @@ int mrp_context_create(int device, mrp_context **out) {
     ctx->device = device;
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->pre, hipStreamNonBlocking);
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->join[i], hipEventDisableTiming);
@@ -123,6 +124,7 @@ void mrp_context_destroy(mrp_context *ctx) {
         if (e) (void) hipEventDestroy(e);
     for (auto &st : ctx->aux)
         if (st) (void) hipStreamDestroy(st);
+    if (ctx->pre) (void) hipStreamDestroy(ctx->pre);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -221,6 +223,11 @@ void mrp_batch_destroy(mrp_batch *batch) {
     (void) hipSetDevice(batch->ctx->device);
     mrp_context *ctx = batch->ctx;
     (void) hipStreamSynchronize(ctx->stream); /* the auxiliary streams were joined into it */
+    for (auto &slot : batch->ev_ring)
+        for (hipEvent_t ev : slot) {
+            if (ev == ctx->last_emission) ctx->last_emission = nullptr;
+            if (ev) (void) hipEventDestroy(ev);
+        }
     delete batch;
     ctx->pool.reclaim();
 }
@@ -902,11 +909,29 @@ int mrp_batch_launch(mrp_batch *b) {
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const MrpBatchDev &d = b->dev;
-    HIP_TRY(hipEventRecord(ctx->ev[0], s));
-    HIP_TRY(mrp_launch_planes(d, s));
-    HIP_TRY(hipEventRecord(ctx->ev[1], s));
+    /* Byte packing / bit planes only read what the host uploaded and write the packed bytes the emission kernel reads, so
+     * they need not wait for the recursion kernels of the previous launch on this context (which read costs, not bytes):
+     * they run on their own stream as soon as the previous launch's emission kernel is done with the packed bytes.  (Resident
+     * levels keep one stream: their launches are separated by host work anyway.) */
+    static const bool use_pre = !(getenv("MRP_PRE_STREAM") && atoi(getenv("MRP_PRE_STREAM")) == 0); /* tuning knob: 0 = one stream */
+    hipStream_t ps = (b->resident || !use_pre) ? s : ctx->pre;
+    const size_t slot = (size_t) (b->n_launches % mrp_batch::EV_RING);
+    if (slot >= b->ev_ring.size()) {
+        std::array<hipEvent_t, 5> fresh{};
+        for (auto &ev : fresh) HIP_TRY(hipEventCreate(&ev));
+        b->ev_ring.push_back(fresh);
+    }
+    const std::array<hipEvent_t, 5> &ev = b->ev_ring[slot];
+    if (b->n_launches >= mrp_batch::EV_RING) HIP_TRY(hipEventSynchronize(ev[2])); /* the launch that used these events has to be over */
+    if (ps != s && ctx->last_emission) HIP_TRY(hipStreamWaitEvent(ps, ctx->last_emission, 0));
+    HIP_TRY(hipEventRecord(ev[0], ps));
+    HIP_TRY(mrp_launch_planes(d, ps));
+    HIP_TRY(hipEventRecord(ev[1], ps));
+    if (ps != s) HIP_TRY(hipStreamWaitEvent(s, ev[1], 0));
+    HIP_TRY(hipEventRecord(ev[4], s));
     HIP_TRY(mrp_launch_emission(d, b->d_tiles.p, b->n_fast_tiles, b->n_tiles_dev - b->n_fast_tiles, s));
-    HIP_TRY(hipEventRecord(ctx->ev[3], s));
+    HIP_TRY(hipEventRecord(ev[3], s));
+    ctx->last_emission = ev[3];
     if (!b->order_f64.empty()) {
         /* stRPHmm_initialiseProbs (hmm.c:752-789) for the accumulate-in-place fp64 path */
         const double neg = -__builtin_inf();
@@ -930,7 +955,8 @@ int mrp_batch_launch(mrp_batch *b) {
     HIP_TRY(hipEventRecord(ctx->join[1], ctx->aux[1]));
     HIP_TRY(hipStreamWaitEvent(s, ctx->join[0], 0));
     HIP_TRY(hipStreamWaitEvent(s, ctx->join[1], 0));
-    HIP_TRY(hipEventRecord(ctx->ev[2], s));
+    HIP_TRY(hipEventRecord(ev[2], s));
+    b->n_launches++;
     b->launched = true;
     return MRP_OK;
 }
@@ -941,14 +967,26 @@ int mrp_batch_stats(mrp_batch *b, mrp_launch_stats *out) {
     if (b->launched) {
         mrp_context *ctx = b->ctx;
         HIP_TRY(hipSetDevice(ctx->device));
-        HIP_TRY(hipEventSynchronize(ctx->ev[2]));
+        /* the launches since the previous call (the most recent one at least), as far back as the ring reaches */
+        const int64_t k = std::min<int64_t>(std::max<int64_t>(b->n_launches - b->stats_mark, 1), std::min<int64_t>(b->n_launches, mrp_batch::EV_RING));
+        b->stats_mark = b->n_launches;
+        double sa = 0, se = 0, sc = 0;
         float a = 0, e = 0, c = 0;
-        HIP_TRY(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
-        HIP_TRY(hipEventElapsedTime(&e, ctx->ev[1], ctx->ev[3]));
-        HIP_TRY(hipEventElapsedTime(&c, ctx->ev[3], ctx->ev[2]));
+        for (int64_t j = 0; j < k; j++) { /* oldest first; the last one is the most recent launch */
+            const auto &ev = b->ev_ring[(size_t) ((b->n_launches - k + j) % mrp_batch::EV_RING)];
+            HIP_TRY(hipEventSynchronize(ev[2]));
+            HIP_TRY(hipEventElapsedTime(&a, ev[0], ev[1]));
+            HIP_TRY(hipEventElapsedTime(&e, ev[4], ev[3]));
+            HIP_TRY(hipEventElapsedTime(&c, ev[3], ev[2]));
+            sa += a; se += e; sc += c;
+        }
         out->planes_ms = a;
         out->emission_ms = e;
         out->sweep_ms = c;
+        out->avg_planes_ms = k ? sa / (double) k : 0.0;
+        out->avg_emission_ms = k ? se / (double) k : 0.0;
+        out->avg_sweep_ms = k ? sc / (double) k : 0.0;
+        out->launches_averaged = k;
     }
     return MRP_OK;
 }

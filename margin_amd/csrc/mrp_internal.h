@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <array>
 #include <iterator>
 #include <map>
 #include <memory>
@@ -135,6 +136,8 @@ struct mrp_context {
     hipStream_t stream = nullptr;
     hipStream_t aux[2] = {nullptr, nullptr}; /* size classes of the recursion kernel run side by side */
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t pre = nullptr; /* byte packing / bit planes of a launch run here, beside the recursion kernels of the launch before */
+    hipEvent_t last_emission = nullptr; /* end of the emission kernel of the most recent launch on this context (owned by its batch) */
     hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
     DevPool pool;
     std::vector<mrp_context *> siblings; /* further contexts on the same device (concurrent batches of mrp_phase_reads_many) */
@@ -203,6 +206,10 @@ struct mrp_batch {
     int max_merge_wide = 1, max_merge_mid = 1, max_merge_narrow = 1;
     /* device */
     bool uploaded = false, launched = false;
+    /* events of the most recent launches: [0] planes start, [1] planes end, [2] sweeps end, [3] emission end, [4] emission start */
+    static constexpr int EV_RING = 32;
+    std::vector<std::array<hipEvent_t, 5>> ev_ring;
+    int64_t n_launches = 0, stats_mark = 0; /* stats_mark: launches already reported by an earlier mrp_batch_stats */
     DevBuf<DevHmm> d_hmms;
     DevBuf<DevCol> d_cols;
     DevBuf<DevChunk> d_chunks;
@@ -231,6 +238,7 @@ struct mrp_batch {
         stats = mrp_launch_stats{};
         max_merge_wide = max_merge_mid = max_merge_narrow = 1;
         uploaded = launched = false;
+        n_launches = 0; stats_mark = 0; /* (the events stay: every launch of the emptied batch has been waited for) */
         dev = MrpBatchDev{};
     }
     void bind_pool(DevPool *pl) {
