@@ -139,8 +139,7 @@ def main():
     barrier()
     # The K steps are queued back to back: every launch keeps its own HIP events inside the library (mrp_launch_stats
     # avg_*: the kernels' durations averaged over the launches of the timed region), so nothing waits on the host between
-    # steps and the byte packing of step k + 1 may run beside the recursion kernels of step k, as it does between
-    # different batches of a production run.
+    # steps (with MRP_PRE_STREAM=1 the byte packing of step k + 1 then runs beside the recursion kernels of step k).
     t0 = time.perf_counter()
     for _ in range(args.steps):
         for b_ in bigs:
@@ -190,7 +189,6 @@ def main():
                     whole_step=dict(achieved=whole, frac=whole / HBM_PEAK_GBS, algorithmic_bytes=alg,
                                     moved_bytes_model=moved, moved_GBps=moved / (ms_per_step * 1e-3) / 1e9,
                                     planes_ms=planes_avg, emission_ms=emis_avg, sweep_ms=sweep_avg,
-                                    planes_note="elapsed time of the packing kernels of step k+1 while they share the device with the recursion kernels of step k",
                                     emission_kernel=dict(algorithmic_bytes=alg_emission,
                                                          achieved=alg_emission / (emis_avg * 1e-3) / 1e9)),
                     popcount64_per_s=float(st.popcount_ops) / (ms_per_step * 1e-3))

@@ -911,9 +911,9 @@ int mrp_batch_launch(mrp_batch *b) {
     const MrpBatchDev &d = b->dev;
     /* Byte packing / bit planes only read what the host uploaded and write the packed bytes the emission kernel reads, so
      * they need not wait for the recursion kernels of the previous launch on this context (which read costs, not bytes):
-     * they run on their own stream as soon as the previous launch's emission kernel is done with the packed bytes.  (Resident
-     * levels keep one stream: their launches are separated by host work anyway.) */
-    static const bool use_pre = !(getenv("MRP_PRE_STREAM") && atoi(getenv("MRP_PRE_STREAM")) == 0); /* tuning knob: 0 = one stream */
+     * with MRP_PRE_STREAM=1 they run on their own stream as soon as the previous launch's emission kernel is done with the
+     * packed bytes.  (Resident levels keep one stream: their launches are separated by host work anyway.) */
+    static const bool use_pre = getenv("MRP_PRE_STREAM") && atoi(getenv("MRP_PRE_STREAM")) != 0; /* off unless asked for, see DESIGN.md 4 */
     hipStream_t ps = (b->resident || !use_pre) ? s : ctx->pre;
     const size_t slot = (size_t) (b->n_launches % mrp_batch::EV_RING);
     if (slot >= b->ev_ring.size()) {
