@@ -29,14 +29,20 @@ def main():
     ap.add_argument("--check-host", type=int, default=1, help="compare this many chunks with mrp_phase_reads")
     ap.add_argument("--check-oracle", type=int, default=0)
     ap.add_argument("--groups", type=int, default=1, help="phase the chunks as this many concurrent batches (one host thread + context each)")
+    ap.add_argument("--hifi", action="store_true", help="HiFi-like chunks (SURVEY.md 8d configs 3-5): 35x, reads N(18 kb, 3 kb), 1 %% allele error, 2-4 alleles per site")
     args = ap.parse_args()
     pd = synth.shipped_phase_params()
     params = capi.Params.from_reference_names(pd)
     ctx = capi.Context(0)
     t0 = time.time()
     with ThreadPoolExecutor(max_workers=min(16, args.chunks)) as ex:
-        chunks = list(ex.map(lambda s: synth.make_ont_chunk(seed=s + 1, region_bp=args.sites * 500, n_sites=args.sites,
-                                                            coverage=args.coverage), range(args.chunks)))
+        if args.hifi:
+            make = lambda s: synth.make_ont_chunk(seed=s + 1, region_bp=args.sites * 500, n_sites=args.sites, coverage=35.0, median_len=18_000.0,
+                                                  allele_error=0.01, allele_choices=(2, 3, 4), allele_probs=(0.85, 0.1, 0.05), length_model="normal",
+                                                  normal_sd=3000.0)
+        else:
+            make = lambda s: synth.make_ont_chunk(seed=s + 1, region_bp=args.sites * 500, n_sites=args.sites, coverage=args.coverage)
+        chunks = list(ex.map(make, range(args.chunks)))
     print(f"synth {time.time() - t0:.2f}s", flush=True)
     dchunks = [capi.DeviceChunk.from_chunk(ctx, c) for c in chunks]
     units = sum(c.units for c in chunks)
