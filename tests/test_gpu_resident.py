@@ -349,3 +349,32 @@ def test_resident_many_small_chunks_do_not_depend_on_their_batch(gpu_ctx, orc):
         assert got[i]["reads1"] == ref["reads1"] and got[i]["reads2"] == ref["reads2"]
     for d in dchunks:
         d.close()
+
+
+def test_resident_pruning_rules_over_random_parameters(gpu_ctx, orc):
+    """hmm.c:1049-1163 with thresholds that bite: random (min, max) partitions per column and posterior thresholds from 0 to
+    0.2, on chunks of random shape, all in ONE call per parameter set.  The prune kernel flags every next merge cell of the
+    kept cells before it knows their order (its second stage checks that hmm.c:1090-1100 would keep them all and discards the
+    level otherwise): the call must stay on the resident path and equal the oracle, array for array."""
+    rng = np.random.default_rng(123)
+    for trial in range(6):
+        max_p = int(rng.choice([16, 40, 64, 100, 120]))
+        min_p = int(rng.integers(0, max_p + 1)) if trial % 2 else 0
+        thr = float(rng.choice([0.0, 1e-9, 1e-3, 0.02, 0.2]))
+        pd = _params(minPartitionsInAColumn=min_p, maxPartitionsInAColumn=max_p, minPosteriorProbabilityForPartition=thr)
+        params = capi.Params.from_reference_names(pd)
+        chunks = [synth.make_ont_chunk(seed=700 + 10 * trial + c, region_bp=40_000, n_sites=int(rng.integers(30, 110)),
+                                       coverage=float(rng.integers(10, 40)), allele_error=float(rng.choice([0.02, 0.08, 0.15])))
+                  for c in range(5)]
+        dchunks = [capi.DeviceChunk.from_chunk(gpu_ctx, c) for c in chunks]
+        got, st = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
+        assert st.resident == 1, (min_p, max_p, thr)
+        for chunk, g in zip(chunks, got):
+            oc = orc.OracleChunk(chunk)
+            ref = oc.phase(pd)
+            oc.close()
+            for k in PHASE_KEYS:
+                assert (np.asarray(g[k]) == np.asarray(ref[k])).all(), (k, min_p, max_p, thr)
+            assert g["reads1"] == ref["reads1"] and g["reads2"] == ref["reads2"]
+        for d in dchunks:
+            d.close()
