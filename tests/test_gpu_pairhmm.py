@@ -244,3 +244,30 @@ def test_structural_variant_alleles_are_anchored(gpu_ctx):
     # without the threshold the same pairs take their whole matrix: other numbers (the band cuts probability mass away)
     full, _ = capi.allele_read_supports(gpu_ctx, f, r, bubbles[-1:], expansion=4, sv_threshold=10 ** 9)
     assert (full[0] >= got[-1]).all() and (full[0] != got[-1]).any()
+
+
+def test_degenerate_models_with_zero_probabilities(gpu_ctx):
+    """log(0) = -inf in transitions and emissions (an hmm file may hold exact zeros): no gaps allowed -> pairs of unequal
+    length are impossible (LOG_ZERO), exact-match-only emissions, one-sided gaps.  -inf must come out as -inf, never NaN."""
+    rng = np.random.default_rng(17)
+    t, tr, em = synth.margin_phase_pair_hmm_arrays()
+    no_gaps = capi.PairHmm.from_margin_hmm(3, [1.0, 0.0, 0.0, 1.0, 0.0, 0.0, 1.0, 0.0, 0.0], em)
+    exact = capi.PairHmm.from_margin_hmm(2, tr, [1.0 if i % 5 == 0 else 0.0 for i in range(16)] + em[16:])
+    one_sided = capi.PairHmm.from_margin_hmm(3, [0.8, 0.2, 0.0, 0.5, 0.5, 0.0, 0.0, 0.0, 0.0], em)
+    ms = [no_gaps, exact, one_sided]
+    pairs = []
+    for _ in range(240):
+        a = synth.random_sequence(rng, int(rng.integers(0, 40)), n_rate=0.05)
+        b = a.copy() if rng.random() < 0.4 else synth.evolve_sequence(rng, a, 0.05, 0.05, 0.05)
+        pairs.append((a, b))
+    for _ in range(12):
+        a = synth.random_sequence(rng, int(rng.integers(120, 300)))
+        pairs.append((a, a.copy() if rng.random() < 0.5 else synth.evolve_sequence(rng, a, 0.02, 0.0, 0.02)))
+    pool, xo, xl, yo, yl = pack(pairs)
+    mi = rng.integers(0, 3, size=len(pairs)).astype(np.uint8)
+    out, st = capi.forward_probabilities(gpu_ctx, ms, pool, xo, xl, yo, yl, mi)
+    ref = ph.forward_batch([omodel(m) for m in ms], pool, xo, xl, yo, yl, mi)
+    assert st.pairs_lane > 0 and st.pairs_wave > 0
+    assert not np.isnan(ref).any() and not np.isnan(out).any()
+    assert np.isneginf(ref).sum() > 20 and np.isfinite(ref).sum() > 20
+    assert ((out == ref) | (np.isneginf(out) & np.isneginf(ref))).all()
