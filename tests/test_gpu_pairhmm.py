@@ -271,3 +271,23 @@ def test_degenerate_models_with_zero_probabilities(gpu_ctx):
     assert not np.isnan(ref).any() and not np.isnan(out).any()
     assert np.isneginf(ref).sum() > 20 and np.isfinite(ref).sum() > 20
     assert ((out == ref) | (np.isneginf(out) & np.isneginf(ref))).all()
+
+
+def test_maximum_sizes(gpu_ctx):
+    """the limits of both kernels: x of exactly 100 symbols against reads of up to 1 500 (pair per lane, long rows), and
+    unanchored pairs whose widest diagonal has 1 024 < cells <= 2 048 (the largest launch class of the pair-per-wave kernel)"""
+    rng = np.random.default_rng(29)
+    ms = models3()
+    pairs = [(synth.random_sequence(rng, 100), synth.random_sequence(rng, int(rng.integers(800, 1500)))) for _ in range(70)]
+    pairs += [(synth.random_sequence(rng, int(rng.integers(1, 30))), synth.random_sequence(rng, 1400)) for _ in range(10)]
+    big = []
+    for n in (1030, 1500, 2047):
+        a = synth.random_sequence(rng, n)
+        big.append((a, synth.evolve_sequence(rng, a, 0.02, 0.01, 0.01)))
+    pairs += big
+    pool, xo, xl, yo, yl = pack(pairs)
+    mi = rng.integers(0, 3, size=len(pairs)).astype(np.uint8)
+    out, st = capi.forward_probabilities(gpu_ctx, ms, pool, xo, xl, yo, yl, mi)
+    ref = ph.forward_batch([omodel(m) for m in ms], pool, xo, xl, yo, yl, mi)
+    assert st.pairs_lane == 80 and st.pairs_wave == 3
+    assert np.isfinite(ref).all() and (out == ref).all()
