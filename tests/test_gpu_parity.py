@@ -185,3 +185,34 @@ def test_merge_column_beyond_16_bit_indices(gpu_ctx, small_ont):
     assert (r["merge_forward"] == e0).all() and (r["merge_backward"] == e1).all()
     assert (r["col_total"] == best).all() and r["hmm_forward"][0] == best and r["hmm_backward"][0] == best
     dchunk.close()
+
+
+def test_launches_queued_back_to_back_keep_their_own_events(gpu_ctx, small_ont):
+    """mrp_batch_launch several times without waiting in between (what bench.py's timed region does): every launch has its
+    own HIP events, mrp_batch_stats averages the launches since the previous query, and the results downloaded after the
+    last launch are the oracle's.  Also with the byte packing on its own stream (MRP_PRE_STREAM is read once per process, so
+    only the default is exercised here)."""
+    chunk, res = small_ont
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    flats = res["jobs"]
+    batch = capi.Batch(gpu_ctx)
+    for f in flats:
+        batch.add(capi.Job(dchunk, f, int(f["flags"])))
+    batch.upload()
+    batch.launch()
+    s0 = batch.stats()
+    assert s0.launches_averaged == 1 and s0.avg_sweep_ms == s0.sweep_ms > 0
+    for _ in range(7):
+        batch.launch()
+    s1 = batch.stats()
+    assert s1.launches_averaged == 7 and s1.avg_sweep_ms > 0 and s1.avg_emission_ms > 0 and s1.avg_planes_ms > 0
+    assert s1.n_cells == sum(len(f["partition"]) for f in flats)
+    for _ in range(40):  # more launches than the ring holds
+        batch.launch()
+    s2 = batch.stats()
+    assert s2.launches_averaged == 32
+    batch.download()
+    for f, j in zip(flats, batch.jobs):
+        assert_job_equal(f, j.results(), exact=True)
+    batch.close()
+    dchunk.close()
