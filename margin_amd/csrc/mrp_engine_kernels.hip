@@ -20,6 +20,8 @@
  *                      shares the last bin, exactly as equal doubles tie in the reference).
  *  mrp_compact_kernel  filterMergeCells / relinkCells (hmm.c:964-1019): writes the pruned hmm in the
  *                      fixed-stride resident layout (mrp_engine.h).
+ *  mrp_traceback_kernel stRPHmm_forwardTraceBack (hmm.c:165-219) on the final hmm of a chunk: one wave per hmm walks
+ *                      the columns from the last to the first and returns one partition per column.
  */
 #include <hip/hip_runtime.h>
 #include <stdint.h>
