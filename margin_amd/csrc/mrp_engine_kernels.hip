@@ -784,15 +784,6 @@ __global__ void __launch_bounds__(256) mrp_compact_kernel(MrpBatchDev d, const P
 /* ------------------------------------------------------------------------------------------ */
 /* trace back                                                                                  */
 /* ------------------------------------------------------------------------------------------ */
-/* argmax with the first index winning ties, over the lanes of a wave */
-static __device__ __forceinline__ void wave_argmax_first(int32_t &v, int32_t &idx) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        const int32_t ov = __shfl_xor(v, o, WAVE), oi = __shfl_xor(idx, o, WAVE);
-        if (oi >= 0 && (idx < 0 || ov > v || (ov == v && oi < idx))) { v = ov; idx = oi; }
-    }
-}
-
 __global__ void __launch_bounds__(64) mrp_traceback_kernel(MrpBatchDev d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
                                                            int32_t *__restrict__ err) {
     const int lane = threadIdx.x;
@@ -800,17 +791,61 @@ __global__ void __launch_bounds__(64) mrp_traceback_kernel(MrpBatchDev d, const 
         const PruneHmm h = k_load(hmms + hi);
         const int K = h.n_cols;
         uint32_t want = 0; /* merge cell the chosen cell of column k + 1 comes from */
+        /* The walk is a chain of dependent steps (the chosen cell names the merge cell the next column is filtered by), but
+         * what a step READS does not depend on the chain: the descriptor of a column is requested two steps ahead and its
+         * cells (two per lane: a pruned column has at most 128) one step ahead, so a step is a filter, an argmax over the
+         * wave and a lane broadcast. */
+        struct Cells { uint32_t np[2]; int32_t f[2]; };
+        auto fetch = [&](const SweepCol &c) {
+            Cells r;
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int i = lane + u * WAVE;
+                const bool in = i < c.n_cells && c.n_cells <= 2 * WAVE;
+                r.np[u] = in ? d.cell_np[c.cell_off + i] : 0u;
+                r.f[u] = in ? d.cell_f32[c.cell_off + i] : MRP_NEG_I32;
+            }
+            return r;
+        };
+        SweepCol col = k_load(d.scols + h.col0 + K - 1);
+        SweepCol col_m1 = K > 1 ? k_load(d.scols + h.col0 + K - 2) : col;
+        Cells cur = fetch(col);
         for (int k = K - 1; k >= 0; k--) {
-            const SweepCol col = k_load(d.scols + h.col0 + k);
+            const SweepCol col_m2 = k > 1 ? k_load(d.scols + h.col0 + k - 2) : col_m1;
+            Cells nxt = cur;
+            if (k > 0) nxt = fetch(col_m1);
             /* hmm.c:173-186 (last column: best forward probability) / :196-214 (cells feeding the chosen merge cell) */
             int32_t best = 0, best_i = -1;
-            for (int c = lane; c < col.n_cells; c += WAVE) {
-                if (k + 1 < K && (d.cell_np[col.cell_off + c] & 0xFFFFu) != want) continue;
-                const int32_t f = d.cell_f32[col.cell_off + c];
-                if (f == MRP_NEG_I32) continue; /* -inf never beats the initial -inf of the reference loop ... */
-                if (best_i < 0 || f > best) { best = f; best_i = c; }
+            const bool small = col.n_cells <= 2 * WAVE;
+            if (small) {
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int c = lane + u * WAVE;
+                    if (c >= col.n_cells) continue;
+                    if (k + 1 < K && (cur.np[u] & 0xFFFFu) != want) continue;
+                    const int32_t f = cur.f[u];
+                    if (f == MRP_NEG_I32) continue; /* -inf never beats the initial -inf of the reference loop ... */
+                    if (best_i < 0 || f > best) { best = f; best_i = c; }
+                }
+            } else {
+                for (int c = lane; c < col.n_cells; c += WAVE) {
+                    if (k + 1 < K && (d.cell_np[col.cell_off + c] & 0xFFFFu) != want) continue;
+                    const int32_t f = d.cell_f32[col.cell_off + c];
+                    if (f == MRP_NEG_I32) continue;
+                    if (best_i < 0 || f > best) { best = f; best_i = c; }
+                }
             }
-            wave_argmax_first(best, best_i);
+            {   /* argmax with the first index winning ties, as one unsigned maximum: strides 1..8 by DPP */
+                uint64_t key = best_i < 0 ? 0ull : ((uint64_t) ((uint32_t) best ^ 0x80000000u) << 32) | (uint32_t) (0x7FFFFFFF - best_i);
+#define TB_STEP(J)                                                                                                      \
+                {                                                                                                       \
+                    const uint64_t o = ((uint64_t) lane_xor<J>((uint32_t) (key >> 32), lane) << 32) | lane_xor<J>((uint32_t) key, lane); \
+                    key = o > key ? o : key;                                                                            \
+                }
+                TB_STEP(1) TB_STEP(2) TB_STEP(4) TB_STEP(8) TB_STEP(16) TB_STEP(32)
+#undef TB_STEP
+                best_i = key ? 0x7FFFFFFF - (int32_t) (uint32_t) key : -1;
+            }
             if (best_i < 0) {
                 /* ... except in the last column, where the reference starts from the first cell */
                 if (k + 1 == K) best_i = 0;
@@ -823,7 +858,15 @@ __global__ void __launch_bounds__(64) mrp_traceback_kernel(MrpBatchDev d, const 
                 h.out_n_cells[k] = best_i;
                 h.out_part[k] = d.partition[col.cell_off + best_i];
             }
-            want = d.cell_np[col.cell_off + best_i] >> 16;
+            if (small) {
+                const uint32_t from = best_i < WAVE ? cur.np[0] : cur.np[1];
+                want = (uint32_t) __shfl((int) from, best_i & (WAVE - 1), WAVE) >> 16;
+            } else {
+                want = d.cell_np[col.cell_off + best_i] >> 16;
+            }
+            col = col_m1;
+            col_m1 = col_m2;
+            cur = nxt;
         }
     }
 }
