@@ -318,6 +318,9 @@ typedef struct mrp_variant {
 int mrp_phase_sets(int64_t n_variants, const mrp_variant *v, int64_t min_spanning_reads, double min_binomial_read_split_likelihood,
                    double max_discordant_ratio, int32_t *phase_set_out, int32_t *reason_out);
 double mrp_binomial_p_value(int64_t n, int64_t k); /* bubbleGraph.c:2876-2883 */
+/* bionomialCoefficient (bubbleGraph.c:2860-2874): the unsigned 128-bit value as hi:lo (either may be NULL) and, returned,
+ * converted to double as the reference's test reads it (tests/polisherTest.c:957-963); 0 for k outside [0, n] */
+double mrp_binomial_coefficient(int64_t n, int64_t k, uint64_t *hi, uint64_t *lo);
 
 /* ---------------------------------------------------------------------------------------------------------------
  * Read x allele alignment likelihoods: the banded pair-HMM forward probability that fills

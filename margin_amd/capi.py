@@ -29,7 +29,7 @@ EXPORTED_SYMBOLS = [
     "mrp_hmm_view", "mrp_hmm_forward_backward", "mrp_hmm_prune", "mrp_hmm_forward_trace_back", "mrp_phase_reads",
     "mrp_phase_result_destroy", "mrp_get_rp_hmms_resident", "mrp_phase_reads_many", "mrp_reference_from_bubbles",
     "mrp_profile_seqs_from_bubbles", "mrp_assign_reads_to_haplotypes", "mrp_stitch_create", "mrp_stitch_destroy",
-    "mrp_stitch_chunk", "mrp_stitch_size", "mrp_stitch_lookup", "mrp_phase_sets", "mrp_binomial_p_value",
+    "mrp_stitch_chunk", "mrp_stitch_size", "mrp_stitch_lookup", "mrp_phase_sets", "mrp_binomial_p_value", "mrp_binomial_coefficient",
     "mrp_symbols_from_chars", "mrp_pair_hmm_reverse_complement", "mrp_band_diagonals", "mrp_forward_probabilities",
     "mrp_allele_read_supports", "mrp_kmer_alignment_anchors",
 ]
@@ -237,6 +237,8 @@ def load():
     L.mrp_phase_sets.argtypes = [i64, P(Variant), i64, C.c_double, C.c_double, vp, vp]
     L.mrp_binomial_p_value.argtypes = [i64, i64]
     L.mrp_binomial_p_value.restype = C.c_double
+    L.mrp_binomial_coefficient.argtypes = [i64, i64, P(C.c_uint64), P(C.c_uint64)]
+    L.mrp_binomial_coefficient.restype = C.c_double
     L.mrp_symbols_from_chars.argtypes = [C.c_char_p, i64, vp]
     L.mrp_symbols_from_chars.restype = None
     L.mrp_pair_hmm_reverse_complement.argtypes = [P(PairHmm)]

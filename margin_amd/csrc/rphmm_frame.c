@@ -336,6 +336,13 @@ static unsigned __int128 binomial_coefficient(int64_t n, int64_t k) {
     }
     return ans;
 }
+double mrp_binomial_coefficient(int64_t n, int64_t k, uint64_t *hi, uint64_t *lo) {
+    if (n < 0 || k < 0 || k > n) { if (hi) *hi = 0; if (lo) *lo = 0; return 0.0; }
+    const unsigned __int128 c = binomial_coefficient(n, k);
+    if (hi) *hi = (uint64_t) (c >> 64);
+    if (lo) *lo = (uint64_t) c;
+    return (double) c;
+}
 double mrp_binomial_p_value(int64_t n, int64_t k) {
     unsigned __int128 j = 0;
     k = k < n / 2 ? n - k : k;

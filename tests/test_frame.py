@@ -139,6 +139,23 @@ def test_binomial_p_value_and_coefficient():
     assert fo.binomial_coefficient(60, 30) == math.comb(60, 30)
 
 
+def test_binomial_coefficient_reference_vectors():
+    """test_binomialPValue, tests/polisherTest.c:957-963: the five coefficients the reference asserts (within 0.001 of the
+    double), on the product's 128-bit function and on the oracle's restatement; the exact integers too."""
+    import ctypes as C
+    L = capi.load()
+    for n, k, want in [(10, 5, 252), (20, 15, 15504), (64, 22, 80347448443237920), (64, 10, 151473214816), (64, 32, 1832624140942590534)]:
+        hi, lo = C.c_uint64(0), C.c_uint64(0)
+        d = L.mrp_binomial_coefficient(n, k, C.byref(hi), C.byref(lo))
+        assert abs(d - float(want)) <= 0.001
+        assert (hi.value << 64) | lo.value == want == math.comb(n, k) == fo.binomial_coefficient(n, k)
+    # beyond 64 bits (phase sets over deep pile-ups): still the exact integer while it fits 128 bits
+    hi, lo = C.c_uint64(0), C.c_uint64(0)
+    L.mrp_binomial_coefficient(120, 60, C.byref(hi), C.byref(lo))
+    assert (hi.value << 64) | lo.value == math.comb(120, 60)
+    assert L.mrp_binomial_coefficient(5, 7, None, None) == 0.0
+
+
 @pytest.mark.parametrize("seed,params", [(21, (1, 0.0, 0.5)), (22, (3, 0.0, 0.5)), (23, (2, 0.05, 0.2))])
 def test_phase_sets(seed, params):
     rng = np.random.default_rng(seed)
