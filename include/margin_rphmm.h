@@ -179,7 +179,8 @@ typedef struct mrp_params {
     int32_t max_not_sum_transitions;
     int32_t include_inverted_partitions;
     int32_t include_ancestor_sub_prob;
-    int32_t reserved;
+    int32_t reserved; /* 0.  (Bit 0 is the test suite's fault injection: the resident path reports MRP_ENGINE_ERR_MERGE for
+                       * one hmm of its second level, which must send exactly that chunk to the hashing path.) */
     int64_t min_partitions_in_a_column;
     int64_t max_partitions_in_a_column;
     double min_posterior_probability_for_partition;
@@ -245,14 +246,14 @@ void mrp_phase_result_destroy(mrp_phase_result *r);
  *   -> stRPHmm_prune (hmm.c:1160)
  * of every merge level (coordination.c:263-409); only per-column cell counts return to the host between
  * levels and only the final, pruned hmms are copied back.  Max-plus mode (maxNotSumTransitions, every
- * shipped parameter file) with at most 120 partitions per column; otherwise MRP_ERR_UNSUPPORTED
+ * shipped parameter file) with at most 116 partitions per column; otherwise MRP_ERR_UNSUPPORTED
  * (mrp_get_rp_hmms_resident) or the per-chunk path is taken (mrp_phase_reads_many, stats->resident = 0). */
 int mrp_get_rp_hmms_resident(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *reads, const int32_t *read_index,
                              int64_t n, const mrp_params *params, mrp_hmm ***hmms_out, int64_t *n_out);
 
 typedef struct mrp_phase_many_stats {
     int32_t resident;  /* 1: the device-resident merge was used */
-    int32_t reserved;
+    int32_t fallback_chunks; /* chunks of a resident call that one of the kernels' checks sent to the per-chunk hashing path */
     int64_t levels, hmms, columns, cells, merge_cells; /* of the merge levels */
     double device_ms, cross_ms, sweep_ms, prune_ms;    /* summed HIP-event times of the merge levels */
 } mrp_phase_many_stats;

@@ -106,7 +106,7 @@ class PhaseResult(C.Structure):
 
 
 class PhaseManyStats(C.Structure):
-    _fields_ = [("resident", C.c_int32), ("reserved", C.c_int32), ("levels", C.c_int64), ("hmms", C.c_int64),
+    _fields_ = [("resident", C.c_int32), ("fallback_chunks", C.c_int32), ("levels", C.c_int64), ("hmms", C.c_int64),
                 ("columns", C.c_int64), ("cells", C.c_int64), ("merge_cells", C.c_int64), ("device_ms", C.c_double),
                 ("cross_ms", C.c_double), ("sweep_ms", C.c_double), ("prune_ms", C.c_double)]
 

@@ -173,11 +173,12 @@ struct mrp_engine_level_state {
     std::unique_ptr<Segment> seg;
     DevBuf<CrossCol> d_cc;
     DevBuf<PruneHmm> d_ph;
-    DevBuf<int32_t> d_col_hmm, d_nkept, d_nkeptm, d_err;
+    DevBuf<int32_t> d_col_hmm, d_nkept, d_nkeptm, d_err, d_err_hmm;
     DevBuf<uint16_t> d_kept, d_keptm;
     DevBuf<uint32_t> d_kept_np;
     /* results, in the context's page-locked staging buffer (so the copies are asynchronous) */
-    int32_t *nc = nullptr, *nm = nullptr, *err = nullptr;
+    int32_t *nc = nullptr, *nm = nullptr, *err = nullptr, *err_hmm = nullptr;
+    std::vector<int32_t> perm; /* position in the (sorted) PruneHmm array -> index into x */
     uint64_t *path_part = nullptr; /* final level */
     double *fb = nullptr;
     bool final_level = false;
@@ -313,6 +314,7 @@ static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         HostVec<PruneHmm> sorted((size_t) n);
         for (int64_t j = 0; j < n; j++) { sorted[(size_t) j] = ph[(size_t) perm[(size_t) j]]; pos[(size_t) perm[(size_t) j]] = (int32_t) j; }
         ph.swap(sorted);
+        L->perm.swap(perm);
         mrp_parallel_for(total_cols, 65536, [&](int64_t c) { col_hmm[(size_t) c] = pos[(size_t) col_hmm[(size_t) c]]; });
     }
 
@@ -322,6 +324,7 @@ static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     const double tD = eng_now();
     PruneParams pp = e->pp;
     pp.max_cells = 1; pp.max_merge = 1;
+    pp.pad = (e->params.reserved & 1) && e->stats.levels == 1 ? 1 : 0; /* test hook, see mrp_params.reserved */
     for (size_t i = 0; i < b->hmms.size(); i++) {
         if (!b->outs[i].int_path) return mrp_set_error(MRP_ERR_UNSUPPORTED, "cross product hmm outside the int32 recursion kernel's range");
         pp.max_cells = std::max(pp.max_cells, b->hmms[i].max_cells);
@@ -337,7 +340,7 @@ static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
                 (long long) ns, (long long) cs, (long long) longest_s, (long long) nb2, (long long) cb, (long long) longest_b);
     }
     DevPool *pl = &ctx->pool;
-    L->d_cc.pool = pl; L->d_ph.pool = pl; L->d_col_hmm.pool = L->d_nkept.pool = L->d_nkeptm.pool = L->d_err.pool = pl;
+    L->d_cc.pool = pl; L->d_ph.pool = pl; L->d_col_hmm.pool = L->d_nkept.pool = L->d_nkeptm.pool = L->d_err.pool = L->d_err_hmm.pool = pl;
     L->d_kept.pool = L->d_keptm.pool = pl; L->d_kept_np.pool = pl;
     ENG_TRY(L->d_cc.upload(cc, s));
     ENG_TRY(L->d_ph.upload(ph, s));
@@ -351,36 +354,41 @@ static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     }
     ENG_TRY(L->d_err.alloc(64));
     ENG_TRY(hipMemsetAsync(L->d_err.p, 0, 256, s));
+    ENG_TRY(L->d_err_hmm.alloc((size_t) n));
+    ENG_TRY(hipMemsetAsync(L->d_err_hmm.p, 0, sizeof(int32_t) * (size_t) n, s));
     PruneScratch sc{};
     sc.kept = L->d_kept.p; sc.kept_np = L->d_kept_np.p; sc.keptm = L->d_keptm.p; sc.n_kept = L->d_nkept.p; sc.n_keptm = L->d_nkeptm.p;
     sc.err = L->d_err.p;
+    sc.err_hmm = L->d_err_hmm.p;
     /* the pageable host vectors above are read by the queued copies: wait for them before they go out of scope */
     ENG_TRY(hipStreamSynchronize(s));
 
     const double tE = eng_now();
     ENG_TRY(hipEventRecord(e->ev[0], s));
-    ENG_TRY(mrp_launch_cross(L->d_cc.p, total_cols, b->d_partition.p, b->d_np.p, L->d_err.p, s));
+    ENG_TRY(mrp_launch_cross(L->d_cc.p, total_cols, b->d_partition.p, b->d_np.p, L->d_err.p, L->d_col_hmm.p, L->d_err_hmm.p, s));
     ENG_TRY(hipEventRecord(e->ev[1], s));
     rc = mrp_batch_launch(b);
     if (rc != MRP_OK) return rc;
     ENG_TRY(hipEventRecord(e->ev[2], s));
     if (final_level) {
-        ENG_TRY(mrp_launch_traceback(b->dev, L->d_ph.p, n, L->d_err.p, s));
+        ENG_TRY(mrp_launch_traceback(b->dev, L->d_ph.p, n, L->d_err.p, L->d_err_hmm.p, s));
     } else {
-        ENG_TRY(mrp_launch_prune(b->dev, L->d_ph.p, n, pp, sc, s));
+        ENG_TRY(mrp_launch_prune(b->dev, L->d_cc.p, L->d_ph.p, n, pp, sc, s));
         ENG_TRY(mrp_launch_compact(b->dev, L->d_ph.p, L->d_col_hmm.p, total_cols, pp, sc, s));
     }
     ENG_TRY(hipEventRecord(e->ev[3], s));
     L->final_level = final_level;
     {
         const size_t cols8 = ((size_t) total_cols + 1) & ~(size_t) 1; /* keep the 8-byte arrays aligned */
-        ENG_TRY(ctx->pinned_reserve(64 + cols8 * 4 * 2 + cols8 * 8 + (size_t) n * 16));
+        const size_t n8 = ((size_t) n + 1) & ~(size_t) 1;
+        ENG_TRY(ctx->pinned_reserve(64 + cols8 * 4 * 2 + cols8 * 8 + (size_t) n * 16 + n8 * 4));
         char *base = (char *) ctx->pinned;
         L->err = (int32_t *) base;
         L->path_part = (uint64_t *) (base + 64);
         L->fb = (double *) (base + 64 + cols8 * 8);
         L->nc = (int32_t *) (base + 64 + cols8 * 8 + (size_t) n * 16);
         L->nm = L->nc + cols8;
+        L->err_hmm = L->nm + cols8;
     }
     ENG_TRY(hipMemcpyAsync(L->nc, seg->n_cells.p, sizeof(int32_t) * (size_t) total_cols, hipMemcpyDeviceToHost, s));
     if (final_level) {
@@ -390,7 +398,8 @@ static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         ENG_TRY(hipMemcpyAsync(L->nm, seg->n_merge.p, sizeof(int32_t) * (size_t) total_cols, hipMemcpyDeviceToHost, s));
     }
     ENG_TRY(hipMemcpyAsync(L->err, L->d_err.p, 16, hipMemcpyDeviceToHost, s));
-#ifdef PRUNE_EXP_CLOCK
+    ENG_TRY(hipMemcpyAsync(L->err_hmm, L->d_err_hmm.p, sizeof(int32_t) * (size_t) n, hipMemcpyDeviceToHost, s));
+#if defined(PRUNE_EXP_CLOCK) || defined(PRUNE_EXP_CLOCK2)
     ENG_TRY(hipMemcpyAsync(L->clk, L->d_err.p + 4, 96, hipMemcpyDeviceToHost, s));
 #endif
     L->t_launched = eng_now();
@@ -412,17 +421,26 @@ int mrp_engine_level_end(mrp_engine *e) {
     if (getenv("MRP_TIMING"))
         fprintf(stderr, "  level: %lld hmms %lld cols %lld cells: host build + upload %.1f ms, kernels (after launch) %.1f ms\n",
                 (long long) L->n, (long long) L->total_cols, (long long) L->level_cells, L->t_launched - L->t_begin, eng_now() - L->t_launched);
-#ifdef PRUNE_EXP_CLOCK
-    fprintf(stderr, "  prune clocks (wave 0 of every hmm, shader cycles):");
+#if defined(PRUNE_EXP_CLOCK) || defined(PRUNE_EXP_CLOCK2)
+    fprintf(stderr, "  prune clocks (first hmm; work, wait per role: chain, lists 1, lists 2, tables, bins group 0, bins group 1; shader cycles):");
     for (int i = 0; i < 12; i++) fprintf(stderr, " %llu", L->clk[i]);
     fprintf(stderr, "\n");
 #endif
-    if (L->err[0] & MRP_ENGINE_ERR_POSTERIOR) return mrp_set_error(MRP_ERR_ARG, "ERROR: invalid prob (f + b exceeds the column total)");
-    if (L->err[0] & MRP_ENGINE_ERR_RANGE) return mrp_set_error(MRP_ERR_LOOKUP, "device-resident merge: transition index out of range");
-    if (L->err[0] & MRP_ENGINE_ERR_MERGE)
-        return mrp_set_error(MRP_ERR_UNSUPPORTED, "device-resident merge: a merge cell reached from the kept cells falls below the posterior threshold");
-    if (L->err[0] & MRP_ENGINE_ERR_STRUCTURE)
-        return mrp_set_error(MRP_ERR_UNSUPPORTED, "device-resident merge: a parent hmm is not in complement-pair order");
+    /* Per hmm: a parent outside the closed-form cross product's pair order, or a merge cell the kept cells lead to that
+     * hmm.c:1090-1100 would drop, means "not handled on the device": the caller redoes that hmm's chunk on the hashing path
+     * (whatever else the kernels flagged for it came from the discarded arrays).  Posterior / range violations on an hmm
+     * that is otherwise fine are the reference's st_errAbort cases. */
+    for (int64_t i = 0; i < L->n; i++) L->x[i].err = 0;
+    if (L->err[0] != 0) {
+        for (int64_t j = 0; j < L->n; j++) {
+            const int32_t bits = L->err_hmm[j];
+            if (bits == 0) continue;
+            L->x[(size_t) L->perm[(size_t) j]].err = bits;
+            if (bits & (MRP_ENGINE_ERR_STRUCTURE | MRP_ENGINE_ERR_MERGE)) continue;
+            if (bits & MRP_ENGINE_ERR_POSTERIOR) return mrp_set_error(MRP_ERR_ARG, "ERROR: invalid prob (f + b exceeds the column total)");
+            return mrp_set_error(MRP_ERR_LOOKUP, "device-resident merge: transition index out of range");
+        }
+    }
     int64_t colbase = 0;
     for (int64_t i = 0; i < L->n; i++) {
         memcpy(L->x[i].n_cells, L->nc + colbase, sizeof(int32_t) * (size_t) L->x[i].n_cols);

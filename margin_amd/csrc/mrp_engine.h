@@ -69,7 +69,8 @@ struct PruneScratch {
     uint16_t *keptm;        /* [n_cols * S] kept merge cells of the merge column after each column */
     int32_t *n_kept;        /* [n_cols] */
     int32_t *n_keptm;       /* [n_cols] */
-    int32_t *err;           /* [4] bit flags: MRP_ENGINE_ERR_* */
+    int32_t *err;           /* [4] bit flags: MRP_ENGINE_ERR_* (all hmms of the level) */
+    int32_t *err_hmm;       /* [n_hmms] the same per hmm, indexed like the PruneHmm array */
 };
 
 #define MRP_ENGINE_ERR_STRUCTURE 1 /* a parent is not in complement-pair order: closed-form cross product not valid */
@@ -77,17 +78,20 @@ struct PruneScratch {
 #define MRP_ENGINE_ERR_RANGE 4     /* index out of range */
 #define MRP_ENGINE_ERR_MERGE 8     /* a next merge cell of the kept cells would itself be pruned (hmm.c:1090-1100): not handled on the device */
 
-/* largest column the prune kernel handles (LDS candidate list) */
-#define MRP_PRUNE_MAX_CELLS 14400
-#define MRP_PRUNE_MAX_S 120 /* with 120 * 120 candidate cells the prune kernel's LDS (157 KB) still fits a CU */
+/* largest column the prune kernel handles (cell and merge cell indices travel in 14 bits) */
+#define MRP_PRUNE_MAX_CELLS 13824 /* 6 waves x 64 lanes x 36 cells: what one bin-streaming group of the prune kernel holds in registers */
+#define MRP_PRUNE_MAX_S 116 /* 116 * 116 cells per cross product column <= MRP_PRUNE_MAX_CELLS */
 
 hipError_t mrp_launch_cross(const CrossCol *cols_dev, int64_t n_cols, uint64_t *partition, uint32_t *cell_np, int32_t *err,
-                            hipStream_t stream);
-hipError_t mrp_launch_prune(const MrpBatchDev &d, const PruneHmm *hmms_dev, int64_t n_hmms, PruneParams p, PruneScratch s,
-                            hipStream_t stream);
+                            const int32_t *col_hmm_dev, int32_t *err_hmm, hipStream_t stream);
+/* ccols_dev: the level's cross product descriptors, indexed like the batch's columns (the prune kernel enumerates the
+ * cells linked to a kept merge cell from the parents' transition arrays) */
+hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, const PruneHmm *hmms_dev, int64_t n_hmms, PruneParams p,
+                            PruneScratch s, hipStream_t stream);
 /* stRPHmm_forwardTraceBack (hmm.c:165-219) for every hmm of the level: out_n_cells[k] = cell index,
  * out_part[k] = its partition */
-hipError_t mrp_launch_traceback(const MrpBatchDev &d, const PruneHmm *hmms_dev, int64_t n_hmms, int32_t *err, hipStream_t stream);
+hipError_t mrp_launch_traceback(const MrpBatchDev &d, const PruneHmm *hmms_dev, int64_t n_hmms, int32_t *err, int32_t *err_hmm,
+                                hipStream_t stream);
 hipError_t mrp_launch_compact(const MrpBatchDev &d, const PruneHmm *hmms_dev, const int32_t *col_hmm_dev, int64_t n_cols,
                               PruneParams p, PruneScratch s, hipStream_t stream);
 

@@ -27,6 +27,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <mutex>
 
 #include "mrp_engine.h"
 #include "../../include/margin_rphmm.h"
@@ -108,7 +109,8 @@ static __device__ int verify_side(const uint64_t *part, const uint32_t *np, uint
 
 __global__ void __launch_bounds__(256) mrp_cross_kernel(const CrossCol *__restrict__ cols, int64_t n_cols,
                                                         uint64_t *__restrict__ partition, uint32_t *__restrict__ cell_np,
-                                                        int32_t *__restrict__ err) {
+                                                        int32_t *__restrict__ err, const int32_t *__restrict__ col_hmm,
+                                                        int32_t *__restrict__ err_hmm) {
     for (int64_t col = blockIdx.x; col < n_cols; col += gridDim.x) {
         const CrossCol c = k_load(cols + col);
         const bool inv = (c.flags & MRP_XF_INVERTED) != 0;
@@ -119,7 +121,7 @@ __global__ void __launch_bounds__(256) mrp_cross_kernel(const CrossCol *__restri
         bad |= verify_side(c.b_part, c.b_np, C2, c.d2, c.Mb, c.Pb, c.out_b, c.in_b, inv,
                            (c.flags & MRP_XF_OUT_B_PAIRED) != 0, (c.flags & MRP_XF_IN_B_PAIRED) != 0);
         if ((!c.a_part && C1 != 1u) || (!c.b_part && C2 != 1u)) bad |= MRP_ENGINE_ERR_RANGE;
-        if (bad) atomicOr(err, bad);
+        if (bad) { atomicOr(err, bad); atomicOr(err_hmm + col_hmm[col], bad); }
         if (__syncthreads_or(bad)) { /* the level is discarded by the host; keep the arrays defined meanwhile */
             for (uint32_t e = threadIdx.x; e < C; e += blockDim.x) {
                 partition[c.x_cell_off + e] = 0ull;
@@ -156,25 +158,17 @@ __global__ void __launch_bounds__(256) mrp_cross_kernel(const CrossCol *__restri
 }
 
 hipError_t mrp_launch_cross(const CrossCol *cols_dev, int64_t n_cols, uint64_t *partition, uint32_t *cell_np, int32_t *err,
-                            hipStream_t stream) {
+                            const int32_t *col_hmm_dev, int32_t *err_hmm, hipStream_t stream) {
     if (n_cols <= 0) return hipSuccess;
     const int64_t grid = n_cols < 65536 ? n_cols : 65536;
-    hipLaunchKernelGGL(mrp_cross_kernel, dim3((unsigned) grid), dim3(256), 0, stream, cols_dev, n_cols, partition, cell_np, err);
+    hipLaunchKernelGGL(mrp_cross_kernel, dim3((unsigned) grid), dim3(256), 0, stream, cols_dev, n_cols, partition, cell_np, err, col_hmm_dev,
+                       err_hmm);
     return hipGetLastError();
 }
 
 /* ------------------------------------------------------------------------------------------ */
 /* prune                                                                                       */
 /* ------------------------------------------------------------------------------------------ */
-/* profiling aid: build with -DPRUNE_EXP_CLOCK to sum the shader cycles wave 0 spends in each section of a column
- * (read back and printed by mrp_engine.cpp; profiles/r01/prune_sections_v3.txt) */
-#ifdef PRUNE_EXP_CLOCK
-#define CLK(slot) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); if (wave == 0) clk[slot] += t_ - tlast; tlast = t_; } while (0)
-#else
-#define CLK(slot) do { } while (0)
-#endif
-#define PRUNE_CPT 16 /* cells per lane held in registers: a column has at most 16 * (threads of the workgroup) cells */
-
 /* n kept of n_link candidates whose first g pass the posterior threshold: the loop of hmm.c:1073-1079 /
  * :1094-1100 ("while n > min && (n > max || last.posterior < threshold) drop last") in closed form */
 static __device__ __forceinline__ int kept_count(int n_link, int g, int min_p, int max_p) {
@@ -183,14 +177,17 @@ static __device__ __forceinline__ int kept_count(int n_link, int g, int min_p, i
     return n > min_p ? n : min_p;
 }
 
-static __device__ __forceinline__ int posterior_bin(int32_t f, int32_t b, int64_t total, int n_bins, int *errbits) {
+/* posterior bin of a cell or merge cell: total - f - b, all three exact integers below 2^30 in magnitude (the int32
+ * recursion kernel only takes hmms whose cost bound is below 2^30, and f + b counts every column at most once), so the
+ * difference is formed in 32 bits -- in 64 bits the compiler widens every f and b it holds in registers */
+static __device__ __forceinline__ int posterior_bin(int32_t f, int32_t b, int32_t total, int n_bins, int *errbits) {
     if (f == MRP_NEG_I32 || b == MRP_NEG_I32) return n_bins - 1; /* exp(-inf) = 0 */
-    const int64_t s = total - (int64_t) f - (int64_t) b;
+    const int32_t s = total - f - b;
     if (s < 0) { *errbits |= MRP_ENGINE_ERR_POSTERIOR; return 0; }
     return s < n_bins - 1 ? (int) s : n_bins - 1;
 }
 
-/* Cross-lane primitives of the single-wave section, on the DPP path where gfx950 has one (tools/ubench/dpp_prims.hip
+/* Cross-lane primitives of the single-wave sections, on the DPP path where gfx950 has one (tools/ubench/dpp_prims.hip
  * checks them against the __shfl versions and times them: bitonic128 0.58 us vs 1.10 us, scan 0.07 vs 0.20 us). */
 template <int CTRL, int ROWMASK = 0xf>
 static __device__ __forceinline__ uint32_t dpp_mov(uint32_t x) {
@@ -249,20 +246,37 @@ static __device__ __forceinline__ void wave_bitonic_sort128(uint32_t &k0, uint32
     bitonic_merge<64>(k0, k1, lane);
     bitonic_merge<128>(k0, k1, lane);
 }
+/* orders this wave's LDS traffic for the compiler (the LDS itself executes one wave's instructions in issue order) */
+static __device__ __forceinline__ void wave_lds_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
 
-/* One workgroup per hmm.  Per column there are two phases separated by a barrier each:
- *   [A] all waves: the column's cells (np, f, b were loaded into registers while the previous column was
- *       processed) are tested against the kept flags of the previous merge column, binned by posterior and
- *       appended, in list order, to the candidate list in LDS;
- *   [B] wave 0 alone, without further barriers: cutoff bin from the histogram, ordered selection of the <= S kept
- *       cells, kept flags of their next merge cells -- all the next column's [A] needs.  Everything else a column
- *       produces (stable sort of the kept cells, distinct next merge cells in order of first use, their posteriors,
- *       stable sort, lists to HBM) is done one and two columns later by waves 1 and 2, beside wave 0's [B] of the
- *       columns that follow, from double-buffered copies of the selection.  The loads of the next column are already in flight. */
-/* the few arrays of the level's batch the prune kernel reads (the whole MrpBatchDev by value costs ~60 SGPRs) */
+/*
+ * stRPHmm_prune for the cross products of a level, one workgroup per hmm.
+ *
+ * What the forward pass (stRPHmm_pruneForwards, hmm.c:1049-1109) needs of a column is small: the cells LINKED to a kept
+ * merge cell of the previous merge column -- typically a hundred or two of the column's thousands (the cells of a cross
+ * product column are all pairs (c1, c2) of the parents' cells; a kept merge cell (i, j) links exactly the pairs with
+ * prev(c1) = i and prev(c2) = j).  So the candidates are ENUMERATED from the <= 128 kept merge cells and the parents'
+ * transition arrays (<= 128 entries per side, inverted into per-merge-cell lists), never searched for among the cells:
+ *
+ *   wave 0        the sequential chain, without a barrier inside a column: kept merge cells -> candidates (64 per slot, as
+ *                 many slots as the column needs; cell index by the closed form of the cross product order) -> posterior
+ *                 bins (LDS gathers) -> cutoff bin by histogram -> selection (ties in the cutoff bin by list order = cell
+ *                 index, ranked through a bitmap) -> the distinct next merge cells of the selection = the kept merge cells
+ *                 of the next column, listed with their per-side indices.
+ *   wave 1, 2     one and two columns behind: stable sort of the selection, kept lists to HBM, posteriors of the merge
+ *                 cells, kept merge list (stRPHmm_pruneForwards' list building; nothing on the chain reads it).
+ *   wave 3        inverts the parents' prev arrays of the NEXT column (loaded one column earlier), zeroes the histogram.
+ *   waves 4..     two groups alternating over the columns: stream f and b of a whole column (the only bulk traffic: 8 B
+ *                 per cell, requested two columns ahead) and leave its posterior bins in LDS as 16-bit values.
+ *
+ * Selection, tie order and list contents are those of the reference: sorting by (bin, cell index) is the stable sort of
+ * the linked cells (in list order) by descending posterior (hmm.c:1043, :1071).
+ */
 struct PruneIn {
     const SweepCol *scols;
-    const uint32_t *cell_np;
+    const CrossCol *ccols;
     const int32_t *cell_f32, *cell_b32, *merge_f32, *merge_b32;
     const double *hmm_fb;
 };
@@ -274,106 +288,102 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t prune_rsrc(const void *
     return __builtin_amdgcn_make_buffer_rsrc((void *) (((uint64_t) hi << 32) | lo), 0, bytes, 0x00020000);
 }
 
-template <int T>
+/* profiling aid: build with -DPRUNE_EXP_CLOCK (both mrp_engine.cpp and this file) to sum, for the first hmm of a launch, the
+ * shader cycles each role spends working and waiting at the column barrier (printed by mrp_engine.cpp under MRP_TIMING) */
+#ifdef PRUNE_EXP_CLOCK
+#define ROLE_CLK_INIT() uint64_t clk_work = 0, clk_wait = 0, clk_t = __builtin_amdgcn_s_memtime()
+#define ROLE_BARRIER() do { const uint64_t t1_ = __builtin_amdgcn_s_memtime(); lds_barrier(); const uint64_t t2_ = __builtin_amdgcn_s_memtime(); \
+                            clk_work += t1_ - clk_t; clk_wait += t2_ - t1_; clk_t = t2_; } while (0)
+#define ROLE_CLK_DONE(slot) do { if (hi_ == 0 && lane == 0) { atomicAdd((unsigned long long *) (sc.err + 4) + 2 * (slot), (unsigned long long) clk_work); \
+                                 atomicAdd((unsigned long long *) (sc.err + 4) + 2 * (slot) + 1, (unsigned long long) clk_wait); } } while (0)
+#else
+#define ROLE_CLK_INIT() do { } while (0)
+#define ROLE_BARRIER() lds_barrier()
+#define ROLE_CLK_DONE(slot) do { } while (0)
+#endif
+
+#ifdef PRUNE_EXP_CLOCK2 /* sections of the chain wave instead: kept merge cells, candidates, histogram + cutoff, selection, ties, next merge cells */
+#define SEC_INIT() uint64_t sec_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t sec_t = __builtin_amdgcn_s_memtime()
+#define SEC(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); sec_[i] += t_ - sec_t; sec_t = t_; } while (0)
+#define SEC_DONE() do { if (hi_ == 0 && lane == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd((unsigned long long *) (sc.err + 4) + i_, (unsigned long long) sec_[i_]); } while (0)
+#else
+#define SEC_INIT() do { } while (0)
+#define SEC(i) do { } while (0)
+#define SEC_DONE() do { } while (0)
+#endif
+
+#define PRUNE_SP 128  /* slots of the selection buffers (S <= MRP_PRUNE_MAX_S) */
+#define PRUNE_TAB 5   /* per side and buffer: cnt, start, list, nx, pv, 128 entries each */
+
+template <int T, int CPT>
 __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
                                                       PruneParams p, PruneScratch sc) {
     constexpr int W = T / WAVE;
+    constexpr int NBG = (W - 4) / 2;     /* waves per bin-streaming group */
+    constexpr int LG = NBG * WAVE;       /* lanes per group */
+    static_assert(W >= 6 && ((W - 4) & 1) == 0, "role layout");
     extern __shared__ uint32_t lds[];
     const int S = p.S;
     const int nb = p.n_bins;
     const int nb_r = 1024; /* 16 bins per lane of the cutoff search: bin b lives at (b & 15) * 64 + (b >> 4) */
-    const int cap_c = ((p.max_cells > p.max_merge ? p.max_cells : p.max_merge) + 3) & ~3;
+    const int cap_c = (p.max_cells + 3) & ~3;
     /* LDS layout (dwords) */
-    /* the selection of a column lives in one of two buffers: wave 0 fills buffer k & 1 while wave 1 turns buffer (k - 1) & 1
-     * into the sorted lists of column k - 1 */
-    uint32_t *sel = lds;              /* [2][4][S]: gsel (bin << 16 | cell, above the cutoff bin), gnp (next | prev << 16), esel (cell, in the cutoff bin), enp */
-    uint32_t *um = sel + 8 * S;       /* [S] posterior bin of the merge cell each selected cell leads to (selection order); wave 1 */
-    uint32_t *s1 = um + S;            /* [2][2][S] stage 1 -> stage 2: next | prev and merge posterior bin per sorted kept cell */
-    uint32_t *sh = s1 + 4 * S;        /* [64] per-wave counters [0, W); n, nG of the two selection buffers at [32, 36); n of the stage-1 buffers at [36, 38) */
-    uint32_t *stg = sh + 64;          /* [W][4][64] staging of linked cells: cell, transitions, f, b */
-    uint32_t *hist = stg + W * 4 * WAVE; /* [2][nb_r] */
-    uint32_t *cand = hist + 2 * nb_r; /* [cap_c] linked cells of the column, list order per wave segment: bin << 16 | cell */
-    uint32_t *cand_np = cand + cap_c; /* [cap_c] */
-    uint32_t *htab_key = cand_np + cap_c; /* [256] merge cell -> first kept cell that uses it (open addressing); wave 1 */
-    uint32_t *htab_val = htab_key + 256;  /* [256] */
-    uint8_t *flags = reinterpret_cast<uint8_t *>(htab_val + 256); /* [max_merge] kept flag per merge cell */
+    uint32_t *sel = lds;                       /* [2][2][SP] selection of column k in buffer k & 1: key = bin << 14 | cell, np = next | prev << 16 */
+    uint32_t *um = sel + 4 * PRUNE_SP;         /* [SP] posterior bin of the merge cell each selected cell leads to (selection order); wave 1 */
+    uint32_t *s1 = um + PRUNE_SP;              /* [2][2][SP] stage 1 -> stage 2: next | prev and merge posterior bin per sorted kept cell */
+    uint32_t *sh = s1 + 4 * PRUNE_SP;          /* [64] counters: n of the selection buffers at [32, 34), of the stage-1 buffers at [36, 38), of the kept merge lists at [40, 42) */
+    uint32_t *hist = sh + 64;                  /* [2][nb_r] */
+    uint32_t *bmp_c = hist + 2 * nb_r;         /* [512] cells of the cutoff bin, by cell index */
+    uint32_t *bmp_m = bmp_c + 512;             /* [512] next merge cells seen */
+    uint32_t *kml = bmp_m + 512;               /* [2][SP] kept merge cells leading into column k, buffer k & 1 */
+    uint32_t *minfo = kml + 2 * PRUNE_SP;      /* [SP][2] per kept merge cell: what its candidates need (wave 0) */
+    uint32_t *heads = minfo + 2 * PRUNE_SP;    /* [512] "a range starts here" marks of one chunk of candidates, zero between uses (wave 0) */
+    uint32_t *pref = heads + 512;              /* [512] marks before each word of the cutoff bin's bitmap (wave 0) */
+    uint32_t *tab = pref + 512;                /* [2 buffers][2 sides][PRUNE_TAB][128] */
+    uint32_t *htab_key = tab + 4 * PRUNE_TAB * 128; /* [256] merge cell -> first kept cell that uses it (open addressing); wave 2 */
+    uint32_t *htab_val = htab_key + 256;       /* [256] */
+    uint8_t *flags = reinterpret_cast<uint8_t *>(htab_val + 256); /* [max_merge] kept flag per merge cell (backward pass) */
+    uint16_t *bins = reinterpret_cast<uint16_t *>(flags + ((p.max_merge + 15) & ~15)); /* [2][cap_c] posterior bin per cell */
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
-    int errbits = 0;
-#ifdef PRUNE_EXP_CLOCK
-    uint64_t clk[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
-    uint64_t tlast = __builtin_amdgcn_s_memtime();
-#endif
+    const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     for (int64_t hi_ = blockIdx.x; hi_ < n_hmms; hi_ += gridDim.x) {
+        int errbits = 0;
         const PruneHmm h = k_load(hmms + hi_);
         const int K = h.n_cols;
-        const int64_t total = (int64_t) d.hmm_fb[2 * h.hmm_index]; /* max mode: the same integer for every column */
+        const int32_t total = (int32_t) d.hmm_fb[2 * h.hmm_index]; /* max mode: the same integer for every column */
         for (int i = tid; i < 2 * nb_r; i += T) hist[i] = 0;
-        if (tid < 2) sh[40 + tid] = 0u;
+        for (int i = tid; i < 1024; i += T) bmp_c[i] = 0; /* both bitmaps */
+        for (int i = tid; i < 512; i += T) heads[i] = 0;
         for (int i = tid; i < (p.max_merge + 3) / 4; i += T) reinterpret_cast<uint32_t *>(flags)[i] = 0;
-        int n_prev = 0, nG_prev = 0; /* wave 0: the selection whose next merge cells own the kept flags */
-        int64_t mcell_prev = 0;       /* first merge cell of the merge column after the previous column */
-
-        uint32_t r_np[PRUNE_CPT];
-        int32_t r_f[PRUNE_CPT], r_b[PRUNE_CPT];
-        SweepCol col = k_load(d.scols + h.col0);
-        SweepCol col_next = K > 1 ? k_load(d.scols + h.col0 + 1) : col;
-        /* this wave's share of the column: [lo, hi), 64 cells per step */
-#define PRUNE_SHARE(colv, lo_, hi_v, nj_)                                                     \
-        const int per_##nj_ = (((colv).n_cells + W - 1) / W + 63) & ~63;                      \
-        const int lo_ = wave * per_##nj_ < (colv).n_cells ? wave * per_##nj_ : (colv).n_cells; \
-        const int hi_v = lo_ + per_##nj_ < (colv).n_cells ? lo_ + per_##nj_ : (colv).n_cells; \
-        const int nj_ = (hi_v - lo_ + 63) >> 6;
-#define PRUNE_LOAD(colv, lo_, hi_v, nj_)                                                      \
-        {                                                                                     \
-            /* buffer loads: one descriptor per array over this wave's share, the hardware's range check instead of an \
-             * exec mask per load (out of range reads 0 and is never looked at), immediate offsets */ \
-            const int64_t first_ = (colv).cell_off + lo_;                                     \
-            const int bytes_ = __builtin_amdgcn_readfirstlane((hi_v - lo_) * 4);              \
-            const auto rn_ = prune_rsrc(d.cell_np + first_, bytes_);                          \
-            const auto rf_ = prune_rsrc(d.cell_f32 + first_, bytes_);                         \
-            const auto rb_ = prune_rsrc(d.cell_b32 + first_, bytes_);                         \
-            _Pragma("unroll") for (int j = 0; j < PRUNE_CPT; j++) {                           \
-                if (j < nj_) { /* wave-uniform */                                              \
-                    r_np[j] = (uint32_t) __builtin_amdgcn_raw_buffer_load_b32(rn_, lane * 4 + j * WAVE * 4, 0, 0); \
-                    r_f[j] = (int32_t) __builtin_amdgcn_raw_buffer_load_b32(rf_, lane * 4 + j * WAVE * 4, 0, 0);   \
-                    r_b[j] = (int32_t) __builtin_amdgcn_raw_buffer_load_b32(rb_, lane * 4 + j * WAVE * 4, 0, 0);   \
-                }                                                                             \
-            }                                                                                 \
-        }
-        {
-            PRUNE_SHARE(col, lo0, hi0, nj0)
-            (void) nj0;
-            PRUNE_LOAD(col, lo0, hi0, nj0)
-        }
+        if (tid < 64) sh[tid] = 0u;
         __syncthreads();
 
-        /* The sorted lists of a finished selection, in two stages one column apart, so that neither is longer than wave 0's
-         * part of a column.  Nothing later in the forward pass reads them: the kept flags were already set by wave 0 from
-         * the unsorted selection.
+        /* The sorted lists of a finished selection, in two stages one column apart.  Nothing later in the forward pass
+         * reads them: the next column's kept merge cells were already listed by wave 0 from the unsorted selection.
          * Stage 1 (wave 1, column kk from selection buffer kk & 1): stable sort of the kept cells, kept lists to HBM, the
          * posterior bins of the merge cells they lead to; leaves next | prev and that bin per sorted kept cell in LDS. */
         auto lists_stage1 = [&](int kk, int64_t mcell_off) {
             const int b = kk & 1;
-            const uint32_t *gsel = sel + b * 4 * S, *gnp = gsel + S, *esel = gnp + S, *enp = esel + S;
-            uint32_t *snp = s1 + b * 2 * S, *sbin = snp + S;
-            const int n = (int) sh[32 + 2 * b], nG = (int) sh[33 + 2 * b];
+            const uint32_t *skey = sel + b * 2 * PRUNE_SP, *snp_in = skey + PRUNE_SP;
+            uint32_t *snp = s1 + b * 2 * PRUNE_SP, *sbin = snp + PRUNE_SP;
+            const int n = (int) sh[32 + b];
             const int64_t lcol = h.col0 + kk;
             const bool has_merge = kk + 1 < K;
-            uint32_t key[2], my_np[2], my_c[2], my_src[2];
+            uint32_t key[2];
             int32_t pre_mf[2] = {0, 0}, pre_mb[2] = {0, 0};
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int i = lane + u * WAVE;
-                /* stable descending sort of the kept cells (stList_sort :1071): smaller bin = larger posterior; the key
-                 * bin | list position | cell is unique, so a bitonic sort in registers is stable by construction */
-                key[u] = i < nG ? ((gsel[i] >> 16) << 21) | ((uint32_t) i << 14) | (gsel[i] & 0x3FFFu) : 0xFFFFFFFFu;
+                /* stable descending sort of the kept cells (stList_sort :1071): smaller bin = larger posterior, then list
+                 * order = cell index; the slot rides along in the low bits: bin (10) | cell (14) | slot (7) */
+                key[u] = i < n ? (skey[i] << 7) | (uint32_t) i : 0xFFFFFFFFu;
                 /* the posteriors of the merge cells the selected cells lead to are requested now, for the selection in
-                 * its unsorted order, and consumed after the sort (slot i of the selection = um[i] below) */
+                 * its unsorted order, and consumed after the sort */
                 if (has_merge && i < n) {
-                    const uint32_t m = (i < nG ? gnp[i] : enp[i - nG]) & 0xFFFFu;
+                    const uint32_t m = snp_in[i] & 0xFFFFu;
                     pre_mf[u] = d.merge_f32[mcell_off + m];
                     pre_mb[u] = d.merge_b32[mcell_off + m];
                 }
@@ -385,18 +395,17 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
                     const int i = lane + u * WAVE;
                     if (i < n) um[i] = (uint32_t) posterior_bin(pre_mf[u], pre_mb[u], total, nb, &errbits);
                 }
+                wave_lds_fence();
             }
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 const int i = lane + u * WAVE;
-                if (i < nG) { my_c[u] = key[u] & 0x3FFFu; my_np[u] = gnp[(key[u] >> 14) & 0x7Fu]; my_src[u] = (key[u] >> 14) & 0x7Fu; }
-                else if (i < n) { my_c[u] = esel[i - nG]; my_np[u] = enp[i - nG]; my_src[u] = (uint32_t) i; }
-                else { my_c[u] = 0u; my_np[u] = 0u; my_src[u] = 0u; }
                 if (i < n) {
-                    sc.kept[lcol * S + i] = (uint16_t) my_c[u];
-                    sc.kept_np[lcol * S + i] = my_np[u];
-                    snp[i] = my_np[u];
-                    if (has_merge) sbin[i] = um[my_src[u]];
+                    const uint32_t src = key[u] & 0x7Fu, cell = (key[u] >> 7) & 0x3FFFu, np_ = snp_in[src];
+                    sc.kept[lcol * S + i] = (uint16_t) cell;
+                    sc.kept_np[lcol * S + i] = np_;
+                    snp[i] = np_;
+                    if (has_merge) sbin[i] = um[src];
                 }
             }
             if (lane == 0) { sc.n_kept[lcol] = n; sh[36 + b] = (uint32_t) n; }
@@ -405,7 +414,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
          * kept merge list to HBM. */
         auto lists_stage2 = [&](int kk) {
             const int b = kk & 1;
-            const uint32_t *snp = s1 + b * 2 * S, *sbin = snp + S;
+            const uint32_t *snp = s1 + b * 2 * PRUNE_SP, *sbin = snp + PRUNE_SP;
             const int n = (int) sh[36 + b];
             const int64_t lcol = h.col0 + kk;
             int mn = 0;
@@ -413,6 +422,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
                 /* getLinkedMergeCells :989-1004: distinct next merge cells in order of first use (sorted order of the
                  * kept cells): a 256-slot open-addressing table, merge cell -> smallest sorted index that uses it */
                 for (int i = lane; i < 256; i += WAVE) { htab_key[i] = 0xFFFFFFFFu; htab_val[i] = 0xFFFFFFFFu; }
+                wave_lds_fence();
                 uint32_t my_m[2] = {0u, 0u};
                 int slot[2] = {0, 0};
 #pragma unroll
@@ -431,6 +441,7 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
                         atomicMin(&htab_val[q], (uint32_t) i);
                     }
                 }
+                wave_lds_fence();
                 bool first[2];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
@@ -452,11 +463,11 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
                 }
                 const int gm = __popcll(__ballot(pass_thr[0] != 0)) + __popcll(__ballot(pass_thr[1] != 0));
                 mn = kept_count(mnl, gm, p.min_p, p.max_p);
-                /* Wave 0 has flagged EVERY distinct next merge cell.  That is what :1090-1100 keeps: a merge cell's
+                /* Wave 0 has kept EVERY distinct next merge cell.  That is what :1090-1100 keeps: a merge cell's
                  * posterior is at least that of any cell leading to it (max mode, exact integers), so whenever more
                  * than min_p cells were kept they all pass the threshold, and so do their merge cells.  Checked, not
-                 * assumed: a violation discards the level (the host falls back to the per-chunk path). */
-                if (mn != mnl) errbits |= MRP_ENGINE_ERR_MERGE;
+                 * assumed: a violation discards the hmm (the host redoes its chunk on the hashing path). */
+                if (mn != mnl || (p.pad && hi_ == 0 && kk == 0)) errbits |= MRP_ENGINE_ERR_MERGE; /* p.pad: fault injection of the tests */
                 /* stable descending sort by posterior (:1090) */
                 wave_bitonic_sort128(mkey[0], mkey[1], lane);
 #pragma unroll
@@ -467,160 +478,467 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
             }
             if (lane == 0) sc.n_keptm[lcol] = mn;
         };
-        /* ---- stRPHmm_pruneForwards hmm.c:1049-1109 ---- */
-        for (int k = 0; k < K; k++) {
-            uint32_t *hk = hist + (k & 1) * nb_r;
-            const int bpl = 16; /* bins per lane of the cutoff search */
-            CLK(0);
-            PRUNE_SHARE(col, lo, hi, nj)
-            /* [A] linked cells (getLinkedCells :1021-1047) in list order.  Few cells are linked (a hundred or so kept
-             * merge cells lead into the column), so the loop over the cells only tests and stages them; posterior bin,
-             * candidate list and histogram are done for 64 staged cells at a time with all lanes busy. */
-            uint32_t *sg = stg + wave * 4 * WAVE;
-            int cnt = 0, staged = 0;
-#define PRUNE_FLUSH(count_)                                                                       \
-            {                                                                                     \
-                if (lane < (count_)) {                                                            \
-                    const uint32_t c_ = sg[lane], np_ = sg[WAVE + lane];                          \
-                    const int bin_ = posterior_bin((int32_t) sg[2 * WAVE + lane], (int32_t) sg[3 * WAVE + lane], total, nb, &errbits); \
-                    cand[lo + cnt + lane] = ((uint32_t) bin_ << 16) | c_;                         \
-                    cand_np[lo + cnt + lane] = np_;                                               \
-                    atomicAdd(&hk[(bin_ & 15) * WAVE + (bin_ >> 4)], 1u);                         \
-                }                                                                                 \
-                cnt += (count_);                                                                  \
+
+        /* ---- stRPHmm_pruneForwards hmm.c:1049-1109 ----
+         * Every role runs its own loop over the columns (the registers of one role are not live in the others); all of them
+         * pass the same barriers: one after the prologue, one per column, one before the last merge list. */
+        if (wave == 0) {
+            if (lane == 0) {
+                kml[0] = 0u;   /* column 0: every cell is "linked" (one virtual merge cell in front of it) */
+                sh[40] = 1u;
             }
+            CrossCol cc = k_load(d.ccols + h.col0);
+            CrossCol cc_next = K > 1 ? k_load(d.ccols + h.col0 + 1) : cc;
+            lds_barrier();
+            ROLE_CLK_INIT();
+            SEC_INIT();
+            for (int k = 0; k < K; k++) {
+                SEC(7);
+                /* the descriptor of the column after next: requested first, so that its latency hides behind this column's work
+                 * (a scalar load issued just before the barrier would be waited for there: the barrier drains lgkmcnt) */
+                CrossCol cc_ahead = cc_next;
+                if (k + 2 < K) cc_ahead = k_load(d.ccols + h.col0 + k + 2);
+                const int b = k & 1;
+                uint32_t *skey = sel + b * 2 * PRUNE_SP, *snp = skey + PRUNE_SP;
+                const uint32_t *tA = tab + b * 2 * PRUNE_TAB * 128, *tB = tA + PRUNE_TAB * 128;
+                const uint32_t *cntA = tA, *startA = tA + 128, *listA = tA + 256, *nxA = tA + 384;
+                const uint32_t *cntB = tB, *startB = tB + 128, *listB = tB + 256, *nxB = tB + 384;
+                const uint16_t *bin_k = bins + b * cap_c;
+                uint32_t *hk = hist + b * nb_r;
+                uint32_t *kmn = kml + (b ^ 1) * PRUNE_SP; /* the kept merge cells leading into column k + 1 */
+                const bool inv = (cc.flags & MRP_XF_INVERTED) != 0;
+                const uint32_t C2 = cc.C2 > 128u ? 128u : cc.C2, Mb = cc.Mb;
+                const bool a_cp = inv && cc.a_part && cc.d1 > 0, b_cp = inv && cc.b_part && cc.d2 > 0;
+                const bool out_ap = (cc.flags & MRP_XF_OUT_A_PAIRED) != 0, out_bp = (cc.flags & MRP_XF_OUT_B_PAIRED) != 0;
+                const bool has_next = k + 1 < K;
+                const int nkm = (int) sh[40 + b];
+                /* this lane's kept merge cells (two at most): the parents' cells each links, as list ranges.  An entry of the
+                 * list is m | i << 14 | j << 21: the merge cell and its index on either side (what links the parents' cells) */
+                uint32_t off_[2];
+                int tot[2];
+                {
+                    uint32_t m_[2], sa[2], sb_[2];
+                    int nbb[2];
 #pragma unroll
-            for (int j = 0; j < PRUNE_CPT; j++) {
-                if (j < nj) {
-                    const int c = lo + j * WAVE + lane;
-                    const bool linked = c < hi && (k == 0 || flags[r_np[j] >> 16] != 0);
-                    const uint64_t m = __ballot(linked);
-                    if (m) { /* wave-uniform */
-                        const int nl = __popcll(m);
-                        const int pos = staged + (int) lanemask_lt_count(m, lane);
-                        if (linked && pos < WAVE) { sg[pos] = (uint32_t) c; sg[WAVE + pos] = r_np[j]; sg[2 * WAVE + pos] = (uint32_t) r_f[j]; sg[3 * WAVE + pos] = (uint32_t) r_b[j]; }
-                        if (staged + nl >= WAVE) {
-                            PRUNE_FLUSH(WAVE)
-                            if (linked && pos >= WAVE) { sg[pos - WAVE] = (uint32_t) c; sg[pos] = r_np[j]; sg[WAVE + pos] = (uint32_t) r_f[j]; sg[2 * WAVE + pos] = (uint32_t) r_b[j]; }
-                            staged = staged + nl - WAVE;
-                        } else {
-                            staged += nl;
+                    for (int u = 0; u < 2; u++) {
+                        const int idx = lane + u * WAVE;
+                        const bool has = idx < nkm;
+                        const uint32_t ent = has ? kml[b * PRUNE_SP + idx] : 0u;
+                        m_[u] = ent & 0x3FFFu;
+                        const uint32_t i = (ent >> 14) & 127u, j = (ent >> 21) & 127u;
+                        sa[u] = startA[i]; sb_[u] = startB[j];
+                        const int na = has ? (int) cntA[i] : 0;
+                        nbb[u] = has ? (int) cntB[j] : 0;
+                        tot[u] = na * nbb[u];
+                    }
+                    /* candidate q of the column belongs to the kept merge cell whose range [off, off + tot) holds it: ranges in
+                     * list order of the kept merge cells (first all of this wave's "u = 0" entries, then the "u = 1" ones) */
+                    const int i0 = wave_incl_scan(tot[0], lane);
+                    const int t0 = __builtin_amdgcn_readlane(i0, WAVE - 1);
+                    off_[0] = (uint32_t) (i0 - tot[0]);
+                    off_[1] = (uint32_t) t0;
+                    if (nkm > WAVE) {
+                        const int i1 = wave_incl_scan(tot[1], lane);
+                        off_[1] = (uint32_t) (t0 + i1 - tot[1]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 2; u++) { /* what a candidate needs of its kept merge cell: two dwords */
+                        const int idx = lane + u * WAVE;
+                        if (idx < nkm) *reinterpret_cast<uint2 *>(minfo + 2 * idx) = make_uint2(m_[u] | ((uint32_t) nbb[u] << 14), off_[u] | (sa[u] << 14) | (sb_[u] << 21));
+                    }
+                }
+                int L;
+                {
+                    const int l0 = wave_incl_scan(tot[0] + tot[1], lane);
+                    L = __builtin_amdgcn_readlane(l0, WAVE - 1);
+                }
+                SEC(0);
+                const bool thr_all = p.thr_bin >= nb - 1;
+                const bool keep_all = L <= p.min_p || (thr_all && L <= p.max_p); /* the loop of :1073-1079 drops nothing */
+                /* One chunk = up to 512 consecutive candidates in eight slots of 64 (slot j, lane l: candidate q0 + 64 j + l);
+                 * only the ns slots the chunk needs are worked on (a column links 130 cells on average: two or three slots).
+                 * Per slot: the owner (the kept merge cell whose range holds the candidate) by a prefix maximum over "a range
+                 * starts here" marks, the owner's record, the two parent cells from the inverted lists, the cell index by
+                 * the closed form of the cross product order, its posterior bin.  The slots' chains are independent. */
+                uint32_t key[8], aux[8]; /* bin << 14 | cell (0xFFFFFFFF: none);  c1 | c2 << 8 | prev merge cell << 16 */
+                auto load_chunk = [&](int q0) -> int {
+                    const int left = L - q0;
+                    const int ns = left >= 512 ? 8 : (left + 63) >> 6;
+#pragma unroll
+                    for (int u = 0; u < 2; u++) { /* marks: index + 1 of the kept merge cell whose range starts (or continues) here */
+                        const int idx = lane + u * WAVE;
+                        const int lo = (int) off_[u], hi = lo + tot[u];
+                        if (tot[u] > 0 && hi > q0 && lo < q0 + 512) heads[lo > q0 ? lo - q0 : 0] = (uint32_t) idx + 1u;
+                    }
+                    wave_lds_fence();
+                    uint32_t own[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        own[j] = 0u;
+                        if (j < ns) { own[j] = heads[j * WAVE + lane]; heads[j * WAVE + lane] = 0u; } /* left clean for the next use */
+                    }
+                    uint32_t carry = 0u; /* the latest mark of the slots before */
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        if (j < ns) { /* inclusive prefix maximum over the lanes (marks grow with the position: max = latest) */
+                            uint32_t v = own[j], t;
+                            t = dpp_mov<0x111>(v); if ((lane & 15) >= 1) v = t > v ? t : v;
+                            t = dpp_mov<0x112>(v); if ((lane & 15) >= 2) v = t > v ? t : v;
+                            t = dpp_mov<0x114>(v); if ((lane & 15) >= 4) v = t > v ? t : v;
+                            t = dpp_mov<0x118>(v); if ((lane & 15) >= 8) v = t > v ? t : v;
+                            t = dpp_mov<0x142, 0xa>(v); if ((lane & 31) >= 16) v = t > v ? t : v;
+                            t = dpp_mov<0x143, 0xc>(v); if (lane >= 32) v = t > v ? t : v;
+                            v = v > carry ? v : carry;
+                            own[j] = v;
+                            carry = (uint32_t) __builtin_amdgcn_readlane((int) v, WAVE - 1);
                         }
                     }
-                }
-            }
-            if (staged > 0) PRUNE_FLUSH(staged)
-#undef PRUNE_FLUSH
-            if (lane == 0) { sh[wave] = (uint32_t) cnt; atomicAdd(&sh[40 + (k & 1)], (uint32_t) cnt); }
-            CLK(1);
-            /* the next column's cells are requested now and consumed after the two barriers below */
-            const SweepCol cur = col;
-            if (k + 1 < K) {
-                col = col_next; /* its descriptor was requested one column ago */
-                if (k + 2 < K) col_next = k_load(d.scols + h.col0 + k + 2);
-                PRUNE_SHARE(col, lo1, hi1, nj1)
-                (void) nj1;
-                PRUNE_LOAD(col, lo1, hi1, nj1)
-            }
-            CLK(2);
-            lds_barrier();
-            CLK(3);
-            if (wave == 1) {
-                if (k > 0) lists_stage1(k - 1, mcell_prev);
-            } else if (wave == 2) {
-                if (k > 1) lists_stage2(k - 2);
-            } else if (wave > 2) {
-                uint32_t *hn = hist + ((k + 1) & 1) * nb_r;
-                for (int i = lane + (wave - 3) * WAVE; i < nb_r; i += T - 3 * WAVE) hn[i] = 0;
-            }
-            if (wave == 0) {
-                uint32_t *gsel = sel + (k & 1) * 4 * S, *gnp = gsel + S, *esel = gnp + S, *enp = esel + S;
-                /* [B] cutoff bin and quota */
-                const int n_link = (int) sh[40 + (k & 1)]; /* summed by the waves at the end of [A] */
-                if (lane == 0) sh[40 + ((k + 1) & 1)] = 0u;
-                /* lane l owns the bpl consecutive bins [l * bpl, (l + 1) * bpl); the histogram is stored lane-major, so these
-                 * reads are conflict-free and the search has a fixed, short cost wherever the cutoff lies (the posteriors of
-                 * the linked cells spread over hundreds of bins) */
-                int v[16];
-                int tot = 0, pass = 0;
+                    uint32_t w0[8], w1[8];
 #pragma unroll
-                for (int q = 0; q < 16; q++) {
-                    v[q] = q < bpl ? (int) hk[q * WAVE + lane] : 0;
-                    tot += v[q];
-                    if (lane * bpl + q <= p.thr_bin) pass += v[q];
-                }
-                const int incl = wave_incl_scan(tot, lane);
-                const int g = p.thr_bin >= nb - 1 ? n_link : __shfl(wave_incl_scan(pass, lane), WAVE - 1, WAVE);
-                const int n = kept_count(n_link, g, p.min_p, p.max_p);
-                const int ex = incl - tot;
-                int myB = -1, myQ = 0;
-                const bool owner_lane = n > 0 && ex < n && n <= incl;
-                if (owner_lane) {
-                    int cum = ex;
+                    for (int j = 0; j < 8; j++) {
+                        key[j] = 0xFFFFFFFFu;
+                        if (j < ns) {
+                            const bool act = j * WAVE + lane < left && own[j] > 0u;
+                            const uint2 r = act ? *reinterpret_cast<const uint2 *>(minfo + 2 * (own[j] - 1u)) : make_uint2(0u, 0u);
+                            w0[j] = r.x; w1[j] = r.y;
+                            if (act) key[j] = 0u;
+                        }
+                    }
+                    uint32_t c1_[8], c2_[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        if (j < ns) {
+                            const uint32_t nbq = (w0[j] >> 14) & 0xFFu, off = w1[j] & 0x3FFFu, sa = (w1[j] >> 14) & 0x7Fu, sb = (w1[j] >> 21) & 0x7Fu;
+                            const uint32_t t = (uint32_t) (q0 + j * WAVE + lane) - off;
+                            /* t = x * nb + y, nb <= 128: exact through a float reciprocal (t < 2^14) */
+                            uint32_t x = (uint32_t) ((float) t * __builtin_amdgcn_rcpf((float) (nbq ? nbq : 1u)));
+                            if (x * nbq > t) x--;
+                            if ((x + 1u) * nbq <= t) x++;
+                            const uint32_t y = t - x * nbq;
+                            c1_[j] = listA[(sa + x) & 127u];
+                            c2_[j] = listB[(sb + y) & 127u];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        if (j < ns) {
+                            const uint32_t e = key[j] == 0u ? pair_index(c1_[j], c2_[j], C2, inv, a_cp, b_cp) : 0u;
+                            aux[j] = c1_[j] | (c2_[j] << 8) | ((w0[j] & 0x3FFFu) << 16);
+                            const uint32_t bin_ = bin_k[e];
+                            if (key[j] == 0u) key[j] = (bin_ << 14) | e;
+                        }
+                    }
+                    return ns;
+                };
+                /* a selected candidate: its slot of the selection, and -- the first time its next merge cell is seen -- that merge
+                 * cell as a kept merge cell of the next column.  Called in wave-uniform control flow, `take` per lane. */
+                int cm = 0;
+                auto emit = [&](bool take, int pos, uint32_t key_, uint32_t aux_) {
+                    const uint32_t ii = nxA[aux_ & 0x7Fu], jj = nxB[(aux_ >> 8) & 0x7Fu];
+                    const uint32_t nxt = has_next ? pair_index(ii, jj, Mb, inv, out_ap, out_bp) : 0u;
+                    if (take) { skey[pos] = key_; snp[pos] = nxt | (aux_ & 0xFFFF0000u); }
+                    if (has_next) {
+                        bool first = false;
+                        if (take) {
+                            const uint32_t bit = 1u << (nxt & 31u);
+                            first = (atomicOr(&bmp_m[(nxt >> 5) & 511u], bit) & bit) == 0u;
+                        }
+                        const uint64_t fm = __ballot(first);
+                        if (first) kmn[cm + __popcll(fm & lt_mask)] = nxt | (ii << 14) | (jj << 21);
+                        cm += __popcll(fm);
+                    }
+                };
+                const int n_chunks = (L + 511) >> 9;
+                int n = 0;
+                if (keep_all) {
+                    int at = 0;
+                    for (int c = 0; c < n_chunks; c++) {
+                        const int ns = load_chunk(c << 9);
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            if (j < ns) {
+                                const bool act = key[j] != 0xFFFFFFFFu;
+                                const uint64_t am = __ballot(act);
+                                emit(act, at + __popcll(am & lt_mask), key[j], aux[j]);
+                                at += __popcll(am);
+                            }
+                        }
+                    }
+                    n = at;
+                    SEC(1);
+                } else {
+                    /* pass 1: histogram of the posterior bins */
+                    int ns = 0;
+                    for (int c = 0; c < n_chunks; c++) {
+                        ns = load_chunk(c << 9);
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (j < ns && key[j] != 0xFFFFFFFFu) {
+                                const int bin_ = (int) (key[j] >> 14);
+                                atomicAdd(&hk[(bin_ & 15) * WAVE + (bin_ >> 4)], 1u);
+                            }
+                    }
+                    wave_lds_fence();
+                    SEC(2);
+                    /* cutoff bin and quota: lane l owns the 16 consecutive bins [16 l, 16 l + 16); the histogram is stored
+                     * lane-major, so these reads are conflict-free and the search has a fixed, short cost */
+                    int v[16];
+                    int tot_l = 0, pass = 0;
+                    const int thr_rel = p.thr_bin - lane * 16; /* bins q <= thr_rel of this lane pass the threshold */
 #pragma unroll
                     for (int q = 0; q < 16; q++) {
-                        if (myB < 0 && cum + v[q] >= n) { myB = lane * bpl + q; myQ = n - cum; }
-                        cum += v[q];
+                        v[q] = (int) hk[q * WAVE + lane];
+                        tot_l += v[q];
+                        if (q <= thr_rel) pass += v[q];
                     }
-                }
-                const uint64_t om = __ballot(owner_lane);
-                const int src = om ? __ffsll((unsigned long long) om) - 1 : 0;
-                const int srcu = __builtin_amdgcn_readfirstlane(src); /* wave-uniform: v_readlane instead of ds_bpermute */
-                const int B = om ? __builtin_amdgcn_readlane(myB, srcu) : -1;
-                const int quota = om ? __builtin_amdgcn_readlane(myQ, srcu) : 0;
-                const int nG = n - quota;
-                CLK(4);
-                /* ordered selection over the wave segments (list order) */
-                {
+                    const int incl = wave_incl_scan(tot_l, lane);
+                    const int g = thr_all ? L : __builtin_amdgcn_readlane(wave_incl_scan(pass, lane), WAVE - 1);
+                    n = kept_count(L, g, p.min_p, p.max_p);
+                    const int ex = incl - tot_l;
+                    int myq = -1, myQ = 0, myV = 0;
+                    const bool owner_lane = n > 0 && ex < n && n <= incl;
+                    if (owner_lane) {
+                        int cum = ex;
+#pragma unroll
+                        for (int q = 0; q < 16; q++) {
+                            if (myq < 0 && cum + v[q] >= n) { myq = q; myQ = n - cum; myV = v[q]; }
+                            cum += v[q];
+                        }
+                    }
+                    const int myB = lane * 16 + myq;
+                    const uint64_t om = __ballot(owner_lane);
+                    const int srcu = __builtin_amdgcn_readfirstlane(om ? __ffsll((unsigned long long) om) - 1 : 0);
+                    const int B = om ? __builtin_amdgcn_readlane(myB, srcu) : -1;
+                    const int quota = om ? __builtin_amdgcn_readlane(myQ, srcu) : 0;
+                    const int in_B = om ? __builtin_amdgcn_readlane(myV, srcu) : 0;
+                    const int nG = n - quota;
+                    const bool whole_bin = in_B == quota; /* the cutoff bin is kept entirely: no ranking needed */
+                    SEC(3);
+                    /* pass 2: the cells above the cutoff bin; those in it are kept directly or marked by cell index */
                     int gc = 0, ec = 0;
-                    for (int w = 0; w < W && (gc < nG || ec < quota); w++) {
-                        const int per_w = ((cur.n_cells + W - 1) / W + 63) & ~63;
-                        const int base = w * per_w;
-                        const int cw = (int) sh[w];
-                        for (int i0 = 0; i0 < cw && (gc < nG || ec < quota); i0 += WAVE) {
-                            const int i = i0 + lane;
-                            const bool valid = i < cw;
-                            const uint32_t e = valid ? cand[base + i] : 0u;
-                            const int bin = (int) (e >> 16);
-                            const bool is_g = valid && bin < B, is_e = valid && bin == B;
+                    for (int c = 0; c < n_chunks; c++) {
+                        if (n_chunks > 1) ns = load_chunk(c << 9); /* a single chunk is still in the registers */
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            if (j >= ns) continue;
+                            const int bin_ = key[j] != 0xFFFFFFFFu ? (int) (key[j] >> 14) : nb;
+                            const bool is_g = bin_ < B, is_e = bin_ == B;
                             const uint64_t mg = __ballot(is_g), me = __ballot(is_e);
-                            if (is_g) {
-                                const int pos = gc + (int) lanemask_lt_count(mg, lane);
-                                gsel[pos] = e;
-                                gnp[pos] = cand_np[base + i];
-                            }
-                            if (is_e) {
-                                const int pe = ec + (int) lanemask_lt_count(me, lane);
-                                if (pe < quota) { esel[pe] = e & 0xFFFFu; enp[pe] = cand_np[base + i]; }
+                            const bool take = is_g || (is_e && whole_bin);
+                            emit(take, is_g ? gc + __popcll(mg & lt_mask) : nG + ec + __popcll(me & lt_mask), key[j], aux[j]);
+                            if (is_e && !whole_bin) {
+                                const uint32_t e = key[j] & 0x3FFFu;
+                                atomicOr(&bmp_c[e >> 5], 1u << (e & 31u));
                             }
                             gc += __popcll(mg);
                             ec += __popcll(me);
                         }
                     }
+                    SEC(4);
+                    if (!whole_bin && quota > 0) {
+                        /* the first `quota` cells of the cutoff bin in list order (= by cell index): a cell's rank is the number
+                         * of marks below it -- marks before its bitmap word (prefix counts, lane l owns words 8 l .. 8 l + 7) plus
+                         * those below it in the word */
+                        wave_lds_fence();
+                        {
+                            uint32_t w[8];
+                            int cnt_l = 0;
+#pragma unroll
+                            for (int q = 0; q < 8; q++) { w[q] = bmp_c[lane * 8 + q]; cnt_l += __popc(w[q]); }
+                            int run = wave_incl_scan(cnt_l, lane) - cnt_l;
+#pragma unroll
+                            for (int q = 0; q < 8; q++) { pref[lane * 8 + q] = (uint32_t) run; run += __popc(w[q]); }
+                        }
+                        wave_lds_fence();
+                        for (int c = 0; c < n_chunks; c++) {
+                            if (n_chunks > 1) ns = load_chunk(c << 9);
+#pragma unroll
+                            for (int j = 0; j < 8; j++) {
+                                if (j >= ns) continue;
+                                const bool is_e = key[j] != 0xFFFFFFFFu && (int) (key[j] >> 14) == B;
+                                const uint32_t e = key[j] & 0x3FFFu, wd = is_e ? e >> 5 : 0u;
+                                const int rank = (int) pref[wd] + __popc(bmp_c[wd] & ((1u << (e & 31u)) - 1u));
+                                emit(is_e && rank < quota, nG + rank, key[j], aux[j]);
+                            }
+                        }
+                        wave_lds_fence();
+                        for (int c = 0; c < n_chunks; c++) { /* the marks go */
+                            if (n_chunks > 1) ns = load_chunk(c << 9);
+#pragma unroll
+                            for (int j = 0; j < 8; j++)
+                                if (j < ns && key[j] != 0xFFFFFFFFu && (int) (key[j] >> 14) == B) bmp_c[(key[j] & 0x3FFFu) >> 5] = 0u;
+                        }
+                    }
                 }
-                CLK(5);
-                if (lane == 0) { sh[32 + 2 * (k & 1)] = (uint32_t) n; sh[33 + 2 * (k & 1)] = (uint32_t) nG; }
-                /* the kept flags: those of the previous merge column go (its selection still sits in the other buffer),
-                 * those of the merge column after this one are the next merge cells of the selection */
-                {
-                    const uint32_t *pg = sel + ((k + 1) & 1) * 4 * S + S, *pe = pg + 2 * S;
-                    for (int i = lane; i < n_prev; i += WAVE) flags[(i < nG_prev ? pg[i] : pe[i - nG_prev]) & 0xFFFFu] = 0;
-                    if (k + 1 < K)
-                        for (int i = lane; i < n; i += WAVE) flags[(i < nG ? gnp[i] : enp[i - nG]) & 0xFFFFu] = 1;
+                wave_lds_fence();
+                SEC(5);
+                if (lane == 0) { sh[32 + b] = (uint32_t) n; sh[40 + (b ^ 1)] = (uint32_t) cm; }
+                /* the marks of the next merge cells go */
+                if (has_next) {
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const int idx = lane + u * WAVE;
+                        if (idx < cm) bmp_m[((kmn[idx] & 0x3FFFu) >> 5) & 511u] = 0u;
+                    }
                 }
-                n_prev = k + 1 < K ? n : 0;
-                nG_prev = nG;
-                CLK(8);
+                SEC(6);
+                cc = cc_next;
+                cc_next = cc_ahead;
+                ROLE_BARRIER();
             }
-            mcell_prev = cur.mcell_off;
+            ROLE_CLK_DONE(0);
+            SEC_DONE();
             lds_barrier();
-            CLK(9);
+        } else if (wave == 1) {
+            int64_t mcell_prev = 0; /* first merge cell of the merge column after column k - 1 */
+            SweepCol scur = k_load(d.scols + h.col0);
+            lds_barrier();
+            ROLE_CLK_INIT();
+            for (int k = 0; k < K; k++) {
+                if (k > 0) lists_stage1(k - 1, mcell_prev);
+                mcell_prev = scur.mcell_off;
+                if (k + 1 < K) scur = k_load(d.scols + h.col0 + k + 1);
+                ROLE_BARRIER();
+            }
+            ROLE_CLK_DONE(1);
+            lists_stage1(K - 1, mcell_prev);
+            lds_barrier();
+        } else if (wave == 2) {
+            lds_barrier();
+            ROLE_CLK_INIT();
+            for (int k = 0; k < K; k++) {
+                if (k > 1) lists_stage2(k - 2);
+                ROLE_BARRIER();
+            }
+            ROLE_CLK_DONE(2);
+            if (K > 1) lists_stage2(K - 2);
+            lds_barrier();
+            lists_stage2(K - 1);
+        } else if (wave == 3) {
+            /* wave 3: the parents' transitions of the column after next */
+            uint32_t r_na[2] = {0u, 0u}, r_nb[2] = {0u, 0u};
+            CrossCol tcc = {};
+            int tcol = 0;
+            auto tab_load = [&]() {
+                if (tcol < K) {
+                    tcc = k_load(d.ccols + h.col0 + tcol);
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const uint32_t c = (uint32_t) (lane + u * WAVE);
+                        r_na[u] = (tcc.a_np && c < tcc.C1) ? tcc.a_np[c] : 0u;
+                        r_nb[u] = (tcc.b_np && c < tcc.C2) ? tcc.b_np[c] : 0u;
+                    }
+                }
+            };
+            auto tab_build_side = [&](uint32_t *t5, const uint32_t (&rn)[2], uint32_t C, uint32_t P, uint32_t in_kind, uint32_t out_kind) {
+                uint32_t *cnt = t5, *start = t5 + 128, *list = t5 + 256, *nx = t5 + 384, *pv = t5 + 512;
+                const uint32_t G = P < 1u ? 1u : (P > 128u ? 128u : P);
+                cnt[lane] = 0u; cnt[lane + WAVE] = 0u;
+                wave_lds_fence();
+                uint32_t rank[2] = {0u, 0u}, grp_[2] = {0u, 0u};
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t c = (uint32_t) (lane + u * WAVE);
+                    if (c < C) {
+                        uint32_t pvi = in_kind == MRP_CONN_REAL ? (rn[u] >> 16) : (in_kind == MRP_CONN_IDENT ? c : 0u);
+                        const uint32_t nxi = out_kind == MRP_CONN_REAL ? (rn[u] & 0xFFFFu) : (out_kind == MRP_CONN_IDENT ? c : 0u);
+                        if (pvi >= G) { errbits |= MRP_ENGINE_ERR_RANGE; pvi = 0u; }
+                        pv[c] = pvi; nx[c] = nxi;
+                        grp_[u] = pvi;
+                        rank[u] = atomicAdd(&cnt[pvi], 1u);
+                    }
+                }
+                wave_lds_fence();
+                /* exclusive scan of the group sizes (two per lane: groups lane and lane + 64) */
+                const int c0 = (int) cnt[lane], c1 = (int) cnt[lane + WAVE];
+                const int i0 = wave_incl_scan(c0, lane);
+                const int t0 = __shfl(i0, WAVE - 1, WAVE);
+                const int i1 = wave_incl_scan(c1, lane);
+                start[lane] = (uint32_t) (i0 - c0);
+                start[lane + WAVE] = (uint32_t) (t0 + i1 - c1);
+                wave_lds_fence();
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const uint32_t c = (uint32_t) (lane + u * WAVE);
+                    if (c < C) list[start[grp_[u]] + rank[u]] = c;
+                }
+            };
+            auto tab_build = [&]() { /* tables of column tcol into buffer tcol & 1, from the registers loaded last time */
+                if (tcol < K) {
+                    uint32_t *tb = tab + (tcol & 1) * 2 * PRUNE_TAB * 128;
+                    uint32_t C1 = tcc.C1, C2 = tcc.C2;
+                    if (C1 > 128u || C2 > 128u) { errbits |= MRP_ENGINE_ERR_RANGE; C1 = C1 > 128u ? 128u : C1; C2 = C2 > 128u ? 128u : C2; }
+                    tab_build_side(tb, r_na, C1, tcc.Pa, tcc.in_a, tcc.out_a);
+                    tab_build_side(tb + PRUNE_TAB * 128, r_nb, C2, tcc.Pb, tcc.in_b, tcc.out_b);
+                }
+            };
+
+            /* the parents' transitions: tables of column 0, request for column 1 */
+            tcol = 0; tab_load(); tab_build();
+            tcol = 1; tab_load();
+            lds_barrier();
+            ROLE_CLK_INIT();
+            for (int k = 0; k < K; k++) {
+                /* tables of column k + 1 (loaded while column k - 1 was worked on), then the request for k + 2 */
+                tab_build();
+                tcol++;
+                tab_load();
+                uint32_t *hn = hist + ((k + 1) & 1) * nb_r;
+                for (int i = lane; i < nb_r; i += WAVE) hn[i] = 0u;
+                ROLE_BARRIER();
+            }
+            ROLE_CLK_DONE(3);
+            lds_barrier();
+        } else {
+            /* bins groups (waves 4..): group g handles the columns g, g + 2, ...  A step of its loop stores the bins of the
+             * column whose f and b sit in the registers and requests the column after next into the same registers; the
+             * group is idle during the other group's step.  Loads are issued for every register slot whatever the column's
+             * size (beyond the column -- and beyond the last column -- the buffer descriptor's range check returns 0 without
+             * touching memory): a load under a condition would make every slot a loop-carried merge of old and new value,
+             * which costs a second register set. */
+            int32_t r_f[CPT], r_b[CPT];
+            const int bw = wave - 4, grp = bw & 1, gidx = bw >> 1;
+            const int base_c = gidx * WAVE + lane, voff = base_c * 4;
+            int n_have = 0; /* cells of the column in the registers */
+            auto bins_load = [&](int col) {
+                const bool valid = col < K;
+                const SweepCol c = k_load(d.scols + h.col0 + (valid ? col : 0));
+                n_have = valid ? c.n_cells : 0;
+                const int bytes_ = __builtin_amdgcn_readfirstlane(n_have * 4);
+                const auto rf_ = prune_rsrc(d.cell_f32 + c.cell_off, bytes_);
+                const auto rb_ = prune_rsrc(d.cell_b32 + c.cell_off, bytes_);
+#pragma unroll
+                for (int j = 0; j < CPT; j++) { /* one lane offset for all loads; the step from load to load rides in the scalar offset */
+                    r_f[j] = (int32_t) __builtin_amdgcn_raw_buffer_load_b32(rf_, voff, j * LG * 4, 0);
+                    r_b[j] = (int32_t) __builtin_amdgcn_raw_buffer_load_b32(rb_, voff, j * LG * 4, 0);
+                }
+            };
+            auto bins_store = [&](int col) { /* the bins of column col into buffer col & 1 */
+                uint16_t *dst = bins + (col & 1) * cap_c;
+                const int nj = (n_have + LG - 1) / LG;
+#pragma unroll
+                for (int j = 0; j < CPT; j++) {
+                    if (j < nj) { /* (the lane's cell against a scalar bound, the step in the store's immediate offset: no
+                                   * per-slot index registers) */
+                        if (base_c < n_have - j * LG) dst[base_c + j * LG] = (uint16_t) posterior_bin(r_f[j], r_b[j], total, nb, &errbits);
+                    }
+                }
+            };
+            /* barrier schedule: one after the prologue (step -1), one per column (steps 0 .. K - 1), one before the last merge
+             * list.  Group 0 acts at steps -1, 1, 3, ... (columns 0, 2, 4, ...), group 1 at steps 0, 2, ... */
+            bins_load(grp);
+            if (grp == 1) lds_barrier(); /* step -1 */
+            ROLE_CLK_INIT();
+            for (int st = grp - 1; st < K; st += 2) {
+                bins_store(st + 1);
+                __builtin_amdgcn_sched_barrier(0); /* the new column's loads reuse the registers of the one just stored */
+                bins_load(st + 3);
+                ROLE_BARRIER();                 /* end of step st */
+                if (st + 1 < K) ROLE_BARRIER(); /* step st + 1: the other group's */
+            }
+            if (gidx == 0) ROLE_CLK_DONE(4 + grp);
+            lds_barrier();
         }
-        /* the lists of the last two columns */
-        if (wave == 1) lists_stage1(K - 1, mcell_prev);
-        if (wave == 2 && K > 1) lists_stage2(K - 2);
-        lds_barrier();
-        if (wave == 2) lists_stage2(K - 1);
         __syncthreads(); /* also makes the lists above visible in global memory */
 
         /* ---- stRPHmm_pruneBackwards hmm.c:1111-1158: lists of at most S entries, one wave; the lists of
@@ -706,41 +1024,49 @@ __global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm 
                 cur = nx1;
                 nx1 = nx2;
             }
+            if (pmk[0]) flags[pm[0]] = 0;
+            if (pmk[1]) flags[pm[1]] = 0;
         }
+        if (errbits) { atomicOr(sc.err, errbits); atomicOr(sc.err_hmm + hi_, errbits); }
         __syncthreads();
     }
-#undef PRUNE_SHARE
-#undef PRUNE_LOAD
-#ifdef PRUNE_EXP_CLOCK
-    CLK(10);
-    if (wave == 0 && lane == 0 && T == 1024)
-        for (int i = 0; i < 12; i++) atomicAdd((unsigned long long *) (sc.err + 4) + i, (unsigned long long) clk[i]);
-#endif
-    if (errbits) atomicOr(sc.err, errbits);
 }
 
-hipError_t mrp_launch_prune(const MrpBatchDev &d, const PruneHmm *hmms_dev, int64_t n_hmms, PruneParams p, PruneScratch s,
-                            hipStream_t stream) {
+static size_t prune_lds_bytes(const PruneParams &p) {
+    const size_t cap = (size_t) ((p.max_cells + 3) & ~3);
+    const size_t dwords = 4 * PRUNE_SP + PRUNE_SP + 4 * PRUNE_SP + 64 + 2 * 1024 + 512 + 512 + 2 * PRUNE_SP + 2 * PRUNE_SP + 512 + 512 + 4 * PRUNE_TAB * 128 + 512;
+    return dwords * 4 + (size_t) ((p.max_merge + 15) & ~15) + 2 * cap * 2 + 16;
+}
+
+hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, const PruneHmm *hmms_dev, int64_t n_hmms, PruneParams p,
+                            PruneScratch s, hipStream_t stream) {
     if (n_hmms <= 0) return hipSuccess;
     if (p.S > MRP_PRUNE_MAX_S || p.max_cells > MRP_PRUNE_MAX_CELLS || p.max_merge > MRP_PRUNE_MAX_CELLS || p.n_bins > 1024) return hipErrorInvalidValue;
-    const size_t cap = (size_t) ((std::max(p.max_cells, p.max_merge) + 3) & ~3);
-    auto lds_for = [&](int threads) { return (size_t) (13 * p.S + 64 + (threads / 64) * 4 * 64 + 2 * 1024 + 2 * cap + 512) * 4 + (size_t) ((p.max_merge + 3) & ~3) + 16; };
-    /* once per process (thread-safe static initialisation: the concurrent halves of a call launch from two host threads) */
-    static const hipError_t configured = [] {
-        hipError_t e = hipFuncSetAttribute((const void *) mrp_prune_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *) mrp_prune_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        return e;
-    }();
-    if (configured != hipSuccess) return configured;
-    if (lds_for(1024) > (size_t) MRP_LDS_BUDGET) return hipErrorInvalidValue;
+    /* once per device (thread-safe: the concurrent halves of a call launch from two host threads) */
+    static std::mutex mu;
+    static bool configured[64] = {false};
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    {
+        std::lock_guard<std::mutex> lock(mu);
+        if (dev >= 0 && dev < 64 && !configured[dev]) {
+            e = hipFuncSetAttribute((const void *) mrp_prune_kernel<512, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess) e = hipFuncSetAttribute((const void *) mrp_prune_kernel<1024, 36>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            configured[dev] = true;
+        }
+    }
+    const size_t lds = prune_lds_bytes(p);
+    if (lds > (size_t) MRP_LDS_BUDGET) return hipErrorInvalidValue;
     const dim3 grid((unsigned) (n_hmms < 65536 ? n_hmms : 65536));
-    const PruneIn in{d.scols, d.cell_np, d.cell_f32, d.cell_b32, d.merge_f32, d.merge_b32, d.hmm_fb};
-    /* 1 024 threads for the big columns even when fewer would hold them: the per-wave share of phase [A] is what the
-     * column's critical path waits for (640 threads measured 8 % slower) */
-    if (p.max_cells <= 256 * PRUNE_CPT)
-        hipLaunchKernelGGL(mrp_prune_kernel<256>, grid, dim3(256), lds_for(256), stream, in, hmms_dev, n_hmms, p, s);
+    const PruneIn in{d.scols, ccols_dev, d.cell_f32, d.cell_b32, d.merge_f32, d.merge_b32, d.hmm_fb};
+    /* the bin-streaming groups hold a column's f and b in registers: 2 waves x 32 cells per lane per group at 512 threads,
+     * 6 waves x 36 at 1 024 */
+    if (p.max_cells <= 2 * WAVE * 32)
+        hipLaunchKernelGGL((mrp_prune_kernel<512, 32>), grid, dim3(512), lds, stream, in, hmms_dev, n_hmms, p, s);
     else
-        hipLaunchKernelGGL(mrp_prune_kernel<1024>, grid, dim3(1024), lds_for(1024), stream, in, hmms_dev, n_hmms, p, s);
+        hipLaunchKernelGGL((mrp_prune_kernel<1024, 36>), grid, dim3(1024), lds, stream, in, hmms_dev, n_hmms, p, s);
     return hipGetLastError();
 }
 
@@ -785,7 +1111,7 @@ __global__ void __launch_bounds__(256) mrp_compact_kernel(MrpBatchDev d, const P
 /* trace back                                                                                  */
 /* ------------------------------------------------------------------------------------------ */
 __global__ void __launch_bounds__(64) mrp_traceback_kernel(MrpBatchDev d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
-                                                           int32_t *__restrict__ err) {
+                                                           int32_t *__restrict__ err, int32_t *__restrict__ err_hmm) {
     const int lane = threadIdx.x;
     for (int64_t hi = blockIdx.x; hi < n_hmms; hi += gridDim.x) {
         const PruneHmm h = k_load(hmms + hi);
@@ -850,7 +1176,7 @@ __global__ void __launch_bounds__(64) mrp_traceback_kernel(MrpBatchDev d, const 
                 /* ... except in the last column, where the reference starts from the first cell */
                 if (k + 1 == K) best_i = 0;
                 else {
-                    if (lane == 0) atomicOr(err, MRP_ENGINE_ERR_RANGE);
+                    if (lane == 0) { atomicOr(err, MRP_ENGINE_ERR_RANGE); atomicOr(err_hmm + hi, MRP_ENGINE_ERR_RANGE); }
                     best_i = 0;
                 }
             }
@@ -871,10 +1197,11 @@ __global__ void __launch_bounds__(64) mrp_traceback_kernel(MrpBatchDev d, const 
     }
 }
 
-hipError_t mrp_launch_traceback(const MrpBatchDev &d, const PruneHmm *hmms_dev, int64_t n_hmms, int32_t *err, hipStream_t stream) {
+hipError_t mrp_launch_traceback(const MrpBatchDev &d, const PruneHmm *hmms_dev, int64_t n_hmms, int32_t *err, int32_t *err_hmm,
+                                hipStream_t stream) {
     if (n_hmms <= 0) return hipSuccess;
     hipLaunchKernelGGL(mrp_traceback_kernel, dim3((unsigned) (n_hmms < 65536 ? n_hmms : 65536)), dim3(64), 0, stream, d, hmms_dev,
-                       n_hmms, err);
+                       n_hmms, err, err_hmm);
     return hipGetLastError();
 }
 

@@ -186,6 +186,7 @@ typedef struct {
     mrp_batch *record;
     int64_t n_sweeps;
     uint32_t max_alleles;
+    int failed; /* resident path: a kernel asked for this chunk to be redone on the hashing path */
 } world;
 
 static int64_t read_byte_offset(const world *w, int32_t read, int32_t site) { /* profileSeq.c:41-47 */
@@ -1528,11 +1529,11 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params) {
     for (int h = 1; h <= max_h && rc == MRP_OK; h++) {
         const double t0 = now_ms();
         int64_t n_items = 0;
-        for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > 0 && lvl[i] == h) n_items++;
+        for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > 0 && lvl[i] == h && !t->a[i].w->failed) n_items++;
         if (n_items == 0) continue;
         level_item *items = xcalloc((size_t) n_items + 1, sizeof(*items));
         n_items = 0;
-        for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > 0 && lvl[i] == h) { items[n_items].t = t; items[n_items].node = i; n_items++; }
+        for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > 0 && lvl[i] == h && !t->a[i].w->failed) { items[n_items].t = t; items[n_items].node = i; n_items++; }
         /* the merges of a level touch disjoint nodes: structure in parallel, device work as one batch */
         parallel_for(n_items, level_prepare, items);
         int64_t n_x = 0;
@@ -1575,6 +1576,9 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params) {
             mrp_hmm *x = xb[i].x;
             x->stride = mrp_engine_stride(e);
             x->d_part = xh[i].d_part; x->d_np = xh[i].d_np;
+            /* outside what the kernels handle (a parent not in complement-pair order, ...): the later levels leave this
+             * chunk out, its caller redoes it on the hashing path */
+            if (rc == MRP_OK && xh[i].err != 0) ((world *) xb[i].w)->failed = 1;
         }
         free(xh); free(xb);
         if (rc == MRP_OK) parallel_for(n_items, level_finish, items);
@@ -1659,6 +1663,7 @@ int mrp_get_rp_hmms_resident(mrp_context *ctx, const mrp_chunk *chunk, const mrp
     rnode_vec tree = {0};
     const int root = r_tree_of_reads(&tree, &w, e, read_index, n, params, NULL);
     rc = root < 0 ? MRP_ERR_ARG : r_run_tree(e, &tree, params);
+    if (rc == MRP_OK && w.failed) rc = mrp_set_error(MRP_ERR_UNSUPPORTED, "device-resident merge: an hmm outside what the kernels handle (pair order / kept merge cells)");
     if (rc == MRP_OK) rc = r_download_path(e, tree.a[root].path);
     if (rc == MRP_OK) {
         hmm_vec *tp = tree.a[root].path;
@@ -1736,7 +1741,7 @@ static void many_setup(int64_t c, void *arg) {
 static void many_final_shadow(int64_t c, void *arg) {
     many_ctl *ctl = arg;
     many_state *m = &ctl->st[c];
-    if (m->root < 0 || m->rc != MRP_OK) return;
+    if (m->root < 0 || m->rc != MRP_OK || m->w.failed) return;
     hmm_vec *joined = ctl->tree->a[m->root].path;
     if (joined->n == 0) return;
     const int32_t S = joined->a[0]->ref_start, E = joined->a[joined->n - 1]->ref_start + joined->a[joined->n - 1]->ref_length;
@@ -1768,7 +1773,8 @@ static void many_final_shadow(int64_t c, void *arg) {
 static void many_finish(int64_t c, void *arg) {
     many_ctl *ctl = arg;
     many_state *m = &ctl->st[c];
-    if (m->hmm) finish_phase_parts(&m->w, m->hmm, m->chosen, m->fwd, m->bwd, ctl->params, m->discarded, m->nd, &ctl->out[c]);
+    if (m->w.failed) ctl->out[c] = NULL; /* redone by the caller on the hashing path */
+    else if (m->hmm) finish_phase_parts(&m->w, m->hmm, m->chosen, m->fwd, m->bwd, ctl->params, m->discarded, m->nd, &ctl->out[c]);
     else ctl->out[c] = result_new(0, 0, ctl->n_reads[c]);
 }
 
@@ -1823,7 +1829,10 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
         }
         if (rc == MRP_OK) rc = mrp_engine_final(e, nj, xh);
         for (int64_t c = 0; c < n_chunks; c++)
-            if (st[c].hmm) { st[c].fwd = xh[st[c].final_index].hmm_forward; st[c].bwd = xh[st[c].final_index].hmm_backward; }
+            if (st[c].hmm) {
+                st[c].fwd = xh[st[c].final_index].hmm_forward; st[c].bwd = xh[st[c].final_index].hmm_backward;
+                if (rc == MRP_OK && xh[st[c].final_index].err != 0) st[c].w.failed = 1;
+            }
         free(xh);
         free(ctl.xfinal);
     }
@@ -1832,6 +1841,14 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
         parallel_for(n_chunks, many_finish, &ctl);
         for (int64_t c = 0; c < n_chunks; c++)
             if (st[c].rc != MRP_OK && rc == MRP_OK) rc = mrp_set_error(st[c].rc, "%s", st[c].err);
+    }
+    int64_t n_failed = 0;
+    for (int64_t c = 0; c < n_chunks && rc == MRP_OK; c++) {
+        if (!st[c].w.failed) continue;
+        /* bubbleGraph_phaseBubbleGraph of this chunk alone, cross products by hashing and prune on the host (mrp_phase_reads) */
+        n_failed++;
+        if (timing) fprintf(stderr, "  chunk %lld left the resident path: redone on the hashing path\n", (long long) c);
+        rc = mrp_phase_reads(ctx, chunks[c], reads[c], n_reads[c], params, NULL, &out[c]);
     }
     tt[5] = now_ms();
     if (timing)
@@ -1845,6 +1862,7 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
         mrp_engine_stats es;
         mrp_engine_get_stats(e, &es);
         stats->resident = 1;
+        stats->fallback_chunks = (int32_t) n_failed;
         stats->levels = es.levels; stats->hmms = es.hmms; stats->columns = es.columns; stats->cells = es.cells;
         stats->merge_cells = es.merge_cells;
         stats->device_ms = es.device_ms; stats->cross_ms = es.cross_ms; stats->sweep_ms = es.sweep_ms; stats->prune_ms = es.prune_ms;
@@ -1926,6 +1944,7 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
             for (int64_t i = 0; i < q->n; i++) out[g + i * G] = q->out[i];
             if (stats && q->rc == MRP_OK) {
                 stats->resident = 1;
+                stats->fallback_chunks += q->stats.fallback_chunks;
                 stats->levels = q->stats.levels > stats->levels ? q->stats.levels : stats->levels;
                 stats->hmms += q->stats.hmms; stats->columns += q->stats.columns; stats->cells += q->stats.cells;
                 stats->merge_cells += q->stats.merge_cells;

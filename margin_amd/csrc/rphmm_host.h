@@ -69,6 +69,9 @@ typedef struct mrp_xhmm {
      * partition (host, caller-allocated), and the totals of the final sweep */
     uint64_t *path_part;
     double hmm_forward, hmm_backward;
+    /* MRP_ENGINE_ERR_* bits the kernels raised for this hmm; non-zero (structure / merge): its results are not valid and
+     * the chunk it belongs to has to be redone on the hashing path */
+    int32_t err;
 } mrp_xhmm;
 
 typedef struct mrp_engine_stats {

@@ -175,7 +175,7 @@ def test_bubbles_to_haplotype_tags_end_to_end(gpu_ctx, orc):
     dchunk.close()
 
 
-@pytest.mark.parametrize("seed,maxp", [(21, 50), (22, 20), (23, 120)])
+@pytest.mark.parametrize("seed,maxp", [(21, 50), (22, 20), (23, 116)])
 def test_resident_unit_test_shape_max_mode(gpu_ctx, orc, seed, maxp):
     """tests/stRPHmmTest.c-shaped input (1..9 alleles per site, so columns mix allele counts and take the general
     emission path) in max-plus mode with the unit tests' trimming (min 0, max N): resident merge == oracle."""
@@ -358,7 +358,7 @@ def test_resident_pruning_rules_over_random_parameters(gpu_ctx, orc):
     level otherwise): the call must stay on the resident path and equal the oracle, array for array."""
     rng = np.random.default_rng(123)
     for trial in range(6):
-        max_p = int(rng.choice([16, 40, 64, 100, 120]))
+        max_p = int(rng.choice([16, 40, 64, 100, 116]))
         min_p = int(rng.integers(0, max_p + 1)) if trial % 2 else 0
         thr = float(rng.choice([0.0, 1e-9, 1e-3, 0.02, 0.2]))
         pd = _params(minPartitionsInAColumn=min_p, maxPartitionsInAColumn=max_p, minPosteriorProbabilityForPartition=thr)
@@ -378,3 +378,60 @@ def test_resident_pruning_rules_over_random_parameters(gpu_ctx, orc):
             assert g["reads1"] == ref["reads1"] and g["reads2"] == ref["reads2"]
         for d in dchunks:
             d.close()
+
+
+def _assert_equals_oracle(orc, chunk, got, pd):
+    oc = orc.OracleChunk(chunk)
+    ref = oc.phase(pd)
+    oc.close()
+    for k in PHASE_KEYS:
+        assert (np.asarray(got[k]) == np.asarray(ref[k])).all(), k
+    assert got["reads1"] == ref["reads1"] and got["reads2"] == ref["reads2"]
+
+
+def test_resident_pair_order_violation_sends_only_that_chunk_to_the_hashing_path(gpu_ctx, orc):
+    """The closed-form cross product needs its parents in complement-pair order.  An ODD maxPartitionsInAColumn makes the
+    prune cut through a (partition, complement) pair wherever a column has more linked cells than that, so the next level's
+    cross kernel raises MRP_ENGINE_ERR_STRUCTURE for the hmms of that chunk: exactly those chunks are redone on the hashing
+    path (stats.fallback_chunks), the shallow chunk of the same call -- at most five reads deep, so no column reaches 51 cells -- stays
+    resident, and every result equals the oracle's."""
+    pd = _params(minPartitionsInAColumn=0, maxPartitionsInAColumn=51)
+    params = capi.Params.from_reference_names(pd)
+    chunks = [synth.make_ont_chunk(seed=81, region_bp=60_000, n_sites=120, coverage=30),
+              synth.make_ont_chunk(seed=82, region_bp=40_000, n_sites=80, coverage=2),
+              synth.make_ont_chunk(seed=83, region_bp=50_000, n_sites=100, coverage=25)]
+    dchunks = [capi.DeviceChunk.from_chunk(gpu_ctx, c) for c in chunks]
+    got, st = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
+    assert st.resident == 1 and st.fallback_chunks == 2
+    for chunk, g in zip(chunks, got):
+        _assert_equals_oracle(orc, chunk, g, pd)
+    # a single chunk through the resident getRPHmms reports the same condition as a status
+    with pytest.raises(capi.MrpError) as ei:
+        capi.get_rp_hmms_resident(gpu_ctx, dchunks[0], chunks[0], capi.Params.from_reference_names(dict(pd, includeAncestorSubProb=0)),
+                                  [i for i, r in enumerate(chunks[0].reads) if r.strand == 1])
+    assert ei.value.code == capi.MRP_ERR_UNSUPPORTED
+    for d in dchunks:
+        d.close()
+
+
+def test_resident_merge_check_failure_sends_only_that_chunk_to_the_hashing_path(gpu_ctx, orc):
+    """MRP_ENGINE_ERR_MERGE -- "a merge cell the kept cells lead to would itself be pruned" (hmm.c:1090-1100) -- cannot be
+    produced by an input in max-plus mode (a merge cell's posterior is at least that of every cell leading to it, so
+    whenever more than minPartitionsInAColumn cells are kept they and their merge cells all pass the threshold); the
+    kernel checks it all the same.  The check's way out is exercised by fault injection (mrp_params.reserved bit 0: one
+    hmm of the second level reports the error): that hmm's chunk, and only it, is redone on the hashing path; results are
+    the oracle's."""
+    pd = _params()
+    params = capi.Params.from_reference_names(pd)
+    params.reserved = 1
+    chunks = [synth.make_ont_chunk(seed=91 + i, region_bp=50_000, n_sites=100, coverage=20 + 4 * i) for i in range(4)]
+    dchunks = [capi.DeviceChunk.from_chunk(gpu_ctx, c) for c in chunks]
+    got, st = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
+    assert st.resident == 1 and st.fallback_chunks == 1
+    for chunk, g in zip(chunks, got):
+        _assert_equals_oracle(orc, chunk, g, pd)
+    params.reserved = 0
+    _, st0 = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
+    assert st0.resident == 1 and st0.fallback_chunks == 0
+    for d in dchunks:
+        d.close()
