@@ -112,8 +112,9 @@ void mrp_context_destroy(mrp_context *ctx) {
     if (!ctx) return;
     for (mrp_context *s : ctx->siblings) mrp_context_destroy(s);
     ctx->siblings.clear();
-    if (ctx->spare_batch) { mrp_batch_destroy(ctx->spare_batch); ctx->spare_batch = nullptr; }
     (void) hipSetDevice(ctx->device);
+    mrp_engine_release_context_cache(ctx);
+    if (ctx->spare_batch) { mrp_batch_destroy(ctx->spare_batch); ctx->spare_batch = nullptr; }
     if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
     ctx->pool.destroy();
     if (ctx->pinned) (void) hipHostFree(ctx->pinned);
@@ -580,165 +581,6 @@ int mrp_host_threads(void) {
         return v;
     }();
     return n;
-}
-
-int mrp_batch_add_resident_bulk(mrp_batch *b, int64_t n, const mrp_xhmm *x, int64_t *cell0_out, int64_t *col0_out) {
-    if (!b || n < 0 || (n > 0 && (!x || !cell0_out || !col0_out))) return fail(MRP_ERR_ARG, "mrp_batch_add_resident_bulk: bad arguments");
-    if (b->uploaded || b->stats.n_hmms > 0) return fail(MRP_ERR_ARG, "mrp_batch_add_resident_bulk: batch not empty");
-    b->resident = true;
-    /* chunk table */
-    std::vector<int32_t> chunk_index((size_t) n);
-    for (int64_t i = 0; i < n; i++) {
-        const mrp_chunk *ch = x[i].chunk;
-        if (!ch || ch->ctx->device != b->ctx->device) return fail(MRP_ERR_ARG, "chunk missing or on a different device");
-        int idx = -1;
-        if (!b->chunks.empty() && b->chunks.back() == ch) idx = (int) b->chunks.size() - 1;
-        for (size_t c = 0; idx < 0 && c < b->chunks.size(); c++)
-            if (b->chunks[c] == ch) idx = (int) c;
-        if (idx < 0) { idx = (int) b->chunks.size(); b->chunks.push_back(ch); }
-        chunk_index[(size_t) i] = idx;
-    }
-    /* pass 1: sizes per hmm */
-    struct Sz { int64_t cells, merge, cols, reads, slots, tiles, tiles_fast; int bad; };
-    std::vector<Sz> sz((size_t) n);
-    mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
-        const mrp_xhmm &h = x[i];
-        const mrp_chunk *ch = h.chunk;
-        Sz s{0, 0, h.n_cols, 0, 0, 0, 0, 0};
-        const bool anc1 = (h.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
-        if (h.n_cols < 1 || !h.cols || !h.col_ref_start || !h.col_length || !h.col_depth || !h.col_read_off) s.bad = 1;
-        for (int k = 0; k < h.n_cols && !s.bad; k++) {
-            const int64_t C = (int64_t) h.cols[k].C1 * h.cols[k].C2;
-            const int32_t st = h.col_ref_start[k], ln = h.col_length[k], dp = h.col_depth[k];
-            if (C < 1 || ln < 1 || st < 0 || (int64_t) st + ln > ch->n_sites || dp < 0 || dp > MRP_MAX_READ_PARTITIONING_DEPTH ||
-                h.col_read_off[k + 1] - h.col_read_off[k] != dp) { s.bad = 1; break; }
-            s.cells += C;
-            if (k + 1 < h.n_cols) s.merge += (int64_t) h.cols[k].Ma * h.cols[k].Mb;
-            s.slots += ch->allele_offset[st + ln] - ch->allele_offset[st];
-            s.tiles += (C + MRP_EMIT_TILE - 1) / MRP_EMIT_TILE;
-            bool uni = !anc1;
-            for (int s2 = 1; s2 < ln && uni; s2++) uni = ch->allele_number[st + s2] == ch->allele_number[st];
-            if (uni) s.tiles_fast += (C + MRP_EMIT_TILE - 1) / MRP_EMIT_TILE;
-        }
-        s.reads = s.bad ? 0 : h.col_read_off[h.n_cols];
-        sz[(size_t) i] = s;
-    });
-    std::vector<int64_t> cell0((size_t) n), mcell0((size_t) n), col0((size_t) n), read0((size_t) n), slot0((size_t) n), tile0((size_t) n), tilef0((size_t) n);
-    int64_t cells = 0, merge = 0, cols = 0, reads = 0, slots = 0, tiles = 0, tiles_fast = 0;
-    for (int64_t i = 0; i < n; i++) {
-        if (sz[(size_t) i].bad) return fail(MRP_ERR_ARG, "device-resident hmm %lld: inconsistent column description", (long long) i);
-        cells = (cells + 3) & ~3ll; /* every hmm starts at a multiple of 4 cells */
-        cell0[(size_t) i] = cells; mcell0[(size_t) i] = merge; col0[(size_t) i] = cols; read0[(size_t) i] = reads;
-        slot0[(size_t) i] = slots; tile0[(size_t) i] = tiles - tiles_fast; /* general tiles before this hmm */
-        tilef0[(size_t) i] = tiles_fast;
-        cells += sz[(size_t) i].cells; merge += sz[(size_t) i].merge; cols += sz[(size_t) i].cols; reads += sz[(size_t) i].reads;
-        slots += sz[(size_t) i].slots; tiles += sz[(size_t) i].tiles; tiles_fast += sz[(size_t) i].tiles_fast;
-    }
-    b->hmms.resize((size_t) n);
-    b->outs.resize((size_t) n);
-    b->cols.resize((size_t) cols);
-    b->scols.resize((size_t) cols);
-    b->pcols.resize((size_t) cols);
-    b->tiles.clear(); /* written on the device (mrp_tiles_kernel): fast tiles first, then the general ones */
-    b->tilecols.resize((size_t) cols);
-    b->n_tiles_dev = tiles;
-    b->n_fast_tiles = tiles_fast;
-    b->read_byte_off.resize((size_t) reads);
-    std::vector<int> unsupported((size_t) n, 0);
-    std::vector<int64_t> alg((size_t) n, 0), prof((size_t) n, 0), pops((size_t) n, 0);
-    /* pass 2: descriptors */
-    mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
-        const mrp_xhmm &xh = x[i];
-        const mrp_chunk *ch = xh.chunk;
-        const int K = xh.n_cols;
-        const bool ancestor = (xh.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
-        DevHmm h{};
-        h.col0 = col0[(size_t) i];
-        h.n_cols = K;
-        h.flags = xh.flags;
-        h.max_merge = 1;
-        h.max_cells = 1;
-        int64_t c_off = cell0[(size_t) i], m_off = mcell0[(size_t) i], s_off = slot0[(size_t) i];
-        int64_t t_gen = tiles_fast + tile0[(size_t) i], t_fast = tilef0[(size_t) i];
-        int64_t l_prof = 0, l_alg = 0, l_pops = 0;
-        int l_unsupported = 0;
-        for (int k = 0; k < K; k++) {
-            const int64_t col = col0[(size_t) i] + k;
-            DevCol c{};
-            c.cell_off = c_off;
-            c.n_cells = (int32_t) ((int64_t) xh.cols[k].C1 * xh.cols[k].C2);
-            c.n_merge = k + 1 < K ? (int32_t) ((int64_t) xh.cols[k].Ma * xh.cols[k].Mb) : 0;
-            c.mcell_off = k + 1 < K ? m_off : 0;
-            c.slot_off = s_off;
-            c.read_off = read0[(size_t) i] + xh.col_read_off[k];
-            c.site_start = xh.col_ref_start[k];
-            c.n_sites = xh.col_length[k];
-            c.depth = xh.col_depth[k];
-            c.n_slots = (int32_t) (ch->allele_offset[c.site_start + c.n_sites] - ch->allele_offset[c.site_start]);
-            c.chunk = chunk_index[(size_t) i];
-            c.flags = xh.flags;
-            int32_t uniform = (int32_t) ch->allele_number[c.site_start];
-            for (int s2 = 1; s2 < c.n_sites; s2++)
-                if ((int32_t) ch->allele_number[c.site_start + s2] != uniform) uniform = 0;
-            if (ancestor)
-                for (int s2 = 0; s2 < c.n_sites; s2++)
-                    if (ch->allele_number[c.site_start + s2] > MRP_MAX_ALLELES) l_unsupported = 1;
-            {
-                const int64_t nt = ((int64_t) c.n_cells + MRP_EMIT_TILE - 1) / MRP_EMIT_TILE;
-                const bool fast = uniform != 0 && !ancestor;
-                TileCol tc{};
-                tc.first = fast ? t_fast : t_gen;
-                tc.uniform_alleles = uniform;
-                (fast ? t_fast : t_gen) += nt;
-                b->tilecols[(size_t) col] = tc;
-            }
-            SweepCol sc{};
-            sc.cell_off = c.cell_off; sc.mcell_off = c.mcell_off; sc.n_cells = c.n_cells; sc.n_merge = c.n_merge;
-            b->scols[(size_t) col] = sc;
-            PlaneCol pc{};
-            pc.pool = ch->dev.pool; pc.read_off = c.read_off; pc.slot_off = c.slot_off; pc.depth = c.depth; pc.n_slots = c.n_slots;
-            pc.need_planes = (uniform == 0 || ancestor) ? 1 : 0;
-            b->pcols[(size_t) col] = pc;
-            b->cols[(size_t) col] = c;
-            h.max_merge = std::max(h.max_merge, c.n_merge);
-            h.max_cells = std::max(h.max_cells, c.n_cells);
-            int64_t per_site = 255ll * c.depth;
-            if (ancestor) per_site += 2ll * ch->max_sub + ch->max_prior;
-            h.cost_bound += per_site * c.n_sites;
-            l_prof += (int64_t) c.depth * c.n_slots; /* (locals: neighbouring hmms are built by different threads) */
-            l_alg += 24ll * c.n_cells + 32ll * c.n_merge + (int64_t) c.depth * c.n_slots + 8;
-            l_pops += (int64_t) c.n_cells * 2 * c.n_slots * 8;
-            c_off += c.n_cells; m_off += c.n_merge; s_off += c.n_slots;
-        }
-        h.n_cells = sz[(size_t) i].cells;
-        h.n_merge = sz[(size_t) i].merge;
-        h.wide_idx = h.max_merge > 65535 ? 1 : 0;
-        if (h.wide_idx) l_unsupported = 1;
-        unsupported[(size_t) i] = l_unsupported;
-        prof[(size_t) i] = l_prof; alg[(size_t) i] = l_alg; pops[(size_t) i] = l_pops;
-        b->hmms[(size_t) i] = h;
-        if (sz[(size_t) i].reads > 0)
-            memcpy(&b->read_byte_off[(size_t) read0[(size_t) i]], xh.read_byte_off, sizeof(int64_t) * (size_t) sz[(size_t) i].reads);
-        JobOut o{nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cell0[(size_t) i], sz[(size_t) i].cells, mcell0[(size_t) i],
-                 sz[(size_t) i].merge, col0[(size_t) i], K};
-        b->outs[(size_t) i] = o;
-    });
-    for (int64_t i = 0; i < n; i++) {
-        if (unsupported[(size_t) i]) return fail(MRP_ERR_UNSUPPORTED, "device-resident hmm %lld is outside the kernels' range", (long long) i);
-        b->stats.profile_bytes += prof[(size_t) i];
-        b->stats.algorithmic_bytes += alg[(size_t) i];
-        b->stats.popcount_ops += pops[(size_t) i];
-        cell0_out[i] = cell0[(size_t) i];
-        col0_out[i] = col0[(size_t) i];
-    }
-    b->n_cells_total = cells;
-    b->n_merge = merge;
-    b->n_slots = slots;
-    b->stats.n_hmms = n;
-    b->stats.n_columns = cols;
-    b->stats.n_cells = cells;
-    b->stats.n_merge_cells = merge;
-    return MRP_OK;
 }
 
 extern "C" {

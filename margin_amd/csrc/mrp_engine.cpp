@@ -1,15 +1,25 @@
 /*
  * mrp_engine.cpp -- host side of the device-resident merge level.
  *
- * One call of mrp_engine_level() performs, for a set of independent overlap components
- * (coordination.c:285-328), what the reference does with
+ * One level performs, for a set of independent overlap components (coordination.c:285-328), what the reference does
+ * with
  *     stRPHmm_createCrossProductOfTwoAlignedHmm (hmm.c:534)  ->  mrp_cross_kernel
- *     stRPHmm_forwardBackward (hmm.c:931)                    ->  plane / emission / recursion kernels
+ *     stRPHmm_forwardBackward (hmm.c:931)                    ->  packing / emission / recursion kernels
  *     stRPHmm_prune (hmm.c:1160)                             ->  mrp_prune_kernel + mrp_compact_kernel
- * without the hmm leaving HBM: the parents are read from, and the pruned result is written to, the
- * fixed-stride resident layout of mrp_engine.h; only the per-column cell counts (4 B per column) come
- * back to the host, which needs them to lay out the next level.  The structural decisions (tiling
- * paths, overlap components, column alignment) are made by rphmm_host.c from read intervals alone.
+ * without the hmm leaving HBM: the parents are read from, and the pruned result is written to, the fixed-stride
+ * resident layout of mrp_engine.h.
+ *
+ * What the host contributes to a level does not depend on any result of the level before: the column structure of the
+ * cross products (sites, reads, connector kinds) and the ADDRESSES at which the parents' per-column counts will be
+ * found.  A level therefore goes through three steps:
+ *     stage   host only: the static description (PlanCol / PlanHmm, read offsets, launch classes from static bounds) is
+ *             built by the worker pool and uploaded on the copy stream -- while the level before is still running;
+ *     launch  the layout kernels turn the parents' counts into sizes, offsets and every kernel descriptor; four totals
+ *             come back (the only host wait of a level, it also ends the level before), the cell arrays are allocated
+ *             and the level's kernels queued;
+ *     end     per-hmm error flags (and, at the final level, the traced-back path) are read.
+ * The structural decisions (tiling paths, overlap components, column alignment) are made by rphmm_host.c from read
+ * intervals alone.
  */
 #include <hip/hip_runtime.h>
 
@@ -37,7 +47,62 @@ struct Segment { /* the pruned hmms produced by one level */
     DevBuf<uint32_t> np;
     DevBuf<int32_t> n_cells, n_merge;
 };
+
+/* page-locked, grow-only host buffer: source of the asynchronous uploads of a staged level */
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~PinnedBuf() { if (p) (void) hipHostFree(p); }
+    hipError_t reserve(size_t want) {
+        if (want <= bytes) return hipSuccess;
+        if (p) (void) hipHostFree(p);
+        p = nullptr; bytes = 0;
+        const size_t sz = std::max<size_t>(want + want / 4, (size_t) 1 << 20);
+        hipError_t e = hipHostMalloc(&p, sz, hipHostMallocDefault);
+        if (e == hipSuccess) bytes = sz;
+        return e;
+    }
+};
 }  // namespace
+
+/* everything one level keeps between its staging and its completion */
+struct mrp_engine_level_state {
+    mrp_batch *b = nullptr;
+    std::unique_ptr<Segment> seg;
+    /* static description, device side */
+    DevBuf<PlanCol> d_plan;
+    DevBuf<PlanHmm> d_phmm;
+    DevBuf<uint16_t> d_dims;
+    DevBuf<LayoutTot> d_tot;
+    DevBuf<LayoutBase> d_base;
+    DevBuf<int64_t> d_totals;
+    DevBuf<CrossCol> d_cc;
+    DevBuf<PruneHmm> d_ph;
+    DevBuf<int32_t> d_col_hmm, d_nkept, d_nkeptm, d_err, d_err_hmm;
+    DevBuf<uint16_t> d_kept, d_keptm;
+    DevBuf<uint32_t> d_kept_np;
+    PinnedBuf stage;        /* host side of the uploads */
+    PinnedBuf results;      /* totals, error flags, final level: path and totals of the sweep */
+    int64_t *totals = nullptr;
+    int32_t *err = nullptr, *err_hmm = nullptr, *path_cell = nullptr;
+    uint64_t *path_part = nullptr;
+    double *fb = nullptr;
+    std::vector<int32_t> perm; /* position in the (sorted) PruneHmm array -> index into x */
+    bool final_level = false;
+    unsigned long long clk[12] = {0};
+    mrp_xhmm *x = nullptr;
+    int64_t n = 0, total_cols = 0, n_slots = 0, n_reads = 0;
+    PruneParams pp{};
+    double t_begin = 0, t_staged = 0, t_launch_ms = 0;
+    hipEvent_t uploaded = nullptr; /* end of the uploads on the copy stream */
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    ~mrp_engine_level_state() {
+        if (uploaded) (void) hipEventDestroy(uploaded);
+        for (auto &e_ : ev)
+            if (e_) (void) hipEventDestroy(e_);
+        if (b) mrp_batch_destroy(b);
+    }
+};
 
 struct mrp_engine {
     mrp_context *ctx = nullptr;
@@ -45,11 +110,13 @@ struct mrp_engine {
     PruneParams pp{};
     DevBuf<uint64_t> leaf_part;
     DevBuf<uint32_t> leaf_np;
+    DevBuf<int32_t> leaf_count;
     std::vector<std::unique_ptr<Segment>> segments;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     mrp_engine_stats stats{};
-    struct mrp_engine_level_state *cur = nullptr; /* a level between begin and end */
-    mrp_batch *spare = nullptr;                   /* the batch object of the previous level, emptied */
+    mrp_engine_level_state *staged = nullptr;  /* staged, not launched */
+    mrp_engine_level_state *running = nullptr; /* launched, not ended */
+    std::vector<mrp_batch *> spare;            /* emptied batch objects (host arrays keep their capacity) */
+    std::vector<mrp_engine_level_state *> spare_levels; /* level states whose pinned buffers are reused */
 };
 
 static double eng_now() {
@@ -58,7 +125,27 @@ static double eng_now() {
     return 1e3 * ts.tv_sec + 1e-6 * ts.tv_nsec;
 }
 
-static void mrp_engine_level_abandon(mrp_engine *e);
+/* back to the empty state; the batch object and the pinned buffers stay with the engine for the next level */
+static void level_retire(mrp_engine *e, mrp_engine_level_state *L) {
+    if (!L) return;
+    mrp_context *ctx = e->ctx;
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->stream); /* before the buffers go back to the pool */
+    (void) hipStreamSynchronize(ctx->pre);
+    if (L->b) {
+        L->b->recycle();
+        e->spare.push_back(L->b);
+        L->b = nullptr;
+    }
+    L->seg.reset();
+    L->d_plan.release(); L->d_phmm.release(); L->d_dims.release(); L->d_tot.release(); L->d_base.release(); L->d_totals.release();
+    L->d_cc.release(); L->d_ph.release(); L->d_col_hmm.release(); L->d_nkept.release(); L->d_nkeptm.release(); L->d_err.release();
+    L->d_err_hmm.release(); L->d_kept.release(); L->d_keptm.release(); L->d_kept_np.release();
+    L->perm.clear();
+    L->x = nullptr; L->n = 0;
+    e->spare_levels.push_back(L);
+    ctx->pool.reclaim();
+}
 
 extern "C" {
 
@@ -98,18 +185,23 @@ int mrp_engine_create(mrp_context *ctx, const mrp_params *params, mrp_engine **o
     }
     e->leaf_part.pool = &ctx->pool;
     e->leaf_np.pool = &ctx->pool;
-    {
+    e->leaf_count.pool = &ctx->pool;
+    {   /* what the last engine of this context left behind */
         std::lock_guard<std::mutex> lock(ctx->sibling_mu);
-        e->spare = ctx->spare_batch;
-        ctx->spare_batch = nullptr;
+        if (ctx->spare_batch) { e->spare.push_back(ctx->spare_batch); ctx->spare_batch = nullptr; }
+        e->spare.insert(e->spare.end(), ctx->spare_batches.begin(), ctx->spare_batches.end());
+        ctx->spare_batches.clear();
+        e->spare_levels.swap(ctx->spare_levels);
     }
     hipError_t he = e->leaf_part.alloc(4);
     if (he == hipSuccess) he = e->leaf_np.alloc(4);
+    if (he == hipSuccess) he = e->leaf_count.alloc(4);
     const uint64_t lp[4] = {1, 0, 0, 0}; /* stRPHmm_construct hmm.c:97-133 */
     const uint32_t ln[4] = {0, 0, 0, 0};
+    const int32_t lc[4] = {2, 0, 0, 0};  /* its single column has two cells */
     if (he == hipSuccess) he = hipMemcpy(e->leaf_part.p, lp, sizeof(lp), hipMemcpyHostToDevice);
     if (he == hipSuccess) he = hipMemcpy(e->leaf_np.p, ln, sizeof(ln), hipMemcpyHostToDevice);
-    for (int i = 0; i < 4 && he == hipSuccess; i++) he = hipEventCreate(&e->ev[i]);
+    if (he == hipSuccess) he = hipMemcpy(e->leaf_count.p, lc, sizeof(lc), hipMemcpyHostToDevice);
     if (he != hipSuccess) {
         mrp_engine_destroy(e);
         return mrp_set_error(MRP_ERR_HIP, "engine setup failed: %s", hipGetErrorString(he));
@@ -120,34 +212,40 @@ int mrp_engine_create(mrp_context *ctx, const mrp_params *params, mrp_engine **o
 
 void mrp_engine_destroy(mrp_engine *e) {
     if (!e) return;
-    (void) hipSetDevice(e->ctx->device);
-    const double t0 = eng_now();
-    (void) hipStreamSynchronize(e->ctx->stream);
-    const double t1 = eng_now();
-    for (auto &ev : e->ev)
-        if (ev) (void) hipEventDestroy(ev);
     mrp_context *ctx = e->ctx;
-    mrp_engine_level_abandon(e);
-    const double t2 = eng_now();
-    if (e->spare) { /* kept for the next engine of this context */
+    (void) hipSetDevice(ctx->device);
+    (void) hipStreamSynchronize(ctx->stream);
+    (void) hipStreamSynchronize(ctx->pre);
+    if (e->staged) { level_retire(e, e->staged); e->staged = nullptr; }
+    if (e->running) { level_retire(e, e->running); e->running = nullptr; }
+    {   /* kept for the next engine of this context */
         std::lock_guard<std::mutex> lock(ctx->sibling_mu);
-        if (!ctx->spare_batch) { ctx->spare_batch = e->spare; e->spare = nullptr; }
+        for (auto *L : e->spare_levels) ctx->spare_levels.push_back(L);
+        for (mrp_batch *b : e->spare) ctx->spare_batches.push_back(b);
     }
-    if (e->spare) mrp_batch_destroy(e->spare);
-    const double t3 = eng_now();
+    e->spare_levels.clear();
+    e->spare.clear();
     delete e;
-    const double t4 = eng_now();
     ctx->pool.reclaim();
-    if (getenv("MRP_TIMING"))
-        fprintf(stderr, "  engine destroy: sync %.1f ms, events %.1f, spare batch %.1f, segments %.1f, reclaim %.1f\n", t1 - t0, t2 - t1, t3 - t2, t4 - t3,
-                eng_now() - t4);
 }
+
+}  /* extern "C" */
+
+void mrp_engine_release_context_cache(mrp_context *ctx) {
+    for (auto *L : ctx->spare_levels) delete L;
+    ctx->spare_levels.clear();
+    for (mrp_batch *b : ctx->spare_batches) mrp_batch_destroy(b);
+    ctx->spare_batches.clear();
+}
+
+extern "C" {
 
 int32_t mrp_engine_stride(const mrp_engine *e) { return e->pp.S; }
 
-void mrp_engine_leaf(const mrp_engine *e, const uint64_t **part, const uint32_t **np) {
+void mrp_engine_leaf(const mrp_engine *e, const uint64_t **part, const uint32_t **np, const int32_t **n_cells) {
     *part = e->leaf_part.p;
     *np = e->leaf_np.p;
+    *n_cells = e->leaf_count.p;
 }
 
 void mrp_engine_get_stats(const mrp_engine *e, mrp_engine_stats *out) { *out = e->stats; }
@@ -167,319 +265,475 @@ int mrp_engine_sync(mrp_engine *e) {
 
 }  /* extern "C" */
 
-/* everything one level keeps between its launch and its completion */
-struct mrp_engine_level_state {
-    mrp_batch *b = nullptr;
-    std::unique_ptr<Segment> seg;
-    DevBuf<CrossCol> d_cc;
-    DevBuf<PruneHmm> d_ph;
-    DevBuf<int32_t> d_col_hmm, d_nkept, d_nkeptm, d_err, d_err_hmm;
-    DevBuf<uint16_t> d_kept, d_keptm;
-    DevBuf<uint32_t> d_kept_np;
-    /* results, in the context's page-locked staging buffer (so the copies are asynchronous) */
-    int32_t *nc = nullptr, *nm = nullptr, *err = nullptr, *err_hmm = nullptr;
-    std::vector<int32_t> perm; /* position in the (sorted) PruneHmm array -> index into x */
-    uint64_t *path_part = nullptr; /* final level */
-    double *fb = nullptr;
-    bool final_level = false;
-    unsigned long long clk[12] = {0};
-    mrp_xhmm *x = nullptr;
-    int64_t n = 0, total_cols = 0, level_cells = 0, level_merge = 0;
-    double t_begin = 0, t_launched = 0;
-    mrp_engine *owner = nullptr;
-    ~mrp_engine_level_state() {
-        if (!b) return;
-        mrp_context *ctx = b->ctx;
-        (void) hipSetDevice(ctx->device);
-        (void) hipStreamSynchronize(ctx->stream); /* before the buffers go back to the pool */
-        if (owner && !owner->spare) {
-            b->recycle();
-            owner->spare = b;
-        } else {
-            mrp_batch_destroy(b);
-        }
-        ctx->pool.reclaim();
-    }
-};
+/* static upper bound of the cells one side contributes to a cross product column: a pruned column has at most S cells,
+ * and never more than the bipartitions of its reads */
+static inline int64_t side_bound(int depth, int S) { return depth >= 7 ? S : std::min<int64_t>(S, (int64_t) 1 << depth); }
 
-static void mrp_engine_level_abandon(mrp_engine *e) {
-    delete e->cur;
-    e->cur = nullptr;
-}
-
-extern "C" {
-
-
-static int level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) {
+/* ---- stage: the static description of a level, built and uploaded while the level before runs ---- */
+static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) {
     if (!e || n < 0 || (n > 0 && !x)) return mrp_set_error(MRP_ERR_ARG, "mrp_engine_level: bad arguments");
-    if (e->cur) return mrp_set_error(MRP_ERR_ARG, "mrp_engine_level_begin: the previous level was not completed");
+    if (e->staged) return mrp_set_error(MRP_ERR_ARG, "mrp_engine_level_stage: a staged level was not launched");
     if (n == 0) return MRP_OK;
     mrp_context *ctx = e->ctx;
     ENG_TRY(hipSetDevice(ctx->device));
-    hipStream_t s = ctx->stream;
+    hipStream_t cs = ctx->pre; /* copy stream: nothing here depends on the kernels in flight */
     const int S = e->pp.S;
-    const bool inv = e->params.include_inverted_partitions != 0;
-    std::unique_ptr<mrp_engine_level_state> L(new (std::nothrow) mrp_engine_level_state());
+    std::unique_ptr<mrp_engine_level_state> L;
+    if (!e->spare_levels.empty()) { L.reset(e->spare_levels.back()); e->spare_levels.pop_back(); }
+    else L.reset(new (std::nothrow) mrp_engine_level_state());
     if (!L) return mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
     L->t_begin = eng_now();
     L->x = x;
     L->n = n;
-
-    int64_t total_cols = 0;
-    for (int64_t i = 0; i < n; i++) {
-        if (x[i].n_cols < 1 || !x[i].cols || !x[i].n_cells || (!final_level && !x[i].n_merge)) return mrp_set_error(MRP_ERR_ARG, "mrp_engine_level: bad hmm %lld", (long long) i);
-        total_cols += x[i].n_cols;
-        for (int k = 0; k < x[i].n_cols; k++) { /* range checks the kernels rely on */
-            const mrp_xcol &c = x[i].cols[k];
-            const int64_t C = (int64_t) c.C1 * c.C2, M = (int64_t) c.Ma * c.Mb;
-            if (C < 1 || C > MRP_PRUNE_MAX_CELLS) return mrp_set_error(MRP_ERR_UNSUPPORTED, "cross product column with %lld cells", (long long) C);
-            if (k + 1 < x[i].n_cols && (M < 1 || M > MRP_PRUNE_MAX_CELLS)) return mrp_set_error(MRP_ERR_UNSUPPORTED, "cross product merge column with %lld cells", (long long) M);
-        }
+    L->final_level = final_level;
+    if (!L->uploaded) {
+        ENG_TRY(hipEventCreateWithFlags(&L->uploaded, hipEventDisableTiming));
+        for (auto &ev : L->ev) ENG_TRY(hipEventCreate(&ev));
     }
+
+    /* sizes that do not depend on counts */
+    std::vector<int64_t> col0((size_t) n + 1), read0((size_t) n + 1), slot0((size_t) n + 1);
+    int64_t total_cols = 0, total_reads = 0, total_slots = 0;
+    for (int64_t i = 0; i < n; i++) {
+        const mrp_xhmm &h = x[i];
+        if (h.n_cols < 1 || !h.cols || !h.col_ref_start || !h.col_length || !h.col_depth || !h.col_read_off || !h.chunk)
+            return mrp_set_error(MRP_ERR_ARG, "mrp_engine_level: bad hmm %lld", (long long) i);
+        if (h.chunk->ctx->device != ctx->device) return mrp_set_error(MRP_ERR_ARG, "chunk missing or on a different device");
+        col0[(size_t) i] = total_cols; read0[(size_t) i] = total_reads;
+        total_cols += h.n_cols;
+        total_reads += h.col_read_off[h.n_cols];
+    }
+    col0[(size_t) n] = total_cols;
+    if (total_cols > 0x7FFFFFFFll) return mrp_set_error(MRP_ERR_UNSUPPORTED, "level with %lld columns", (long long) total_cols);
     L->total_cols = total_cols;
-    ENG_TRY(hipStreamSynchronize(s)); /* nothing of an earlier level or sweep is in flight: */
-    ctx->pool.reclaim();              /* blocks released since then can be reused */
+    L->n_reads = total_reads;
+
+    if (e->spare.empty()) {
+        mrp_batch *nb = nullptr;
+        int rc = mrp_batch_create(ctx, &nb);
+        if (rc != MRP_OK) return rc;
+        L->b = nb;
+    } else {
+        L->b = e->spare.back();
+        e->spare.pop_back();
+    }
+    mrp_batch *b = L->b;
+    b->resident = true;
+    /* chunk table */
+    std::vector<int32_t> chunk_index((size_t) n);
+    for (int64_t i = 0; i < n; i++) {
+        const mrp_chunk *ch = x[i].chunk;
+        int idx = -1;
+        if (!b->chunks.empty() && b->chunks.back() == ch) idx = (int) b->chunks.size() - 1;
+        for (size_t c = 0; idx < 0 && c < b->chunks.size(); c++)
+            if (b->chunks[c] == ch) idx = (int) c;
+        if (idx < 0) { idx = (int) b->chunks.size(); b->chunks.push_back(ch); }
+        chunk_index[(size_t) i] = idx;
+    }
+    /* pass 1 (parallel): allele slots per hmm, static bounds, validity */
+    struct Bound { int64_t slots, cells, merge; int32_t max_cells, max_merge; int64_t cost; int bad; };
+    std::vector<Bound> bd((size_t) n);
+    mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
+        const mrp_xhmm &h = x[i];
+        const mrp_chunk *ch = h.chunk;
+        const bool anc = (h.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
+        Bound q{0, 0, 0, 1, 1, 0, 0};
+        for (int k = 0; k < h.n_cols && !q.bad; k++) {
+            const mrp_xcol &c = h.cols[k];
+            const int32_t st = h.col_ref_start[k], ln = h.col_length[k], dp = h.col_depth[k];
+            if (ln < 1 || st < 0 || (int64_t) st + ln > ch->n_sites || dp < 0 || dp > MRP_MAX_READ_PARTITIONING_DEPTH ||
+                h.col_read_off[k + 1] - h.col_read_off[k] != dp || (int) c.d1 + (int) c.d2 != dp) { q.bad = 1; break; }
+            q.slots += ch->allele_offset[st + ln] - ch->allele_offset[st];
+            const int64_t C = side_bound(c.d1, S) * side_bound(c.d2, S);
+            q.cells += C;
+            q.max_cells = (int32_t) std::max<int64_t>(q.max_cells, C);
+            if (k + 1 < h.n_cols) {
+                const int64_t Ma = c.out_a == MRP_CONN_ZERO ? 1 : side_bound(c.d1, S), Mb = c.out_b == MRP_CONN_ZERO ? 1 : side_bound(c.d2, S);
+                q.merge += Ma * Mb;
+                q.max_merge = (int32_t) std::max<int64_t>(q.max_merge, Ma * Mb);
+            }
+            int64_t per_site = 255ll * dp;
+            if (anc) {
+                per_site += 2ll * ch->max_sub + ch->max_prior;
+                for (int s2 = 0; s2 < ln; s2++)
+                    if (ch->allele_number[st + s2] > MRP_MAX_ALLELES) q.bad = 2;
+            }
+            q.cost += per_site * ln;
+        }
+        bd[(size_t) i] = q;
+    });
+    for (int64_t i = 0; i < n; i++) {
+        const Bound &q = bd[(size_t) i];
+        if (q.bad == 1) return mrp_set_error(MRP_ERR_ARG, "device-resident hmm %lld: inconsistent column description", (long long) i);
+        if (q.bad == 2 || q.max_cells > MRP_PRUNE_MAX_CELLS || q.max_merge > MRP_PRUNE_MAX_CELLS || q.cells >= (1ll << 30) || q.cost >= (1ll << 30))
+            return mrp_set_error(MRP_ERR_UNSUPPORTED, "device-resident hmm %lld is outside the kernels' range", (long long) i);
+        slot0[(size_t) i] = total_slots;
+        total_slots += q.slots;
+    }
+    L->n_slots = total_slots;
+
+    /* the level's output: the pruned hmms, fixed stride (the final level keeps one traced-back cell per column) */
     L->seg.reset(new (std::nothrow) Segment());
     if (!L->seg) return mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
     Segment *seg = L->seg.get();
-    seg->part.pool = &ctx->pool;
-    seg->np.pool = &ctx->pool;
-    seg->n_cells.pool = seg->n_merge.pool = &ctx->pool;
-    const int64_t out_stride = final_level ? 1 : S; /* the final level keeps one traced-back cell per column */
+    DevPool *pl = &ctx->pool;
+    seg->part.pool = pl; seg->np.pool = pl; seg->n_cells.pool = seg->n_merge.pool = pl;
+    const int64_t out_stride = final_level ? 1 : S;
     ENG_TRY(seg->part.alloc((size_t) (total_cols * out_stride)));
     ENG_TRY(seg->np.alloc((size_t) (final_level ? 1 : total_cols * S)));
     ENG_TRY(seg->n_cells.alloc((size_t) total_cols));
     ENG_TRY(seg->n_merge.alloc((size_t) total_cols));
 
-    const double tA = eng_now();
-    int rc = MRP_OK;
-    L->owner = e;
-    if (e->spare) { L->b = e->spare; e->spare = nullptr; }
-    else rc = mrp_batch_create(ctx, &L->b);
-    if (rc != MRP_OK) return rc;
-    mrp_batch *b = L->b;
-    std::vector<int64_t> cell0((size_t) n), col0((size_t) n);
-    rc = mrp_batch_add_resident_bulk(b, n, x, cell0.data(), col0.data());
-    if (rc != MRP_OK) return rc;
-    const double tB = eng_now();
-    HostVec<CrossCol> cc((size_t) total_cols); /* filled entirely below */
-    HostVec<PruneHmm> ph((size_t) n);
-    HostVec<int32_t> col_hmm((size_t) total_cols);
+    /* host staging: one page-locked block holding every array that is uploaded */
+    auto al = [](size_t v) { return (v + 63) & ~(size_t) 63; };
+    const size_t o_plan = 0, o_phmm = o_plan + al(sizeof(PlanCol) * (size_t) total_cols), o_ph = o_phmm + al(sizeof(PlanHmm) * (size_t) n),
+                 o_colhmm = o_ph + al(sizeof(PruneHmm) * (size_t) n), o_rbo = o_colhmm + al(4 * (size_t) total_cols),
+                 o_pack = o_rbo + al(8 * (size_t) total_reads), o_plane = o_pack + al(4 * (size_t) total_cols),
+                 o_ow = o_plane + al(4 * (size_t) total_cols), o_om = o_ow + al(4 * (size_t) n), o_on = o_om + al(4 * (size_t) n),
+                 o_chunks = o_on + al(4 * (size_t) n), o_end = o_chunks + al(sizeof(DevChunk) * b->chunks.size());
+    ENG_TRY(L->stage.reserve(o_end));
+    char *hb = (char *) L->stage.p;
+    PlanCol *plan = (PlanCol *) (hb + o_plan);
+    PlanHmm *phmm = (PlanHmm *) (hb + o_phmm);
+    PruneHmm *ph = (PruneHmm *) (hb + o_ph);
+    int32_t *col_hmm = (int32_t *) (hb + o_colhmm);
+    int64_t *rbo = (int64_t *) (hb + o_rbo);
+    int32_t *pack_list = (int32_t *) (hb + o_pack), *plane_list = (int32_t *) (hb + o_plane);
+    int32_t *ord_w = (int32_t *) (hb + o_ow), *ord_m = (int32_t *) (hb + o_om), *ord_n = (int32_t *) (hb + o_on);
+    DevChunk *hchunks = (DevChunk *) (hb + o_chunks);
+    for (size_t c = 0; c < b->chunks.size(); c++) hchunks[c] = b->chunks[c]->dev;
+
+    /* pass 2 (parallel): the plan */
     mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
         mrp_xhmm &h = x[i];
+        const mrp_chunk *ch = h.chunk;
         const int K = h.n_cols;
+        const bool anc = (h.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
         const int64_t colbase = col0[(size_t) i];
-        int64_t c_off = cell0[(size_t) i];
+        int64_t s_off = slot0[(size_t) i];
         for (int k = 0; k < K; k++) {
             const mrp_xcol &c = h.cols[k];
-            CrossCol &o = cc[(size_t) (colbase + k)];
-            memset(&o, 0, sizeof(o));
+            PlanCol &o = plan[colbase + k];
             o.a_part = c.a_part; o.b_part = c.b_part; o.a_np = c.a_np; o.b_np = c.b_np;
-            o.x_cell_off = c_off;
-            c_off += (int64_t) c.C1 * c.C2;
-            o.C1 = c.C1; o.C2 = c.C2; o.d1 = c.d1; o.d2 = c.d2;
-            uint8_t fl = inv ? MRP_XF_INVERTED : 0;
-            if (k + 1 < K) {
-                o.Ma = c.Ma; o.Mb = c.Mb; o.out_a = c.out_a; o.out_b = c.out_b;
-                if (c.out_a_paired) fl |= MRP_XF_OUT_A_PAIRED;
-                if (c.out_b_paired) fl |= MRP_XF_OUT_B_PAIRED;
-            }
-            if (k > 0) {
-                const mrp_xcol &q = h.cols[k - 1];
-                o.Pa = q.Ma; o.Pb = q.Mb; o.in_a = q.out_a; o.in_b = q.out_b;
-                if (q.out_a_paired) fl |= MRP_XF_IN_A_PAIRED;
-                if (q.out_b_paired) fl |= MRP_XF_IN_B_PAIRED;
-            }
-            o.flags = fl;
-            col_hmm[(size_t) (colbase + k)] = (int32_t) i;
+            o.a_ncells = c.a_ncells; o.b_ncells = c.b_ncells; o.a_nmerge = c.a_nmerge; o.b_nmerge = c.b_nmerge;
+            o.read_off = read0[(size_t) i] + h.col_read_off[k];
+            o.slot_off = s_off;
+            o.site_start = h.col_ref_start[k]; o.n_sites = h.col_length[k]; o.depth = h.col_depth[k];
+            o.n_slots = (int32_t) (ch->allele_offset[o.site_start + o.n_sites] - ch->allele_offset[o.site_start]);
+            s_off += o.n_slots;
+            o.chunk = chunk_index[(size_t) i];
+            int32_t uniform = (int32_t) ch->allele_number[o.site_start];
+            for (int s2 = 1; s2 < o.n_sites; s2++)
+                if ((int32_t) ch->allele_number[o.site_start + s2] != uniform) uniform = 0;
+            o.uniform_alleles = uniform;
+            o.d1 = c.d1; o.d2 = c.d2; o.out_a = c.out_a; o.out_b = c.out_b;
+            o.out_a_paired = c.out_a_paired; o.out_b_paired = c.out_b_paired;
+            o.need_planes = (uniform == 0 || anc) ? 1 : 0;
+            o.last = k + 1 == K ? 1 : 0;
+            o.pad = 0;
         }
-        PruneHmm &p = ph[(size_t) i];
-        p.col0 = colbase;
-        p.n_cols = K;
-        p.hmm_index = (int32_t) i;
-        p.out_part = seg->part.p + colbase * out_stride;
-        p.out_np = final_level ? seg->np.p : seg->np.p + colbase * S;
-        p.out_n_cells = seg->n_cells.p + colbase;
-        p.out_n_merge = seg->n_merge.p + colbase;
-        h.d_part = p.out_part; h.d_np = p.out_np;
+        PlanHmm &p = phmm[i];
+        p.col0 = colbase; p.n_cols = K; p.flags = h.flags; p.cost_bound = bd[(size_t) i].cost;
+        if (h.col_read_off[K] > 0) memcpy(rbo + read0[(size_t) i], h.read_byte_off, sizeof(int64_t) * (size_t) h.col_read_off[K]);
+        PruneHmm &q = ph[i];
+        q.col0 = colbase; q.n_cols = K; q.hmm_index = (int32_t) i;
+        q.out_part = seg->part.p + colbase * out_stride;
+        q.out_np = final_level ? seg->np.p : seg->np.p + colbase * S;
+        q.out_n_cells = seg->n_cells.p + colbase;
+        q.out_n_merge = seg->n_merge.p + colbase;
+        h.d_part = q.out_part; h.d_np = q.out_np; h.d_ncells = q.out_n_cells; h.d_nmerge = q.out_n_merge;
+        h.err = 0;
     });
-    L->level_cells = b->stats.n_cells;
-    L->level_merge = b->stats.n_merge_cells;
-    /* the prune kernel walks one hmm per workgroup and its columns one after the other: longest hmms first, so that the
-     * launch does not end with a long chain that started late */
+    /* packing lists (columns of the fast emission path / those that need bit planes) */
+    int64_t n_pack = 0, n_plane = 0;
+    for (int64_t c = 0; c < total_cols; c++) {
+        if (plan[c].need_planes) plane_list[n_plane++] = (int32_t) c;
+        else pack_list[n_pack++] = (int32_t) c;
+    }
+    /* launch classes of the recursion kernel, from the static bounds; largest first inside a class */
+    b->order_wide.clear(); b->order_mid.clear(); b->order_narrow.clear(); b->order_f64.clear();
+    b->max_merge_wide = b->max_merge_mid = b->max_merge_narrow = 1;
     {
-        std::vector<int32_t> perm((size_t) n), pos((size_t) n);
-        for (int64_t i = 0; i < n; i++) perm[(size_t) i] = (int32_t) i;
-        std::stable_sort(perm.begin(), perm.end(), [&](int32_t a, int32_t c) { return ph[(size_t) a].n_cols > ph[(size_t) c].n_cols; });
-        HostVec<PruneHmm> sorted((size_t) n);
-        for (int64_t j = 0; j < n; j++) { sorted[(size_t) j] = ph[(size_t) perm[(size_t) j]]; pos[(size_t) perm[(size_t) j]] = (int32_t) j; }
-        ph.swap(sorted);
-        L->perm.swap(perm);
-        mrp_parallel_for(total_cols, 65536, [&](int64_t c) { col_hmm[(size_t) c] = pos[(size_t) col_hmm[(size_t) c]]; });
-    }
-
-    const double tC = eng_now();
-    rc = mrp_batch_upload(b);
-    if (rc != MRP_OK) return rc;
-    const double tD = eng_now();
-    PruneParams pp = e->pp;
-    pp.max_cells = 1; pp.max_merge = 1;
-    pp.pad = (e->params.reserved & 1) && e->stats.levels == 1 ? 1 : 0; /* test hook, see mrp_params.reserved */
-    for (size_t i = 0; i < b->hmms.size(); i++) {
-        if (!b->outs[i].int_path) return mrp_set_error(MRP_ERR_UNSUPPORTED, "cross product hmm outside the int32 recursion kernel's range");
-        pp.max_cells = std::max(pp.max_cells, b->hmms[i].max_cells);
-        pp.max_merge = std::max(pp.max_merge, b->hmms[i].max_merge);
-    }
-    if (getenv("MRP_TIMING")) {
-        int64_t ns = 0, cs = 0, nb2 = 0, cb = 0, longest_s = 0, longest_b = 0;
-        for (size_t i = 0; i < b->hmms.size(); i++) {
-            if (b->hmms[i].max_cells <= 4096) { ns++; cs += b->hmms[i].n_cols; longest_s = std::max<int64_t>(longest_s, b->hmms[i].n_cols); }
-            else { nb2++; cb += b->hmms[i].n_cols; longest_b = std::max<int64_t>(longest_b, b->hmms[i].n_cols); }
+        std::vector<std::pair<int64_t, int32_t>> wide, mid, narrow;
+        for (int64_t i = 0; i < n; i++) {
+            const Bound &q = bd[(size_t) i];
+            if (q.max_cells <= 256) narrow.push_back({-q.cells, (int32_t) i});
+            else if (q.max_merge <= 4096) mid.push_back({-q.cells, (int32_t) i});
+            else wide.push_back({-q.cells, (int32_t) i});
         }
-        fprintf(stderr, "    prune classes: <=4096 cells/column: %lld hmms %lld cols (longest %lld); larger: %lld hmms %lld cols (longest %lld)\n",
-                (long long) ns, (long long) cs, (long long) longest_s, (long long) nb2, (long long) cb, (long long) longest_b);
+        auto plan_class = [&](std::vector<std::pair<int64_t, int32_t>> &v, std::vector<int32_t> &order, int32_t *dst, int *mm) {
+            std::sort(v.begin(), v.end());
+            int m = 1;
+            for (size_t j = 0; j < v.size(); j++) {
+                order.push_back(v[j].second);
+                dst[j] = v[j].second;
+                m = std::max(m, bd[(size_t) v[j].second].max_merge);
+            }
+            *mm = m;
+        };
+        plan_class(wide, b->order_wide, ord_w, &b->max_merge_wide);
+        plan_class(mid, b->order_mid, ord_m, &b->max_merge_mid);
+        plan_class(narrow, b->order_narrow, ord_n, &b->max_merge_narrow);
     }
-    DevPool *pl = &ctx->pool;
+    /* the prune kernel walks one hmm per workgroup, its columns one after the other: longest hmms first */
+    {
+        L->perm.resize((size_t) n);
+        std::vector<int32_t> pos((size_t) n);
+        for (int64_t i = 0; i < n; i++) L->perm[(size_t) i] = (int32_t) i;
+        std::stable_sort(L->perm.begin(), L->perm.end(), [&](int32_t a, int32_t c) { return x[a].n_cols > x[c].n_cols; });
+        std::vector<PruneHmm> sorted((size_t) n);
+        for (int64_t j = 0; j < n; j++) { sorted[(size_t) j] = ph[L->perm[(size_t) j]]; pos[(size_t) L->perm[(size_t) j]] = (int32_t) j; }
+        memcpy(ph, sorted.data(), sizeof(PruneHmm) * (size_t) n);
+        mrp_parallel_for(n, std::max<int64_t>(1, n / 64), [&](int64_t i) {
+            for (int64_t c = col0[(size_t) i]; c < col0[(size_t) i + 1]; c++) col_hmm[c] = pos[(size_t) i];
+        });
+    }
+    PruneParams &pp = L->pp;
+    pp = e->pp;
+    pp.max_cells = 1; pp.max_merge = 1;
+    for (int64_t i = 0; i < n; i++) {
+        pp.max_cells = std::max(pp.max_cells, bd[(size_t) i].max_cells);
+        pp.max_merge = std::max(pp.max_merge, bd[(size_t) i].max_merge);
+    }
+    pp.pad = (e->params.reserved & 1) && e->stats.levels + (e->running ? 1 : 0) == 1 ? 1 : 0; /* test hook, see mrp_params.reserved */
+
+    /* device side of the description + the descriptor arrays the layout kernels fill */
+    b->bind_pool(pl);
+    L->d_plan.pool = pl; L->d_phmm.pool = pl; L->d_dims.pool = pl; L->d_tot.pool = pl; L->d_base.pool = pl; L->d_totals.pool = pl;
     L->d_cc.pool = pl; L->d_ph.pool = pl; L->d_col_hmm.pool = L->d_nkept.pool = L->d_nkeptm.pool = L->d_err.pool = L->d_err_hmm.pool = pl;
     L->d_kept.pool = L->d_keptm.pool = pl; L->d_kept_np.pool = pl;
-    ENG_TRY(L->d_cc.upload(cc, s));
-    ENG_TRY(L->d_ph.upload(ph, s));
-    ENG_TRY(L->d_col_hmm.upload(col_hmm, s));
-    if (!final_level) {
+    ENG_TRY(L->d_plan.alloc((size_t) total_cols)); ENG_TRY(L->d_phmm.alloc((size_t) n)); ENG_TRY(L->d_dims.alloc(4 * (size_t) total_cols));
+    ENG_TRY(L->d_tot.alloc((size_t) n)); ENG_TRY(L->d_base.alloc((size_t) n)); ENG_TRY(L->d_totals.alloc(8));
+    ENG_TRY(L->d_cc.alloc((size_t) total_cols)); ENG_TRY(L->d_ph.alloc((size_t) n)); ENG_TRY(L->d_col_hmm.alloc((size_t) total_cols));
+    ENG_TRY(L->d_err.alloc(64)); ENG_TRY(L->d_err_hmm.alloc((size_t) n));
+    ENG_TRY(b->d_hmms.alloc((size_t) n)); ENG_TRY(b->d_cols.alloc((size_t) total_cols)); ENG_TRY(b->d_scols.alloc((size_t) total_cols));
+    ENG_TRY(b->d_pcols.alloc((size_t) total_cols)); ENG_TRY(b->d_tilecols.alloc((size_t) total_cols));
+    ENG_TRY(b->d_chunks.alloc(b->chunks.size())); ENG_TRY(b->d_read_byte_off.alloc((size_t) total_reads));
+    ENG_TRY(b->d_pack_list.alloc((size_t) n_pack)); ENG_TRY(b->d_plane_list.alloc((size_t) n_plane));
+    ENG_TRY(b->d_order_wide.alloc(b->order_wide.size())); ENG_TRY(b->d_order_mid.alloc(b->order_mid.size()));
+    ENG_TRY(b->d_order_narrow.alloc(b->order_narrow.size())); ENG_TRY(b->d_order_f64.alloc(1));
+    auto up = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
+        return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs) : hipSuccess;
+    };
+    ENG_TRY(up(L->d_plan.p, plan, sizeof(PlanCol) * (size_t) total_cols));
+    ENG_TRY(up(L->d_phmm.p, phmm, sizeof(PlanHmm) * (size_t) n));
+    ENG_TRY(up(L->d_ph.p, ph, sizeof(PruneHmm) * (size_t) n));
+    ENG_TRY(up(L->d_col_hmm.p, col_hmm, 4 * (size_t) total_cols));
+    ENG_TRY(up(b->d_read_byte_off.p, rbo, 8 * (size_t) total_reads));
+    ENG_TRY(up(b->d_pack_list.p, pack_list, 4 * (size_t) n_pack));
+    ENG_TRY(up(b->d_plane_list.p, plane_list, 4 * (size_t) n_plane));
+    ENG_TRY(up(b->d_order_wide.p, ord_w, 4 * b->order_wide.size()));
+    ENG_TRY(up(b->d_order_mid.p, ord_m, 4 * b->order_mid.size()));
+    ENG_TRY(up(b->d_order_narrow.p, ord_n, 4 * b->order_narrow.size()));
+    ENG_TRY(up(b->d_chunks.p, hchunks, sizeof(DevChunk) * b->chunks.size()));
+    ENG_TRY(hipMemsetAsync(L->d_err.p, 0, 256, cs));
+    ENG_TRY(hipMemsetAsync(L->d_err_hmm.p, 0, sizeof(int32_t) * (size_t) n, cs));
+    ENG_TRY(hipEventRecord(L->uploaded, cs));
+    /* results come back into a second page-locked block */
+    {
+        const size_t cols8 = ((size_t) total_cols + 1) & ~(size_t) 1, n8 = ((size_t) n + 1) & ~(size_t) 1;
+        ENG_TRY(L->results.reserve(128 + n8 * 4 + (final_level ? cols8 * 8 + cols8 * 4 + (size_t) n * 16 : 0)));
+        char *rb = (char *) L->results.p;
+        L->totals = (int64_t *) rb;
+        L->err = (int32_t *) (rb + 64);
+        L->err_hmm = (int32_t *) (rb + 128);
+        L->path_part = (uint64_t *) (rb + 128 + n8 * 4);
+        L->fb = (double *) (rb + 128 + n8 * 4 + cols8 * 8);
+        L->path_cell = (int32_t *) (rb + 128 + n8 * 4 + cols8 * 8 + (size_t) n * 16);
+    }
+    b->stats.n_hmms = n;
+    b->stats.n_columns = total_cols;
+    L->t_staged = eng_now();
+    e->staged = L.release();
+    return MRP_OK;
+}
+
+/* ---- end: the per-hmm error flags of the running level (and the final level's results) ---- */
+static int level_finish(mrp_engine *e) {
+    if (!e->running) return MRP_OK;
+    mrp_engine_level_state *Lp = e->running;
+    e->running = nullptr;
+    mrp_context *ctx = e->ctx;
+    int rc = MRP_OK;
+    hipError_t se = hipSetDevice(ctx->device);
+    if (se == hipSuccess) se = hipStreamSynchronize(ctx->stream);
+    if (se != hipSuccess) rc = mrp_set_error(MRP_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(se));
+    if (rc == MRP_OK && getenv("MRP_TIMING")) {
+        fprintf(stderr, "  level: %lld hmms %lld cols %lld cells: staged in %.1f ms, launch (layout + totals + queue) %.1f ms\n", (long long) Lp->n,
+                (long long) Lp->total_cols, (long long) Lp->totals[0], Lp->t_staged - Lp->t_begin, Lp->t_launch_ms);
+#if defined(PRUNE_EXP_CLOCK) || defined(PRUNE_EXP_CLOCK2)
+        fprintf(stderr, "  prune clocks (first hmm; shader cycles):");
+        for (int i = 0; i < 12; i++) fprintf(stderr, " %llu", Lp->clk[i]);
+        fprintf(stderr, "\n");
+#endif
+    }
+    /* Per hmm: a parent outside the closed-form cross product's pair order, or a merge cell the kept cells lead to that
+     * hmm.c:1090-1100 would drop, means "not handled on the device": the caller redoes that hmm's chunk on the hashing path
+     * (whatever else the kernels flagged for it came from the discarded arrays).  Posterior / range violations on an hmm
+     * that is otherwise fine are the reference's st_errAbort cases. */
+    if (rc == MRP_OK && Lp->err[0] != 0) {
+        for (int64_t j = 0; j < Lp->n && rc == MRP_OK; j++) {
+            const int32_t bits = Lp->err_hmm[j];
+            if (bits == 0) continue;
+            Lp->x[(size_t) Lp->perm[(size_t) j]].err = bits;
+            if (bits & (MRP_ENGINE_ERR_STRUCTURE | MRP_ENGINE_ERR_MERGE)) continue;
+            if (bits & MRP_ENGINE_ERR_POSTERIOR) rc = mrp_set_error(MRP_ERR_ARG, "ERROR: invalid prob (f + b exceeds the column total)");
+            else rc = mrp_set_error(MRP_ERR_LOOKUP, "device-resident merge: transition index out of range");
+        }
+    }
+    if (rc == MRP_OK && Lp->final_level) {
+        int64_t colbase = 0;
+        for (int64_t i = 0; i < Lp->n; i++) {
+            if (Lp->x[i].n_cells) memcpy(Lp->x[i].n_cells, Lp->path_cell + colbase, sizeof(int32_t) * (size_t) Lp->x[i].n_cols);
+            if (Lp->x[i].path_part) memcpy(Lp->x[i].path_part, Lp->path_part + colbase, sizeof(uint64_t) * (size_t) Lp->x[i].n_cols);
+            Lp->x[i].hmm_forward = Lp->fb[(size_t) (2 * i)];
+            Lp->x[i].hmm_backward = Lp->fb[(size_t) (2 * i + 1)];
+            colbase += Lp->x[i].n_cols;
+        }
+    }
+    if (rc == MRP_OK) {
+        float t_cross = 0, t_sweep = 0, t_prune = 0;
+        (void) hipEventElapsedTime(&t_cross, Lp->ev[0], Lp->ev[1]);
+        (void) hipEventElapsedTime(&t_sweep, Lp->ev[1], Lp->ev[2]);
+        (void) hipEventElapsedTime(&t_prune, Lp->ev[2], Lp->ev[3]);
+        e->stats.levels += 1;
+        e->stats.hmms += Lp->n;
+        e->stats.columns += Lp->total_cols;
+        e->stats.cells += Lp->totals[0];
+        e->stats.merge_cells += Lp->totals[1];
+        e->stats.cross_ms += t_cross;
+        e->stats.sweep_ms += t_sweep;
+        e->stats.prune_ms += t_prune;
+        e->stats.device_ms += t_cross + t_sweep + t_prune;
+        e->segments.push_back(std::move(Lp->seg));
+    }
+    level_retire(e, Lp);
+    return rc;
+}
+
+/* ---- launch: layout on the device, four totals back, allocation, the level's kernels ---- */
+static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
+    mrp_context *ctx = e->ctx;
+    ENG_TRY(hipSetDevice(ctx->device));
+    hipStream_t s = ctx->stream;
+    mrp_batch *b = L->b;
+    const int64_t n = L->n, total_cols = L->total_cols;
+    const double t0 = eng_now();
+    LayoutOut lo{};
+    lo.dims = L->d_dims.p; lo.tot = L->d_tot.p; lo.base = L->d_base.p; lo.totals = L->d_totals.p;
+    lo.hmms = b->d_hmms.p; lo.cols = b->d_cols.p; lo.scols = b->d_scols.p; lo.pcols = b->d_pcols.p; lo.tilecols = b->d_tilecols.p;
+    lo.ccols = L->d_cc.p;
+    ENG_TRY(hipStreamWaitEvent(s, L->uploaded, 0));
+    ENG_TRY(mrp_launch_layout(L->d_plan.p, L->d_phmm.p, n, total_cols, b->d_chunks.p, e->pp.S,
+                              e->params.include_inverted_partitions ? MRP_XF_INVERTED : 0u, lo, s));
+    ENG_TRY(hipMemcpyAsync(L->totals, L->d_totals.p, 32, hipMemcpyDeviceToHost, s));
+    /* the one host wait of a level: it also ends the level before (its error flags are in) */
+    int rc = level_finish(e);
+    if (rc != MRP_OK) return rc;
+    ENG_TRY(hipStreamSynchronize(s));
+    ctx->pool.reclaim(); /* the blocks of the level before can be reused */
+    const int64_t cells = L->totals[0], merge = L->totals[1], tiles_fast = L->totals[2], tiles = L->totals[2] + L->totals[3];
+    b->n_cells_total = cells; b->n_merge = merge; b->n_slots = L->n_slots; b->n_tiles_dev = tiles; b->n_fast_tiles = tiles_fast;
+    b->stats.n_cells = cells; b->stats.n_merge_cells = merge;
+    b->stats.algorithmic_bytes = 24 * cells + 32 * merge + 8 * total_cols;
+    const size_t nC = (size_t) cells;
+    ENG_TRY(b->d_partition.alloc(nC)); ENG_TRY(b->d_np.alloc(nC)); ENG_TRY(b->d_cost.alloc(nC));
+    ENG_TRY(b->d_f32.alloc(nC)); ENG_TRY(b->d_b32.alloc(nC));
+    ENG_TRY(b->d_mf32.alloc((size_t) merge)); ENG_TRY(b->d_mb32.alloc((size_t) merge));
+    ENG_TRY(b->d_tiles.alloc((size_t) tiles));
+    ENG_TRY(b->d_planes.alloc((size_t) L->n_slots * 8)); ENG_TRY(b->d_slot_total.alloc((size_t) L->n_slots));
+    ENG_TRY(b->d_slot_bytes.alloc((size_t) L->n_slots * 16));
+    ENG_TRY(b->d_total.alloc((size_t) total_cols)); ENG_TRY(b->d_hmm_fb.alloc(2 * (size_t) n));
+    MrpBatchDev &d = b->dev;
+    d = MrpBatchDev{};
+    d.hmms = b->d_hmms.p; d.cols = b->d_cols.p; d.chunks = b->d_chunks.p; d.read_byte_off = b->d_read_byte_off.p;
+    d.partition = b->d_partition.p; d.scols = b->d_scols.p; d.pcols = b->d_pcols.p;
+    d.pack_list = b->d_pack_list.p; d.plane_list = b->d_plane_list.p;
+    d.n_pack_list = (int64_t) b->d_pack_list.n; d.n_plane_list = (int64_t) b->d_plane_list.n;
+    d.cell_np = b->d_np.p; d.planes = b->d_planes.p; d.slot_total = b->d_slot_total.p; d.slot_bytes = b->d_slot_bytes.p;
+    d.cell_cost = b->d_cost.p; d.cell_f32 = b->d_f32.p; d.cell_b32 = b->d_b32.p; d.merge_f32 = b->d_mf32.p; d.merge_b32 = b->d_mb32.p;
+    d.col_total = b->d_total.p; d.hmm_fb = b->d_hmm_fb.p;
+    d.n_hmms = n; d.n_cols = total_cols; d.n_cells = cells; d.n_merge = merge; d.n_slots = L->n_slots;
+    b->uploaded = true;
+    b->outs.clear(); /* device-only */
+
+    const int S = e->pp.S;
+    if (!L->final_level) {
         ENG_TRY(L->d_kept.alloc((size_t) total_cols * S));
         ENG_TRY(L->d_keptm.alloc((size_t) total_cols * S));
         ENG_TRY(L->d_kept_np.alloc((size_t) total_cols * S));
         ENG_TRY(L->d_nkept.alloc((size_t) total_cols));
         ENG_TRY(L->d_nkeptm.alloc((size_t) total_cols));
     }
-    ENG_TRY(L->d_err.alloc(64));
-    ENG_TRY(hipMemsetAsync(L->d_err.p, 0, 256, s));
-    ENG_TRY(L->d_err_hmm.alloc((size_t) n));
-    ENG_TRY(hipMemsetAsync(L->d_err_hmm.p, 0, sizeof(int32_t) * (size_t) n, s));
     PruneScratch sc{};
     sc.kept = L->d_kept.p; sc.kept_np = L->d_kept_np.p; sc.keptm = L->d_keptm.p; sc.n_kept = L->d_nkept.p; sc.n_keptm = L->d_nkeptm.p;
     sc.err = L->d_err.p;
     sc.err_hmm = L->d_err_hmm.p;
-    /* the pageable host vectors above are read by the queued copies: wait for them before they go out of scope */
-    ENG_TRY(hipStreamSynchronize(s));
 
-    const double tE = eng_now();
-    ENG_TRY(hipEventRecord(e->ev[0], s));
+    Segment *seg = L->seg.get();
+    ENG_TRY(mrp_launch_tiles(b->d_cols.p, b->d_tilecols.p, total_cols, b->d_tiles.p, s));
+    ENG_TRY(hipEventRecord(L->ev[0], s));
     ENG_TRY(mrp_launch_cross(L->d_cc.p, total_cols, b->d_partition.p, b->d_np.p, L->d_err.p, L->d_col_hmm.p, L->d_err_hmm.p, s));
-    ENG_TRY(hipEventRecord(e->ev[1], s));
+    ENG_TRY(hipEventRecord(L->ev[1], s));
     rc = mrp_batch_launch(b);
     if (rc != MRP_OK) return rc;
-    ENG_TRY(hipEventRecord(e->ev[2], s));
-    if (final_level) {
+    ENG_TRY(hipEventRecord(L->ev[2], s));
+    if (L->final_level) {
         ENG_TRY(mrp_launch_traceback(b->dev, L->d_ph.p, n, L->d_err.p, L->d_err_hmm.p, s));
     } else {
-        ENG_TRY(mrp_launch_prune(b->dev, L->d_cc.p, L->d_ph.p, n, pp, sc, s));
-        ENG_TRY(mrp_launch_compact(b->dev, L->d_ph.p, L->d_col_hmm.p, total_cols, pp, sc, s));
+        ENG_TRY(mrp_launch_prune(b->dev, L->d_cc.p, L->d_ph.p, n, L->pp, sc, s));
+        ENG_TRY(mrp_launch_compact(b->dev, L->d_ph.p, L->d_col_hmm.p, total_cols, L->pp, sc, s));
     }
-    ENG_TRY(hipEventRecord(e->ev[3], s));
-    L->final_level = final_level;
-    {
-        const size_t cols8 = ((size_t) total_cols + 1) & ~(size_t) 1; /* keep the 8-byte arrays aligned */
-        const size_t n8 = ((size_t) n + 1) & ~(size_t) 1;
-        ENG_TRY(ctx->pinned_reserve(64 + cols8 * 4 * 2 + cols8 * 8 + (size_t) n * 16 + n8 * 4));
-        char *base = (char *) ctx->pinned;
-        L->err = (int32_t *) base;
-        L->path_part = (uint64_t *) (base + 64);
-        L->fb = (double *) (base + 64 + cols8 * 8);
-        L->nc = (int32_t *) (base + 64 + cols8 * 8 + (size_t) n * 16);
-        L->nm = L->nc + cols8;
-        L->err_hmm = L->nm + cols8;
-    }
-    ENG_TRY(hipMemcpyAsync(L->nc, seg->n_cells.p, sizeof(int32_t) * (size_t) total_cols, hipMemcpyDeviceToHost, s));
-    if (final_level) {
+    ENG_TRY(hipEventRecord(L->ev[3], s));
+    if (L->final_level) {
+        ENG_TRY(hipMemcpyAsync(L->path_cell, seg->n_cells.p, sizeof(int32_t) * (size_t) total_cols, hipMemcpyDeviceToHost, s));
         ENG_TRY(hipMemcpyAsync(L->path_part, seg->part.p, sizeof(uint64_t) * (size_t) total_cols, hipMemcpyDeviceToHost, s));
         ENG_TRY(hipMemcpyAsync(L->fb, b->dev.hmm_fb, sizeof(double) * (size_t) (2 * n), hipMemcpyDeviceToHost, s));
-    } else {
-        ENG_TRY(hipMemcpyAsync(L->nm, seg->n_merge.p, sizeof(int32_t) * (size_t) total_cols, hipMemcpyDeviceToHost, s));
     }
     ENG_TRY(hipMemcpyAsync(L->err, L->d_err.p, 16, hipMemcpyDeviceToHost, s));
     ENG_TRY(hipMemcpyAsync(L->err_hmm, L->d_err_hmm.p, sizeof(int32_t) * (size_t) n, hipMemcpyDeviceToHost, s));
 #if defined(PRUNE_EXP_CLOCK) || defined(PRUNE_EXP_CLOCK2)
     ENG_TRY(hipMemcpyAsync(L->clk, L->d_err.p + 4, 96, hipMemcpyDeviceToHost, s));
 #endif
-    L->t_launched = eng_now();
-    if (getenv("MRP_TIMING"))
-        fprintf(stderr, "    begin: checks+segment %.1f ms, bulk add %.1f, cross descriptors %.1f, batch upload %.1f, engine upload %.1f, launches %.1f\n",
-                tA - L->t_begin, tB - tA, tC - tB, tD - tC, tE - tD, L->t_launched - tE);
-    e->cur = L.release();
+    L->t_launch_ms = eng_now() - t0;
     return MRP_OK;
 }
 
+static int level_launch(mrp_engine *e) {
+    if (!e->staged) return level_finish(e); /* an empty level still ends the one before */
+    mrp_engine_level_state *L = e->staged;
+    e->staged = nullptr;
+    int rc = level_launch_impl(e, L);
+    if (rc != MRP_OK) { level_retire(e, L); return rc; }
+    e->running = L;
+    return MRP_OK;
+}
+
+extern "C" {
+
+int mrp_engine_level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x) { return level_stage(e, n, x, false); }
+int mrp_engine_final_stage(mrp_engine *e, int64_t n, mrp_xhmm *x) { return level_stage(e, n, x, true); }
+int mrp_engine_level_launch(mrp_engine *e) { return level_launch(e); }
 int mrp_engine_level_end(mrp_engine *e) {
     if (!e) return mrp_set_error(MRP_ERR_ARG, "mrp_engine_level_end: NULL engine");
-    if (!e->cur) return MRP_OK; /* an empty level */
-    std::unique_ptr<mrp_engine_level_state> L(e->cur);
-    e->cur = nullptr;
-    mrp_context *ctx = e->ctx;
-    ENG_TRY(hipSetDevice(ctx->device));
-    ENG_TRY(hipStreamSynchronize(ctx->stream));
-    if (getenv("MRP_TIMING"))
-        fprintf(stderr, "  level: %lld hmms %lld cols %lld cells: host build + upload %.1f ms, kernels (after launch) %.1f ms\n",
-                (long long) L->n, (long long) L->total_cols, (long long) L->level_cells, L->t_launched - L->t_begin, eng_now() - L->t_launched);
-#if defined(PRUNE_EXP_CLOCK) || defined(PRUNE_EXP_CLOCK2)
-    fprintf(stderr, "  prune clocks (first hmm; work, wait per role: chain, lists 1, lists 2, tables, bins group 0, bins group 1; shader cycles):");
-    for (int i = 0; i < 12; i++) fprintf(stderr, " %llu", L->clk[i]);
-    fprintf(stderr, "\n");
-#endif
-    /* Per hmm: a parent outside the closed-form cross product's pair order, or a merge cell the kept cells lead to that
-     * hmm.c:1090-1100 would drop, means "not handled on the device": the caller redoes that hmm's chunk on the hashing path
-     * (whatever else the kernels flagged for it came from the discarded arrays).  Posterior / range violations on an hmm
-     * that is otherwise fine are the reference's st_errAbort cases. */
-    for (int64_t i = 0; i < L->n; i++) L->x[i].err = 0;
-    if (L->err[0] != 0) {
-        for (int64_t j = 0; j < L->n; j++) {
-            const int32_t bits = L->err_hmm[j];
-            if (bits == 0) continue;
-            L->x[(size_t) L->perm[(size_t) j]].err = bits;
-            if (bits & (MRP_ENGINE_ERR_STRUCTURE | MRP_ENGINE_ERR_MERGE)) continue;
-            if (bits & MRP_ENGINE_ERR_POSTERIOR) return mrp_set_error(MRP_ERR_ARG, "ERROR: invalid prob (f + b exceeds the column total)");
-            return mrp_set_error(MRP_ERR_LOOKUP, "device-resident merge: transition index out of range");
-        }
-    }
-    int64_t colbase = 0;
-    for (int64_t i = 0; i < L->n; i++) {
-        memcpy(L->x[i].n_cells, L->nc + colbase, sizeof(int32_t) * (size_t) L->x[i].n_cols);
-        if (L->final_level) {
-            if (L->x[i].path_part) memcpy(L->x[i].path_part, L->path_part + colbase, sizeof(uint64_t) * (size_t) L->x[i].n_cols);
-            L->x[i].hmm_forward = L->fb[(size_t) (2 * i)];
-            L->x[i].hmm_backward = L->fb[(size_t) (2 * i + 1)];
-        } else {
-            memcpy(L->x[i].n_merge, L->nm + colbase, sizeof(int32_t) * (size_t) L->x[i].n_cols);
-        }
-        colbase += L->x[i].n_cols;
-    }
-    float t_cross = 0, t_sweep = 0, t_prune = 0;
-    ENG_TRY(hipEventElapsedTime(&t_cross, e->ev[0], e->ev[1]));
-    ENG_TRY(hipEventElapsedTime(&t_sweep, e->ev[1], e->ev[2]));
-    ENG_TRY(hipEventElapsedTime(&t_prune, e->ev[2], e->ev[3]));
-    e->stats.levels += 1;
-    e->stats.hmms += L->n;
-    e->stats.columns += L->total_cols;
-    e->stats.cells += L->level_cells;
-    e->stats.merge_cells += L->level_merge;
-    e->stats.cross_ms += t_cross;
-    e->stats.sweep_ms += t_sweep;
-    e->stats.prune_ms += t_prune;
-    e->stats.device_ms += t_cross + t_sweep + t_prune;
-    e->segments.push_back(std::move(L->seg));
-    return MRP_OK;
+    return level_finish(e);
 }
 
-int mrp_engine_level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x) { return level_begin(e, n, x, false); }
+int mrp_engine_level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x) {
+    int rc = level_stage(e, n, x, false);
+    if (rc == MRP_OK) rc = level_launch(e);
+    return rc;
+}
 
 int mrp_engine_level(mrp_engine *e, int64_t n, mrp_xhmm *x) {
-    int rc = level_begin(e, n, x, false);
+    int rc = mrp_engine_level_begin(e, n, x);
     if (rc == MRP_OK) rc = mrp_engine_level_end(e);
     return rc;
 }
 
 int mrp_engine_final(mrp_engine *e, int64_t n, mrp_xhmm *x) {
-    int rc = level_begin(e, n, x, true);
+    int rc = level_stage(e, n, x, true);
+    if (rc == MRP_OK) rc = level_launch(e);
     if (rc == MRP_OK) rc = mrp_engine_level_end(e);
     return rc;
 }

@@ -43,6 +43,56 @@ struct CrossCol {
     uint8_t pad;
 };
 
+/* ---- layout of a level on the device ------------------------------------------------------------------------
+ * The host describes a level by what does not depend on any forward/backward result: the column structure of the cross
+ * products (sites, reads, connector kinds, masks) and WHERE the parents' per-column cell / merge cell counts will be
+ * found in HBM once the level that produces them has run.  The sizes of the cross product columns (C1 x C2 cells,
+ * Ma x Mb merge cells), every offset derived from them and all kernel descriptors are computed here, on the device;
+ * the host reads back four totals per level (what its allocator needs). */
+struct PlanCol {
+    const uint64_t *a_part, *b_part;    /* parents' cells (NULL = gap column: one cell, partition 0) */
+    const uint32_t *a_np, *b_np;
+    const int32_t *a_ncells, *b_ncells; /* device: cells of the parent column (NULL = 1) */
+    const int32_t *a_nmerge, *b_nmerge; /* device: merge cells of the parent's merge column after it (REAL connectors) */
+    int64_t read_off;                   /* first entry of the column in the batch's read_byte_off */
+    int64_t slot_off;                   /* first allele slot of the column in the batch */
+    int32_t site_start, n_sites, depth, n_slots;
+    int32_t chunk;                      /* index into the batch's DevChunk table */
+    int32_t uniform_alleles;            /* allele count shared by the column's sites, 0 if they differ */
+    uint8_t d1, d2, out_a, out_b;       /* depth per side, connector kinds out of the column (MRP_CONN_*) */
+    uint8_t out_a_paired, out_b_paired, need_planes, last; /* last: last column of its hmm */
+    uint32_t pad;
+};
+struct PlanHmm {
+    int64_t col0;        /* first column of the hmm in the level */
+    int32_t n_cols;
+    uint32_t flags;      /* MRP_FLAG_* of the sweep */
+    int64_t cost_bound;
+};
+struct LayoutTot {       /* per hmm, after the counting pass */
+    int64_t cells, merge;
+    int32_t tiles_fast, tiles_gen, max_cells, max_merge;
+};
+struct LayoutBase {      /* per hmm, after the scan over the hmms */
+    int64_t cell0, mcell0, tile_fast0, tile_gen0;
+};
+struct LayoutOut {       /* everything the layout kernels write */
+    uint16_t *dims;      /* [n_cols][4] C1, C2, Ma, Mb (scratch between the passes) */
+    LayoutTot *tot;      /* [n_hmms] */
+    LayoutBase *base;    /* [n_hmms] */
+    int64_t *totals;     /* [4] cells (padded to a multiple of 4 per hmm), merge cells, fast tiles, general tiles */
+    DevHmm *hmms;
+    DevCol *cols;
+    SweepCol *scols;
+    PlaneCol *pcols;
+    TileCol *tilecols;
+    CrossCol *ccols;
+};
+/* plan_dev / hmms_dev: PlanCol [n_cols], PlanHmm [n_hmms]; chunks_dev: the batch's DevChunk table; S: cells a pruned column
+ * can have at most (parents' counts are clamped to it, so that a discarded parent cannot blow the level up) */
+hipError_t mrp_launch_layout(const PlanCol *plan_dev, const PlanHmm *hmms_dev, int64_t n_hmms, int64_t n_cols, const DevChunk *chunks_dev,
+                             int32_t S, uint32_t xflags, LayoutOut out, hipStream_t stream);
+
 /* one cross product hmm of a level, as the prune kernels see it */
 struct PruneHmm {
     int64_t col0;           /* first column in the level's batch column arrays / in the scratch lists */

@@ -167,6 +167,180 @@ hipError_t mrp_launch_cross(const CrossCol *cols_dev, int64_t n_cols, uint64_t *
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* layout of a level: sizes, offsets and kernel descriptors from the parents' counts           */
+/* ------------------------------------------------------------------------------------------ */
+static __device__ __forceinline__ int32_t layout_count(const int32_t *p, int32_t S) {
+    if (!p) return 1;
+    const int32_t v = *p;
+    return v < 1 ? 1 : (v > S ? S : v); /* (a discarded parent may hold anything: the level stays within its static bounds) */
+}
+static __device__ __forceinline__ int wave_sum_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, WAVE);
+    return v;
+}
+static __device__ __forceinline__ int wave_max_i32(int v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const int t = __shfl_xor(v, o, WAVE); v = t > v ? t : v; }
+    return v;
+}
+
+/* pass 1, one wave per hmm: C1, C2, Ma, Mb of every column; per hmm the sums the scan needs */
+__global__ void __launch_bounds__(256) mrp_layout_count_kernel(const PlanCol *__restrict__ plan, const PlanHmm *__restrict__ ph, int64_t n_hmms,
+                                                               int32_t S, LayoutOut o) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t w = (int64_t) blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+    if (w >= n_hmms) return;
+    const PlanHmm h = ph[w];
+    const bool ancestor = (h.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
+    int64_t cells = 0, merge = 0;
+    int tf = 0, tg = 0, mc = 1, mm = 1;
+    for (int k = lane; k < h.n_cols; k += WAVE) {
+        const PlanCol c = plan[h.col0 + k];
+        const int C1 = layout_count(c.a_ncells, S), C2 = layout_count(c.b_ncells, S);
+        int Ma = 0, Mb = 0;
+        if (!c.last) {
+            Ma = c.out_a == MRP_CONN_REAL ? layout_count(c.a_nmerge, S) : (c.out_a == MRP_CONN_IDENT ? C1 : 1);
+            Mb = c.out_b == MRP_CONN_REAL ? layout_count(c.b_nmerge, S) : (c.out_b == MRP_CONN_IDENT ? C2 : 1);
+        }
+        uint16_t *dm = o.dims + 4 * (h.col0 + k);
+        dm[0] = (uint16_t) C1; dm[1] = (uint16_t) C2; dm[2] = (uint16_t) Ma; dm[3] = (uint16_t) Mb;
+        const int C = C1 * C2, M = Ma * Mb;
+        cells += C; merge += M;
+        const int nt = (C + MRP_EMIT_TILE - 1) / MRP_EMIT_TILE;
+        if (c.uniform_alleles != 0 && !ancestor) tf += nt; else tg += nt;
+        mc = C > mc ? C : mc;
+        mm = M > mm ? M : mm;
+    }
+    /* (an hmm has at most 2^31 cells: checked on the host against the static bounds) */
+    const int lo = wave_sum_i32((int) (cells & 0xFFFF)), hi = wave_sum_i32((int) (cells >> 16));
+    const int mlo = wave_sum_i32((int) (merge & 0xFFFF)), mhi = wave_sum_i32((int) (merge >> 16));
+    tf = wave_sum_i32(tf); tg = wave_sum_i32(tg); mc = wave_max_i32(mc); mm = wave_max_i32(mm);
+    if (lane == 0) {
+        LayoutTot t;
+        t.cells = ((int64_t) hi << 16) + lo; t.merge = ((int64_t) mhi << 16) + mlo;
+        t.tiles_fast = tf; t.tiles_gen = tg; t.max_cells = mc; t.max_merge = mm;
+        o.tot[w] = t;
+    }
+}
+
+/* pass 2, one workgroup: where every hmm starts (cells padded to a multiple of 4 per hmm), the totals, the DevHmm records */
+__global__ void __launch_bounds__(1024) mrp_layout_scan_kernel(const PlanHmm *__restrict__ ph, int64_t n_hmms, LayoutOut o) {
+    __shared__ int64_t part[1024][4];
+    const int t = threadIdx.x;
+    const int64_t per = (n_hmms + 1023) / 1024, lo = (int64_t) t * per, hi = lo + per < n_hmms ? lo + per : n_hmms;
+    int64_t s[4] = {0, 0, 0, 0};
+    for (int64_t i = lo; i < hi; i++) {
+        const LayoutTot x = o.tot[i];
+        s[0] += (x.cells + 3) & ~3ll; s[1] += x.merge; s[2] += x.tiles_fast; s[3] += x.tiles_gen;
+    }
+    for (int q = 0; q < 4; q++) part[t][q] = s[q];
+    __syncthreads();
+    if (t == 0) {
+        int64_t run[4] = {0, 0, 0, 0};
+        for (int i = 0; i < 1024; i++)
+            for (int q = 0; q < 4; q++) { const int64_t v = part[i][q]; part[i][q] = run[q]; run[q] += v; }
+        for (int q = 0; q < 4; q++) o.totals[q] = run[q];
+    }
+    __syncthreads();
+    for (int q = 0; q < 4; q++) s[q] = part[t][q];
+    for (int64_t i = lo; i < hi; i++) {
+        const LayoutTot x = o.tot[i];
+        const PlanHmm h = ph[i];
+        LayoutBase b;
+        b.cell0 = s[0]; b.mcell0 = s[1]; b.tile_fast0 = s[2]; b.tile_gen0 = s[3];
+        o.base[i] = b;
+        DevHmm d;
+        d.col0 = h.col0; d.n_cols = h.n_cols; d.flags = h.flags; d.max_merge = x.max_merge; d.max_cells = x.max_cells;
+        d.wide_idx = 0; d.pad = 0; d.n_cells = x.cells; d.n_merge = x.merge; d.cost_bound = h.cost_bound;
+        o.hmms[i] = d;
+        s[0] += (x.cells + 3) & ~3ll; s[1] += x.merge; s[2] += x.tiles_fast; s[3] += x.tiles_gen;
+    }
+}
+
+/* exclusive prefix sum over the wave (shuffles: the DPP scans of the prune kernel are defined further down) */
+static __device__ __forceinline__ int wave_excl_scan_shfl(int v, int lane, int *total) {
+    int x = v;
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) { const int t = __shfl_up(x, o, WAVE); if (lane >= o) x += t; }
+    *total = __shfl(x, WAVE - 1, WAVE);
+    return x - v;
+}
+
+/* pass 3, one wave per hmm: the offsets of its columns and every per-column descriptor of the level's kernels */
+__global__ void __launch_bounds__(256) mrp_layout_fill_kernel(const PlanCol *__restrict__ plan, const PlanHmm *__restrict__ ph, int64_t n_hmms,
+                                                              const DevChunk *__restrict__ chunks, uint32_t xflags, LayoutOut o) {
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int64_t w = (int64_t) blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
+    if (w >= n_hmms) return;
+    const PlanHmm h = ph[w];
+    const LayoutBase base = o.base[w];
+    const bool ancestor = (h.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
+    int64_t c_off = base.cell0, m_off = base.mcell0, t_fast = base.tile_fast0, t_gen = o.totals[2] + base.tile_gen0;
+    for (int k0 = 0; k0 < h.n_cols; k0 += WAVE) {
+        const int k = k0 + lane;
+        const bool in = k < h.n_cols;
+        const int64_t col = h.col0 + (in ? k : 0);
+        const PlanCol c = plan[col];
+        const uint16_t *dm = o.dims + 4 * col;
+        const int C1 = in ? dm[0] : 0, C2 = in ? dm[1] : 0, Ma = in ? dm[2] : 0, Mb = in ? dm[3] : 0;
+        const int C = C1 * C2, M = Ma * Mb;
+        const int nt = (C + MRP_EMIT_TILE - 1) / MRP_EMIT_TILE;
+        const bool fast = c.uniform_alleles != 0 && !ancestor;
+        int tc, tm, tf, tg;
+        const int xc = wave_excl_scan_shfl(C, lane, &tc), xm = wave_excl_scan_shfl(M, lane, &tm);
+        const int xf = wave_excl_scan_shfl(in && fast ? nt : 0, lane, &tf), xg = wave_excl_scan_shfl(in && !fast ? nt : 0, lane, &tg);
+        if (in) {
+            DevCol dc;
+            dc.cell_off = c_off + xc; dc.mcell_off = c.last ? 0 : m_off + xm; dc.slot_off = c.slot_off; dc.read_off = c.read_off;
+            dc.n_cells = C; dc.n_merge = M; dc.site_start = c.site_start; dc.n_sites = c.n_sites; dc.depth = c.depth; dc.n_slots = c.n_slots;
+            dc.chunk = c.chunk; dc.flags = h.flags;
+            o.cols[col] = dc;
+            SweepCol sc;
+            sc.cell_off = dc.cell_off; sc.mcell_off = dc.mcell_off; sc.n_cells = C; sc.n_merge = M; sc.pad[0] = 0; sc.pad[1] = 0;
+            o.scols[col] = sc;
+            PlaneCol pc;
+            pc.pool = chunks[c.chunk].pool; pc.read_off = c.read_off; pc.slot_off = c.slot_off; pc.depth = c.depth; pc.n_slots = c.n_slots;
+            pc.need_planes = c.need_planes; pc.pad = 0;
+            o.pcols[col] = pc;
+            TileCol tcl;
+            tcl.first = fast ? t_fast + xf : t_gen + xg; tcl.uniform_alleles = c.uniform_alleles; tcl.pad = 0;
+            o.tilecols[col] = tcl;
+            CrossCol x;
+            x.a_part = c.a_part; x.b_part = c.b_part; x.a_np = c.a_np; x.b_np = c.b_np;
+            x.x_cell_off = dc.cell_off;
+            x.C1 = (uint16_t) C1; x.C2 = (uint16_t) C2; x.Ma = (uint16_t) Ma; x.Mb = (uint16_t) Mb;
+            x.d1 = c.d1; x.d2 = c.d2;
+            uint8_t fl = (uint8_t) xflags;
+            x.out_a = c.last ? 0 : c.out_a; x.out_b = c.last ? 0 : c.out_b;
+            if (!c.last) { if (c.out_a_paired) fl |= MRP_XF_OUT_A_PAIRED; if (c.out_b_paired) fl |= MRP_XF_OUT_B_PAIRED; }
+            x.Pa = 0; x.Pb = 0; x.in_a = 0; x.in_b = 0;
+            if (k > 0) { /* the connector that enters the column is the one that leaves the column before */
+                const PlanCol q = plan[col - 1];
+                const uint16_t *qm = o.dims + 4 * (col - 1);
+                x.Pa = qm[2]; x.Pb = qm[3]; x.in_a = q.out_a; x.in_b = q.out_b;
+                if (q.out_a_paired) fl |= MRP_XF_IN_A_PAIRED;
+                if (q.out_b_paired) fl |= MRP_XF_IN_B_PAIRED;
+            }
+            x.flags = fl; x.pad = 0;
+            o.ccols[col] = x;
+        }
+        c_off += tc; m_off += tm; t_fast += tf; t_gen += tg;
+    }
+}
+
+hipError_t mrp_launch_layout(const PlanCol *plan_dev, const PlanHmm *hmms_dev, int64_t n_hmms, int64_t n_cols, const DevChunk *chunks_dev,
+                             int32_t S, uint32_t xflags, LayoutOut out, hipStream_t stream) {
+    if (n_hmms <= 0) return hipSuccess;
+    (void) n_cols;
+    const unsigned g = (unsigned) ((n_hmms + 3) / 4);
+    hipLaunchKernelGGL(mrp_layout_count_kernel, dim3(g), dim3(256), 0, stream, plan_dev, hmms_dev, n_hmms, S, out);
+    hipLaunchKernelGGL(mrp_layout_scan_kernel, dim3(1), dim3(1024), 0, stream, hmms_dev, n_hmms, out);
+    hipLaunchKernelGGL(mrp_layout_fill_kernel, dim3(g), dim3(256), 0, stream, plan_dev, hmms_dev, n_hmms, chunks_dev, xflags, out);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* prune                                                                                       */
 /* ------------------------------------------------------------------------------------------ */
 /* n kept of n_link candidates whose first g pass the posterior threshold: the loop of hmm.c:1073-1079 /

@@ -145,6 +145,10 @@ struct mrp_context {
     /* the emptied batch object of the last resident engine on this context: its host arrays keep their capacity (and their
      * mapped pages) from one mrp_phase_reads_many call to the next */
     struct mrp_batch *spare_batch = nullptr;
+    /* and its level objects (page-locked staging blocks, events) with a second emptied batch: kept from call to call, allocating
+     * page-locked memory takes milliseconds and synchronizes the device (owned here, managed by mrp_engine.cpp) */
+    std::vector<struct mrp_engine_level_state *> spare_levels;
+    std::vector<struct mrp_batch *> spare_batches;
     /* page-locked host staging for the small per-level results of the resident engine (grow-only) */
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
@@ -257,14 +261,11 @@ int mrp_batch_add_impl(mrp_batch *b, const mrp_hmm_job *job, bool resident, int6
                        int64_t *col0_out);
 
 
-/* appends n device-resident hmms (cells produced by mrp_cross_kernel) to an empty batch; descriptors are
- * built by host threads in parallel.  cell0 / col0 [n] receive each hmm's first cell / column. */
-int mrp_batch_add_resident_bulk(mrp_batch *b, int64_t n, const mrp_xhmm *x, int64_t *cell0, int64_t *col0);
-
-
 #include <atomic>
 #include <thread>
 extern "C" void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void *), void *arg);
+/* releases what mrp_engine.cpp parked in the context (mrp_context_destroy) */
+void mrp_engine_release_context_cache(mrp_context *ctx);
 template <class F>
 static inline void mrp_parallel_for(int64_t n, int64_t grain, F f) {
     mrp_pool_run(n, grain, [](int64_t i, void *a) { (*static_cast<F *>(a))(i); }, &f);

@@ -112,6 +112,49 @@ static inline uint64_t merge_bits(uint64_t p1, uint64_t p2, int64_t d1) { /* :21
 }
 static inline uint64_t invert_partition(uint64_t p, int64_t depth) { return accept_mask(depth) & ~p; } /* :37-42 */
 
+/* Blocks of the shadow hmms of the device-resident merge: tens of thousands per call, a few hundred bytes to a few hundred
+ * kilobytes each, all dead by the end of the call.  Through malloc the large ones are mapped and unmapped one by one (and
+ * page-faulted in again by the next call); here they are kept on per-size-class stacks (powers of two) and reused warm. */
+#define SHADOW_MIN_LOG 9
+#define SHADOW_CLASSES 20 /* 512 B .. 256 MB */
+static struct { pthread_mutex_t mu; void **stack; int64_t n, cap; } g_shadow[SHADOW_CLASSES];
+static pthread_once_t g_shadow_once = PTHREAD_ONCE_INIT;
+static void shadow_pool_init(void) { for (int i = 0; i < SHADOW_CLASSES; i++) pthread_mutex_init(&g_shadow[i].mu, NULL); }
+static int shadow_class(size_t bytes) {
+    int c = 0;
+    while (((size_t) 1 << (c + SHADOW_MIN_LOG)) < bytes) c++;
+    return c;
+}
+/* per-thread front of the pool (the worker threads are persistent): the shared stacks are touched a batch at a time */
+#define SHADOW_TL 16
+static __thread struct { void *slot[SHADOW_CLASSES][SHADOW_TL]; int n[SHADOW_CLASSES]; } t_shadow;
+static void *shadow_alloc(size_t bytes, int *cls_out) {
+    pthread_once(&g_shadow_once, shadow_pool_init);
+    const int c = shadow_class(bytes);
+    if (c >= SHADOW_CLASSES) { *cls_out = -1; return xmalloc(bytes); }
+    *cls_out = c;
+    if (t_shadow.n[c] == 0) { /* refill: up to half a front from the shared stack */
+        pthread_mutex_lock(&g_shadow[c].mu);
+        while (t_shadow.n[c] < SHADOW_TL / 2 && g_shadow[c].n > 0) t_shadow.slot[c][t_shadow.n[c]++] = g_shadow[c].stack[--g_shadow[c].n];
+        pthread_mutex_unlock(&g_shadow[c].mu);
+    }
+    if (t_shadow.n[c] > 0) return t_shadow.slot[c][--t_shadow.n[c]];
+    return xmalloc((size_t) 1 << (c + SHADOW_MIN_LOG));
+}
+static void shadow_release(void *p, int cls) {
+    if (cls < 0) { free(p); return; }
+    if (t_shadow.n[cls] == SHADOW_TL) { /* spill half of the front */
+        pthread_mutex_lock(&g_shadow[cls].mu);
+        if (g_shadow[cls].n + SHADOW_TL / 2 > g_shadow[cls].cap) {
+            g_shadow[cls].cap = g_shadow[cls].cap ? 2 * g_shadow[cls].cap : 256;
+            g_shadow[cls].stack = xrealloc(g_shadow[cls].stack, sizeof(void *) * (size_t) g_shadow[cls].cap);
+        }
+        while (t_shadow.n[cls] > SHADOW_TL / 2) g_shadow[cls].stack[g_shadow[cls].n++] = t_shadow.slot[cls][--t_shadow.n[cls]];
+        pthread_mutex_unlock(&g_shadow[cls].mu);
+    }
+    t_shadow.slot[cls][t_shadow.n[cls]++] = p;
+}
+
 /* ------------------------------------------------------------------------------------------ */
 /* the flat hmm                                                                                */
 /* ------------------------------------------------------------------------------------------ */
@@ -136,17 +179,20 @@ struct mrp_hmm {
     double fwd, bwd;
     int has_results;
     /* device-resident form (mrp_engine.cpp): no host cell arrays; column k's cells are at
-     * d_part + k * stride, its counts in rc_cells / rc_merge (merge column after column k) */
+     * d_part + k * stride, its counts at d_ncells[k] / d_nmerge[k] (merge column after column k): they are not known to
+     * the host while the merge levels run, only their addresses are */
     int resident, leaf; /* leaf: the single column {1, 0} of stRPHmm_construct, shared by all such hmms */
     int32_t stride;
     const uint64_t *d_part;
     const uint32_t *d_np;
-    VEC(int32_t) rc_cells, rc_merge;
+    const int32_t *d_ncells, *d_nmerge; /* device: cells per column, merge cells of the merge column after it */
+    VEC(int32_t) rc_cells, rc_merge;   /* host copies, fetched only when the hmm is downloaded */
     /* shadows are one allocation: the struct followed by its exactly sized arrays (and the cross product
      * descriptors of the level that builds it); arrays outside [this, this + arena_bytes) are malloc'd */
     size_t arena_bytes;
     mrp_xcol *xcols;
     int in_block; /* the struct lives inside a block owned by someone else (the leaves of a run) */
+    int pool_class; /* shadows: size class of the block in the shadow pool (-1: plain malloc), +1; 0 = not from the pool */
 };
 
 static int64_t hmm_K(const mrp_hmm *h) { return h->col_start.n; }
@@ -173,7 +219,9 @@ void mrp_hmm_destroy(mrp_hmm *h) {
                       h->mfrom.a, h->mto.a, h->rc_cells.a, h->rc_merge.a};
     for (size_t i = 0; i < sizeof(arrays) / sizeof(arrays[0]); i++) hmm_free_array(h, arrays[i]);
     hmm_free_results(h);
-    if (!h->in_block) free(h);
+    if (h->in_block) return;
+    if (h->pool_class != 0) shadow_release(h, h->pool_class - 1);
+    else free(h);
 }
 
 /* per-job view of the reads + chunk the structural code works against */
@@ -1238,11 +1286,13 @@ static mrp_hmm *r_shadow_new(int64_t K, int64_t D, int64_t n_reads, int with_xco
 #undef AL8
     if (bytes_out) *bytes_out = bytes;
     if (bytes_out && !place) return NULL; /* size query */
-    char *blk = place ? place : xmalloc(bytes);
+    int cls = 0;
+    char *blk = place ? place : shadow_alloc(bytes, &cls);
     mrp_hmm *h = (mrp_hmm *) blk;
     memset(h, 0, sizeof(*h));
     h->arena_bytes = bytes;
     h->in_block = place != NULL;
+    h->pool_class = place ? 0 : cls + 1;
     h->resident = 1;
 #define AT(vec, off, capacity) do { (vec).a = (void *) (blk + (off)); (vec).n = 0; (vec).cap = (capacity); } while (0)
     AT(h->reads, o_reads, n_reads); AT(h->col_start, o_start, K); AT(h->col_len, o_len, K); AT(h->col_depth, o_depth, K);
@@ -1272,29 +1322,30 @@ static mrp_hmm *r_hmm_from_read(const world *w, int32_t read, const mrp_engine *
     h->max_depth = 1;
     h->stride = 4;
     h->leaf = 1;
-    mrp_engine_leaf(e, &h->d_part, &h->d_np);
+    mrp_engine_leaf(e, &h->d_part, &h->d_np, &h->d_ncells);
+    h->d_nmerge = NULL;
     h->rc_cells.a[0] = 2; h->rc_cells.n = 1;
     return h;
 }
 
-static inline int32_t r_piece_cells(const piece *p) { return p->h ? p->h->rc_cells.a[p->k] : 1; }
-
-/* what one side contributes to the connector that leaves piece p */
-static void r_conn_of(const piece *p, uint8_t *kind, uint16_t *M, uint8_t *paired, uint64_t *mask_from, uint64_t *mask_to) {
+/* what one side contributes to the connector that leaves piece p: its kind, where the number of its merge cells will be
+ * found (REAL connectors; an IDENT connector has one merge cell per cell of the piece, a ZERO connector one) */
+static void r_conn_of(const piece *p, uint8_t *kind, const int32_t **nmerge, uint8_t *paired, uint64_t *mask_from, uint64_t *mask_to) {
+    *nmerge = NULL;
     switch (p->out) {
         case CONN_REAL:
-            *kind = MRP_CONN_REAL; *M = (uint16_t) p->h->rc_merge.a[p->k];
+            *kind = MRP_CONN_REAL; *nmerge = p->h->d_nmerge + p->k;
             *mask_from = p->h->mask_from.a[p->k]; *mask_to = p->h->mask_to.a[p->k];
             break;
         case CONN_IDENT: /* column.c:86-101 */
-            *kind = MRP_CONN_IDENT; *M = (uint16_t) r_piece_cells(p);
+            *kind = MRP_CONN_IDENT;
             *mask_from = *mask_to = accept_mask(piece_depth(p));
             break;
         case CONN_ZERO: /* hmm.c:324-331 */
-            *kind = MRP_CONN_ZERO; *M = 1; *mask_from = *mask_to = 0;
+            *kind = MRP_CONN_ZERO; *mask_from = *mask_to = 0;
             break;
         default:
-            *kind = MRP_CONN_NONE; *M = 0; *mask_from = *mask_to = 0;
+            *kind = MRP_CONN_NONE; *mask_from = *mask_to = 0;
     }
     *paired = *mask_from != 0;
 }
@@ -1349,12 +1400,13 @@ static int r_cross_shadow(const world *w, const piece_vec *A, const piece_vec *B
         c->a_np = pa->h ? pa->h->d_np + (int64_t) pa->k * pa->h->stride : NULL;
         c->b_part = pb->h ? pb->h->d_part + (int64_t) pb->k * pb->h->stride : NULL;
         c->b_np = pb->h ? pb->h->d_np + (int64_t) pb->k * pb->h->stride : NULL;
-        c->C1 = (uint16_t) r_piece_cells(pa); c->C2 = (uint16_t) r_piece_cells(pb);
+        c->a_ncells = pa->h ? pa->h->d_ncells + pa->k : NULL;
+        c->b_ncells = pb->h ? pb->h->d_ncells + pb->k : NULL;
         c->d1 = (uint8_t) d1; c->d2 = (uint8_t) d2;
         if (s + 1 < n) { /* merge column hmm.c:686-740 */
             uint64_t fa, ta, fb, tb;
-            r_conn_of(pa, &c->out_a, &c->Ma, &c->out_a_paired, &fa, &ta);
-            r_conn_of(pb, &c->out_b, &c->Mb, &c->out_b_paired, &fb, &tb);
+            r_conn_of(pa, &c->out_a, &c->a_nmerge, &c->out_a_paired, &fa, &ta);
+            r_conn_of(pb, &c->out_b, &c->b_nmerge, &c->out_b_paired, &fb, &tb);
             const int32_t d1n = piece_depth(&A->a[s + 1]);
             c->mask_from = merge_bits(fa, fb, d1);
             c->mask_to = merge_bits(ta, tb, d1n);
@@ -1506,10 +1558,30 @@ static void level_prepare(int64_t i, void *arg) {
     it->rc = r_prepare_merge(nd->w, l, r, it->res, &it->xs, &it->garbage);
     if (it->rc != MRP_OK) snprintf(it->err, sizeof(it->err), "%s", mrp_last_error());
 }
+static void level_drop_garbage(int64_t i, void *arg) { /* the parents' shadows of one merge */
+    level_item *it = &((level_item *) arg)[i];
+    for (int64_t j = 0; j < it->garbage.n; j++) mrp_hmm_destroy(it->garbage.a[j]);
+    free(it->garbage.a);
+    it->garbage.a = NULL;
+    it->garbage.n = 0;
+}
 static void level_finish(int64_t i, void *arg) {
     level_item *it = &((level_item *) arg)[i];
     rnode *nd = &it->t->a[it->node];
     sort_hmms(nd->w, it->res->a, it->res->n); /* coordination.c:336 */
+}
+/* what the host keeps of a level while it is on the device */
+typedef struct {
+    level_item *items; int64_t n_items;
+    mrp_xhmm *xh; xbuild *xb; int64_t n_x;
+} level_run;
+static void level_run_settle(level_run *r, int rc_ok) { /* the level has ended: its error flags are in */
+    for (int64_t i = 0; i < r->n_x; i++)
+        /* outside what the kernels handle (a parent not in complement-pair order, ...): the later levels leave this
+         * chunk out, its caller redoes it on the hashing path */
+        if (rc_ok && r->xh[i].err != 0) ((world *) r->xb[i].w)->failed = 1;
+    free(r->xh); free(r->xb); free(r->items);
+    memset(r, 0, sizeof(*r));
 }
 static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params) {
     int max_h = 0;
@@ -1526,6 +1598,10 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params) {
     }
     const uint32_t flags = sweep_flags(params);
     int rc = MRP_OK;
+    /* The host's part of level h -- structure of the merged hmms, their description for the device -- needs nothing the
+     * device computes (only the ADDRESSES of level h - 1's results, fixed when that level was staged): it is done while
+     * level h - 1 runs.  The one wait per level is inside mrp_engine_level_launch. */
+    level_run prev = {0};
     for (int h = 1; h <= max_h && rc == MRP_OK; h++) {
         const double t0 = now_ms();
         int64_t n_items = 0;
@@ -1536,6 +1612,7 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params) {
         for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > 0 && lvl[i] == h && !t->a[i].w->failed) { items[n_items].t = t; items[n_items].node = i; n_items++; }
         /* the merges of a level touch disjoint nodes: structure in parallel, device work as one batch */
         parallel_for(n_items, level_prepare, items);
+        const double ta = now_ms();
         int64_t n_x = 0;
         for (int64_t i = 0; i < n_items; i++) {
             n_x += items[i].xs.n;
@@ -1547,43 +1624,51 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params) {
         for (int64_t i = 0; i < n_items; i++) {
             for (int64_t j = 0; j < items[i].xs.n; j++) xb[n_x++] = items[i].xs.a[j];
             free(items[i].xs.a);
+            items[i].xs.a = NULL;
         }
         for (int64_t i = 0; i < n_x; i++) {
             mrp_hmm *x = xb[i].x;
             const int64_t K = hmm_K(x);
-            x->rc_cells.n = K; x->rc_merge.n = K; /* capacity K in the shadow's arena */
             xh[i].chunk = xb[i].w->chunk;
             xh[i].n_cols = (int32_t) K;
             xh[i].flags = flags;
             xh[i].cols = xb[i].cols;
             xh[i].col_ref_start = x->col_start.a; xh[i].col_length = x->col_len.a; xh[i].col_depth = x->col_depth.a;
             xh[i].col_read_off = x->read_off.a; xh[i].read_byte_off = x->read_byte_off.a;
-            xh[i].n_cells = x->rc_cells.a; xh[i].n_merge = x->rc_merge.a;
             ((world *) xb[i].w)->n_sweeps += 1; /* coordination.c:312: one forward/backward per overlap component */
         }
-        const double t1 = now_ms();
-        if (rc == MRP_OK) rc = mrp_engine_level_begin(e, n_x, xh);
-        /* while the device works: drop the parents' shadows */
-        const double t2 = now_ms();
-        for (int64_t i = 0; i < n_items; i++) {
-            for (int64_t j = 0; j < items[i].garbage.n; j++) mrp_hmm_destroy(items[i].garbage.a[j]);
-            free(items[i].garbage.a);
-        }
-        T_ADD(4, t2);
-        if (rc == MRP_OK) rc = mrp_engine_level_end(e);
-        g_t_prepare += t1 - t0; g_t_level += now_ms() - t1;
-        for (int64_t i = 0; i < n_x; i++) {
+        const double tb = now_ms();
+        if (rc == MRP_OK) rc = mrp_engine_level_stage(e, n_x, xh);
+        const double tc = now_ms();
+        /* where the level's results will be is known from here on: the next level can be described against them */
+        for (int64_t i = 0; i < n_x && rc == MRP_OK; i++) {
             mrp_hmm *x = xb[i].x;
             x->stride = mrp_engine_stride(e);
-            x->d_part = xh[i].d_part; x->d_np = xh[i].d_np;
-            /* outside what the kernels handle (a parent not in complement-pair order, ...): the later levels leave this
-             * chunk out, its caller redoes it on the hashing path */
-            if (rc == MRP_OK && xh[i].err != 0) ((world *) xb[i].w)->failed = 1;
+            x->d_part = xh[i].d_part; x->d_np = xh[i].d_np; x->d_ncells = xh[i].d_ncells; x->d_nmerge = xh[i].d_nmerge;
         }
-        free(xh); free(xb);
         if (rc == MRP_OK) parallel_for(n_items, level_finish, items);
         for (int64_t i = 0; i < n_items; i++) t->a[items[i].node].path = items[i].res;
-        free(items);
+        const double t1 = now_ms();
+        /* the wait for level h - 1, then level h goes to the device */
+        if (rc == MRP_OK) rc = mrp_engine_level_launch(e);
+        else (void) mrp_engine_level_end(e);
+        level_run_settle(&prev, rc == MRP_OK);
+        /* while the device works: drop the parents' shadows */
+        const double t2 = now_ms();
+        parallel_for(n_items, level_drop_garbage, items);
+        T_ADD(4, t2);
+        g_t_prepare += t1 - t0; g_t_level += now_ms() - t1;
+        if (getenv("MRP_TIMING"))
+            fprintf(stderr, "    host level %d: prepare %.2f ms, gather %.2f, stage %.2f, sort %.2f | launch (waits for the level before) %.2f | settle+garbage %.2f\n",
+                    h, ta - t0, tb - ta, tc - tb, t1 - tc, t2 - t1, now_ms() - t2);
+        prev.items = items; prev.n_items = n_items; prev.xh = xh; prev.xb = xb; prev.n_x = n_x;
+    }
+    {
+        const double t1 = now_ms();
+        const int rc2 = mrp_engine_level_end(e);
+        if (rc == MRP_OK) rc = rc2;
+        level_run_settle(&prev, rc == MRP_OK);
+        g_t_level += now_ms() - t1;
     }
     free(lvl);
     return rc;
@@ -1592,7 +1677,7 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params) {
 /* resident shadow -> ordinary flat hmm on the host; phase 0 queues the copies, phase 1 (after
  * mrp_engine_sync) unpacks them */
 typedef struct { uint64_t *part; uint32_t *np; } r_staging;
-static int r_download_begin(mrp_engine *e, const mrp_hmm *h, r_staging *st) {
+static int r_download_begin(mrp_engine *e, mrp_hmm *h, r_staging *st) {
     const int64_t K = hmm_K(h), n = K * h->stride;
     memset(st, 0, sizeof(*st));
     if (h->leaf) return MRP_OK; /* a stRPHmm_construct hmm: nothing to fetch */
@@ -1600,6 +1685,10 @@ static int r_download_begin(mrp_engine *e, const mrp_hmm *h, r_staging *st) {
     st->np = xmalloc(sizeof(uint32_t) * (size_t) n);
     int rc = mrp_engine_fetch(e, st->part, h->d_part, (int64_t) sizeof(uint64_t) * n);
     if (rc == MRP_OK) rc = mrp_engine_fetch(e, st->np, h->d_np, (int64_t) sizeof(uint32_t) * n);
+    /* the per-column counts (capacity K in the shadow's arena) */
+    h->rc_cells.n = K; h->rc_merge.n = K;
+    if (rc == MRP_OK) rc = mrp_engine_fetch(e, h->rc_cells.a, h->d_ncells, (int64_t) sizeof(int32_t) * K);
+    if (rc == MRP_OK) rc = mrp_engine_fetch(e, h->rc_merge.a, h->d_nmerge, (int64_t) sizeof(int32_t) * K);
     return rc;
 }
 static void r_download_end(mrp_hmm *h, r_staging *st) {
@@ -1634,7 +1723,7 @@ static void r_download_end(mrp_hmm *h, r_staging *st) {
     }
     free(st->part); free(st->np);
     h->resident = 0;
-    h->d_part = NULL; h->d_np = NULL;
+    h->d_part = NULL; h->d_np = NULL; h->d_ncells = NULL; h->d_nmerge = NULL;
 }
 static int r_download_path(mrp_engine *e, hmm_vec *tp) {
     r_staging *st = xcalloc((size_t) tp->n + 1, sizeof(*st));
