@@ -1,19 +1,28 @@
 #!/usr/bin/env python3
 """Benchmark of the stRPHmm forward/backward hot path on MI355X.
 
-Workload (BASELINE.json configs[1]): synthetic 1 Mb chunks, 2 000 biallelic het
-sites, 30x ONT-like reads, shipped ONT haplotag parameters (max-plus mode, 100 partitions per
-column).  One *step* = every forward/backward sweep needed to phase a batch of such chunks (all
-overlap components of every tiling-path merge level + the final sweep of each chunk), with the
-flattened HMMs already resident in HBM: bit-plane kernel -> emission kernel -> recursion kernel.
-A single 2 000-column HMM is a strictly sequential chain, so the chip is filled by keeping the
-sweeps of many independent chunks in flight (the reference's own parallel axis, phase.c:276).
+Workload (BASELINE.json configs[1]): synthetic 1 Mb chunks, 2 000 biallelic het sites, 30x ONT-like
+reads, shipped ONT haplotag parameters (max-plus mode, 100 partitions per column).
 
-The job set is produced by the product's host pipeline (margin_amd/csrc/rphmm_host.c) running the
-real merge recursion with device sweeps; it is recorded into one device batch and replayed in the
-timed region.  The oracle is used only by the cpu_baseline leg.
+One *step* = phasing every chunk of the GPU once, end to end, through the product's C-ABI (mrp_phase_reads_many):
+tiling paths, every merge level (cross product -> forward/backward -> prune, resident in HBM), the final sweep with the
+ancestor model, trace back, genome fragments and the read bipartition -- everything bubbleGraph_phaseBubbleGraph does from
+profile sequences on.  Inputs (profile bytes, site tables) are resident in HBM when the timed region starts.
+`value` = het-sites x reads of all chunks x steps / wall time: the rate at which chunks are actually phased.
 
-Prints ONE JSON line on rank 0 (see the contract in the task description).
+Beside it, as evidence for the kernels (not as the headline):
+  roofline      the forward/backward recursion kernel (the kernel that moves the algorithmic bytes of SURVEY.md 8d) replayed
+                over ALL sweeps of the same chunks as one batch: HIP-event duration per launch against its algorithmic bytes;
+                `traffic` = HBM bytes of that launch from the committed rocprofv3 PMC pass (profiles/r02/traffic.json);
+                `path` = the algorithmic bytes of all sweeps over the wall time of the real step.
+  queue         the same chunks through the host work queue from HOST memory (upload included, PCIe-inclusive rate)
+  alignment     the pair-HMM kernel family that produces the profile bytes
+  cpu_baseline  the oracle (CPU restatement of the reference) on a bounded sample of the same chunks, N = 1 only
+
+Launch: `python bench.py` (one GPU), or one rank per GPU under torch.distributed.run with --gpus N = WORLD_SIZE (chunks
+are sharded by rank, no collective on the data path), or `python bench.py --gpus N` in ONE process: the library's work
+queue (mrp_queue_*) then drives N devices itself.  Any other combination is refused.
+Prints ONE JSON line on rank 0.
 """
 from __future__ import annotations
 
@@ -21,7 +30,6 @@ import argparse
 import json
 import os
 import sys
-import threading
 import time
 from concurrent.futures import ThreadPoolExecutor
 
@@ -35,23 +43,19 @@ HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--chunks", type=int, default=int(os.environ.get("MRP_BENCH_CHUNKS", "96")),
-                    help="synthetic 1 Mb chunks resident per GPU")
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--chunks", type=int, default=int(os.environ.get("MRP_BENCH_CHUNKS", "96")), help="synthetic 1 Mb chunks per GPU")
     ap.add_argument("--sites", type=int, default=2000)
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--threads", type=int, default=int(os.environ.get("MRP_BENCH_THREADS", "0")))
+    ap.add_argument("--phase-groups", type=int, default=2, help="concurrent halves inside mrp_phase_reads_many")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-pipeline", action="store_true", help="skip the end-to-end device-resident phasing leg")
-    ap.add_argument("--pipeline-runs", type=int, default=3)
+    ap.add_argument("--no-roofline", action="store_true", help="skip the kernel replay leg (it needs ~20 s of host work to record the sweeps)")
+    ap.add_argument("--roofline-steps", type=int, default=20)
+    ap.add_argument("--queue-runs", type=int, default=2, help="runs of the host-memory work queue leg (0: skip)")
     ap.add_argument("--align-chunks", type=int, default=4, help="chunks whose read x allele pairs the alignment leg scores (0: skip)")
     ap.add_argument("--align-runs", type=int, default=3)
-    ap.add_argument("--pipeline-groups", type=int, default=1,
-                    help="additional caller-side split of the chunks into concurrent mrp_phase_reads_many calls (the call itself "
-                         "already runs two interleaved halves on sibling contexts, MRP_PHASE_GROUPS)")
-    ap.add_argument("--split", type=int, default=int(os.environ.get("MRP_BENCH_SPLIT", "1")),
-                    help="record the chunks into this many device batches launched on separate streams (their kernels overlap)")
     return ap.parse_args()
 
 
@@ -61,14 +65,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     n_gpus = args.gpus
+    # one rank per GPU (the driver's launch), or one process that drives the N devices through the library's queue
+    if world != 1 and world != n_gpus:
+        sys.exit(f"bench.py: --gpus {n_gpus} but WORLD_SIZE={world}: launch one rank per GPU (torch.distributed.run --nproc-per-node {n_gpus}) "
+                 f"or a single process")
+    single_process_multi = world == 1 and n_gpus > 1
 
     import torch
     dist = None
     if world > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        # rehearsal knobs (not used by the driver): several ranks may share one card with gloo
-        backend = os.environ.get("MRP_BENCH_BACKEND", "nccl")
+        backend = os.environ.get("MRP_BENCH_BACKEND", "nccl")  # rehearsal knob: gloo with several ranks on one card
         if "MRP_BENCH_DEVICE" in os.environ:
             local_rank = int(os.environ["MRP_BENCH_DEVICE"])
         torch.cuda.set_device(local_rank)
@@ -82,175 +90,169 @@ def main():
     import numpy as np
     from margin_amd import capi, sharding, synth
 
+    if single_process_multi and capi.load().mrp_device_count() < n_gpus:
+        sys.exit(f"bench.py: --gpus {n_gpus} in one process, but only {capi.load().mrp_device_count()} device(s) are visible")
+
     params_dict = synth.shipped_phase_params()
     params = capi.Params.from_reference_names(params_dict)
-    n_chunks = args.chunks
-    cpu_share = max(1, (os.cpu_count() or 8) // max(1, world if world > 1 else 1))
+    n_chunks = args.chunks * (n_gpus if single_process_multi else 1)
+    cpu_share = max(1, (os.cpu_count() or 8) // max(1, world))
     n_threads = args.threads or min(16, cpu_share, n_chunks)
-
-    ctxs = [capi.Context(local_rank) for _ in range(max(1, args.split))]
-    bigs = [capi.Batch(c) for c in ctxs]
-    main_ctx, big = ctxs[0], bigs[0]
-    keep = []           # device chunks must outlive the batch
-    host_chunks = [None] * n_chunks
-    units_lock = threading.Lock()
-    totals = dict(units=0, sweeps=0, reads=0)
-    tls = threading.local()
-
     seeds = sharding.chunk_seeds(rank, n_chunks)
-
-    def build_one(i):
-        if not hasattr(tls, "ctx"):
-            tls.ctx = capi.Context(local_rank)  # one context (stream) per host thread
-        seed = seeds[i]
-        chunk = synth.make_ont_chunk(seed=seed, region_bp=args.sites * 500, n_sites=args.sites,
-                                     coverage=args.coverage)
-        dchunk = capi.DeviceChunk.from_chunk(tls.ctx, chunk)
-        res = capi.phase_reads(tls.ctx, dchunk, chunk, params, record=bigs[i % len(bigs)])
-        with units_lock:
-            keep.append(dchunk)
-            totals["units"] += chunk.units
-            totals["sweeps"] += res["n_sweeps"]
-            totals["reads"] += len(chunk.reads)
-        host_chunks[i] = chunk
-        return chunk if i == 0 else None
 
     t0 = time.time()
     with ThreadPoolExecutor(max_workers=n_threads) as ex:
-        first = list(ex.map(build_one, range(n_chunks)))[0]
-    t_build = time.time() - t0
-    for b_ in bigs:
-        b_.upload()
-    for c_ in ctxs:
-        c_.synchronize()
+        chunks = list(ex.map(lambda s: synth.make_ont_chunk(seed=s, region_bp=args.sites * 500, n_sites=args.sites, coverage=args.coverage), seeds))
+    t_synth = time.time() - t0
+    units = float(sum(c.units for c in chunks))
+    for c in chunks:
+        capi.read_records(c)
 
     def barrier():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
+    reduce_dev = "cuda" if (dist is not None and dist.get_backend() == "nccl") else None
+
+    # ---- the timed region: every chunk phased end to end, K times -------------------------------------------------
+    if single_process_multi:
+        queue = capi.Queue(list(range(n_gpus)))
+        descs = capi.chunk_descs(chunks)
+        step = lambda: queue.phase(chunks, params, chunks_per_batch=max(1, args.chunks // 2), descs=descs, convert=False)[1]
+    else:
+        ctx = capi.Context(local_rank)
+        ctx.set_phase_groups(args.phase_groups)
+        dchunks = [capi.DeviceChunk.from_chunk(ctx, c) for c in chunks]
+        step = lambda: capi.phase_reads_many(ctx, dchunks, chunks, params, convert=False)[1]
     for _ in range(args.warmup):
-        for b_ in bigs:
-            b_.launch()
-    for c_ in ctxs:
-        c_.synchronize()
-    for b_ in bigs:
-        b_.stats()  # closes the averaging window of the warm-up launches
+        step()
     barrier()
-    # The K steps are queued back to back: every launch keeps its own HIP events inside the library (mrp_launch_stats
-    # avg_*: the kernels' durations averaged over the launches of the timed region), so nothing waits on the host between
-    # steps (with MRP_PRE_STREAM=1 the byte packing of step k + 1 then runs beside the recursion kernels of step k).
     t0 = time.perf_counter()
+    st = None
     for _ in range(args.steps):
-        for b_ in bigs:
-            b_.launch()
-    for c_ in ctxs:
-        c_.synchronize()
+        st = step()
     barrier()
     elapsed = time.perf_counter() - t0
-    s = bigs[-1].stats()
-    assert s.launches_averaged == min(args.steps, 32)  # the library keeps the events of a batch's 32 most recent launches
-    planes_ms, emission_ms, sweep_ms = [s.avg_planes_ms], [s.avg_emission_ms], [s.avg_sweep_ms]
-    reduce_dev = "cuda" if (dist is not None and dist.get_backend() == "nccl") else None
-    elapsed, units_all = sharding.reduce_elapsed_and_units(dist, elapsed, float(totals["units"]), device=reduce_dev)
-
-    sts = [b_.stats() for b_ in bigs]
-    st = sts[0]
-    for o_ in sts[1:]:
-        for f_ in ("n_hmms", "n_columns", "n_cells", "n_merge_cells", "profile_bytes", "algorithmic_bytes", "popcount_ops"):
-            setattr(st, f_, getattr(st, f_) + getattr(o_, f_))
+    elapsed, units_all = sharding.reduce_elapsed_and_units(dist, elapsed, units, device=reduce_dev)
     value = units_all * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
-    sweep_avg = float(np.mean(sweep_ms))
-    emis_avg = float(np.mean(emission_ms))
-    planes_avg = float(np.mean(planes_ms))
-    alg = float(st.algorithmic_bytes)
-    # B = sum_k 24*C_k + 32*M_k + D_k*Al_k + 8 for the whole sweep.  The sweep is three
-    # kernels here; each is credited with the algorithmic bytes it is responsible for:
-    #   emission kernel : partition read 8*C (+ the profile bytes D*Al via the plane kernel)
-    #   recursion kernel: f and b 16*C, merge cells 32*M, column totals 8*K      <- dominant kernel
-    C, M, K = float(st.n_cells), float(st.n_merge_cells), float(st.n_columns)
-    alg_sweep = 16.0 * C + 32.0 * M + 8.0 * K
-    alg_emission = 8.0 * C
-    achieved = alg_sweep / (sweep_avg * 1e-3) / 1e9
-    whole = alg / (ms_per_step * 1e-3) / 1e9
-    # HBM bytes the kernels actually move per launch (by construction; PMC cross-check in profiles/):
-    #   emission 8*C read + 4*C write; recursion 2 * (8*C read + 4*C write) + 2 * 4*M write
-    moved = 12.0 * C + 24.0 * C + 8.0 * M
-    roofline = dict(bound="hbm", kernel="mrp_sweep_i32_kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                    frac=achieved / HBM_PEAK_GBS, traffic=None,
-                    # PMC counters cannot be read from inside this process; measured with rocprofv3 (separate --pmc passes,
-                    # FETCH_SIZE doubled on gfx950 as MI355X_MICROARCH.md prescribes) on the same command at 32 chunks:
-                    traffic_profile=dict(source="profiles/r01/replay_32chunks_v3_summary.txt",
-                                         hbm_bytes_per_algorithmic_byte=0.79,
-                                         note="recursion kernel, 3 size classes: 2 x FETCH_SIZE 2.68 GB + WRITE_SIZE 4.52 GB = 9.88 GB per step "
-                                              "against 12.5 GB algorithmic (results are stored as int32, the reference's formula counts doubles)"),
-                    algorithmic_bytes_per_launch=alg_sweep, kernel_ms=sweep_avg,
-                    whole_step=dict(achieved=whole, frac=whole / HBM_PEAK_GBS, algorithmic_bytes=alg,
-                                    moved_bytes_model=moved, moved_GBps=moved / (ms_per_step * 1e-3) / 1e9,
-                                    planes_ms=planes_avg, emission_ms=emis_avg, sweep_ms=sweep_avg,
-                                    emission_kernel=dict(algorithmic_bytes=alg_emission,
-                                                         achieved=alg_emission / (emis_avg * 1e-3) / 1e9)),
-                    popcount64_per_s=float(st.popcount_ops) / (ms_per_step * 1e-3))
 
-    out = dict(metric="het-sites x reads phased/sec (stRPHmm forward/backward sweeps, 30x ONT synthetic)",
-               value=value, unit="het-site-reads/s", n_gpus=n_gpus, steps=args.steps, warmup=args.warmup,
-               ms_per_step=ms_per_step, higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int32",
-               data="synthetic",
-               config=dict(workload=f"configs[1]: synthetic 1 Mb chunk, {args.sites} het sites, {args.coverage:g}x ONT reads, "
-                                    f"shipped ONT haplotag params; {n_chunks} chunks resident per GPU, all merge-level + final sweeps",
-                           chunks_per_gpu=n_chunks, hmms_per_gpu=int(st.n_hmms), columns_per_gpu=int(st.n_columns),
-                           cells_per_gpu=int(st.n_cells), merge_cells_per_gpu=int(st.n_merge_cells),
-                           units_per_gpu=int(totals["units"]), sweeps_per_gpu=int(totals["sweeps"]),
-                           parallelism=f"{world} process(es), one per GPU, chunks sharded, no collectives",
-                           host_build_s=t_build, host_threads=n_threads),
-               roofline=roofline)
+    cfg = dict(workload=f"configs[1]: synthetic 1 Mb chunk, {args.sites} het sites, {args.coverage:g}x ONT reads, shipped ONT haplotag params; "
+                        f"{args.chunks} chunks per GPU phased end to end per step (mrp_phase_reads_many: all merge levels resident in HBM, final sweep, "
+                        f"trace back, genome fragments)",
+               chunks_per_gpu=args.chunks, units_per_gpu=int(units) // (n_gpus if single_process_multi else 1),
+               parallelism=(f"1 process, {n_gpus} devices, host work queue (mrp_queue_phase_chunks), no collectives" if single_process_multi else
+                            f"{world} process(es), one per GPU, chunks sharded by rank, no collectives"),
+               host_threads=min(16, os.cpu_count() or 1), synth_s=t_synth)
+    out = dict(metric="het-sites x reads phased/sec (30x ONT synthetic chunks, end to end: every merge level + final sweep)",
+               value=value, unit="het-site-reads/s", n_gpus=n_gpus, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
+               higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int32", data="synthetic", config=cfg)
+    if not single_process_multi:
+        out["step_detail"] = dict(resident=int(st.resident), fallback_chunks=int(st.fallback_chunks), levels=int(st.levels), hmms=int(st.hmms),
+                                  columns=int(st.columns), cells=int(st.cells), merge_cells=int(st.merge_cells), device_ms=float(st.device_ms),
+                                  cross_ms=float(st.cross_ms), sweep_ms=float(st.sweep_ms), prune_ms=float(st.prune_ms),
+                                  note="device_ms: summed HIP-event time of the levels' kernels of the last step (concurrent halves add up)")
+    else:
+        out["step_detail"] = dict(batches=int(st.batches), fallback_chunks=int(st.fallback_chunks),
+                                  chunks_per_device=[int(st.chunks_per_device[d]) for d in range(n_gpus)],
+                                  busy_ms_per_device=[float(st.busy_ms_per_device[d]) for d in range(n_gpus)],
+                                  note="inputs in host memory: the upload of every batch is inside the timed region")
 
-    if not args.no_pipeline:
-        # End-to-end leg: the same chunks phased from profile sequences to haplotypes by
-        # mrp_phase_reads_many -- tiling paths, every merge level (cross product -> forward/backward -> prune, resident
-        # in HBM), fused final sweep, trace back, genome fragments.  Wall clock around the C call, inputs (profile bytes,
-        # site tables) already on the device; it is reported beside the headline value, not as it.
-        G = max(1, min(args.pipeline_groups, n_chunks))
-        gctx = [capi.Context(local_rank) for _ in range(G)]
-        gchunks = [host_chunks[g::G] for g in range(G)]
-        pdch = [[capi.DeviceChunk.from_chunk(gctx[g], c) for c in gchunks[g]] for g in range(G)]
-        for c in host_chunks:
-            capi.read_records(c)
-
-        def run_groups():
-            with ThreadPoolExecutor(max_workers=G) as ex:
-                return list(ex.map(lambda g: capi.phase_reads_many(gctx[g], pdch[g], gchunks[g], params, convert=False)[1], range(G)))
-
-        run_groups()  # warm-up: allocator cache, pinned buffers
+    # ---- the same chunks from HOST memory through the work queue (PCIe-inclusive) --------------------------------
+    if args.queue_runs > 0 and not single_process_multi:
+        q = capi.Queue([local_rank])
+        descs = capi.chunk_descs(chunks)
+        q.phase(chunks, params, chunks_per_batch=max(1, args.chunks // 2), descs=descs, convert=False)
         barrier()
         t0 = time.perf_counter()
-        psts = None
-        for _ in range(args.pipeline_runs):
-            psts = run_groups()
+        for _ in range(args.queue_runs):
+            _, qst = q.phase(chunks, params, chunks_per_batch=max(1, args.chunks // 2), descs=descs, convert=False)
         barrier()
-        p_el = time.perf_counter() - t0
-        p_el, p_units = sharding.reduce_elapsed_and_units(dist, p_el, float(totals["units"]), device=reduce_dev)
-        out["pipeline"] = dict(what="mrp_phase_reads_many: profile sequences -> haplotypes, all merge levels resident on the device",
-                               value=p_units * args.pipeline_runs / p_el, unit="het-site-reads/s",
-                               ms_per_batch=1e3 * p_el / args.pipeline_runs, chunks_per_gpu=n_chunks, runs=args.pipeline_runs,
-                               concurrent_batches=G * int(os.environ.get("MRP_PHASE_GROUPS", "2")), resident=int(all(p.resident for p in psts)), levels=int(psts[0].levels),
-                               hmms=int(sum(p.hmms for p in psts)), columns=int(sum(p.columns for p in psts)),
-                               cells=int(sum(p.cells for p in psts)), device_ms=float(sum(p.device_ms for p in psts)),
-                               cross_ms=float(sum(p.cross_ms for p in psts)), sweep_ms=float(sum(p.sweep_ms for p in psts)),
-                               prune_ms=float(sum(p.prune_ms for p in psts)),
-                               host_threads=int(os.environ.get("MRP_HOST_THREADS", "0")) or min(16, os.cpu_count() or 1))
-        for grp in pdch:
-            for d_ in grp:
-                d_.close()
-        for c_ in gctx:
-            c_.close()
+        q_el = time.perf_counter() - t0
+        q_el, q_units = sharding.reduce_elapsed_and_units(dist, q_el, units, device=reduce_dev)
+        out["queue"] = dict(what="mrp_queue_phase_chunks: chunks in host memory, sorted by estimated cost, pulled in batches by one worker per device; "
+                                 "site tables and profile bytes uploaded per batch (PCIe-inclusive)",
+                            value=q_units * args.queue_runs / q_el, unit="het-site-reads/s", ms_per_run=1e3 * q_el / args.queue_runs,
+                            batches=int(qst.batches), runs=args.queue_runs)
+        q.close()
 
-    if args.align_chunks > 0:
+    # ---- kernel evidence: all sweeps of the same chunks replayed as one batch (rank 0) ---------------------------
+    if not args.no_roofline and rank == 0 and not single_process_multi:
+        rctx = capi.Context(local_rank)
+        big = capi.Batch(rctx)
+        tls_ctx = {}
+        keep = []
+
+        def record_one(i):
+            import threading
+            me = threading.get_ident()
+            if me not in tls_ctx:
+                tls_ctx[me] = capi.Context(local_rank)
+            dch = capi.DeviceChunk.from_chunk(tls_ctx[me], chunks[i])
+            keep.append(dch)
+            return capi.phase_reads(tls_ctx[me], dch, chunks[i], params, record=big)["n_sweeps"]
+
+        n_rec = min(args.chunks, len(chunks))
+        t0 = time.time()
+        with ThreadPoolExecutor(max_workers=n_threads) as ex:
+            sweeps = sum(ex.map(record_one, range(n_rec)))
+        t_build = time.time() - t0
+        big.upload()
+        for _ in range(3):
+            big.launch()
+        rctx.synchronize()
+        big.stats()
+        done, sw, em, pl = 0, 0.0, 0.0, 0.0
+        t0 = time.perf_counter()
+        while done < args.roofline_steps:  # the library keeps the events of a batch's 32 most recent launches
+            k = min(32, args.roofline_steps - done)
+            for _ in range(k):
+                big.launch()
+            s = big.stats()
+            assert s.launches_averaged == k
+            sw += s.avg_sweep_ms * k; em += s.avg_emission_ms * k; pl += s.avg_planes_ms * k
+            done += k
+        r_el = time.perf_counter() - t0
+        s = big.stats()
+        sweep_avg, emis_avg, planes_avg = sw / done, em / done, pl / done
+        C, M, K = float(s.n_cells), float(s.n_merge_cells), float(s.n_columns)
+        # B = sum_k 24*C_k + 32*M_k + D_k*Al_k + 8 per sweep.  The recursion kernel is credited with the
+        # bytes it is responsible for (f and b 16*C, merge cells 32*M, column totals 8*K), the emission kernel with 8*C.
+        alg = float(s.algorithmic_bytes)
+        alg_sweep = 16.0 * C + 32.0 * M + 8.0 * K
+        achieved = alg_sweep / (sweep_avg * 1e-3) / 1e9
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r02", "traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            if int(tj.get("chunks", -1)) == n_rec:  # measured on this workload
+                traffic, traffic_src = float(tj["sweep_kernel_hbm_bytes_per_launch"]), tj.get("source")
+        replay_ms = 1e3 * r_el / done
+        rec_units = float(sum(c.units for c in chunks[:n_rec]))
+        out["roofline"] = dict(bound="hbm", kernel="mrp_sweep_i32_kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                               frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                               algorithmic_bytes_per_launch=alg_sweep, kernel_ms=sweep_avg,
+                               what=f"all {sweeps} forward/backward sweeps of {n_rec} chunks (every merge level + final) recorded by the hashing path and "
+                                    f"replayed as ONE dependency-free batch: the kernels' throughput, not a phasing rate",
+                               moved_bytes_model=24.0 * C + 8.0 * M,
+                               replay=dict(ms_per_launch=replay_ms, units_per_s=rec_units / (replay_ms * 1e-3), planes_ms=planes_avg, emission_ms=emis_avg,
+                                           sweep_ms=sweep_avg, algorithmic_bytes=alg, frac=alg / (replay_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                           emission_kernel=dict(algorithmic_bytes=8.0 * C, achieved=8.0 * C / (emis_avg * 1e-3) / 1e9),
+                                           host_record_s=t_build),
+                               # the path's fraction: algorithmic bytes of every sweep of a step over the wall time of the REAL step
+                               path=dict(algorithmic_bytes=alg * args.chunks / n_rec, ms_per_step=ms_per_step,
+                                         achieved=alg * args.chunks / n_rec / (ms_per_step * 1e-3) / 1e9,
+                                         frac=alg * args.chunks / n_rec / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS))
+        big.close()
+        for d_ in keep:
+            d_.close()
+    if dist is not None:
+        dist.barrier()
+
+    if args.align_chunks > 0 and not single_process_multi:
         # Alignment leg: the banded pair-HMM forward probability of every read substring against every
-        # allele of every site (bubbleGraph.c:1421-1464), the numbers that become the profile bytes the sweep above reads.
-        # value = pairs / kernel time (HIP events inside the library, strings already on the device); the rate of the
-        # whole call (classification, upload, download) is given beside it.
+        # allele of every site (bubbleGraph.c:1421-1464), the numbers that become the profile bytes the sweeps read.
         t_hmm, t_tr, t_em = synth.margin_phase_pair_hmm_arrays()
         fwd = capi.PairHmm.from_margin_hmm(t_hmm, t_tr, t_em)
         a_models = [fwd, fwd.reverse_complement()]
@@ -302,35 +304,37 @@ def main():
         actx.close()
 
     if rank == 0 and not args.no_cpu_baseline and n_gpus == 1:
-        # CPU baseline: the oracle (C restatement of the reference's linked-list/hash implementation, -O3 -mpopcnt)
-        # phasing one chunk per thread -- the reference's own parallel axis (phase.c:276) -- on a bounded sample of
-        # the same workload; only the time inside its stRPHmm_forwardBackward calls is counted, like the GPU value.
+        # CPU baseline: the oracle (C restatement of the reference's linked-list/hash implementation, -O3 -mpopcnt) phasing
+        # one chunk per thread -- the reference's own parallel axis (phase.c:276) -- on a bounded sample of the same chunks,
+        # end to end like the GPU value (tiling paths, every merge level with prune, final sweep, trace back, fragments).
         from oracle import orc
-        n_thr = max(1, min(16, os.cpu_count() or 1, n_chunks))
+        n_thr = max(1, min(16, os.cpu_count() or 1, len(chunks)))
 
         def cpu_one(c):
             oc = orc.OracleChunk(c)
+            t1 = time.perf_counter()
             r = oc.phase(params_dict)
+            dt = time.perf_counter() - t1
             oc.close()
-            return r["fb_seconds"], r["fb_calls"]
+            return dt, r["fb_seconds"], r["fb_calls"]
 
         t_cpu = time.perf_counter()
         with ThreadPoolExecutor(max_workers=n_thr) as ex:
-            res = list(ex.map(cpu_one, host_chunks[:n_thr]))
+            res = list(ex.map(cpu_one, chunks[:n_thr]))
         t_cpu = time.perf_counter() - t_cpu
-        sample_units = sum(c.units for c in host_chunks[:n_thr])
-        slowest = max(r[0] for r in res)
-        out["cpu_baseline"] = dict(value=sample_units / slowest, unit="het-site-reads/s", cores=n_thr, kind="port",
-                                   sample=f"{n_thr} of {n_chunks} chunks, one per thread: all {sum(r[1] for r in res)} sweeps "
-                                          f"({sample_units} units); slowest thread spent {slowest:.2f} s in forward/backward "
-                                          f"(whole phasing of the sample: {t_cpu:.1f} s wall)",
-                                   per_core=first.units / res[0][0])
+        sample_units = sum(c.units for c in chunks[:n_thr])
+        out["cpu_baseline"] = dict(value=sample_units / t_cpu, unit="het-site-reads/s", cores=n_thr, kind="port",
+                                   sample=f"{n_thr} of {len(chunks)} chunks, one per thread, phased end to end by the oracle: {t_cpu:.1f} s wall "
+                                          f"({sum(r[2] for r in res)} sweeps; {max(r[1] for r in res):.2f} s of the slowest thread inside forward/backward)",
+                                   per_core=chunks[0].units / res[0][0])
     if rank == 0:
         print(json.dumps(out))
-    for b_ in bigs:
-        b_.close()
-    for d in keep:
-        d.close()
+    if single_process_multi:
+        queue.close()
+    else:
+        for d_ in dchunks:
+            d_.close()
+        ctx.close()
     if dist is not None:
         dist.destroy_process_group()
 

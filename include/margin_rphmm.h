@@ -59,6 +59,12 @@ int mrp_device_count(void);
 int mrp_context_create(int device, mrp_context **out);
 void mrp_context_destroy(mrp_context *ctx);
 int mrp_context_synchronize(mrp_context *ctx);
+/* mrp_phase_reads_many splits its chunks into this many interleaved batches that run concurrently on the context and its
+ * sibling contexts (one batch's host work beside the others' kernels); 1..8, default 2 */
+int mrp_context_set_phase_groups(mrp_context *ctx, int groups);
+/* size of the host worker pool shared by all contexts (structure of the merge levels, descriptors, classification of
+ * alignment pairs); default min(16, cores); takes effect for workers not yet started */
+int mrp_set_host_threads(int n);
 
 /*
  * Chunk = stReference + all stProfileSeq bytes of one genome chunk, uploaded once.
@@ -264,6 +270,47 @@ typedef struct mrp_phase_many_stats {
 int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *const *chunks, const mrp_read *const *reads,
                          const int64_t *n_reads, const mrp_params *params, mrp_phase_result **out,
                          mrp_phase_many_stats *stats);
+
+/* ---- the chunks of a node's worth of work over its GPUs ---------------------------------------------
+ * Replaces the chunk loop of phase.c:276-473 together with its ordering (phase.c:257-263, chunks by estimated depth,
+ * largest first) and its schedule ("#pragma omp parallel for schedule(dynamic,1)", :276-279), with devices in the role
+ * of the threads: one host thread and one context per entry of devices[] pull the next batch of chunks_per_batch
+ * consecutive chunks of that order, upload them (mrp_chunk_create), phase them (mrp_phase_reads_many) and store the
+ * results at the chunks' own positions of out[].  Chunks are independent until stitching: no collective, no traffic
+ * between devices.  A device may be listed more than once (two workers sharing it). */
+#define MRP_MAX_QUEUE_DEVICES 16
+typedef struct mrp_chunk_desc {     /* one genome chunk in host memory: what mrp_chunk_create and mrp_phase_reads take */
+    int64_t n_sites;
+    const uint32_t *allele_number;
+    const uint16_t *substitution_log_probs, *allele_prior_log_probs; /* NULL = all zero */
+    const uint8_t *profile_pool;
+    int64_t pool_bytes;
+    const mrp_read *reads;
+    int64_t n_reads;
+} mrp_chunk_desc;
+typedef struct mrp_queue_stats {
+    int32_t n_devices, reserved;
+    int64_t batches, fallback_chunks;
+    int64_t chunks_per_device[MRP_MAX_QUEUE_DEVICES];
+    int64_t units_per_device[MRP_MAX_QUEUE_DEVICES];  /* het-sites x reads phased by each worker */
+    double busy_ms_per_device[MRP_MAX_QUEUE_DEVICES]; /* host wall time each worker spent on its batches (upload included) */
+} mrp_queue_stats;
+typedef struct mrp_queue mrp_queue; /* the workers' contexts (device allocator caches, staging), kept from call to call */
+int mrp_queue_create(const int32_t *devices, int32_t n_devices, mrp_queue **out);
+void mrp_queue_destroy(mrp_queue *q);
+int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc *chunks, const mrp_params *params, int64_t chunks_per_batch,
+                           mrp_phase_result **out, mrp_queue_stats *stats);
+/* create + phase + destroy */
+int mrp_phase_chunks_on_devices(const int32_t *devices, int32_t n_devices, int64_t n_chunks, const mrp_chunk_desc *chunks,
+                                const mrp_params *params, int64_t chunks_per_batch, mrp_phase_result **out, mrp_queue_stats *stats);
+/* the order of the queue alone (host only): order_out[n_chunks] = chunk indices, largest cost first, ties in input
+ * order; batch_of_chunk_out (optional) = the batch each chunk travels in */
+int mrp_queue_plan(int64_t n_chunks, const int64_t *cost, int64_t chunks_per_batch, int64_t *order_out, int64_t *batch_of_chunk_out);
+/* the queue itself with stand-in workers that sleep usec_per_cost microseconds per unit of cost instead of phasing (host
+ * only; what the CPU test-suite drives): worker_of_chunk_out[i] = the worker that took chunk i, sequence_out[i]
+ * (optional) = the global position at which it was taken */
+int mrp_queue_dry_run(int32_t n_workers, int64_t n_chunks, const int64_t *cost, int64_t chunks_per_batch, double usec_per_cost,
+                      int32_t *worker_of_chunk_out, int64_t *sequence_out);
 
 /* ---- the frame around the path: host code, no device needed ----------------------- */
 

@@ -23,7 +23,7 @@ FLAG_INCLUDE_ANCESTOR_SUB_PROB = 2
 #: every symbol include/margin_rphmm.h declares (checked by the CPU test-suite)
 EXPORTED_SYMBOLS = [
     "mrp_last_error", "mrp_version", "mrp_device_count", "mrp_context_create", "mrp_context_destroy",
-    "mrp_context_synchronize", "mrp_chunk_create", "mrp_chunk_destroy", "mrp_fb_run", "mrp_batch_create",
+    "mrp_context_synchronize", "mrp_context_set_phase_groups", "mrp_set_host_threads", "mrp_chunk_create", "mrp_chunk_destroy", "mrp_fb_run", "mrp_batch_create",
     "mrp_batch_add", "mrp_batch_upload", "mrp_batch_launch", "mrp_batch_download", "mrp_batch_destroy",
     "mrp_batch_stats", "mrp_count_bit_vectors", "mrp_emissions", "mrp_get_rp_hmms", "mrp_hmm_destroy", "mrp_free",
     "mrp_hmm_view", "mrp_hmm_forward_backward", "mrp_hmm_prune", "mrp_hmm_forward_trace_back", "mrp_phase_reads",
@@ -31,7 +31,8 @@ EXPORTED_SYMBOLS = [
     "mrp_profile_seqs_from_bubbles", "mrp_assign_reads_to_haplotypes", "mrp_stitch_create", "mrp_stitch_destroy",
     "mrp_stitch_chunk", "mrp_stitch_size", "mrp_stitch_lookup", "mrp_phase_sets", "mrp_binomial_p_value", "mrp_binomial_coefficient",
     "mrp_symbols_from_chars", "mrp_pair_hmm_reverse_complement", "mrp_band_diagonals", "mrp_forward_probabilities",
-    "mrp_allele_read_supports", "mrp_kmer_alignment_anchors",
+    "mrp_allele_read_supports", "mrp_kmer_alignment_anchors", "mrp_phase_chunks_on_devices", "mrp_queue_plan", "mrp_queue_dry_run", "mrp_queue_create", "mrp_queue_destroy",
+    "mrp_queue_phase_chunks",
 ]
 
 
@@ -109,6 +110,21 @@ class PhaseManyStats(C.Structure):
     _fields_ = [("resident", C.c_int32), ("fallback_chunks", C.c_int32), ("levels", C.c_int64), ("hmms", C.c_int64),
                 ("columns", C.c_int64), ("cells", C.c_int64), ("merge_cells", C.c_int64), ("device_ms", C.c_double),
                 ("cross_ms", C.c_double), ("sweep_ms", C.c_double), ("prune_ms", C.c_double)]
+
+
+MAX_QUEUE_DEVICES = 16
+
+
+class ChunkDesc(C.Structure):
+    _fields_ = [("n_sites", C.c_int64), ("allele_number", C.c_void_p), ("substitution_log_probs", C.c_void_p),
+                ("allele_prior_log_probs", C.c_void_p), ("profile_pool", C.c_void_p), ("pool_bytes", C.c_int64),
+                ("reads", C.POINTER(ReadRec)), ("n_reads", C.c_int64)]
+
+
+class QueueStats(C.Structure):
+    _fields_ = [("n_devices", C.c_int32), ("reserved", C.c_int32), ("batches", C.c_int64), ("fallback_chunks", C.c_int64),
+                ("chunks_per_device", C.c_int64 * MAX_QUEUE_DEVICES), ("units_per_device", C.c_int64 * MAX_QUEUE_DEVICES),
+                ("busy_ms_per_device", C.c_double * MAX_QUEUE_DEVICES)]
 
 
 class Bubbles(C.Structure):
@@ -196,6 +212,8 @@ def load():
     L.mrp_context_destroy.argtypes = [vp]
     L.mrp_context_destroy.restype = None
     L.mrp_context_synchronize.argtypes = [vp]
+    L.mrp_context_set_phase_groups.argtypes = [vp, C.c_int]
+    L.mrp_set_host_threads.argtypes = [C.c_int]
     L.mrp_chunk_create.argtypes = [vp, i64, vp, vp, vp, vp, i64, P(vp)]
     L.mrp_chunk_destroy.argtypes = [vp]
     L.mrp_chunk_destroy.restype = None
@@ -248,6 +266,13 @@ def load():
     L.mrp_allele_read_supports.argtypes = [vp, P(PairHmm), P(PairHmm), i64, vp, vp, vp, i64, vp, vp, vp, vp, vp, i64, i64, vp, P(PairHmmStats)]
     L.mrp_kmer_alignment_anchors.argtypes = [vp, i64, vp, i64, vp]
     L.mrp_kmer_alignment_anchors.restype = i64
+    L.mrp_phase_chunks_on_devices.argtypes = [vp, i32, i64, P(ChunkDesc), P(Params), i64, P(P(PhaseResult)), P(QueueStats)]
+    L.mrp_queue_create.argtypes = [vp, i32, P(vp)]
+    L.mrp_queue_destroy.argtypes = [vp]
+    L.mrp_queue_destroy.restype = None
+    L.mrp_queue_phase_chunks.argtypes = [vp, i64, P(ChunkDesc), P(Params), i64, P(P(PhaseResult)), P(QueueStats)]
+    L.mrp_queue_plan.argtypes = [i64, vp, i64, vp, vp]
+    L.mrp_queue_dry_run.argtypes = [i32, i64, vp, i64, C.c_double, vp, vp]
     _lib = L
     return L
 
@@ -266,6 +291,9 @@ class Context:
 
     def synchronize(self):
         _check(load().mrp_context_synchronize(self.h))
+
+    def set_phase_groups(self, groups: int):
+        _check(load().mrp_context_set_phase_groups(self.h, groups))
 
     def close(self):
         if self.h:
@@ -553,6 +581,90 @@ def phase_reads_many(ctx: Context, dchunks: Sequence[DeviceChunk], chunks: Seque
         out.append(_phase_result_dict(res[i].contents) if convert else None)
         L.mrp_phase_result_destroy(res[i])
     return out, st
+
+
+# ---- the work queue over the GPUs of a node (mrp_queue.cpp) -----------------------------------
+
+def chunk_descs(chunks):
+    """mrp_chunk_desc[] for margin_amd.synth.Chunk objects; returns (ctypes array, keep-alive list)"""
+    n = len(chunks)
+    arr = (ChunkDesc * max(n, 1))()
+    keep = []
+    for i, c in enumerate(chunks):
+        an = np.ascontiguousarray(c.allele_number, dtype=np.uint32)
+        sub = np.ascontiguousarray(c.sub, dtype=np.uint16)
+        prior = np.ascontiguousarray(c.prior, dtype=np.uint16)
+        pool = np.ascontiguousarray(c.pool, dtype=np.uint8)
+        recs, names = read_records(c)
+        keep.append((an, sub, prior, pool, recs, names))
+        arr[i].n_sites = an.shape[0]
+        arr[i].allele_number = an.ctypes.data
+        arr[i].substitution_log_probs = sub.ctypes.data if sub.size else None
+        arr[i].allele_prior_log_probs = prior.ctypes.data if prior.size else None
+        arr[i].profile_pool = pool.ctypes.data if pool.size else None
+        arr[i].pool_bytes = pool.size
+        arr[i].reads = C.cast(recs, C.POINTER(ReadRec))
+        arr[i].n_reads = len(c.reads)
+    return arr, keep
+
+
+def phase_chunks_on_devices(devices, chunks, params: Params, chunks_per_batch: int = 48, descs=None, convert: bool = True):
+    """mrp_phase_chunks_on_devices -> (list of result dicts in input order, QueueStats)"""
+    L = load()
+    n = len(chunks)
+    arr, _keep = descs if descs is not None else chunk_descs(chunks)
+    dev = (C.c_int32 * len(devices))(*devices)
+    res = (C.POINTER(PhaseResult) * max(n, 1))()
+    st = QueueStats()
+    _check(L.mrp_phase_chunks_on_devices(C.cast(dev, C.c_void_p), len(devices), n, arr, C.byref(params), chunks_per_batch, res, C.byref(st)))
+    out = []
+    for i in range(n):
+        out.append(_phase_result_dict(res[i].contents) if convert else None)
+        L.mrp_phase_result_destroy(res[i])
+    return out, st
+
+
+class Queue:
+    """mrp_queue: the workers (one per listed device) with their contexts, for repeated calls"""
+
+    def __init__(self, devices):
+        dev = (C.c_int32 * len(devices))(*devices)
+        self.h = C.c_void_p()
+        _check(load().mrp_queue_create(C.cast(dev, C.c_void_p), len(devices), C.byref(self.h)))
+
+    def phase(self, chunks, params: Params, chunks_per_batch: int = 48, descs=None, convert: bool = True):
+        L = load()
+        n = len(chunks)
+        arr, _keep = descs if descs is not None else chunk_descs(chunks)
+        res = (C.POINTER(PhaseResult) * max(n, 1))()
+        st = QueueStats()
+        _check(L.mrp_queue_phase_chunks(self.h, n, arr, C.byref(params), chunks_per_batch, res, C.byref(st)))
+        out = []
+        for i in range(n):
+            out.append(_phase_result_dict(res[i].contents) if convert else None)
+            L.mrp_phase_result_destroy(res[i])
+        return out, st
+
+    def close(self):
+        if self.h:
+            load().mrp_queue_destroy(self.h)
+            self.h = None
+
+
+def queue_plan(cost, chunks_per_batch: int):
+    cost = np.ascontiguousarray(cost, dtype=np.int64)
+    order = np.zeros(len(cost), dtype=np.int64)
+    batch = np.zeros(len(cost), dtype=np.int64)
+    _check(load().mrp_queue_plan(len(cost), cost.ctypes.data, chunks_per_batch, order.ctypes.data, batch.ctypes.data))
+    return order, batch
+
+
+def queue_dry_run(n_workers: int, cost, chunks_per_batch: int, usec_per_cost: float = 0.0):
+    cost = np.ascontiguousarray(cost, dtype=np.int64)
+    worker = np.full(len(cost), -1, dtype=np.int32)
+    seq = np.full(len(cost), -1, dtype=np.int64)
+    _check(load().mrp_queue_dry_run(n_workers, len(cost), cost.ctypes.data, chunks_per_batch, usec_per_cost, worker.ctypes.data, seq.ctypes.data))
+    return worker, seq
 
 
 # ---- the frame around the path (rphmm_frame.c): host only -------------------------------------

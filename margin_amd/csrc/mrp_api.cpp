@@ -573,15 +573,26 @@ extern "C" void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void 
     P.jobs.erase(std::find(P.jobs.begin(), P.jobs.end(), &j));
 }
 
+static std::atomic<int> g_host_threads{0};
 int mrp_host_threads(void) {
-    static const int n = []() {
-        const char *e = getenv("MRP_HOST_THREADS");
-        int v = e ? atoi(e) : 0;
-        if (v <= 0) v = (int) std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
-        return v;
-    }();
+    int n = g_host_threads.load();
+    if (n <= 0) {
+        n = (int) std::min<unsigned>(16u, std::max(1u, std::thread::hardware_concurrency()));
+        g_host_threads.store(n);
+    }
     return n;
 }
+int mrp_set_host_threads(int n) {
+    if (n < 1 || n > 256) return fail(MRP_ERR_ARG, "mrp_set_host_threads: %d outside 1..256", n);
+    g_host_threads.store(n);
+    return MRP_OK;
+}
+int mrp_context_set_phase_groups(mrp_context *ctx, int groups) {
+    if (!ctx || groups < 1 || groups > 8) return fail(MRP_ERR_ARG, "mrp_context_set_phase_groups: bad arguments");
+    ctx->phase_groups = groups;
+    return MRP_OK;
+}
+int mrp_context_phase_groups(const mrp_context *ctx) { return ctx->phase_groups; }
 
 extern "C" {
 
@@ -751,12 +762,7 @@ int mrp_batch_launch(mrp_batch *b) {
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t s = ctx->stream;
     const MrpBatchDev &d = b->dev;
-    /* Byte packing / bit planes only read what the host uploaded and write the packed bytes the emission kernel reads, so
-     * they need not wait for the recursion kernels of the previous launch on this context (which read costs, not bytes):
-     * with MRP_PRE_STREAM=1 they run on their own stream as soon as the previous launch's emission kernel is done with the
-     * packed bytes.  (Resident levels keep one stream: their launches are separated by host work anyway.) */
-    static const bool use_pre = getenv("MRP_PRE_STREAM") && atoi(getenv("MRP_PRE_STREAM")) != 0; /* off unless asked for, see DESIGN.md 4 */
-    hipStream_t ps = (b->resident || !use_pre) ? s : ctx->pre;
+    hipStream_t ps = s; /* byte packing / bit planes ahead of the emission kernel, on the same stream */
     const size_t slot = (size_t) (b->n_launches % mrp_batch::EV_RING);
     if (slot >= b->ev_ring.size()) {
         std::array<hipEvent_t, 5> fresh{};
@@ -786,9 +792,7 @@ int mrp_batch_launch(mrp_batch *b) {
     HIP_TRY(hipEventRecord(ctx->fork, s));
     HIP_TRY(hipStreamWaitEvent(ctx->aux[0], ctx->fork, 0));
     HIP_TRY(hipStreamWaitEvent(ctx->aux[1], ctx->fork, 0));
-    static const int t_wide = getenv("MRP_T_WIDE") ? atoi(getenv("MRP_T_WIDE")) : 512;   /* tuning knobs */
-    static const int t_mid = getenv("MRP_T_MID") ? atoi(getenv("MRP_T_MID")) : 512;
-    static const int t_narrow = getenv("MRP_T_NARROW") ? atoi(getenv("MRP_T_NARROW")) : 64;
+    const int t_wide = 512, t_mid = 512, t_narrow = 64; /* workgroup sizes of the recursion kernel's classes (measured) */
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_wide.p, (int64_t) b->order_wide.size(), t_wide, b->max_merge_wide, s));
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_mid.p, (int64_t) b->order_mid.size(), t_mid, b->max_merge_mid, ctx->aux[0]));
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), t_narrow, b->max_merge_narrow, ctx->aux[1]));

@@ -136,10 +136,11 @@ struct mrp_context {
     hipStream_t stream = nullptr;
     hipStream_t aux[2] = {nullptr, nullptr}; /* size classes of the recursion kernel run side by side */
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t pre = nullptr; /* byte packing / bit planes of a launch run here, beside the recursion kernels of the launch before */
+    hipStream_t pre = nullptr; /* copy stream: uploads of a staged level of the resident engine, beside the kernels of the level before */
     hipEvent_t last_emission = nullptr; /* end of the emission kernel of the most recent launch on this context (owned by its batch) */
     hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
     DevPool pool;
+    int phase_groups = 2; /* concurrent halves of mrp_phase_reads_many (mrp_context_set_phase_groups) */
     std::vector<mrp_context *> siblings; /* further contexts on the same device (concurrent batches of mrp_phase_reads_many) */
     std::mutex sibling_mu;
     /* the emptied batch object of the last resident engine on this context: its host arrays keep their capacity (and their

@@ -1997,8 +1997,8 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
     if (stats) memset(stats, 0, sizeof(*stats));
     for (int64_t c = 0; c < n_chunks; c++) out[c] = NULL;
     /* the levels of a batch alternate host work (structure, descriptors) and device work; two interleaved halves of the
-     * chunks, each with its own context and host thread, keep both busy (MRP_PHASE_GROUPS, default 2) */
-    int G = getenv("MRP_PHASE_GROUPS") ? atoi(getenv("MRP_PHASE_GROUPS")) : 2;
+     * chunks, each with its own context and host thread, keep both busy */
+    int G = mrp_context_phase_groups(ctx); /* mrp_context_set_phase_groups, default 2 */
     if (G < 1) G = 1;
     if (G > 8) G = 8;
     if (n_chunks < 4 * G) G = 1;

@@ -31,8 +31,9 @@ int mrp_context_device(const mrp_context *ctx);
 /* a further context (stream, allocator cache) on the same device, owned by ctx and destroyed with it; i = 0, 1, ... */
 mrp_context *mrp_context_sibling(mrp_context *ctx, int i);
 int mrp_set_error(int code, const char *fmt, ...);
-/* host worker threads for structural code and descriptor building (MRP_HOST_THREADS, default min(16, cores)) */
+/* host worker threads for structural code and descriptor building (mrp_set_host_threads, default min(16, cores)) */
 int mrp_host_threads(void);
+int mrp_context_phase_groups(const mrp_context *ctx);
 /* fn(i, arg) for every i in [0, n), grain indices at a time, on the caller and the persistent worker pool (mrp_api.cpp) */
 void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void *), void *arg);
 

@@ -1,0 +1,97 @@
+"""The host-side work queue over the GPUs of a node (mrp_queue.cpp; reference: phase.c:257-263 chunk order by estimated
+depth, largest first, and phase.c:276-279 "schedule(dynamic,1)").  CPU: the order and the queue itself with stand-in
+workers.  GPU: two workers sharing device 0 phase a set of chunks; results equal the oracle's whatever worker took them."""
+import numpy as np
+import pytest
+
+from margin_amd import capi, synth
+
+
+def test_queue_order_largest_first_ties_in_input_order():
+    cost = np.array([5, 9, 9, 1, 7, 9, 0, 3], dtype=np.int64)
+    order, batch = capi.queue_plan(cost, 3)
+    assert order.tolist() == [1, 2, 5, 4, 0, 7, 3, 6]           # phase.c:257-263, stable on ties
+    assert batch[order].tolist() == [0, 0, 0, 1, 1, 1, 2, 2]   # consecutive chunks of that order travel together
+    order1, batch1 = capi.queue_plan(cost, 1)
+    assert order1.tolist() == order.tolist() and sorted(batch1.tolist()) == list(range(8))
+    empty, _ = capi.queue_plan(np.zeros(0, dtype=np.int64), 4)
+    assert len(empty) == 0
+
+
+@pytest.mark.parametrize("n_workers,per_batch", [(1, 1), (2, 1), (3, 2), (8, 1), (16, 4)])
+def test_queue_dry_run_is_complete_ordered_and_dynamic(n_workers, per_batch):
+    """Every chunk is taken exactly once; a worker takes its batches in the queue's order (largest first); the schedule is
+    dynamic: with one very expensive batch, the worker that holds it takes no other while the rest drain the queue."""
+    rng = np.random.default_rng(n_workers * 10 + per_batch)
+    cost = rng.integers(1, 50, size=97).astype(np.int64)
+    worker, seq = capi.queue_dry_run(n_workers, cost, per_batch, usec_per_cost=2.0)
+    assert (worker >= 0).all() and (worker < n_workers).all()
+    assert sorted(seq.tolist()) == list(range(len(cost)))
+    order, batch = capi.queue_plan(cost, per_batch)
+    for w in range(n_workers):
+        mine = [i for i in order if worker[i] == w]          # in queue order
+        assert [seq[i] for i in mine] == sorted(seq[i] for i in mine)
+    # chunks of one batch go to one worker
+    for b in range(int(batch.max()) + 1):
+        assert len(set(worker[batch == b].tolist())) == 1
+    if n_workers >= 2:
+        big = cost.copy()
+        big[13] = 40_000  # 80 ms at 2 us per unit: the others are through long before
+        worker, _ = capi.queue_dry_run(n_workers, big, 1, usec_per_cost=2.0)
+        holder = worker[13]
+        assert (worker == holder).sum() <= 2  # the expensive chunk heads the queue; its worker gets at most the wake-up race's second
+
+
+def test_queue_rejects_bad_arguments():
+    L = capi.load()
+    cost = np.ones(4, dtype=np.int64)
+    w = np.zeros(4, dtype=np.int32)
+    assert L.mrp_queue_dry_run(0, 4, cost.ctypes.data, 1, 0.0, w.ctypes.data, None) == capi.MRP_ERR_ARG
+    assert L.mrp_queue_dry_run(capi.MAX_QUEUE_DEVICES + 1, 4, cost.ctypes.data, 1, 0.0, w.ctypes.data, None) == capi.MRP_ERR_ARG
+    # without a device the real queue fails loudly: no CPU fallback
+    if L.mrp_device_count() == 0:
+        import ctypes as C
+        q = C.c_void_p()
+        dev = (C.c_int32 * 1)(0)
+        assert L.mrp_queue_create(C.cast(dev, C.c_void_p), 1, C.byref(q)) == capi.MRP_ERR_NO_DEVICE
+
+
+@pytest.mark.gpu
+def test_two_workers_on_one_device_phase_every_chunk(orc):
+    """mrp_queue_phase_chunks with the device listed twice: two host threads, two contexts, batches of 3 chunks pulled
+    from the shared queue; every chunk's result sits at its own position and equals the oracle's; a second call on the
+    same queue object reuses the workers' contexts."""
+    specs = [(3, 90, 20), (5, 150, 35), (11, 60, 12), (12, 30, 8), (13, 120, 25), (14, 40, 30), (15, 100, 18), (16, 70, 28)]
+    chunks = [synth.make_ont_chunk(seed=s, region_bp=n * 500, n_sites=n, coverage=c) for s, n, c in specs]
+    empty = synth.make_ont_chunk(seed=99, region_bp=10_000, n_sites=20, coverage=5)
+    empty.reads = []
+    chunks.insert(4, empty)
+    pd = synth.shipped_phase_params()
+    params = capi.Params.from_reference_names(pd)
+    q = capi.Queue([0, 0])
+    try:
+        got, st = q.phase(chunks, params, chunks_per_batch=3)
+        assert st.n_devices == 2 and st.batches == 3 and sum(st.chunks_per_device[:2]) == len(chunks)
+        assert sum(st.units_per_device[:2]) == sum(c.units for c in chunks) and st.fallback_chunks == 0
+        for chunk, g in zip(chunks, got):
+            if not chunk.reads:
+                assert g["length"] == 0 and g["reads1"] == [] and g["reads2"] == []
+                continue
+            oc = orc.OracleChunk(chunk)
+            ref = oc.phase(pd)
+            oc.close()
+            for k in ("hap1", "hap2", "genotype", "ancestor", "support1", "support2", "genotype_probs", "hap_probs1", "hap_probs2"):
+                assert (np.asarray(g[k]) == np.asarray(ref[k])).all(), k
+            assert g["reads1"] == ref["reads1"] and g["reads2"] == ref["reads2"]
+        again, st2 = q.phase(chunks, params, chunks_per_batch=5)
+        assert st2.batches == 2
+        for a, b in zip(got, again):
+            assert (np.asarray(a["hap1"]) == np.asarray(b["hap1"])).all() and a["reads1"] == b["reads1"]
+    finally:
+        q.close()
+    # the one-shot form, one worker
+    one, st1 = capi.phase_chunks_on_devices([0], chunks[:3], params, chunks_per_batch=2)
+    assert st1.batches == 2 and all((np.asarray(a["hap1"]) == np.asarray(b["hap1"])).all() for a, b in zip(one, got[:3]))
+    with pytest.raises(capi.MrpError) as ei:
+        capi.phase_chunks_on_devices([7], chunks[:1], params)
+    assert ei.value.code == capi.MRP_ERR_ARG

@@ -34,6 +34,10 @@ def main():
     pd = synth.shipped_phase_params()
     params = capi.Params.from_reference_names(pd)
     ctx = capi.Context(0)
+    if os.environ.get("MRP_PHASE_GROUPS"):
+        ctx.set_phase_groups(int(os.environ["MRP_PHASE_GROUPS"]))
+    if os.environ.get("MRP_HOST_THREADS"):
+        capi.load().mrp_set_host_threads(int(os.environ["MRP_HOST_THREADS"]))
     t0 = time.time()
     with ThreadPoolExecutor(max_workers=min(16, args.chunks)) as ex:
         if args.hifi:
