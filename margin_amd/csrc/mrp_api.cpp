@@ -180,6 +180,10 @@ int mrp_chunk_create(mrp_context *ctx, int64_t n_sites, const uint32_t *allele_n
     for (uint16_t v : sub) ch->max_sub = std::max<uint32_t>(ch->max_sub, v);
     for (uint16_t v : prior) ch->max_prior = std::max<uint32_t>(ch->max_prior, v);
     hipStream_t s = ctx->stream;
+    /* from the context's caching allocator: a work queue creates and destroys a batch of chunks per call */
+    ch->d_allele_number.pool = ch->d_allele_offset.pool = ch->d_sub_offset.pool = &ctx->pool;
+    ch->d_sub.pool = ch->d_prior.pool = &ctx->pool;
+    ch->d_pool.pool = &ctx->pool;
     hipError_t e = ch->d_allele_number.upload(ch->allele_number, s);
     if (e == hipSuccess) e = ch->d_allele_offset.upload(ch->allele_offset, s);
     if (e == hipSuccess) e = ch->d_sub_offset.upload(ch->sub_offset, s);
