@@ -63,6 +63,14 @@ mrp_context *mrp_context_sibling(mrp_context *ctx, int i) {
     while ((int) ctx->siblings.size() <= i) {
         mrp_context *s = nullptr;
         if (mrp_context_create(ctx->device, &s) != MRP_OK) return nullptr;
+        s->phase_groups = 1;
+        /* every pool of the family knows the others (out-of-memory retry) */
+        std::vector<mrp_context *> family(ctx->siblings);
+        family.push_back(ctx);
+        for (mrp_context *o : family) {
+            if (o->pool.n_peers < 16) o->pool.peers[o->pool.n_peers++] = &s->pool;
+            if (s->pool.n_peers < 16) s->pool.peers[s->pool.n_peers++] = &o->pool;
+        }
         ctx->siblings.push_back(s);
     }
     return ctx->siblings[(size_t) i];
@@ -115,7 +123,7 @@ void mrp_context_destroy(mrp_context *ctx) {
     (void) hipSetDevice(ctx->device);
     mrp_engine_release_context_cache(ctx);
     if (ctx->spare_batch) { mrp_batch_destroy(ctx->spare_batch); ctx->spare_batch = nullptr; }
-    if (ctx->stream) (void) hipStreamSynchronize(ctx->stream);
+    (void) hipDeviceSynchronize(); /* the auxiliary and copy streams too */
     ctx->pool.destroy();
     if (ctx->pinned) (void) hipHostFree(ctx->pinned);
     for (auto &e : ctx->ev)
@@ -648,6 +656,9 @@ int mrp_batch_upload(mrp_batch *b) {
     const double u1 = now_();
     std::vector<DevChunk> chunks;
     for (auto *c : b->chunks) chunks.push_back(c->dev);
+    std::vector<int32_t> pack_list, plane_list;
+    /* declared after the staging vectors: an early return drains the stream before they are destroyed */
+    struct Drain { hipStream_t s; ~Drain() { (void) hipStreamSynchronize(s); } } drain{s};
 
     HIP_TRY(b->d_hmms.upload(b->hmms, s));
     HIP_TRY(b->d_cols.upload(b->cols, s));
@@ -684,7 +695,6 @@ int mrp_batch_upload(mrp_batch *b) {
         b->n_tiles_dev = (int64_t) b->tiles.size();
         HIP_TRY(b->d_tiles.upload(b->tiles, s));
     }
-    std::vector<int32_t> pack_list, plane_list;
     pack_list.reserve(b->pcols.size());
     for (size_t i = 0; i < b->pcols.size(); i++) (b->pcols[i].need_planes ? plane_list : pack_list).push_back((int32_t) i);
     HIP_TRY(b->d_pack_list.upload(pack_list, s));
@@ -938,18 +948,9 @@ static int one_column(mrp_context *ctx, const mrp_chunk *chunk, int32_t first_si
 static int run_planes(mrp_context *ctx, const mrp_chunk *chunk, const DevCol &col, const int64_t *read_byte_off,
                       DevBuf<DevCol> &d_col, DevBuf<DevChunk> &d_chunk, DevBuf<int64_t> &d_off,
                       DevBuf<uint64_t> &d_planes, DevBuf<uint32_t> &d_tot) {
-    static thread_local DevBuf<uint32_t> d_bytes;
-    static thread_local DevBuf<PlaneCol> d_pcol;
     hipStream_t s = ctx->stream;
-    std::vector<DevCol> hc(1, col);
-    std::vector<DevChunk> hch(1, chunk->dev);
-    std::vector<int64_t> ho(read_byte_off, read_byte_off + col.depth);
-    HIP_TRY(d_col.upload(hc, s));
-    HIP_TRY(d_chunk.upload(hch, s));
-    HIP_TRY(d_off.upload(ho, s));
-    HIP_TRY(d_planes.alloc((size_t) col.n_slots * 8));
-    HIP_TRY(d_tot.alloc((size_t) col.n_slots));
-    HIP_TRY(d_bytes.alloc((size_t) col.n_slots * 16));
+    DevBuf<uint32_t> d_bytes;
+    DevBuf<PlaneCol> d_pcol;
     PlaneCol pc{};
     pc.pool = chunk->dev.pool;
     pc.read_off = 0;
@@ -957,7 +958,20 @@ static int run_planes(mrp_context *ctx, const mrp_chunk *chunk, const DevCol &co
     pc.depth = col.depth;
     pc.n_slots = col.n_slots;
     pc.need_planes = 1;
+    /* host staging of the queued uploads */
+    std::vector<DevCol> hc(1, col);
+    std::vector<DevChunk> hch(1, chunk->dev);
+    std::vector<int64_t> ho(read_byte_off, read_byte_off + col.depth);
     std::vector<PlaneCol> hpc(1, pc);
+    /* declared last, so it runs first: whatever way this function is left, the stream is drained before the staging vectors
+     * above and the scratch buffers (written by the kernel) go */
+    struct Drain { hipStream_t s; ~Drain() { (void) hipStreamSynchronize(s); } } drain{s};
+    HIP_TRY(d_col.upload(hc, s));
+    HIP_TRY(d_chunk.upload(hch, s));
+    HIP_TRY(d_off.upload(ho, s));
+    HIP_TRY(d_planes.alloc((size_t) col.n_slots * 8));
+    HIP_TRY(d_tot.alloc((size_t) col.n_slots));
+    HIP_TRY(d_bytes.alloc((size_t) col.n_slots * 16));
     HIP_TRY(d_pcol.upload(hpc, s));
     MrpBatchDev d{};
     d.pcols = d_pcol.p;

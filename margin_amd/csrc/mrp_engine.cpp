@@ -291,6 +291,8 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         for (auto &ev : L->ev) ENG_TRY(hipEventCreate(&ev));
     }
 
+    double tm[8]; int tmi = 0;
+    tm[tmi++] = eng_now();
     /* sizes that do not depend on counts */
     std::vector<int64_t> col0((size_t) n + 1), read0((size_t) n + 1), slot0((size_t) n + 1);
     int64_t total_cols = 0, total_reads = 0, total_slots = 0;
@@ -330,6 +332,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         if (idx < 0) { idx = (int) b->chunks.size(); b->chunks.push_back(ch); }
         chunk_index[(size_t) i] = idx;
     }
+    tm[tmi++] = eng_now();
     /* pass 1 (parallel): allele slots per hmm, static bounds, validity */
     struct Bound { int64_t slots, cells, merge; int32_t max_cells, max_merge; int64_t cost; int bad; };
     std::vector<Bound> bd((size_t) n);
@@ -372,6 +375,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     }
     L->n_slots = total_slots;
 
+    tm[tmi++] = eng_now();
     /* the level's output: the pruned hmms, fixed stride (the final level keeps one traced-back cell per column) */
     L->seg.reset(new (std::nothrow) Segment());
     if (!L->seg) return mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
@@ -403,9 +407,12 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     DevChunk *hchunks = (DevChunk *) (hb + o_chunks);
     for (size_t c = 0; c < b->chunks.size(); c++) hchunks[c] = b->chunks[c]->dev;
 
+    tm[tmi++] = eng_now();
     /* pass 2 (parallel): the plan */
+    std::vector<int32_t> n_planes_of((size_t) n, 0);
     mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
         mrp_xhmm &h = x[i];
+        int32_t planes_here = 0;
         const mrp_chunk *ch = h.chunk;
         const int K = h.n_cols;
         const bool anc = (h.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
@@ -429,6 +436,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
             o.d1 = c.d1; o.d2 = c.d2; o.out_a = c.out_a; o.out_b = c.out_b;
             o.out_a_paired = c.out_a_paired; o.out_b_paired = c.out_b_paired;
             o.need_planes = (uniform == 0 || anc) ? 1 : 0;
+            planes_here += o.need_planes;
             o.last = k + 1 == K ? 1 : 0;
             o.pad = 0;
         }
@@ -443,12 +451,26 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         q.out_n_merge = seg->n_merge.p + colbase;
         h.d_part = q.out_part; h.d_np = q.out_np; h.d_ncells = q.out_n_cells; h.d_nmerge = q.out_n_merge;
         h.err = 0;
+        n_planes_of[(size_t) i] = planes_here;
     });
-    /* packing lists (columns of the fast emission path / those that need bit planes) */
+    tm[tmi++] = eng_now();
+    /* packing lists (columns of the fast emission path / those that need bit planes): positions by a prefix sum over the
+     * hmms, filled in parallel */
     int64_t n_pack = 0, n_plane = 0;
-    for (int64_t c = 0; c < total_cols; c++) {
-        if (plan[c].need_planes) plane_list[n_plane++] = (int32_t) c;
-        else pack_list[n_pack++] = (int32_t) c;
+    {
+        std::vector<int64_t> plane0((size_t) n + 1), pack0((size_t) n + 1);
+        for (int64_t i = 0; i < n; i++) {
+            plane0[(size_t) i] = n_plane; pack0[(size_t) i] = n_pack;
+            n_plane += n_planes_of[(size_t) i];
+            n_pack += x[i].n_cols - n_planes_of[(size_t) i];
+        }
+        mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
+            int64_t a = plane0[(size_t) i], c2 = pack0[(size_t) i];
+            for (int64_t c = col0[(size_t) i]; c < col0[(size_t) i + 1]; c++) {
+                if (plan[c].need_planes) plane_list[a++] = (int32_t) c;
+                else pack_list[c2++] = (int32_t) c;
+            }
+        });
     }
     /* launch classes of the recursion kernel, from the static bounds; largest first inside a class */
     b->order_wide.clear(); b->order_mid.clear(); b->order_narrow.clear(); b->order_f64.clear();
@@ -479,8 +501,14 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     {
         L->perm.resize((size_t) n);
         std::vector<int32_t> pos((size_t) n);
-        for (int64_t i = 0; i < n; i++) L->perm[(size_t) i] = (int32_t) i;
-        std::stable_sort(L->perm.begin(), L->perm.end(), [&](int32_t a, int32_t c) { return x[a].n_cols > x[c].n_cols; });
+        {   /* stable counting sort by descending number of columns */
+            int32_t max_cols = 1;
+            for (int64_t i = 0; i < n; i++) max_cols = std::max(max_cols, x[i].n_cols);
+            std::vector<int64_t> at((size_t) max_cols + 2, 0);
+            for (int64_t i = 0; i < n; i++) at[(size_t) (max_cols - x[i].n_cols) + 1]++;
+            for (size_t q = 1; q < at.size(); q++) at[q] += at[q - 1];
+            for (int64_t i = 0; i < n; i++) L->perm[(size_t) at[(size_t) (max_cols - x[i].n_cols)]++] = (int32_t) i;
+        }
         std::vector<PruneHmm> sorted((size_t) n);
         for (int64_t j = 0; j < n; j++) { sorted[(size_t) j] = ph[L->perm[(size_t) j]]; pos[(size_t) L->perm[(size_t) j]] = (int32_t) j; }
         memcpy(ph, sorted.data(), sizeof(PruneHmm) * (size_t) n);
@@ -497,6 +525,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     }
     pp.pad = (e->params.reserved & 1) && e->stats.levels + (e->running ? 1 : 0) == 1 ? 1 : 0; /* test hook, see mrp_params.reserved */
 
+    tm[tmi++] = eng_now();
     /* device side of the description + the descriptor arrays the layout kernels fill */
     b->bind_pool(pl);
     L->d_plan.pool = pl; L->d_phmm.pool = pl; L->d_dims.pool = pl; L->d_tot.pool = pl; L->d_base.pool = pl; L->d_totals.pool = pl;
@@ -544,6 +573,9 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     b->stats.n_hmms = n;
     b->stats.n_columns = total_cols;
     L->t_staged = eng_now();
+    if (getenv("MRP_TIMING"))
+        fprintf(stderr, "      stage: sizes+chunks %.2f ms, bounds %.2f, segment+staging %.2f, plan %.2f, lists+classes+order %.2f, allocs+uploads %.2f\n", tm[1] - tm[0],
+                tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], tm[5] - tm[4], L->t_staged - tm[5]);
     e->staged = L.release();
     return MRP_OK;
 }

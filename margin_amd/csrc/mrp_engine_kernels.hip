@@ -27,9 +27,9 @@
 #include <stdint.h>
 
 #include <algorithm>
-#include <mutex>
 
 #include "mrp_engine.h"
+#include "mrp_internal.h"
 #include "../../include/margin_rphmm.h"
 
 #define WAVE 64
@@ -490,7 +490,7 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t prune_rsrc(const void *
 #define PRUNE_TAB 5   /* per side and buffer: cnt, start, list, nx, pv, 128 entries each */
 
 template <int T, int CPT>
-__global__ void __launch_bounds__(T) mrp_prune_kernel(PruneIn d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
+__global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
                                                       PruneParams p, PruneScratch sc) {
     constexpr int W = T / WAVE;
     constexpr int NBG = (W - 4) / 2;     /* waves per bin-streaming group */
@@ -1217,20 +1217,13 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, con
     if (n_hmms <= 0) return hipSuccess;
     if (p.S > MRP_PRUNE_MAX_S || p.max_cells > MRP_PRUNE_MAX_CELLS || p.max_merge > MRP_PRUNE_MAX_CELLS || p.n_bins > 1024) return hipErrorInvalidValue;
     /* once per device (thread-safe: the concurrent halves of a call launch from two host threads) */
-    static std::mutex mu;
-    static bool configured[64] = {false};
-    int dev = 0;
-    hipError_t e = hipGetDevice(&dev);
-    if (e != hipSuccess) return e;
-    {
-        std::lock_guard<std::mutex> lock(mu);
-        if (dev >= 0 && dev < 64 && !configured[dev]) {
-            e = hipFuncSetAttribute((const void *) mrp_prune_kernel<512, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess) e = hipFuncSetAttribute((const void *) mrp_prune_kernel<1024, 36>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e != hipSuccess) return e;
-            configured[dev] = true;
-        }
-    }
+    static PerDeviceOnce once;
+    const hipError_t configured = once.run([] {
+        hipError_t e = hipFuncSetAttribute((const void *) mrp_prune_kernel<512, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *) mrp_prune_kernel<1024, 36>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return e;
+    });
+    if (configured != hipSuccess) return configured;
     const size_t lds = prune_lds_bytes(p);
     if (lds > (size_t) MRP_LDS_BUDGET) return hipErrorInvalidValue;
     const dim3 grid((unsigned) (n_hmms < 65536 ? n_hmms : 65536));

@@ -23,6 +23,24 @@
 #include "mrp_kernels.h"
 #include "rphmm_host.h"
 
+/* A kernel attribute (the opt-in to more than 64 KB of dynamic LDS) belongs to the function ON A DEVICE: set once per device,
+ * by whichever context of that device launches first (the C-ABI lets one process hold contexts on several devices). */
+struct PerDeviceOnce {
+    std::mutex mu;
+    bool done[64] = {false};
+    template <class F> hipError_t run(F f) {
+        int dev = 0;
+        hipError_t e = hipGetDevice(&dev);
+        if (e != hipSuccess) return e;
+        if (dev < 0 || dev >= 64) return f();
+        std::lock_guard<std::mutex> lock(mu);
+        if (done[dev]) return hipSuccess;
+        e = f();
+        if (e == hipSuccess) done[dev] = true;
+        return e;
+    }
+};
+
 /* std::vector whose resize() leaves trivially constructible elements uninitialised: the descriptor arrays of a level
  * are tens of megabytes that the filling threads overwrite entirely; zero-filling them first is a serial pass. */
 template <class T>
@@ -44,6 +62,11 @@ struct DevPool {
     std::vector<std::pair<size_t, void *>> pending;
     size_t cached_bytes = 0;                 /* bytes in free_blocks */
     size_t cache_limit = (size_t) 64 << 30;  /* beyond this the largest cached blocks go back to the driver */
+    /* the pools of the other contexts of the same device (siblings of mrp_phase_reads_many's concurrent halves, their
+     * parent): when the driver is out of memory their idle blocks are given back too */
+    DevPool *peers[16] = {nullptr};
+    int n_peers = 0;
+    std::mutex *peers_mu = nullptr;
     static size_t size_class(size_t bytes) {
         if (bytes < 256) bytes = 256;
         const int lg = 63 - __builtin_clzll((unsigned long long) bytes);
@@ -67,6 +90,12 @@ struct DevPool {
         if (e != hipSuccess) { /* give the cache back and try once more */
             (void) hipGetLastError();
             trim();
+            e = hipMalloc(p, cls);
+        }
+        if (e != hipSuccess && n_peers > 0) { /* ... and what idles in the other contexts of this device */
+            (void) hipGetLastError();
+            for (int i = 0; i < n_peers; i++)
+                if (peers[i]) peers[i]->trim();
             e = hipMalloc(p, cls);
         }
         return e;

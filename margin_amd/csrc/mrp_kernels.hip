@@ -24,6 +24,7 @@
 #include <stdint.h>
 
 #include "mrp_device.h"
+#include "mrp_internal.h"
 #include "mrp_kernels.h"
 #include "../../include/margin_rphmm.h"
 
@@ -779,10 +780,11 @@ hipError_t mrp_launch_sweep_i32(const MrpBatchDev &d, const int32_t *order_dev, 
     if (max_merge < WAVE) max_merge = WAVE; /* per-lane dummy slots of the branch-free cell step */
     const size_t lds = (size_t) (2 * max_merge + 4) * sizeof(int32_t) + SWEEP_WIN * sizeof(int2);
     auto k = mrp_sweep_i32_kernel;
-    /* the attribute is process-wide state: raise it once to the device maximum, never per launch
-     * (concurrent host threads launch different size classes) */
-    static const hipError_t attr_status =
-        hipFuncSetAttribute((const void *) mrp_sweep_i32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    /* once per device, never per launch (concurrent host threads launch different size classes) */
+    static PerDeviceOnce once;
+    const hipError_t attr_status = once.run([] {
+        return hipFuncSetAttribute((const void *) mrp_sweep_i32_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    });
     if (attr_status != hipSuccess) return attr_status;
     hipLaunchKernelGGL(k, dim3((unsigned) (2 * n)), dim3(block_threads), lds, stream, d, order_dev, max_merge);
     return hipGetLastError();

@@ -690,6 +690,8 @@ int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int3
     DevBuf<PhmLanePair> d_lane[4];
     DevBuf<PhmPair> d_wave[4];
     d_models.pool = d_pool.pool = d_band.pool = d_out.pool = &ctx->pool;
+    /* declared after every host vector the queued copies read: an early return drains the stream before they are destroyed */
+    struct Drain { hipStream_t s; ~Drain() { (void) hipStreamSynchronize(s); } } drain{s};
     PHM_HIP(d_models.upload(hm, s));
     PHM_HIP(d_pool.alloc((size_t) pool_bytes));
     if (pool_bytes) PHM_HIP(hipMemcpyAsync(d_pool.p, pool, (size_t) pool_bytes, hipMemcpyHostToDevice, s));
@@ -700,13 +702,14 @@ int mrp_forward_probabilities(mrp_context *ctx, const mrp_pair_hmm *models, int3
         PHM_HIP(d_lane[c].upload(lane_pairs[c], s));
         PHM_HIP(d_wave[c].upload(wave_pairs[c], s));
     }
-    /* once per process (thread-safe static initialisation; contexts of several host threads may call concurrently) */
-    static const hipError_t configured = [] {
+    /* once per device (contexts of several host threads may call concurrently) */
+    static PerDeviceOnce once;
+    const hipError_t configured = once.run([] {
         hipError_t e = hipFuncSetAttribute((const void *) phm_lane_kernel<PHM_ROWS, true>, hipFuncAttributeMaxDynamicSharedMemorySize, PHM_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *) phm_lane_kernel<PHM_ROWS, false>, hipFuncAttributeMaxDynamicSharedMemorySize, PHM_LDS_BYTES);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *) phm_wave_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PHM_LDS_BYTES);
         return e;
-    }();
+    });
     PHM_HIP(configured);
     /* kernel_ms must not contain the tail of the uploads (the copy engine finishes them behind the event otherwise) */
     if (stats) PHM_HIP(hipStreamSynchronize(s));

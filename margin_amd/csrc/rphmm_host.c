@@ -1322,10 +1322,43 @@ static mrp_hmm *r_hmm_from_read(const world *w, int32_t read, const mrp_engine *
     h->max_depth = 1;
     h->stride = 4;
     h->leaf = 1;
-    mrp_engine_leaf(e, &h->d_part, &h->d_np, &h->d_ncells);
+    if (e) mrp_engine_leaf(e, &h->d_part, &h->d_np, &h->d_ncells);
     h->d_nmerge = NULL;
     h->rc_cells.a[0] = 2; h->rc_cells.n = 1;
     return h;
+}
+
+/* filterReadsByCoverageDepth coordination.c:443-488 on shadow leaves (one block for all reads instead of a dozen small
+ * allocations per read: the coverage filter looks at every read of a chunk) */
+static void r_filter_reads_by_coverage_depth(const world *w, const mrp_params *params, int32_t *filtered, int64_t *nf,
+                                             int32_t *discarded, int64_t *nd) {
+    const int64_t n = w->n_reads;
+    size_t leaf_bytes = 0;
+    r_shadow_new(1, 1, 1, 0, NULL, &leaf_bytes);
+    char *block = xmalloc(leaf_bytes * (size_t) (n + 1));
+    mrp_hmm **hmms = xmalloc(sizeof(*hmms) * (size_t) (n + 1));
+    for (int64_t i = 0; i < n; i++) hmms[i] = r_hmm_from_read(w, (int32_t) i, NULL, block + leaf_bytes * (size_t) i);
+    path_vec paths = tiling_paths_from(w, hmms, n);
+    free(hmms);
+    keyed *a = xmalloc(sizeof(keyed) * (size_t) (paths.n + 1)), *t = xmalloc(sizeof(keyed) * (size_t) (paths.n + 1));
+    for (int64_t i = 0; i < paths.n; i++) {
+        int64_t total = 0;
+        for (int64_t j = 0; j < paths.a[i]->n; j++) total += w->reads[paths.a[i]->a[j]->reads.a[0]].length;
+        a[i].idx = i; a[i].key = (double) total;
+    }
+    keyed_sort_desc(a, paths.n, t);
+    int64_t np = paths.n;
+    *nf = 0; *nd = 0;
+    while (np > params->max_coverage_depth) {
+        hmm_vec *tp = paths.a[a[--np].idx];
+        for (int64_t j = tp->n - 1; j >= 0; j--) discarded[(*nd)++] = tp->a[j]->reads.a[0];
+    }
+    while (np > 0) {
+        hmm_vec *tp = paths.a[a[--np].idx];
+        for (int64_t j = tp->n - 1; j >= 0; j--) filtered[(*nf)++] = tp->a[j]->reads.a[0];
+    }
+    for (int64_t i = 0; i < paths.n; i++) free_path(paths.a[i], 0);
+    free(paths.a); free(a); free(t); free(block);
 }
 
 /* what one side contributes to the connector that leaves piece p: its kind, where the number of its merge cells will be
@@ -1583,7 +1616,9 @@ static void level_run_settle(level_run *r, int rc_ok) { /* the level has ended: 
     free(r->xh); free(r->xb); free(r->items);
     memset(r, 0, sizeof(*r));
 }
-static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params) {
+/* pending: if not NULL the last level is left running (the caller stages what comes next beside it, then launches / ends and
+ * settles *pending); otherwise the last level is ended here */
+static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, level_run *pending) {
     int max_h = 0;
     for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > max_h) max_h = t->a[i].height;
     /* Level of a merge node = as late as its parent allows (every root at the last level), not its height: the merges
@@ -1663,7 +1698,9 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params) {
                     h, ta - t0, tb - ta, tc - tb, t1 - tc, t2 - t1, now_ms() - t2);
         prev.items = items; prev.n_items = n_items; prev.xh = xh; prev.xb = xb; prev.n_x = n_x;
     }
-    {
+    if (pending && rc == MRP_OK) {
+        *pending = prev;
+    } else {
         const double t1 = now_ms();
         const int rc2 = mrp_engine_level_end(e);
         if (rc == MRP_OK) rc = rc2;
@@ -1751,7 +1788,7 @@ int mrp_get_rp_hmms_resident(mrp_context *ctx, const mrp_chunk *chunk, const mrp
     if (rc != MRP_OK) return rc;
     rnode_vec tree = {0};
     const int root = r_tree_of_reads(&tree, &w, e, read_index, n, params, NULL);
-    rc = root < 0 ? MRP_ERR_ARG : r_run_tree(e, &tree, params);
+    rc = root < 0 ? MRP_ERR_ARG : r_run_tree(e, &tree, params, NULL);
     if (rc == MRP_OK && w.failed) rc = mrp_set_error(MRP_ERR_UNSUPPORTED, "device-resident merge: an hmm outside what the kernels handle (pair order / kept merge cells)");
     if (rc == MRP_OK) rc = r_download_path(e, tree.a[root].path);
     if (rc == MRP_OK) {
@@ -1808,7 +1845,7 @@ static void many_setup(int64_t c, void *arg) {
         int32_t *filtered = xmalloc(sizeof(int32_t) * (size_t) nr);
         m->discarded = xmalloc(sizeof(int32_t) * (size_t) nr);
         int64_t nf;
-        filter_reads_by_coverage_depth(&m->w, ctl->params, filtered, &nf, m->discarded, &m->nd); /* :2699 */
+        r_filter_reads_by_coverage_depth(&m->w, ctl->params, filtered, &nf, m->discarded, &m->nd); /* :2699 */
         uint8_t *is_disc = xcalloc((size_t) nr, 1);
         for (int64_t i = 0; i < m->nd; i++) is_disc[m->discarded[i]] = 1;
         int32_t *fwd = xmalloc(sizeof(int32_t) * (size_t) nr), *rev = xmalloc(sizeof(int32_t) * (size_t) nr);
@@ -1881,7 +1918,7 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
     const int timing = getenv("MRP_TIMING") != NULL;
     double tt[6];
     tt[0] = now_ms(); g_t_prepare = g_t_level = 0;
-    memset(g_ns, 0, sizeof(g_ns));
+    for (int q = 0; q < 6; q++) __atomic_store_n(&g_ns[q], 0, __ATOMIC_RELAXED); /* (diagnostics shared by the concurrent halves) */
     many_ctl ctl = {st, ctx, chunks, reads, n_reads, params, &pc, e, &tree, out, NULL, 0};
     tt[3] = tt[2] = 0;
     parallel_for(n_chunks, many_setup, &ctl);
@@ -1900,7 +1937,8 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
         m->tree.a = NULL; m->tree.n = m->tree.cap = 0;
     }
     tt[1] = now_ms();
-    if (rc == MRP_OK) rc = r_run_tree(e, &tree, &pc);
+    level_run pending = {0}; /* the last merge level: still on the device while the final stage is described */
+    if (rc == MRP_OK) rc = r_run_tree(e, &tree, &pc, &pending);
     tt[2] = now_ms();
     tt[3] = now_ms();
     /* fuse the joined path (:2745-2747), final sweep with the ancestor model (:2748-2749) and trace back (:2755) on
@@ -1916,7 +1954,12 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
             if (st[c].rc != MRP_OK && rc == MRP_OK) rc = mrp_set_error(st[c].rc, "%s", st[c].err);
             if (st[c].hmm) { st[c].final_index = nj; xh[nj++] = ctl.xfinal[c]; }
         }
-        if (rc == MRP_OK) rc = mrp_engine_final(e, nj, xh);
+        if (rc == MRP_OK) rc = mrp_engine_final_stage(e, nj, xh);
+        /* the wait for the last merge level (its error flags mark the chunks to redo), then the final stage goes */
+        if (rc == MRP_OK) rc = mrp_engine_level_launch(e);
+        else (void) mrp_engine_level_end(e);
+        level_run_settle(&pending, rc == MRP_OK);
+        if (rc == MRP_OK) rc = mrp_engine_level_end(e);
         for (int64_t c = 0; c < n_chunks; c++)
             if (st[c].hmm) {
                 st[c].fwd = xh[st[c].final_index].hmm_forward; st[c].bwd = xh[st[c].final_index].hmm_backward;
@@ -1924,6 +1967,9 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
             }
         free(xh);
         free(ctl.xfinal);
+    } else {
+        (void) mrp_engine_level_end(e);
+        level_run_settle(&pending, 0);
     }
     tt[4] = now_ms();
     if (rc == MRP_OK) {
