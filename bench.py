@@ -49,7 +49,8 @@ def parse_args():
     ap.add_argument("--sites", type=int, default=2000)
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--threads", type=int, default=int(os.environ.get("MRP_BENCH_THREADS", "0")))
-    ap.add_argument("--phase-groups", type=int, default=2, help="concurrent halves inside mrp_phase_reads_many")
+    ap.add_argument("--phase-groups", type=int, default=0,
+                    help="concurrent halves inside mrp_phase_reads_many (0: one below 160 chunks, two from there on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the kernel replay leg (it needs ~20 s of host work to record the sweeps)")
     ap.add_argument("--roofline-steps", type=int, default=20)
@@ -122,6 +123,8 @@ def main():
         step = lambda: queue.phase(chunks, params, chunks_per_batch=max(1, args.chunks // 2), descs=descs, convert=False)[1]
     else:
         ctx = capi.Context(local_rank)
+        if args.phase_groups <= 0:
+            args.phase_groups = 1 if args.chunks < 160 else 2
         ctx.set_phase_groups(args.phase_groups)
         dchunks = [capi.DeviceChunk.from_chunk(ctx, c) for c in chunks]
         step = lambda: capi.phase_reads_many(ctx, dchunks, chunks, params, convert=False)[1]

@@ -185,8 +185,10 @@ typedef struct mrp_params {
     int32_t max_not_sum_transitions;
     int32_t include_inverted_partitions;
     int32_t include_ancestor_sub_prob;
-    int32_t reserved; /* 0.  (Bit 0 is the test suite's fault injection: the resident path reports MRP_ENGINE_ERR_MERGE for
-                       * one hmm of its second level, which must send exactly that chunk to the hashing path.) */
+    int32_t reserved; /* 0.  (Test suite only.  Bit 0, fault injection: the resident path reports MRP_ENGINE_ERR_MERGE for one
+                       * hmm of its second level, which must send exactly that chunk to the hashing path.  Bit 1: the
+                       * resident merge levels run the separate cross product and emission kernels -- the path the final
+                       * level and the ancestor model take -- instead of the one-pass kernel, for A/B parity and timing.) */
     int64_t min_partitions_in_a_column;
     int64_t max_partitions_in_a_column;
     double min_posterior_probability_for_partition;

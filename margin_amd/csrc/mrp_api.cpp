@@ -791,6 +791,7 @@ int mrp_batch_launch(mrp_batch *b) {
     HIP_TRY(hipEventRecord(ev[1], ps));
     if (ps != s) HIP_TRY(hipStreamWaitEvent(s, ev[1], 0));
     HIP_TRY(hipEventRecord(ev[4], s));
+    if (b->pre_sweep) HIP_TRY(b->pre_sweep(s)); /* resident merge levels: cross product + emission in one pass */
     HIP_TRY(mrp_launch_emission(d, b->d_tiles.p, b->n_fast_tiles, b->n_tiles_dev - b->n_fast_tiles, s));
     HIP_TRY(hipEventRecord(ev[3], s));
     ctx->last_emission = ev[3];

@@ -89,6 +89,7 @@ struct mrp_engine_level_state {
     double *fb = nullptr;
     std::vector<int32_t> perm; /* position in the (sorted) PruneHmm array -> index into x */
     bool final_level = false;
+    bool fused = false; /* cross product and emission in one kernel, no partition array (merge levels, no ancestor model) */
     unsigned long long clk[12] = {0};
     mrp_xhmm *x = nullptr;
     int64_t n = 0, total_cols = 0, n_slots = 0, n_reads = 0;
@@ -286,6 +287,10 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     L->x = x;
     L->n = n;
     L->final_level = final_level;
+    L->fused = !final_level && !(e->params.reserved & 2);
+    for (int64_t i = 0; i < n && L->fused; i++)
+        if (x[i].flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) L->fused = false;
+    const bool fused = L->fused;
     if (!L->uploaded) {
         ENG_TRY(hipEventCreateWithFlags(&L->uploaded, hipEventDisableTiming));
         for (auto &ev : L->ev) ENG_TRY(hipEventCreate(&ev));
@@ -435,7 +440,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
             o.uniform_alleles = uniform;
             o.d1 = c.d1; o.d2 = c.d2; o.out_a = c.out_a; o.out_b = c.out_b;
             o.out_a_paired = c.out_a_paired; o.out_b_paired = c.out_b_paired;
-            o.need_planes = (uniform == 0 || anc) ? 1 : 0;
+            o.need_planes = (!fused && (uniform == 0 || anc)) ? 1 : 0; /* bit planes: the general emission kernel only */
             planes_here += o.need_planes;
             o.last = k + 1 == K ? 1 : 0;
             o.pad = 0;
@@ -669,10 +674,12 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
     b->stats.n_cells = cells; b->stats.n_merge_cells = merge;
     b->stats.algorithmic_bytes = 24 * cells + 32 * merge + 8 * total_cols;
     const size_t nC = (size_t) cells;
-    ENG_TRY(b->d_partition.alloc(nC)); ENG_TRY(b->d_np.alloc(nC)); ENG_TRY(b->d_cost.alloc(nC));
+    if (L->fused) { b->d_partition.release(); b->n_tiles_dev = 0; b->n_fast_tiles = 0; }
+    else ENG_TRY(b->d_partition.alloc(nC));
+    ENG_TRY(b->d_np.alloc(nC)); ENG_TRY(b->d_cost.alloc(nC));
     ENG_TRY(b->d_f32.alloc(nC)); ENG_TRY(b->d_b32.alloc(nC));
     ENG_TRY(b->d_mf32.alloc((size_t) merge)); ENG_TRY(b->d_mb32.alloc((size_t) merge));
-    ENG_TRY(b->d_tiles.alloc((size_t) tiles));
+    if (!L->fused) ENG_TRY(b->d_tiles.alloc((size_t) tiles));
     ENG_TRY(b->d_planes.alloc((size_t) L->n_slots * 8)); ENG_TRY(b->d_slot_total.alloc((size_t) L->n_slots));
     ENG_TRY(b->d_slot_bytes.alloc((size_t) L->n_slots * 16));
     ENG_TRY(b->d_total.alloc((size_t) total_cols)); ENG_TRY(b->d_hmm_fb.alloc(2 * (size_t) n));
@@ -703,18 +710,30 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
     sc.err_hmm = L->d_err_hmm.p;
 
     Segment *seg = L->seg.get();
-    ENG_TRY(mrp_launch_tiles(b->d_cols.p, b->d_tilecols.p, total_cols, b->d_tiles.p, s));
-    ENG_TRY(hipEventRecord(L->ev[0], s));
-    ENG_TRY(mrp_launch_cross(L->d_cc.p, total_cols, b->d_partition.p, b->d_np.p, L->d_err.p, L->d_col_hmm.p, L->d_err_hmm.p, s));
-    ENG_TRY(hipEventRecord(L->ev[1], s));
+    if (L->fused) {
+        /* the packed profile bytes first (mrp_batch_launch), then cross product + emission in one pass; no tiles, no
+         * partitions, the batch's own emission launch finds nothing to do */
+        ENG_TRY(hipEventRecord(L->ev[0], s));
+        ENG_TRY(hipEventRecord(L->ev[1], s));
+        b->pre_sweep = [L](hipStream_t st) -> hipError_t {
+            return mrp_launch_cross_emit(L->d_cc.p, L->b->dev, L->d_err.p, L->d_col_hmm.p, L->d_err_hmm.p, st);
+        };
+    } else {
+        b->pre_sweep = nullptr;
+        ENG_TRY(mrp_launch_tiles(b->d_cols.p, b->d_tilecols.p, total_cols, b->d_tiles.p, s));
+        ENG_TRY(hipEventRecord(L->ev[0], s));
+        ENG_TRY(mrp_launch_cross(L->d_cc.p, total_cols, b->d_partition.p, b->d_np.p, L->d_err.p, L->d_col_hmm.p, L->d_err_hmm.p, s));
+        ENG_TRY(hipEventRecord(L->ev[1], s));
+    }
     rc = mrp_batch_launch(b);
+    b->pre_sweep = nullptr;
     if (rc != MRP_OK) return rc;
     ENG_TRY(hipEventRecord(L->ev[2], s));
     if (L->final_level) {
         ENG_TRY(mrp_launch_traceback(b->dev, L->d_ph.p, n, L->d_err.p, L->d_err_hmm.p, s));
     } else {
         ENG_TRY(mrp_launch_prune(b->dev, L->d_cc.p, L->d_ph.p, n, L->pp, sc, s));
-        ENG_TRY(mrp_launch_compact(b->dev, L->d_ph.p, L->d_col_hmm.p, total_cols, L->pp, sc, s));
+        ENG_TRY(mrp_launch_compact(b->dev, L->d_cc.p, L->d_ph.p, L->d_col_hmm.p, total_cols, L->pp, sc, s));
     }
     ENG_TRY(hipEventRecord(L->ev[3], s));
     if (L->final_level) {

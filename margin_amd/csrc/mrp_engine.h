@@ -134,6 +134,10 @@ struct PruneScratch {
 
 hipError_t mrp_launch_cross(const CrossCol *cols_dev, int64_t n_cols, uint64_t *partition, uint32_t *cell_np, int32_t *err,
                             const int32_t *col_hmm_dev, int32_t *err_hmm, hipStream_t stream);
+/* Cross product and emission in one pass (merge levels without the ancestor substitution model): writes d.cell_np and
+ * d.cell_cost from the parents' cells and the packed profile bytes (d.slot_bytes, d.slot_total); no partition array. */
+hipError_t mrp_launch_cross_emit(const CrossCol *cols_dev, const MrpBatchDev &d, int32_t *err, const int32_t *col_hmm_dev, int32_t *err_hmm,
+                                 hipStream_t stream);
 /* ccols_dev: the level's cross product descriptors, indexed like the batch's columns (the prune kernel enumerates the
  * cells linked to a kept merge cell from the parents' transition arrays) */
 hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, const PruneHmm *hmms_dev, int64_t n_hmms, PruneParams p,
@@ -142,7 +146,8 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, con
  * out_part[k] = its partition */
 hipError_t mrp_launch_traceback(const MrpBatchDev &d, const PruneHmm *hmms_dev, int64_t n_hmms, int32_t *err, int32_t *err_hmm,
                                 hipStream_t stream);
-hipError_t mrp_launch_compact(const MrpBatchDev &d, const PruneHmm *hmms_dev, const int32_t *col_hmm_dev, int64_t n_cols,
+/* d.partition == NULL: the level was produced by mrp_launch_cross_emit, partitions of the kept cells come from the parents */
+hipError_t mrp_launch_compact(const MrpBatchDev &d, const CrossCol *ccols_dev, const PruneHmm *hmms_dev, const int32_t *col_hmm_dev, int64_t n_cols,
                               PruneParams p, PruneScratch s, hipStream_t stream);
 
 #endif

@@ -52,6 +52,10 @@ static __device__ __forceinline__ T k_load(const T *p) {
 static __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
+/* LDS traffic of ONE wave is in order once its counter has drained: what lanes wrote is visible to the other lanes */
+static __device__ __forceinline__ void wave_lds_fence() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+}
 static __device__ __forceinline__ uint64_t accept_mask(uint32_t depth) { /* partitions.c:13-19 */
     return depth < 64 ? ~(0xFFFFFFFFFFFFFFFFull << depth) : 0xFFFFFFFFFFFFFFFFull;
 }
@@ -76,13 +80,13 @@ static __device__ __forceinline__ uint32_t pair_index(uint32_t i, uint32_t j, ui
 /* ------------------------------------------------------------------------------------------ */
 static __device__ int verify_side(const uint64_t *part, const uint32_t *np, uint32_t C, uint32_t depth, uint32_t M_out,
                                   uint32_t M_in, uint32_t out_kind, uint32_t in_kind, bool inv, bool out_paired,
-                                  bool in_paired) {
+                                  bool in_paired, uint32_t tid, uint32_t nt) {
     if (!part) return 0;
     int bad = 0;
     const bool cells_paired = inv && depth > 0;
     if (cells_paired && (C & 1u)) return MRP_ENGINE_ERR_STRUCTURE;
     const uint64_t acc = accept_mask(depth);
-    for (uint32_t e = threadIdx.x; e < C; e += blockDim.x) {
+    for (uint32_t e = tid; e < C; e += nt) {
         const uint32_t v = np[e], nx = v & 0xFFFFu, pv = v >> 16;
         uint32_t vo = v;
         if (cells_paired) {
@@ -107,6 +111,41 @@ static __device__ int verify_side(const uint64_t *part, const uint32_t *np, uint
     return bad;
 }
 
+/* The ORDER RULE of a cross product column (the one place it is written down on the device; pair_index above is its twin
+ * for merge cells): cell e of the column is the pair (c1, c2) of parent cells.  Plain mode: row-major.  With inverted
+ * partitions: the reference appends the complement right after every new partition, so the cells come as
+ * (2r, h), (2r + 1, partner of h), (2r, h + 1), ... */
+static __device__ __forceinline__ void cross_cell(uint32_t e, uint32_t C2, bool inv, bool a_cells_paired, bool b_cells_paired,
+                                                  uint32_t &c1, uint32_t &c2) {
+    if (!inv) { c1 = e / C2; c2 = e - c1 * C2; }
+    else if (!a_cells_paired) { c1 = 0; c2 = e; }
+    else {
+        const uint32_t r = e / (2u * C2), t = e - r * 2u * C2, h = t >> 1;
+        if (t & 1u) { c1 = 2u * r + 1u; c2 = b_cells_paired ? (h ^ 1u) : h; }
+        else { c1 = 2u * r; c2 = h; }
+    }
+}
+/* ... and the merge cells it feeds (low 16 bits) and is fed by (high 16 bits), from the parents' transitions n1, n2 */
+static __device__ __forceinline__ uint32_t cross_np(const CrossCol &c, bool inv, uint32_t c1, uint32_t c2, uint32_t n1, uint32_t n2) {
+    uint32_t nxt = 0, prv = 0;
+    if (c.out_a != MRP_CONN_NONE) {
+        const uint32_t i = c.out_a == MRP_CONN_REAL ? (n1 & 0xFFFFu) : (c.out_a == MRP_CONN_IDENT ? c1 : 0u);
+        const uint32_t j = c.out_b == MRP_CONN_REAL ? (n2 & 0xFFFFu) : (c.out_b == MRP_CONN_IDENT ? c2 : 0u);
+        nxt = pair_index(i, j, c.Mb, inv, (c.flags & MRP_XF_OUT_A_PAIRED) != 0, (c.flags & MRP_XF_OUT_B_PAIRED) != 0);
+    }
+    if (c.in_a != MRP_CONN_NONE) {
+        const uint32_t i = c.in_a == MRP_CONN_REAL ? (n1 >> 16) : (c.in_a == MRP_CONN_IDENT ? c1 : 0u);
+        const uint32_t j = c.in_b == MRP_CONN_REAL ? (n2 >> 16) : (c.in_b == MRP_CONN_IDENT ? c2 : 0u);
+        prv = pair_index(i, j, c.Pb, inv, (c.flags & MRP_XF_IN_A_PAIRED) != 0, (c.flags & MRP_XF_IN_B_PAIRED) != 0);
+    }
+    return nxt | (prv << 16);
+}
+/* mergePartitionsOrMasks (partitions.c:21-28): side B's reads follow side A's */
+static __device__ __forceinline__ uint64_t cross_partition(const CrossCol &c, uint32_t c1, uint32_t c2) {
+    const uint64_t p1 = c.a_part ? c.a_part[c1] : 0ull, p2 = c.b_part ? c.b_part[c2] : 0ull;
+    return c.d1 < 64 ? (p1 | (p2 << c.d1)) : p1;
+}
+
 __global__ void __launch_bounds__(256) mrp_cross_kernel(const CrossCol *__restrict__ cols, int64_t n_cols,
                                                         uint64_t *__restrict__ partition, uint32_t *__restrict__ cell_np,
                                                         int32_t *__restrict__ err, const int32_t *__restrict__ col_hmm,
@@ -117,9 +156,9 @@ __global__ void __launch_bounds__(256) mrp_cross_kernel(const CrossCol *__restri
         const uint32_t C1 = c.C1, C2 = c.C2, C = C1 * C2;
         const bool a_cells_paired = inv && c.a_part && c.d1 > 0, b_cells_paired = inv && c.b_part && c.d2 > 0;
         int bad = verify_side(c.a_part, c.a_np, C1, c.d1, c.Ma, c.Pa, c.out_a, c.in_a, inv,
-                              (c.flags & MRP_XF_OUT_A_PAIRED) != 0, (c.flags & MRP_XF_IN_A_PAIRED) != 0);
+                              (c.flags & MRP_XF_OUT_A_PAIRED) != 0, (c.flags & MRP_XF_IN_A_PAIRED) != 0, threadIdx.x, blockDim.x);
         bad |= verify_side(c.b_part, c.b_np, C2, c.d2, c.Mb, c.Pb, c.out_b, c.in_b, inv,
-                           (c.flags & MRP_XF_OUT_B_PAIRED) != 0, (c.flags & MRP_XF_IN_B_PAIRED) != 0);
+                           (c.flags & MRP_XF_OUT_B_PAIRED) != 0, (c.flags & MRP_XF_IN_B_PAIRED) != 0, threadIdx.x, blockDim.x);
         if ((!c.a_part && C1 != 1u) || (!c.b_part && C2 != 1u)) bad |= MRP_ENGINE_ERR_RANGE;
         if (bad) { atomicOr(err, bad); atomicOr(err_hmm + col_hmm[col], bad); }
         if (__syncthreads_or(bad)) { /* the level is discarded by the host; keep the arrays defined meanwhile */
@@ -131,28 +170,10 @@ __global__ void __launch_bounds__(256) mrp_cross_kernel(const CrossCol *__restri
         }
         for (uint32_t e = threadIdx.x; e < C; e += blockDim.x) {
             uint32_t c1, c2;
-            if (!inv) { c1 = e / C2; c2 = e - c1 * C2; }
-            else if (!a_cells_paired) { c1 = 0; c2 = e; }
-            else {
-                const uint32_t r = e / (2u * C2), t = e - r * 2u * C2, h = t >> 1;
-                if (t & 1u) { c1 = 2u * r + 1u; c2 = b_cells_paired ? (h ^ 1u) : h; }
-                else { c1 = 2u * r; c2 = h; }
-            }
-            const uint64_t p1 = c.a_part ? c.a_part[c1] : 0ull, p2 = c.b_part ? c.b_part[c2] : 0ull;
+            cross_cell(e, C2, inv, a_cells_paired, b_cells_paired, c1, c2);
             const uint32_t n1 = c.a_part ? c.a_np[c1] : 0u, n2 = c.b_part ? c.b_np[c2] : 0u;
-            uint32_t nxt = 0, prv = 0;
-            if (c.out_a != MRP_CONN_NONE) {
-                const uint32_t i = c.out_a == MRP_CONN_REAL ? (n1 & 0xFFFFu) : (c.out_a == MRP_CONN_IDENT ? c1 : 0u);
-                const uint32_t j = c.out_b == MRP_CONN_REAL ? (n2 & 0xFFFFu) : (c.out_b == MRP_CONN_IDENT ? c2 : 0u);
-                nxt = pair_index(i, j, c.Mb, inv, (c.flags & MRP_XF_OUT_A_PAIRED) != 0, (c.flags & MRP_XF_OUT_B_PAIRED) != 0);
-            }
-            if (c.in_a != MRP_CONN_NONE) {
-                const uint32_t i = c.in_a == MRP_CONN_REAL ? (n1 >> 16) : (c.in_a == MRP_CONN_IDENT ? c1 : 0u);
-                const uint32_t j = c.in_b == MRP_CONN_REAL ? (n2 >> 16) : (c.in_b == MRP_CONN_IDENT ? c2 : 0u);
-                prv = pair_index(i, j, c.Pb, inv, (c.flags & MRP_XF_IN_A_PAIRED) != 0, (c.flags & MRP_XF_IN_B_PAIRED) != 0);
-            }
-            partition[c.x_cell_off + e] = c.d1 < 64 ? (p1 | (p2 << c.d1)) : p1; /* mergePartitionsOrMasks partitions.c:21-28 */
-            cell_np[c.x_cell_off + e] = nxt | (prv << 16);
+            partition[c.x_cell_off + e] = cross_partition(c, c1, c2);
+            cell_np[c.x_cell_off + e] = cross_np(c, inv, c1, c2, n1, n2);
         }
     }
 }
@@ -163,6 +184,346 @@ hipError_t mrp_launch_cross(const CrossCol *cols_dev, int64_t n_cols, uint64_t *
     const int64_t grid = n_cols < 65536 ? n_cols : 65536;
     hipLaunchKernelGGL(mrp_cross_kernel, dim3((unsigned) grid), dim3(256), 0, stream, cols_dev, n_cols, partition, cell_np, err, col_hmm_dev,
                        err_hmm);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------------------------ */
+/* cross product + emission in one pass (merge levels, no ancestor substitution model)          */
+/* ------------------------------------------------------------------------------------------ */
+/*
+ * emissionLogProbability (emissions.c:221-240) of a cross product cell WITHOUT its partition ever being written: the cell
+ * (c1, c2) holds the reads of parent cell c1 followed by those of parent cell c2 (partitions.c:21-28), and
+ * getLogProbOfAllele (emissions.c:125-138) is a sum over the reads of the partition, so per allele slot
+ *      hap1(c1, c2) = tA[slot][c1] + tB[slot][c2],   hap2 = T[slot] - hap1          (emissions.c:144-154)
+ * with tA / tB the per-parent-cell sums over the side's own reads: (C1 + C2) * slots dot products per column instead of
+ * C1 * C2 * slots.  One wave per column.  The tables sit in LDS as packed 16-bit halves, one 16-byte aligned row per parent cell,
+ *      A[c1][slot] = tA | (T - tA) << 16        B[c2][slot] = tB - (tB << 16)
+ * so that ONE 32-bit add yields hap1 in the low and hap2 in the high half (no carry crosses: both are sums of at most 64
+ * bytes), and one v_pk_min_u16 keeps both running minima over the alleles of a site (emissions.c:174-185, :205-207).
+ * With inverted partitions cells 2q, 2q+1 are complements and share their cost (hap1 <-> hap2): a lane computes it once.
+ * HBM traffic: 8 B written per cell (cost + transitions), nothing read per cell.
+ */
+#define XE_WAVES 4
+#ifndef XE_CAP
+#define XE_CAP 1024 /* table dwords per wave: 256 parent cells x 4 allele slots */
+#endif
+#ifndef XE_ROWS
+#define XE_ROWS 16 /* allele slots staged per table fill (LDS per workgroup 29 KB: five workgroups, 20 waves per CU) */
+#endif
+
+typedef unsigned short xe_u16x2 __attribute__((ext_vector_type(2)));
+static __device__ __forceinline__ uint32_t pk_min_u16(uint32_t a, uint32_t b) {
+    const xe_u16x2 r = __builtin_elementwise_min(__builtin_bit_cast(xe_u16x2, a), __builtin_bit_cast(xe_u16x2, b));
+    return __builtin_bit_cast(uint32_t, r);
+}
+/* sum of the profile bytes of the reads in P over one allele slot: bytes are packed four reads to a word */
+template <typename RowPtr>
+static __device__ __forceinline__ uint32_t slot_dot(RowPtr row, uint64_t P, int w4_lo, int w4_hi) {
+    uint32_t sum = 0;
+    for (int w4 = w4_lo; w4 < w4_hi; w4++) {
+        const uint4 bts = *reinterpret_cast<const uint4 *>(row + 4 * w4);
+        const uint32_t bits = (uint32_t) (P >> (16 * w4)) & 0xFFFFu;
+        sum = __builtin_amdgcn_udot4(bts.x, ((bits & 0xFu) * 0x00204081u) & 0x01010101u, sum, false);
+        sum = __builtin_amdgcn_udot4(bts.y, (((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u, sum, false);
+        sum = __builtin_amdgcn_udot4(bts.z, (((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u, sum, false);
+        sum = __builtin_amdgcn_udot4(bts.w, ((bits >> 12) * 0x00204081u) & 0x01010101u, sum, false);
+    }
+    return sum;
+}
+
+/* cost of one cell over the sites of the tables: per site min over alleles of hap1 plus min over alleles of hap2.
+ * pa, pb: the cell's two table rows (slot-minor, 16-byte aligned): four slots per LDS read. */
+static __device__ __forceinline__ uint32_t xe_cost(const uint32_t *pa, const uint32_t *pb, uint32_t nsl, uint64_t ends) {
+    uint32_t cost = 0, m = 0xFFFFFFFFu;
+    for (uint32_t s4 = 0; s4 < nsl; s4 += 4u) {
+        const uint4 a = *reinterpret_cast<const uint4 *>(pa + s4), b = *reinterpret_cast<const uint4 *>(pb + s4);
+        const uint32_t x[4] = {a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w};
+        const uint32_t e4 = (uint32_t) (ends >> s4) & 0xFu, left = nsl - s4; /* wave-uniform */
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            if ((uint32_t) j < left) {
+                m = pk_min_u16(m, x[j]);
+                if (e4 & (1u << j)) { cost += (m & 0xFFFFu) + (m >> 16); m = 0xFFFFFFFFu; }
+            }
+        }
+    }
+    return cost;
+}
+/* Table rows of one side for columns with many parent cells: a lane owns a parent cell (its partition's read bits are
+ * expanded to 0/1 bytes once); the packed bytes of a slot were staged in LDS and every lane reads the same words.
+ * NW4 = 16-read groups the side's reads span; the partition is shifted up to the merged column's read positions, then down
+ * by the first group (rowbuf points at that group's words). */
+template <int NW4, bool SIDE_B>
+static __device__ __forceinline__ void xe_fill_side(uint32_t *rows, uint32_t ST, const uint64_t *__restrict__ part, uint32_t C, uint32_t up,
+                                                    uint32_t down, uint32_t nsl, const uint32_t *rowbuf, const uint32_t *totbuf, int lane) {
+    for (uint32_t cc = lane; cc < ((C + WAVE - 1) & ~(uint32_t) (WAVE - 1)); cc += WAVE) {
+        const bool act = cc < C;
+        uint64_t P = (act && part) ? part[cc] : 0ull;
+        P = up < 64u ? (P << up) >> down : 0ull;
+        uint32_t sel[4 * NW4];
+#pragma unroll
+        for (int w = 0; w < 4 * NW4; w++) sel[w] = ((uint32_t) ((P >> (4 * w)) & 0xFull) * 0x00204081u) & 0x01010101u;
+        for (uint32_t slot = 0; slot < nsl; slot++) {
+            uint32_t t = 0;
+#pragma unroll
+            for (int k = 0; k < NW4; k++) {
+                const uint4 r = *reinterpret_cast<const uint4 *>(rowbuf + slot * 16 + 4 * k);
+                t = __builtin_amdgcn_udot4(r.x, sel[4 * k], t, false);
+                t = __builtin_amdgcn_udot4(r.y, sel[4 * k + 1], t, false);
+                t = __builtin_amdgcn_udot4(r.z, sel[4 * k + 2], t, false);
+                t = __builtin_amdgcn_udot4(r.w, sel[4 * k + 3], t, false);
+            }
+            if (act) rows[cc * ST + slot] = SIDE_B ? t - (t << 16) : (t | ((totbuf[slot] - t) << 16));
+        }
+    }
+}
+
+/* pair_index (the merge cell a cell feeds / is fed by) split into a term per parent cell of side A and two per parent cell of
+ * side B, computed once per parent cell instead of once per cell:
+ *      index(c1, c2) = base(c1) + (sel(c1) ? B1(c2) : B0(c2))
+ * tra[c1] = {out: base | sel << 31, in: base | sel << 31},  trb[c2] = {out: B0 | B1 << 16, in: B0 | B1 << 16}. */
+static __device__ __forceinline__ uint32_t xe_term_a(uint32_t kind, bool none, uint32_t n_idx, uint32_t c1, uint32_t Mb, bool inv, bool a_paired) {
+    const uint32_t i = kind == MRP_CONN_REAL ? n_idx : (kind == MRP_CONN_IDENT ? c1 : 0u);
+    if (none) return 0u;
+    if (!inv) return i * Mb;
+    if (!a_paired) return 0u;
+    return (i & 1u) ? (((i - 1u) * Mb + 1u) | 0x80000000u) : i * Mb;
+}
+static __device__ __forceinline__ uint32_t xe_term_b(uint32_t kind, bool none, uint32_t n_idx, uint32_t c2, bool inv, bool a_paired, bool b_paired) {
+    const uint32_t j = kind == MRP_CONN_REAL ? n_idx : (kind == MRP_CONN_IDENT ? c2 : 0u);
+    if (none) return 0u;
+    if (!inv || !a_paired) return j | (j << 16);
+    return (2u * j) | ((2u * (b_paired ? (j ^ 1u) : j)) << 16);
+}
+static __device__ __forceinline__ void xe_stage_transitions(const CrossCol &c, bool inv, uint2 *tra, uint2 *trb, int lane) {
+    const bool oap = (c.flags & MRP_XF_OUT_A_PAIRED) != 0, obp = (c.flags & MRP_XF_OUT_B_PAIRED) != 0;
+    const bool iap = (c.flags & MRP_XF_IN_A_PAIRED) != 0, ibp = (c.flags & MRP_XF_IN_B_PAIRED) != 0;
+    const bool no_out = c.out_a == MRP_CONN_NONE, no_in = c.in_a == MRP_CONN_NONE;
+    for (uint32_t i = lane; i < min((uint32_t) c.C1, 128u); i += WAVE) {
+        const uint32_t n1 = c.a_part ? c.a_np[i] : 0u;
+        tra[i] = make_uint2(xe_term_a(c.out_a, no_out, n1 & 0xFFFFu, i, c.Mb, inv, oap), xe_term_a(c.in_a, no_in, n1 >> 16, i, c.Pb, inv, iap));
+    }
+    for (uint32_t i = lane; i < min((uint32_t) c.C2, 128u); i += WAVE) {
+        const uint32_t n2 = c.b_part ? c.b_np[i] : 0u;
+        trb[i] = make_uint2(xe_term_b(c.out_b, no_out, n2 & 0xFFFFu, i, inv, oap, obp), xe_term_b(c.in_b, no_in, n2 >> 16, i, inv, iap, ibp));
+    }
+}
+static __device__ __forceinline__ uint32_t xe_np(uint2 a, uint2 b) { /* next | prev << 16 */
+    const uint32_t nxt = (a.x & 0x7FFFFFFFu) + ((int32_t) a.x < 0 ? b.x >> 16 : b.x & 0xFFFFu);
+    const uint32_t prv = (a.y & 0x7FFFFFFFu) + ((int32_t) a.y < 0 ? b.y >> 16 : b.y & 0xFFFFu);
+    return nxt | (prv << 16);
+}
+
+struct __attribute__((packed, aligned(4))) xe_u32x4 { uint32_t x, y, z, w; };
+struct __attribute__((packed, aligned(4))) xe_u32x2 { uint32_t x, y; };
+
+__global__ void __launch_bounds__(XE_WAVES * WAVE) mrp_cross_emit_kernel(const CrossCol *__restrict__ ccols, const DevCol *__restrict__ cols,
+                                                                         const DevChunk *__restrict__ chunks, int64_t n_cols,
+                                                                         const uint32_t *__restrict__ slot_bytes,
+                                                                         const uint32_t *__restrict__ slot_total,
+                                                                         uint32_t *__restrict__ cell_np, uint32_t *__restrict__ cell_cost,
+                                                                         int32_t *__restrict__ err, const int32_t *__restrict__ col_hmm,
+                                                                         int32_t *__restrict__ err_hmm) {
+    __shared__ __attribute__((aligned(16))) uint32_t tab_all[XE_WAVES][XE_CAP];
+    __shared__ __attribute__((aligned(16))) uint32_t row_all[XE_WAVES][XE_ROWS * 16];
+    __shared__ uint32_t tot_all[XE_WAVES][XE_ROWS];
+    __shared__ __attribute__((aligned(16))) uint2 tr_all[XE_WAVES][256]; /* transition terms of the parent cells, see xe_stage_transitions */
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / WAVE));
+    uint32_t *tab = tab_all[wave], *rowbuf = row_all[wave], *totbuf = tot_all[wave];
+    uint2 *tra = tr_all[wave], *trb = tr_all[wave] + 128;
+    for (int64_t col = (int64_t) blockIdx.x * XE_WAVES + wave; col < n_cols; col += (int64_t) gridDim.x * XE_WAVES) {
+        const CrossCol c = k_load(ccols + col);
+        const DevCol dc = k_load(cols + col);
+        const bool inv = (c.flags & MRP_XF_INVERTED) != 0;
+        const uint32_t C1 = c.C1, C2 = c.C2, C = C1 * C2;
+        const bool a_cells_paired = inv && c.a_part && c.d1 > 0, b_cells_paired = inv && c.b_part && c.d2 > 0;
+        /* slots per table fill: rows of the tables are padded to a multiple of four slots, the staging buffer holds XE_ROWS */
+        const uint32_t Cs = C1 + C2;
+        const uint32_t slot_room = (Cs >= 1u && Cs <= 256u) ? min((uint32_t) XE_ROWS, (XE_CAP / Cs) & ~3u) : 0u;
+        const uint32_t A_uni = (dc.flags >> 8) & 0xFFu; /* allele count shared by the column's sites, 0 if they differ (layout kernel) */
+        const int w4_all = (dc.depth + 15) >> 4;
+        const int w4_a = ((int) c.d1 + 15) >> 4, w4_b = (int) c.d1 >> 4;
+        /* everything the column needs from HBM is requested here, independent of each other: the parents' transitions
+         * (staged for the cells' lookups), the first fill's packed bytes, and the pair order check's reads */
+        xe_stage_transitions(c, inv, tra, trb, lane);
+        int bad = 0;
+        {
+            bad = verify_side(c.a_part, c.a_np, C1, c.d1, c.Ma, c.Pa, c.out_a, c.in_a, inv,
+                              (c.flags & MRP_XF_OUT_A_PAIRED) != 0, (c.flags & MRP_XF_IN_A_PAIRED) != 0, lane, WAVE);
+            bad |= verify_side(c.b_part, c.b_np, C2, c.d2, c.Mb, c.Pb, c.out_b, c.in_b, inv,
+                               (c.flags & MRP_XF_OUT_B_PAIRED) != 0, (c.flags & MRP_XF_IN_B_PAIRED) != 0, lane, WAVE);
+        }
+        if ((!c.a_part && C1 != 1u) || (!c.b_part && C2 != 1u) || C1 > 128u || C2 > 128u || (int) c.d1 + (int) c.d2 != dc.depth) bad |= MRP_ENGINE_ERR_RANGE;
+        if (bad) { atomicOr(err, bad); atomicOr(err_hmm + col_hmm[col], bad); }
+        if (__any(bad != 0)) { /* the level is discarded by the host; keep the arrays defined meanwhile */
+            for (uint32_t e = lane; e < C; e += WAVE) { cell_np[c.x_cell_off + e] = 0u; cell_cost[c.x_cell_off + e] = 0u; }
+            continue;
+        }
+        const uint32_t *aoff = A_uni ? nullptr : chunks[dc.chunk].allele_offset + dc.site_start;
+        uint32_t site0 = 0, sl0 = 0;
+        while (site0 < (uint32_t) dc.n_sites) {
+            /* as many whole sites as fit */
+            uint32_t cnt, nsl;
+            uint64_t ends = 0; /* bit (slot): the slot is the last allele of its site */
+            if (A_uni) {
+                cnt = min((uint32_t) dc.n_sites - site0, slot_room / A_uni);
+                nsl = cnt * A_uni;
+                for (uint32_t s_ = 1; s_ <= cnt; s_++) ends |= 1ull << (s_ * A_uni - 1u);
+            } else { /* lane s looks at the end of site site0 + s */
+                const uint32_t base = aoff[site0];
+                const bool have = site0 + (uint32_t) lane < (uint32_t) dc.n_sites;
+                const uint32_t end = have ? aoff[site0 + lane + 1] - base : 0xFFFFFFFFu;
+                const bool fits = have && end <= slot_room;
+                cnt = (uint32_t) __popcll(__ballot(fits));
+                nsl = cnt ? (uint32_t) __builtin_amdgcn_readlane((int) end, (int) cnt - 1) : 0u;
+                ends = (fits && end >= 1u) ? 1ull << (end - 1u) : 0ull;
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) ends |= __shfl_xor(ends, o, WAVE);
+                ends = ((uint64_t) (uint32_t) __builtin_amdgcn_readfirstlane((int) (ends >> 32)) << 32) |
+                       (uint32_t) __builtin_amdgcn_readfirstlane((int) ends); /* wave-uniform: the site loop branches on scalars */
+            }
+            const int64_t slot_g = dc.slot_off + sl0;
+            const bool first_chunk = site0 == 0;
+            if (cnt == 0) {
+                /* A site with more alleles than the tables hold for this many parent cells (rare): its cells are costed
+                 * one by one from their merged partitions, straight from the packed bytes in HBM. */
+                const uint32_t A = A_uni ? A_uni : aoff[site0 + 1] - aoff[site0];
+                for (uint32_t e = lane; e < C; e += WAVE) {
+                    uint32_t c1, c2;
+                    cross_cell(e, C2, inv, a_cells_paired, b_cells_paired, c1, c2);
+                    const uint64_t P = cross_partition(c, c1, c2);
+                    uint32_t m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
+                    for (uint32_t a_ = 0; a_ < A; a_++) {
+                        const uint32_t t = slot_dot(slot_bytes + (slot_g + a_) * 16, P, 0, w4_all);
+                        m1 = min(m1, t);
+                        m2 = min(m2, slot_total[slot_g + a_] - t);
+                    }
+                    const int64_t o = c.x_cell_off + e;
+                    if (first_chunk) {
+                        cell_np[o] = xe_np(tra[c1], trb[c2]);
+                        cell_cost[o] = m1 + m2;
+                    } else cell_cost[o] += m1 + m2;
+                }
+                site0 += 1u;
+                sl0 += A;
+                continue;
+            }
+            const uint32_t ST = (nsl + 3u) & ~3u; /* row stride: 16-byte rows */
+            uint32_t *tb = tab + C1 * ST;
+            {
+                /* the packed bytes and byte sums of the slots: one coalesced read, then LDS */
+                for (uint32_t i = lane; i < nsl * 16u; i += WAVE) rowbuf[i] = slot_bytes[slot_g * 16 + i];
+                if ((uint32_t) lane < nsl) totbuf[lane] = slot_total[slot_g + lane];
+                wave_lds_fence();
+                if (Cs >= 24u) { /* many parent cells: a lane per parent cell */
+                    const uint32_t *rowb = rowbuf + 4 * w4_b;
+                    switch (w4_a) {
+                    case 0: case 1: xe_fill_side<1, false>(tab, ST, c.a_part, C1, 0u, 0u, nsl, rowbuf, totbuf, lane); break;
+                    case 2: xe_fill_side<2, false>(tab, ST, c.a_part, C1, 0u, 0u, nsl, rowbuf, totbuf, lane); break;
+                    case 3: xe_fill_side<3, false>(tab, ST, c.a_part, C1, 0u, 0u, nsl, rowbuf, totbuf, lane); break;
+                    default: xe_fill_side<4, false>(tab, ST, c.a_part, C1, 0u, 0u, nsl, rowbuf, totbuf, lane); break;
+                    }
+                    switch (min(w4_all, 4) - min(w4_b, 3)) { /* d1 = 64: side B has no reads, any group of zero bits will do */
+                    case 0: case 1: xe_fill_side<1, true>(tb, ST, c.b_part, C2, c.d1, 16u * min(w4_b, 3), nsl, rowbuf + 4 * min(w4_b, 3), totbuf, lane); break;
+                    case 2: xe_fill_side<2, true>(tb, ST, c.b_part, C2, c.d1, 16u * w4_b, nsl, rowb, totbuf, lane); break;
+                    case 3: xe_fill_side<3, true>(tb, ST, c.b_part, C2, c.d1, 16u * w4_b, nsl, rowb, totbuf, lane); break;
+                    default: xe_fill_side<4, true>(tb, ST, c.b_part, C2, c.d1, 16u * w4_b, nsl, rowb, totbuf, lane); break;
+                    }
+                } else { /* few parent cells (the low levels: long columns of few cells): lanes along (slot, parent cell) */
+                    for (uint32_t idx = lane; idx < C1 * nsl; idx += WAVE) {
+                        const uint32_t slot = idx / C1, cc = idx - slot * C1;
+                        const uint64_t P = c.a_part ? c.a_part[cc] : 0ull;
+                        const uint32_t t = slot_dot(rowbuf + slot * 16, P, 0, w4_a);
+                        tab[cc * ST + slot] = t | ((totbuf[slot] - t) << 16);
+                    }
+                    for (uint32_t idx = lane; idx < C2 * nsl; idx += WAVE) {
+                        const uint32_t slot = idx / C2, cc = idx - slot * C2;
+                        const uint64_t P = (c.b_part && c.d1 < 64) ? c.b_part[cc] << c.d1 : 0ull;
+                        const uint32_t t = slot_dot(rowbuf + slot * 16, P, w4_b, w4_all);
+                        tb[cc * ST + slot] = t - (t << 16);
+                    }
+                }
+            }
+            wave_lds_fence();
+            if (a_cells_paired) {
+                /* The cells of the column are a grid: row r = pair (2r, 2r + 1) of side A cells, position h = side B cell;
+                 * cells e = 2 (r C2 + h) and e + 1 are complements and share their cost.  A lane keeps ONE h: its side B
+                 * table row and transition terms stay in registers while it walks down the rows; with C2 <= 32 a wave
+                 * takes several rows per step.  Per cell that leaves an add and a packed min per allele slot. */
+                const uint32_t W = C2 >= 33u ? 64u : (C2 >= 17u ? 32u : (C2 >= 9u ? 16u : (C2 >= 5u ? 8u : (C2 >= 3u ? 4u : (C2 >= 2u ? 2u : 1u)))));
+                const uint32_t wsh = 31u - (uint32_t) __builtin_clz(W), R = WAVE >> wsh;
+                const uint32_t hl = (uint32_t) lane & (W - 1u), rl = (uint32_t) lane >> wsh, rows = C1 >> 1;
+                for (uint32_t hb = 0; hb < C2; hb += WAVE) {
+                    const uint32_t h = hb + hl;
+                    const bool hv = h < C2;
+                    const uint32_t hc = hv ? h : 0u, g = b_cells_paired ? (hc ^ 1u) : hc;
+                    const uint2 tbh = trb[hc], tbg = trb[g];
+                    const uint32_t *pb = tb + hc * ST;
+                    uint4 b0 = make_uint4(0, 0, 0, 0), b1 = make_uint4(0, 0, 0, 0);
+                    if (nsl <= 8u) { b0 = *reinterpret_cast<const uint4 *>(pb); if (nsl > 4u) b1 = *reinterpret_cast<const uint4 *>(pb + 4); }
+                    for (uint32_t r = rl; r < rows; r += R) {
+                        const uint32_t *pa = tab + 2u * r * ST;
+                        uint32_t cost;
+                        if (nsl <= 8u) {
+                            uint32_t m = 0xFFFFFFFFu;
+                            cost = 0;
+                            const uint4 a0 = *reinterpret_cast<const uint4 *>(pa);
+                            const uint32_t x0[4] = {a0.x + b0.x, a0.y + b0.y, a0.z + b0.z, a0.w + b0.w};
+#pragma unroll
+                            for (int j = 0; j < 4; j++)
+                                if ((uint32_t) j < nsl) {
+                                    m = pk_min_u16(m, x0[j]);
+                                    if (ends & (1ull << j)) { cost += (m & 0xFFFFu) + (m >> 16); m = 0xFFFFFFFFu; }
+                                }
+                            if (nsl > 4u) {
+                                const uint4 a1 = *reinterpret_cast<const uint4 *>(pa + 4);
+                                const uint32_t x1[4] = {a1.x + b1.x, a1.y + b1.y, a1.z + b1.z, a1.w + b1.w};
+#pragma unroll
+                                for (int j = 0; j < 4; j++)
+                                    if ((uint32_t) (4 + j) < nsl) {
+                                        m = pk_min_u16(m, x1[j]);
+                                        if (ends & (1ull << (4 + j))) { cost += (m & 0xFFFFu) + (m >> 16); m = 0xFFFFFFFFu; }
+                                    }
+                            }
+                        } else cost = xe_cost(pa, pb, nsl, ends);
+                        if (hv) {
+                            const int64_t o = c.x_cell_off + 2 * ((int64_t) r * C2 + h);
+                            if (first_chunk) {
+                                const uint4 ta = *reinterpret_cast<const uint4 *>(tra + 2u * r); /* terms of cells 2r and 2r + 1 */
+                                xe_u32x2 nv = {xe_np(make_uint2(ta.x, ta.y), tbh), xe_np(make_uint2(ta.z, ta.w), tbg)};
+                                *reinterpret_cast<xe_u32x2 *>(cell_np + o) = nv;
+                            } else cost += cell_cost[o];
+                            xe_u32x2 cv = {cost, cost};
+                            *reinterpret_cast<xe_u32x2 *>(cell_cost + o) = cv;
+                        }
+                    }
+                }
+            } else {
+                for (uint32_t e = lane; e < C; e += WAVE) {
+                    uint32_t c1, c2;
+                    cross_cell(e, C2, inv, a_cells_paired, b_cells_paired, c1, c2);
+                    const uint32_t cost = xe_cost(tab + c1 * ST, tb + c2 * ST, nsl, ends);
+                    const int64_t o = c.x_cell_off + e;
+                    if (first_chunk) {
+                        cell_np[o] = xe_np(tra[c1], trb[c2]);
+                        cell_cost[o] = cost;
+                    } else cell_cost[o] += cost;
+                }
+            }
+            wave_lds_fence(); /* the tables are rewritten by the next chunk of sites / the next column */
+            site0 += cnt;
+            sl0 += nsl;
+        }
+    }
+}
+
+hipError_t mrp_launch_cross_emit(const CrossCol *cols_dev, const MrpBatchDev &d, int32_t *err, const int32_t *col_hmm_dev, int32_t *err_hmm,
+                                 hipStream_t stream) {
+    if (d.n_cols <= 0) return hipSuccess;
+    const int64_t wgs = (d.n_cols + XE_WAVES - 1) / XE_WAVES;
+    hipLaunchKernelGGL(mrp_cross_emit_kernel, dim3((unsigned) (wgs < (1 << 20) ? wgs : (1 << 20))), dim3(XE_WAVES * WAVE), 0, stream, cols_dev,
+                       d.cols, d.chunks, d.n_cols, d.slot_bytes, d.slot_total, const_cast<uint32_t *>(d.cell_np), d.cell_cost, err, col_hmm_dev, err_hmm);
     return hipGetLastError();
 }
 
@@ -294,7 +655,7 @@ __global__ void __launch_bounds__(256) mrp_layout_fill_kernel(const PlanCol *__r
             DevCol dc;
             dc.cell_off = c_off + xc; dc.mcell_off = c.last ? 0 : m_off + xm; dc.slot_off = c.slot_off; dc.read_off = c.read_off;
             dc.n_cells = C; dc.n_merge = M; dc.site_start = c.site_start; dc.n_sites = c.n_sites; dc.depth = c.depth; dc.n_slots = c.n_slots;
-            dc.chunk = c.chunk; dc.flags = h.flags;
+            dc.chunk = c.chunk; dc.flags = h.flags | ((uint32_t) (c.uniform_alleles > 255 ? 0 : c.uniform_alleles) << 8); /* bits 8..15: allele count shared by the column's sites (0: they differ) */
             o.cols[col] = dc;
             SweepCol sc;
             sc.cell_off = dc.cell_off; sc.mcell_off = dc.mcell_off; sc.n_cells = C; sc.n_merge = M; sc.pad[0] = 0; sc.pad[1] = 0;
@@ -421,9 +782,6 @@ static __device__ __forceinline__ void wave_bitonic_sort128(uint32_t &k0, uint32
     bitonic_merge<128>(k0, k1, lane);
 }
 /* orders this wave's LDS traffic for the compiler (the LDS itself executes one wave's instructions in issue order) */
-static __device__ __forceinline__ void wave_lds_fence() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-}
 
 /*
  * stRPHmm_prune for the cross products of a level, one workgroup per hmm.
@@ -1240,7 +1598,7 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, con
 /* ------------------------------------------------------------------------------------------ */
 /* compaction: the pruned hmm in the resident layout                                           */
 /* ------------------------------------------------------------------------------------------ */
-__global__ void __launch_bounds__(256) mrp_compact_kernel(MrpBatchDev d, const PruneHmm *__restrict__ hmms,
+__global__ void __launch_bounds__(256) mrp_compact_kernel(MrpBatchDev d, const CrossCol *__restrict__ ccols, const PruneHmm *__restrict__ hmms,
                                                           const int32_t *__restrict__ col_hmm, int64_t n_cols, PruneParams p,
                                                           PruneScratch sc) {
     const int lane = threadIdx.x & (WAVE - 1);
@@ -1252,6 +1610,12 @@ __global__ void __launch_bounds__(256) mrp_compact_kernel(MrpBatchDev d, const P
         const int k = (int) (lcol - h.col0);
         const int K = h.n_cols;
         const SweepCol col = k_load(d.scols + lcol);
+        /* the level wrote no partitions (cross product and emission in one pass): a kept cell's partition comes from its
+         * two parent cells */
+        CrossCol cc = {};
+        if (!d.partition) cc = k_load(ccols + lcol);
+        const bool inv = (cc.flags & MRP_XF_INVERTED) != 0;
+        const bool a_cells_paired = inv && cc.a_part && cc.d1 > 0, b_cells_paired = inv && cc.b_part && cc.d2 > 0;
         const int nk = sc.n_kept[lcol];
         const int nm = k + 1 < K ? sc.n_keptm[lcol] : 0;
         const int nmp = k > 0 ? sc.n_keptm[lcol - 1] : 0;
@@ -1263,7 +1627,13 @@ __global__ void __launch_bounds__(256) mrp_compact_kernel(MrpBatchDev d, const P
             uint32_t new_next = 0, new_prev = 0;
             for (int j = 0; j < nm; j++) new_next += sc.keptm[lcol * S + j] < nx ? 1u : 0u;
             for (int j = 0; j < nmp; j++) new_prev += sc.keptm[(lcol - 1) * S + j] < pv ? 1u : 0u;
-            const uint64_t part = d.partition[col.cell_off + c];
+            uint64_t part;
+            if (d.partition) part = d.partition[col.cell_off + c];
+            else {
+                uint32_t c1, c2;
+                cross_cell(c, cc.C2, inv, a_cells_paired, b_cells_paired, c1, c2);
+                part = cross_partition(cc, c1, c2);
+            }
             h.out_part[(int64_t) k * S + i] = part;
             h.out_np[(int64_t) k * S + i] = new_next | (new_prev << 16);
         }
@@ -1372,11 +1742,11 @@ hipError_t mrp_launch_traceback(const MrpBatchDev &d, const PruneHmm *hmms_dev, 
     return hipGetLastError();
 }
 
-hipError_t mrp_launch_compact(const MrpBatchDev &d, const PruneHmm *hmms_dev, const int32_t *col_hmm_dev, int64_t n_cols,
+hipError_t mrp_launch_compact(const MrpBatchDev &d, const CrossCol *ccols_dev, const PruneHmm *hmms_dev, const int32_t *col_hmm_dev, int64_t n_cols,
                               PruneParams p, PruneScratch s, hipStream_t stream) {
     if (n_cols <= 0) return hipSuccess;
     const int64_t wgs = (n_cols + 3) / 4;
-    hipLaunchKernelGGL(mrp_compact_kernel, dim3((unsigned) (wgs < 65536 ? wgs : 65536)), dim3(256), 0, stream, d, hmms_dev,
+    hipLaunchKernelGGL(mrp_compact_kernel, dim3((unsigned) (wgs < 65536 ? wgs : 65536)), dim3(256), 0, stream, d, ccols_dev, hmms_dev,
                        col_hmm_dev, n_cols, p, s);
     return hipGetLastError();
 }

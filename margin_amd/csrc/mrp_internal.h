@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <array>
+#include <functional>
 #include <iterator>
 #include <map>
 #include <memory>
@@ -149,8 +150,15 @@ struct DevBuf {
         release();
         n = count;
         const size_t bytes = std::max<size_t>(count, 1) * sizeof(T) + 64;
-        if (pool) return pool->alloc((void **) &p, bytes, &cls);
-        return hipMalloc((void **) &p, bytes);
+        hipError_t e = pool ? pool->alloc((void **) &p, bytes, &cls) : hipMalloc((void **) &p, bytes);
+#ifdef MRP_POISON_ALLOC /* debugging aid: every buffer starts as garbage, so a read of a never-written element shows */
+        if (e == hipSuccess) {
+            (void) hipDeviceSynchronize();
+            e = hipMemset(p, 0xA5, bytes);
+            (void) hipDeviceSynchronize();
+        }
+#endif
+        return e;
     }
     template <class A>
     hipError_t upload(const std::vector<T, A> &h, hipStream_t s) {
@@ -228,6 +236,9 @@ struct mrp_batch {
     int64_t n_fast_tiles = 0;
     HostVec<TileCol> tilecols; /* resident batches: the tiles are written on the device from these */
     int64_t n_tiles_dev = 0;   /* their number (tiles stays empty) */
+    /* resident merge levels: launched between the byte packing and the recursion kernels, in place of the emission kernel
+     * (cross product + emission in one pass, mrp_launch_cross_emit) */
+    std::function<hipError_t(hipStream_t)> pre_sweep;
     DevBuf<TileCol> d_tilecols;
     bool need_wide = false;
     std::vector<JobOut> outs;

@@ -225,6 +225,10 @@ class OracleChunk:
         n_out = C.c_int64(0)
         out = L.orc_getRPHmms(arr, len(idx), C.byref(params), C.byref(n_out))
         check_error()
+        # the hmms keep a POINTER to the parameters (stRPHmm.parameters): the ctypes object has to outlive them, also when the
+        # caller passed a temporary
+        self._params_alive = getattr(self, "_params_alive", [])
+        self._params_alive.append(params)
         return [out[i] for i in range(n_out.value)]
 
     def phase(self, params_dict: dict, capture_jobs: bool = False, keep_final: bool = False,

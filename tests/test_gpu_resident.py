@@ -435,3 +435,35 @@ def test_resident_merge_check_failure_sends_only_that_chunk_to_the_hashing_path(
     assert st0.resident == 1 and st0.fallback_chunks == 0
     for d in dchunks:
         d.close()
+
+
+@pytest.mark.parametrize("case", ["biallelic", "mixed_alleles_long_reads", "many_alleles"])
+def test_one_pass_cross_emission_equals_the_two_kernel_path_and_the_oracle(gpu_ctx, orc, case):
+    """Merge levels compute a cell's emission from per-parent-cell tables inside the cross product kernel and write no
+    partition (emissions.c:125-154 is a sum over the reads of the partition, partitions.c:21-28 concatenates the two
+    parents' reads).  Same chunks through the separate cross product + emission kernels (mrp_params.reserved bit 1): both
+    equal the oracle.  The cases cover sites with different allele counts inside one column, columns whose sites do not
+    fit one table fill (long reads: hundreds of allele slots per column at the low levels) and a site with more alleles
+    than the tables hold for wide columns (that chunk takes the hashing path)."""
+    pd = _params()
+    if case == "biallelic":
+        chunks = [synth.make_ont_chunk(seed=301 + i, region_bp=60_000, n_sites=130, coverage=22 + 3 * i) for i in range(3)]
+    elif case == "mixed_alleles_long_reads":
+        chunks = [synth.make_ont_chunk(seed=311 + i, region_bp=150_000, n_sites=700, coverage=18, median_len=60_000.0, sigma=0.3,
+                                       allele_choices=(2, 3, 4, 6), allele_probs=(0.4, 0.3, 0.2, 0.1)) for i in range(2)]
+    else:
+        chunks = [synth.make_ont_chunk(seed=321, region_bp=60_000, n_sites=120, coverage=24, allele_choices=(2, 5, 12, 16),
+                                       allele_probs=(0.55, 0.25, 0.15, 0.05))]
+    dchunks = [capi.DeviceChunk.from_chunk(gpu_ctx, c) for c in chunks]
+    params = capi.Params.from_reference_names(pd)
+    got1, st1 = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
+    params.reserved = 2
+    got2, st2 = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
+    assert st1.resident == 1 and st2.resident == 1 and st2.fallback_chunks == 0
+    if case != "many_alleles":
+        assert st1.fallback_chunks == 0
+    for chunk, a, b in zip(chunks, got1, got2):
+        _assert_equals_oracle(orc, chunk, a, pd)
+        _assert_equals_oracle(orc, chunk, b, pd)
+    for d in dchunks:
+        d.close()
