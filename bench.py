@@ -45,15 +45,16 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chunks", type=int, default=int(os.environ.get("MRP_BENCH_CHUNKS", "96")), help="synthetic 1 Mb chunks per GPU")
+    ap.add_argument("--chunks", type=int, default=int(os.environ.get("MRP_BENCH_CHUNKS", "192")), help="synthetic 1 Mb chunks per GPU")
     ap.add_argument("--sites", type=int, default=2000)
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--threads", type=int, default=int(os.environ.get("MRP_BENCH_THREADS", "0")))
     ap.add_argument("--phase-groups", type=int, default=0,
-                    help="concurrent halves inside mrp_phase_reads_many (0: one below 160 chunks, two from there on)")
+                    help="concurrent batches inside mrp_phase_reads_many (0: the library's choice, one per 24 chunks up to 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the kernel replay leg (it needs ~20 s of host work to record the sweeps)")
     ap.add_argument("--roofline-steps", type=int, default=20)
+    ap.add_argument("--roofline-chunks", type=int, default=96, help="chunks whose sweeps the kernel replay leg records (host work: ~0.2 s per chunk)")
     ap.add_argument("--queue-runs", type=int, default=2, help="runs of the host-memory work queue leg (0: skip)")
     ap.add_argument("--align-chunks", type=int, default=4, help="chunks whose read x allele pairs the alignment leg scores (0: skip)")
     ap.add_argument("--align-runs", type=int, default=3)
@@ -72,6 +73,9 @@ def main():
                  f"or a single process")
     single_process_multi = world == 1 and n_gpus > 1
 
+    # torch initialises HIP before libmargin_rphmm.so is loaded: the library's own default (its concurrent batches need more
+    # hardware queues than the runtime's 4, include/margin_rphmm.h) has to be in the environment by then
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
     import torch
     dist = None
     if world > 1:
@@ -123,8 +127,6 @@ def main():
         step = lambda: queue.phase(chunks, params, chunks_per_batch=max(1, args.chunks // 2), descs=descs, convert=False)[1]
     else:
         ctx = capi.Context(local_rank)
-        if args.phase_groups <= 0:
-            args.phase_groups = 1 if args.chunks < 160 else 2
         ctx.set_phase_groups(args.phase_groups)
         dchunks = [capi.DeviceChunk.from_chunk(ctx, c) for c in chunks]
         step = lambda: capi.phase_reads_many(ctx, dchunks, chunks, params, convert=False)[1]
@@ -196,7 +198,7 @@ def main():
             keep.append(dch)
             return capi.phase_reads(tls_ctx[me], dch, chunks[i], params, record=big)["n_sweeps"]
 
-        n_rec = min(args.chunks, len(chunks))
+        n_rec = min(args.roofline_chunks, args.chunks, len(chunks))
         t0 = time.time()
         with ThreadPoolExecutor(max_workers=n_threads) as ex:
             sweeps = sum(ex.map(record_one, range(n_rec)))

@@ -84,7 +84,12 @@ int mrp_set_error(int code, const char *fmt, ...) {
 }
 
 const char *mrp_last_error(void) { return g_err; }
-const char *mrp_version(void) { return "margin_rphmm 0.1.0 gfx950"; }
+const char *mrp_version(void) { return "margin_rphmm 0.2.0 gfx950"; }
+
+/* Concurrent batches of mrp_phase_reads_many launch on 4 streams each; with the runtime's default of 4 hardware queues their
+ * kernels would serialize (include/margin_rphmm.h, mrp_context_set_phase_groups).  Runs when the library is loaded, i.e.
+ * before this library's first HIP call; never overrides the user's setting. */
+__attribute__((constructor)) static void mrp_runtime_defaults(void) { (void) setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 
 int mrp_device_count(void) {
     int n = 0;
@@ -600,7 +605,7 @@ int mrp_set_host_threads(int n) {
     return MRP_OK;
 }
 int mrp_context_set_phase_groups(mrp_context *ctx, int groups) {
-    if (!ctx || groups < 1 || groups > 8) return fail(MRP_ERR_ARG, "mrp_context_set_phase_groups: bad arguments");
+    if (!ctx || groups < 0 || groups > 8) return fail(MRP_ERR_ARG, "mrp_context_set_phase_groups: bad arguments");
     ctx->phase_groups = groups;
     return MRP_OK;
 }

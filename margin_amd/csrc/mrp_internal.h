@@ -177,7 +177,7 @@ struct mrp_context {
     hipEvent_t last_emission = nullptr; /* end of the emission kernel of the most recent launch on this context (owned by its batch) */
     hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
     DevPool pool;
-    int phase_groups = 2; /* concurrent halves of mrp_phase_reads_many (mrp_context_set_phase_groups) */
+    int phase_groups = 0; /* concurrent batches of mrp_phase_reads_many (mrp_context_set_phase_groups); 0: chosen by batch size */
     std::vector<mrp_context *> siblings; /* further contexts on the same device (concurrent batches of mrp_phase_reads_many) */
     std::mutex sibling_mu;
     /* the emptied batch object of the last resident engine on this context: its host arrays keep their capacity (and their

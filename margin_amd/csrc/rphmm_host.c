@@ -2044,7 +2044,8 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
     for (int64_t c = 0; c < n_chunks; c++) out[c] = NULL;
     /* the levels of a batch alternate host work (structure, descriptors) and device work; two interleaved halves of the
      * chunks, each with its own context and host thread, keep both busy */
-    int G = mrp_context_phase_groups(ctx); /* mrp_context_set_phase_groups, default 2 */
+    int G = mrp_context_phase_groups(ctx); /* mrp_context_set_phase_groups; 0 (default): by batch size */
+    if (G <= 0) G = (int) (n_chunks / 24 > 4 ? 4 : n_chunks / 24); /* measured on MI355X: 4 groups from 96 chunks on, 2 at 48 */
     if (G < 1) G = 1;
     if (G > 8) G = 8;
     if (n_chunks < 4 * G) G = 1;
