@@ -58,6 +58,7 @@ def parse_args():
     ap.add_argument("--queue-runs", type=int, default=2, help="runs of the host-memory work queue leg (0: skip)")
     ap.add_argument("--align-chunks", type=int, default=4, help="chunks whose read x allele pairs the alignment leg scores (0: skip)")
     ap.add_argument("--align-runs", type=int, default=3)
+    ap.add_argument("--sum-chunks", type=int, default=16, help="chunks whose sweeps the log-sum-exp leg replays (0: skip)")
     return ap.parse_args()
 
 
@@ -254,6 +255,34 @@ def main():
             d_.close()
     if dist is not None:
         dist.barrier()
+
+    if args.sum_chunks > 0 and rank == 0 and not single_process_multi:
+        # Sum mode (logAddP with maxNotSumTransitions false, hmm.c:15-20): the sweeps of a few chunks phased by the hashing path
+        # with log-sum-exp transitions, replayed as one batch: mrp_sweep_lse_kernel (merge column in LDS, reproducible sums).
+        sctx = capi.Context(local_rank)
+        sparams = capi.Params.from_reference_names(dict(params_dict, maxNotSumTransitions=0))
+        sbatch = capi.Batch(sctx)
+        skeep = []
+        for i in range(min(args.sum_chunks, len(chunks))):
+            dch = capi.DeviceChunk.from_chunk(sctx, chunks[i])
+            skeep.append(dch)
+            capi.phase_reads(sctx, dch, chunks[i], sparams, record=sbatch)
+        sbatch.upload()
+        sbatch.launch()
+        sctx.synchronize()
+        sbatch.stats()
+        for _ in range(5):
+            sbatch.launch()
+        sctx.synchronize()
+        ss = sbatch.stats()
+        out["sum_mode"] = dict(what="log-sum-exp sweeps (maxNotSumTransitions = false) of the same chunks' merge levels, one batch; fp64, merge "
+                                    "column in LDS, integer-atomic (order-free) accumulation",
+                               chunks=len(skeep), hmms=int(ss.n_hmms), hmms_lds_kernel=int(ss.n_hmms_lse), hmms_generic_kernel=int(ss.n_hmms_generic),
+                               cells=int(ss.n_cells), sweep_ms=float(ss.avg_sweep_ms), cells_per_s=float(ss.n_cells) / (ss.avg_sweep_ms * 1e-3),
+                               dtype="f64", launches=int(ss.launches_averaged))
+        sbatch.close()
+        for d_ in skeep:
+            d_.close()
 
     if args.align_chunks > 0 and not single_process_multi:
         # Alignment leg: the banded pair-HMM forward probability of every read substring against every

@@ -156,6 +156,9 @@ typedef struct mrp_launch_stats {
      * most recent): launches may be queued back to back without waiting for each other, every one keeps its own events */
     double avg_planes_ms, avg_emission_ms, avg_sweep_ms;
     int64_t launches_averaged;
+    /* which recursion kernel the hmms of the batch took: max-plus int32 (merge column in LDS), log-sum-exp with the merge
+     * column in LDS (sum mode, reproducible), generic fp64 (oversize merge columns / 32-bit transitions) */
+    int64_t n_hmms_int32, n_hmms_lse, n_hmms_generic;
 } mrp_launch_stats;
 /* Waits for the launch to finish, then fills stats. */
 int mrp_batch_stats(mrp_batch *batch, mrp_launch_stats *out);

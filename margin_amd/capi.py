@@ -59,7 +59,7 @@ class LaunchStats(C.Structure):
                 ("n_columns", C.c_int64), ("n_cells", C.c_int64), ("n_merge_cells", C.c_int64),
                 ("profile_bytes", C.c_int64), ("algorithmic_bytes", C.c_int64), ("popcount_ops", C.c_int64),
                 ("units", C.c_int64), ("avg_planes_ms", C.c_double), ("avg_emission_ms", C.c_double), ("avg_sweep_ms", C.c_double),
-                ("launches_averaged", C.c_int64)]
+                ("launches_averaged", C.c_int64), ("n_hmms_int32", C.c_int64), ("n_hmms_lse", C.c_int64), ("n_hmms_generic", C.c_int64)]
 
 
 class Params(C.Structure):

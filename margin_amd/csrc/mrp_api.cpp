@@ -628,7 +628,7 @@ int mrp_batch_upload(mrp_batch *b) {
     /* launch plan: int32/LDS path for max-plus HMMs that fit, fp64 path otherwise.  The int32 path is
      * split into size classes (LDS per workgroup = 2 * largest merge column * 4 B) that are launched
      * on separate streams so that small hmms do not inherit the residency of the largest one. */
-    std::vector<std::pair<int64_t, int32_t>> wide, mid, narrow, generic;
+    std::vector<std::pair<int64_t, int32_t>> wide, mid, narrow, generic, lse, lse_big;
     for (size_t i = 0; i < b->hmms.size(); i++) {
         const DevHmm &h = b->hmms[i];
         const int64_t work = b->outs[i].n_cells;
@@ -641,6 +641,9 @@ int mrp_batch_upload(mrp_batch *b) {
             else wide.push_back({-work, (int32_t) i});
         } else {
             generic.push_back({-work, (int32_t) i});
+            /* sum mode with merge columns that fit LDS: the reproducible log-sum-exp kernel */
+            if (!max_mode && !h.wide_idx && h.max_merge <= MRP_LSE_CUR_LDS_MAX_MERGE) lse.push_back({-work, (int32_t) i});
+            else if (!max_mode && !h.wide_idx && h.max_merge <= MRP_LSE_MAX_MERGE) lse_big.push_back({-work, (int32_t) i});
         }
     }
     auto plan = [&](std::vector<std::pair<int64_t, int32_t>> &v, std::vector<int32_t> &order, int *max_merge) {
@@ -656,7 +659,17 @@ int mrp_batch_upload(mrp_batch *b) {
     plan(wide, b->order_wide, &b->max_merge_wide);
     plan(mid, b->order_mid, &b->max_merge_mid);
     plan(narrow, b->order_narrow, &b->max_merge_narrow);
-    plan(generic, b->order_f64, nullptr);
+    plan(generic, b->order_f64, nullptr); /* every hmm with fp64 results */
+    plan(lse, b->order_lse, &b->max_merge_lse);
+    plan(lse_big, b->order_lse_big, &b->max_merge_lse_big);
+    b->order_gen.clear();                  /* ... of which the generic kernel takes what the LDS ones do not */
+    {
+        std::vector<char> in_lse(b->hmms.size(), 0);
+        for (int32_t i : b->order_lse) in_lse[(size_t) i] = 1;
+        for (int32_t i : b->order_lse_big) in_lse[(size_t) i] = 1;
+        for (int32_t i : b->order_f64)
+            if (!in_lse[(size_t) i]) b->order_gen.push_back(i);
+    }
 
     const double u1 = now_();
     std::vector<DevChunk> chunks;
@@ -685,7 +698,9 @@ int mrp_batch_upload(mrp_batch *b) {
     HIP_TRY(b->d_order_wide.upload(b->order_wide, s));
     HIP_TRY(b->d_order_mid.upload(b->order_mid, s));
     HIP_TRY(b->d_order_narrow.upload(b->order_narrow, s));
-    HIP_TRY(b->d_order_f64.upload(b->order_f64, s));
+    HIP_TRY(b->d_order_f64.upload(b->order_gen, s));
+    HIP_TRY(b->d_order_lse.upload(b->order_lse, s));
+    HIP_TRY(b->d_order_lse_big.upload(b->order_lse_big, s));
     const double u2 = now_();
     if (!b->tilecols.empty()) { /* resident batch: the tiles are written on the device */
         HIP_TRY(b->d_tilecols.upload(b->tilecols, s));
@@ -816,7 +831,9 @@ int mrp_batch_launch(mrp_batch *b) {
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_wide.p, (int64_t) b->order_wide.size(), t_wide, b->max_merge_wide, s));
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_mid.p, (int64_t) b->order_mid.size(), t_mid, b->max_merge_mid, ctx->aux[0]));
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), t_narrow, b->max_merge_narrow, ctx->aux[1]));
-    HIP_TRY(mrp_launch_sweep_f64(d, b->d_order_f64.p, (int64_t) b->order_f64.size(), 256, s));
+    HIP_TRY(mrp_launch_sweep_f64(d, b->d_order_f64.p, (int64_t) b->order_gen.size(), 256, s));
+    HIP_TRY(mrp_launch_sweep_lse(d, b->d_order_lse.p, (int64_t) b->order_lse.size(), b->max_merge_lse, s));
+    HIP_TRY(mrp_launch_sweep_lse(d, b->d_order_lse_big.p, (int64_t) b->order_lse_big.size(), std::max(b->max_merge_lse_big, MRP_LSE_CUR_LDS_MAX_MERGE + 2), s));
     HIP_TRY(hipEventRecord(ctx->join[0], ctx->aux[0]));
     HIP_TRY(hipEventRecord(ctx->join[1], ctx->aux[1]));
     HIP_TRY(hipStreamWaitEvent(s, ctx->join[0], 0));
@@ -830,6 +847,9 @@ int mrp_batch_launch(mrp_batch *b) {
 int mrp_batch_stats(mrp_batch *b, mrp_launch_stats *out) {
     if (!b || !out) return fail(MRP_ERR_ARG, "mrp_batch_stats: NULL argument");
     *out = b->stats;
+    out->n_hmms_lse = (int64_t) (b->order_lse.size() + b->order_lse_big.size());
+    out->n_hmms_generic = (int64_t) b->order_gen.size();
+    out->n_hmms_int32 = (int64_t) (b->order_wide.size() + b->order_mid.size() + b->order_narrow.size());
     if (b->launched) {
         mrp_context *ctx = b->ctx;
         HIP_TRY(hipSetDevice(ctx->device));

@@ -478,7 +478,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         });
     }
     /* launch classes of the recursion kernel, from the static bounds; largest first inside a class */
-    b->order_wide.clear(); b->order_mid.clear(); b->order_narrow.clear(); b->order_f64.clear();
+    b->order_wide.clear(); b->order_mid.clear(); b->order_narrow.clear(); b->order_f64.clear(); b->order_lse.clear(); b->order_lse_big.clear(); b->order_gen.clear();
     b->max_merge_wide = b->max_merge_mid = b->max_merge_narrow = 1;
     {
         std::vector<std::pair<int64_t, int32_t>> wide, mid, narrow;

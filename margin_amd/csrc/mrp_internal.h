@@ -247,8 +247,8 @@ struct mrp_batch {
     bool resident = false;     /* cell arrays are produced on the device */
     mrp_launch_stats stats{};
     /* launch plan */
-    std::vector<int32_t> order_wide, order_mid, order_narrow, order_f64;
-    int max_merge_wide = 1, max_merge_mid = 1, max_merge_narrow = 1;
+    std::vector<int32_t> order_wide, order_mid, order_narrow, order_f64, order_lse, order_lse_big, order_gen; /* order_f64 = order_lse + order_lse_big + order_gen */
+    int max_merge_wide = 1, max_merge_mid = 1, max_merge_narrow = 1, max_merge_lse = 1, max_merge_lse_big = 1;
     /* device */
     bool uploaded = false, launched = false;
     /* events of the most recent launches: [0] planes start, [1] planes end, [2] sweeps end, [3] emission end, [4] emission start */
@@ -265,7 +265,7 @@ struct mrp_batch {
     DevBuf<uint32_t> d_next, d_prev, d_np, d_slot_total, d_slot_bytes, d_cost;
     DevBuf<double> d_f, d_b, d_mf, d_mb, d_total, d_hmm_fb;
     DevBuf<int32_t> d_f32, d_b32, d_mf32, d_mb32;
-    DevBuf<int32_t> d_order_wide, d_order_mid, d_order_narrow, d_order_f64, d_pack_list, d_plane_list;
+    DevBuf<int32_t> d_order_wide, d_order_mid, d_order_narrow, d_order_f64, d_order_lse, d_order_lse_big, d_pack_list, d_plane_list;
     DevBuf<EmitTile> d_tiles;
     MrpBatchDev dev{};
     /* back to the empty state, keeping the capacity of the host arrays (the resident engine reuses one batch object for
@@ -275,13 +275,13 @@ struct mrp_batch {
         d_scols.release(); d_pcols.release(); d_next.release(); d_prev.release(); d_np.release(); d_slot_total.release();
         d_slot_bytes.release(); d_cost.release(); d_f.release(); d_b.release(); d_mf.release(); d_mb.release(); d_total.release();
         d_hmm_fb.release(); d_f32.release(); d_b32.release(); d_mf32.release(); d_mb32.release(); d_order_wide.release();
-        d_order_mid.release(); d_order_narrow.release(); d_order_f64.release(); d_tiles.release(); d_pack_list.release(); d_plane_list.release(); d_tilecols.release();
+        d_order_mid.release(); d_order_narrow.release(); d_order_f64.release(); d_order_lse.release(); d_order_lse_big.release(); d_tiles.release(); d_pack_list.release(); d_plane_list.release(); d_tilecols.release();
         chunks.clear(); hmms.clear(); cols.clear(); read_byte_off.clear(); partition.clear(); scols.clear(); pcols.clear();
         cell_next.clear(); cell_prev.clear(); cell_np.clear(); tiles.clear(); tilecols.clear(); outs.clear();
-        order_wide.clear(); order_mid.clear(); order_narrow.clear(); order_f64.clear();
+        order_wide.clear(); order_mid.clear(); order_narrow.clear(); order_f64.clear(); order_lse.clear(); order_lse_big.clear(); order_gen.clear();
         n_fast_tiles = 0; n_tiles_dev = 0; need_wide = false; n_merge = 0; n_slots = 0; n_cells_total = 0; resident = false;
         stats = mrp_launch_stats{};
-        max_merge_wide = max_merge_mid = max_merge_narrow = 1;
+        max_merge_wide = max_merge_mid = max_merge_narrow = max_merge_lse = max_merge_lse_big = 1;
         uploaded = launched = false;
         n_launches = 0; stats_mark = 0; /* (the events stay: every launch of the emptied batch has been waited for) */
         dev = MrpBatchDev{};
@@ -291,7 +291,7 @@ struct mrp_batch {
         d_scols.pool = pl; d_pcols.pool = pl; d_next.pool = pl; d_prev.pool = pl; d_np.pool = pl; d_slot_total.pool = pl;
         d_slot_bytes.pool = pl; d_cost.pool = pl; d_f.pool = pl; d_b.pool = pl; d_mf.pool = pl; d_mb.pool = pl; d_total.pool = pl;
         d_hmm_fb.pool = pl; d_f32.pool = pl; d_b32.pool = pl; d_mf32.pool = pl; d_mb32.pool = pl; d_order_wide.pool = pl;
-        d_order_mid.pool = pl; d_order_narrow.pool = pl; d_order_f64.pool = pl; d_tiles.pool = pl; d_pack_list.pool = pl; d_plane_list.pool = pl; d_tilecols.pool = pl;
+        d_order_mid.pool = pl; d_order_narrow.pool = pl; d_order_f64.pool = pl; d_order_lse.pool = pl; d_order_lse_big.pool = pl; d_tiles.pool = pl; d_pack_list.pool = pl; d_plane_list.pool = pl; d_tilecols.pool = pl;
     }
 };
 

@@ -59,6 +59,11 @@ hipError_t mrp_launch_sweep_i32(const MrpBatchDev &d, const int32_t *order_dev, 
                                 int max_merge, hipStream_t stream);
 hipError_t mrp_launch_sweep_f64(const MrpBatchDev &d, const int32_t *order_dev, int64_t n, int block_threads,
                                 hipStream_t stream);
+/* sum mode with the merge column in LDS: reproducible log-sum-exp (integer atomics), at most MRP_LSE_MAX_MERGE merge cells
+ * per merge column, 16-bit transitions */
+#define MRP_LSE_CUR_LDS_MAX_MERGE 8000 /* 20 B of LDS per merge cell up to here, 12 B above (finished values read back from HBM) */
+#define MRP_LSE_MAX_MERGE 13600
+hipError_t mrp_launch_sweep_lse(const MrpBatchDev &d, const int32_t *order_dev, int64_t n, int max_merge, hipStream_t stream);
 hipError_t mrp_launch_fill_f64(double *p, int64_t n, double v, hipStream_t stream);
 hipError_t mrp_launch_emissions(const DevCol *col_dev, const DevChunk *chunks, const uint64_t *planes,
                                 const uint32_t *slot_total, uint32_t flags, int64_t n_cells,

@@ -896,6 +896,173 @@ hipError_t mrp_launch_sweep_f64(const MrpBatchDev &d, const int32_t *order_dev, 
     return hipGetLastError();
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* log-sum-exp sweep (sum mode, hmm.c:15-20 logAddP with maxNotSumTransitions == false)         */
+/* ------------------------------------------------------------------------------------------ */
+/*
+ * One workgroup per hmm; the merge column being summed lives in LDS.  The reference adds a column's cells into their merge
+ * cells one after the other (forwardCellCalc2 hmm.c:814-825, backwardCellCalc :881-908); floating point addition in a
+ * different order gives different last bits, so a parallel version is only reproducible if its result does not depend on
+ * the order at all.  Here a merge cell's value is  r + log(sum_i exp(v_i - r))  with
+ *   r       the largest contribution, rounded UP to a float: a 32-bit integer atomic max in LDS (order-free), and
+ *   the sum accumulated in 64-bit FIXED POINT (2^-50 units; every term is <= 1, a column has < 2^14 cells): integer
+ *           atomic adds in LDS, associative, hence identical from run to run and for any wave schedule.
+ * A term below 2^-50 of the largest one contributes nothing (35 nats down); the value differs from the reference's sequential
+ * sum by about n 2^-50 relative, i.e. 1e-11 at most per column and well inside the 1e-9 the tests ask for (north star: 1e-5
+ * on posteriors).  Column totals (hmm.c:906-907) and the hmm's forward / backward probability are reductions over ALL cells of
+ * a column: per thread in index order, then across the wave by shuffles, then across the waves in wave order.
+ * LDS: 20 B per merge cell (value f64, sum u64, reference point i32), or 12 B when the finished values are read back from
+ * HBM (merge columns above 8000 cells); hmms with still wider merge columns, or with transitions that need 32 bits, take
+ * mrp_sweep_f64_kernel.
+ */
+#define LSE_KEY_NEG_INF ((int32_t) 0x807FFFFF)
+static __device__ __forceinline__ int32_t lse_key_up(double v) { /* order-preserving integer image of v rounded up to float */
+    float f = (float) v;
+    if ((double) f < v) f = __int_as_float(__float_as_int(f) + (f >= 0.0f ? 1 : -1)); /* next float towards +inf (v finite, f != 0 here or f = -0/+0 -> fine) */
+    const int32_t b = __float_as_int(f);
+    return b >= 0 ? b : (int32_t) (b ^ 0x7FFFFFFF);
+}
+static __device__ __forceinline__ double lse_key_value(int32_t k) {
+    return (double) __int_as_float(k >= 0 ? k : (int32_t) (k ^ 0x7FFFFFFF));
+}
+#define LSE_FIX 1125899906842624.0 /* 2^50 */
+struct LseAcc { double m, s; };     /* running log-sum-exp: value = m + log(s) */
+static __device__ __forceinline__ void lse_push(LseAcc &a, double v) {
+    if (v == -__builtin_inf()) return;
+    if (v > a.m) { a.s = a.s * exp(a.m - v) + 1.0; a.m = v; }
+    else a.s += exp(v - a.m);
+}
+static __device__ __forceinline__ void lse_merge(LseAcc &a, double m, double s) {
+    if (m == -__builtin_inf()) return;
+    if (m > a.m) { a.s = a.s * exp(a.m - m) + s; a.m = m; }
+    else a.s += s * exp(m - a.m);
+}
+static __device__ __forceinline__ double lse_value(const LseAcc &a) { return a.m == -__builtin_inf() ? a.m : a.m + log(a.s); }
+
+/* CUR_LDS: the finished merge column (what the next column's cells read) is kept in LDS too; otherwise it is read back from
+ * the merge_f / merge_b arrays in HBM, which the workgroup has just written (12 B of LDS per merge cell: merge columns up to
+ * the 13 456 cells of two 116-cell parents fit). */
+template <bool CUR_LDS>
+__global__ void __launch_bounds__(512) mrp_sweep_lse_kernel(MrpBatchDev d, const int32_t *__restrict__ order, int max_merge) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lse_lds[];
+    unsigned long long *acc = reinterpret_cast<unsigned long long *>(lse_lds);
+    double *cur = reinterpret_cast<double *>(lse_lds + 8 * (size_t) max_merge);
+    double *part = cur + (CUR_LDS ? max_merge : 0); /* [2 * 8] per-wave partial reductions */
+    int32_t *rkey = reinterpret_cast<int32_t *>(part + 16);
+    const int tid = threadIdx.x, T = blockDim.x, lane = tid & (WAVE - 1), wave = tid / WAVE, n_waves = T / WAVE;
+    const int64_t hmm_index = K_PTR(int32_t, order)[blockIdx.x];
+    const DevHmm h = k_load(d.hmms + hmm_index);
+    const SweepCol *cols = d.scols + h.col0;
+    const int K = h.n_cols;
+    const double NEG = -__builtin_inf();
+    for (int m = tid; m < max_merge; m += T) { rkey[m] = LSE_KEY_NEG_INF; acc[m] = 0ull; if (CUR_LDS) cur[m] = NEG; }
+    __syncthreads();
+
+    /* what a finished merge column holds: value of merge cell m, then the cell is cleared for the next column */
+    auto finish = [&](int m) -> double {
+        const unsigned long long a = acc[m];
+        const double v = a ? lse_key_value(rkey[m]) + log((double) a * (1.0 / LSE_FIX)) : NEG;
+        rkey[m] = LSE_KEY_NEG_INF;
+        acc[m] = 0ull;
+        return v;
+    };
+
+    /* ---------------- forward (hmm.c:827-879) ---------------- */
+    for (int k = 0; k < K; k++) {
+        const SweepCol c = k_load(cols + k);
+        const bool first = (k == 0), last = (k == K - 1);
+        const double *prev_mf = d.merge_f + k_load(cols + (first ? k : k - 1)).mcell_off; /* __syncthreads() below: written, visible */
+        for (int idx = tid; idx < c.n_cells; idx += T) {
+            const int64_t g = c.cell_off + idx;
+            const uint32_t np = d.cell_np[g];
+            const double fv = (first ? 0.0 : (CUR_LDS ? cur[np >> 16] : load_agent(const_cast<double *>(prev_mf + (np >> 16))))) - (double) d.cell_cost[g]; /* forwardCellCalc1 :791, emissions.c:239 */
+            d.cell_f[g] = fv;
+            if (fv != NEG) atomicMax(&rkey[last ? 0u : (np & 0xFFFFu)], lse_key_up(fv));
+        }
+        __syncthreads();
+        for (int idx = tid; idx < c.n_cells; idx += T) {
+            const int64_t g = c.cell_off + idx;
+            const uint32_t to = last ? 0u : (d.cell_np[g] & 0xFFFFu);
+            const double fv = d.cell_f[g];
+            if (fv != NEG) atomicAdd(&acc[to], (unsigned long long) (exp(fv - lse_key_value(rkey[to])) * LSE_FIX)); /* forwardCellCalc2 :814 */
+        }
+        __syncthreads();
+        if (!last) {
+            for (int m = tid; m < c.n_merge; m += T) {
+                const double v = finish(m);
+                if (CUR_LDS) cur[m] = v;
+                d.merge_f[c.mcell_off + m] = v;
+            }
+        } else if (tid == 0) d.hmm_fb[2 * hmm_index] = finish(0); /* stRPHmm.forwardLogProb :872-878 */
+        __syncthreads();
+    }
+    /* ---------------- backward (hmm.c:910-929), column totals (:906-907) ---------------- */
+    for (int k = K - 1; k >= 0; k--) {
+        const SweepCol c = k_load(cols + k);
+        const bool first = (k == 0), last = (k == K - 1);
+        const SweepCol pc = k_load(cols + (first ? k : k - 1));
+        LseAcc tot = {NEG, 0.0};
+        for (int idx = tid; idx < c.n_cells; idx += T) {
+            const int64_t g = c.cell_off + idx;
+            const uint32_t np = d.cell_np[g];
+            const double bv = last ? 0.0 : (CUR_LDS ? cur[np & 0xFFFFu] : load_agent(d.merge_b + c.mcell_off + (np & 0xFFFFu)));
+            d.cell_b[g] = bv;
+            const double p = bv - (double) d.cell_cost[g]; /* backwardCellCalc :881 */
+            if (p != NEG) atomicMax(&rkey[first ? 0u : (np >> 16)], lse_key_up(p));
+            lse_push(tot, d.cell_f[g] + bv);
+        }
+        /* the column total: across the wave by shuffles (fixed tree), then across the waves in wave order */
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const double om = __shfl_xor(tot.m, o, WAVE), os = __shfl_xor(tot.s, o, WAVE);
+            /* both partners must combine the same two operands in the same order: lower lane's value first */
+            LseAcc lo = (lane & o) ? LseAcc{om, os} : tot, hi = (lane & o) ? tot : LseAcc{om, os};
+            lse_merge(lo, hi.m, hi.s);
+            tot = lo;
+        }
+        if (lane == 0) { part[2 * wave] = tot.m; part[2 * wave + 1] = tot.s; }
+        __syncthreads();
+        for (int idx = tid; idx < c.n_cells; idx += T) {
+            const int64_t g = c.cell_off + idx;
+            const uint32_t to = first ? 0u : (d.cell_np[g] >> 16);
+            const double p = d.cell_b[g] - (double) d.cell_cost[g];
+            if (p != NEG) atomicAdd(&acc[to], (unsigned long long) (exp(p - lse_key_value(rkey[to])) * LSE_FIX));
+        }
+        if (tid == 0) {
+            LseAcc t = {NEG, 0.0};
+            for (int w = 0; w < n_waves; w++) lse_merge(t, part[2 * w], part[2 * w + 1]);
+            d.col_total[h.col0 + k] = lse_value(t);
+        }
+        __syncthreads();
+        if (!first) {
+            for (int m = tid; m < pc.n_merge; m += T) {
+                const double v = finish(m);
+                if (CUR_LDS) cur[m] = v;
+                d.merge_b[pc.mcell_off + m] = v;
+            }
+        } else if (tid == 0) d.hmm_fb[2 * hmm_index + 1] = finish(0);
+        __syncthreads();
+    }
+}
+
+hipError_t mrp_launch_sweep_lse(const MrpBatchDev &d, const int32_t *order_dev, int64_t n, int max_merge, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    if (max_merge < 1) max_merge = 1;
+    max_merge = (max_merge + 1) & ~1; /* keeps the arrays behind it 16-byte aligned */
+    const bool cur_lds = max_merge <= MRP_LSE_CUR_LDS_MAX_MERGE;
+    const size_t lds = (size_t) max_merge * (cur_lds ? 20 : 12) + 16 * sizeof(double);
+    static PerDeviceOnce once;
+    const hipError_t attr_status = once.run([] {
+        hipError_t e = hipFuncSetAttribute((const void *) mrp_sweep_lse_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *) mrp_sweep_lse_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        return e;
+    });
+    if (attr_status != hipSuccess) return attr_status;
+    if (cur_lds) hipLaunchKernelGGL(mrp_sweep_lse_kernel<true>, dim3((unsigned) n), dim3(512), lds, stream, d, order_dev, max_merge);
+    else hipLaunchKernelGGL(mrp_sweep_lse_kernel<false>, dim3((unsigned) n), dim3(512), lds, stream, d, order_dev, max_merge);
+    return hipGetLastError();
+}
+
 __global__ void mrp_fill_f64_kernel(double *p, int64_t n, double v) {
     for (int64_t i = (int64_t) blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t) gridDim.x * blockDim.x)
         p[i] = v;

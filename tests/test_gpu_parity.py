@@ -76,6 +76,44 @@ def test_sum_mode_within_tolerance(gpu_ctx, orc, seed):
     oc.close()
 
 
+@pytest.mark.parametrize("shape", ["unit_test", "ont_30x"])
+def test_sum_mode_merge_column_in_lds_is_reproducible(gpu_ctx, orc, shape):
+    """Sum mode with the merge column in LDS (mrp_sweep_lse_kernel): every hmm of the batch takes that kernel, two launches
+    give bit-identical doubles (integer atomics: the result does not depend on the order the cells arrive in), and the values
+    are the oracle's sequential logAddP (hmm.c:15-20) within 1e-9."""
+    from margin_amd.capi import Batch, Job
+    from tests.helpers import job_flags
+    if shape == "unit_test":
+        chunk = synth.make_unit_test_chunk(seed=13, ref_length=200, coverage=18, min_read=10, max_read=70, error_rate=0.05)
+        pd = synth.unit_test_params(max_partitions=60, max_not_sum=0)
+    else:  # shipped parameters on a 30x chunk: merge columns of up to ~10^4 cells (the 12 B / merge cell variant of the kernel)
+        chunk = synth.make_ont_chunk(seed=14, region_bp=120_000, n_sites=240, coverage=30)
+        pd = dict(synth.shipped_phase_params(), maxNotSumTransitions=0)
+    oc = orc.OracleChunk(chunk)
+    res = oc.phase(pd, capture_jobs=True)
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    runs = []
+    for _ in range(2):
+        jobs = [Job(dchunk, f, job_flags(f), True) for f in res["jobs"]]
+        b = Batch(gpu_ctx)
+        for j in jobs:
+            b.add(j)
+        b.upload(); b.launch(); b.download()
+        st = b.stats()
+        assert st.n_hmms_lse == len(jobs) and st.n_hmms_generic == 0 and st.n_hmms_int32 == 0
+        if shape == "ont_30x":
+            assert max(int(np.diff(f["mcol_cell_off"]).max()) for f in res["jobs"] if len(f["mcol_cell_off"]) > 1) > 8000
+        runs.append([j.results() for j in jobs])
+        b.close()
+    for f, r0, r1 in zip(res["jobs"], runs[0], runs[1]):
+        for k in ("cell_forward", "cell_backward", "merge_forward", "merge_backward", "col_total", "hmm_forward", "hmm_backward"):
+            x, y = np.asarray(r0[k]), np.asarray(r1[k])
+            assert ((x == y) | (np.isneginf(x) & np.isneginf(y))).all(), k
+        assert_job_equal(f, r0, exact=False, atol=1e-9)
+    dchunk.close()
+    oc.close()
+
+
 def test_bit_count_vectors_and_emissions_kat(gpu_ctx):
     """tests/stRPHmmTest.c:882-928 on the device: planes and getLogProbOfAllele-based emission
     equal the naive per-read sums, for depth 0..63."""

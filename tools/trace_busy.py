@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Device occupancy of the LAST mrp_phase_reads_many call of a rocprofv3 --kernel-trace run of tools/pipeline_probe.py when the
+call's batches run concurrently: union of the kernels' busy intervals against the call's span, and summed durations per kernel.
+usage: trace_busy.py <rocprof_out_dir> <n_groups>"""
+import csv, glob, sys
+
+d, groups = sys.argv[1], int(sys.argv[2])
+rows = []
+for f in glob.glob(d + "/**/*kernel_trace.csv", recursive=True):
+    rows += list(csv.DictReader(open(f)))
+rows = [r for r in rows if "mrp_" in r["Kernel_Name"]]
+rows.sort(key=lambda r: int(r["Start_Timestamp"]))
+tbs = [i for i, r in enumerate(rows) if "traceback" in r["Kernel_Name"]]
+# the last call holds `groups` trace back kernels; it starts after the trace back before them
+start = tbs[-groups - 1] + 1 if len(tbs) > groups else 0
+sel = rows[start:]
+iv = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in sel)
+t0, t1 = iv[0][0], max(e for _, e in iv)
+busy, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+for s, e in iv[1:]:
+    if s > cur_e:
+        busy += cur_e - cur_s
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+busy += cur_e - cur_s
+tot = {}
+for r in sel:
+    n = r["Kernel_Name"].split("(")[0].replace("void ", "")
+    tot[n] = tot.get(n, 0.0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
+print(f"kernels {len(sel)}, span {(t1 - t0) / 1e6:.2f} ms, device busy (union) {busy / 1e6:.2f} ms = {100.0 * busy / (t1 - t0):.1f} %, summed durations {sum(tot.values()):.2f} ms")
+print("summed durations (ms):", {k: round(v, 2) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])})
