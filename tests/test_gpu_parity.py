@@ -228,8 +228,7 @@ def test_merge_column_beyond_16_bit_indices(gpu_ctx, small_ont):
 def test_launches_queued_back_to_back_keep_their_own_events(gpu_ctx, small_ont):
     """mrp_batch_launch several times without waiting in between (what bench.py's timed region does): every launch has its
     own HIP events, mrp_batch_stats averages the launches since the previous query, and the results downloaded after the
-    last launch are the oracle's.  Also with the byte packing on its own stream (MRP_PRE_STREAM is read once per process, so
-    only the default is exercised here)."""
+    last launch are the oracle's."""
     chunk, res = small_ont
     dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
     flats = res["jobs"]

@@ -48,14 +48,18 @@ def test_resident_get_rp_hmms_matches_oracle(gpu_ctx, orc, seed, n_sites, cov, o
 def test_resident_phase_many_matches_oracle_and_host_path(gpu_ctx, orc):
     """Several chunks of different shapes phased in one call (their merge levels share launches): HP
     partition, haplotype strings and genotype calls equal the oracle's and the per-chunk host path's."""
-    # nine chunks: enough for the call to run them as two concurrent batches (MRP_PHASE_GROUPS) on sibling contexts
+    # nine chunks as two concurrent batches on sibling contexts (the default would need 48 chunks for two)
     specs = [(3, 200, 30, 64), (5, 150, 40, 12), (11, 80, 20, 64), (12, 30, 8, 64), (13, 60, 25, 64), (14, 90, 15, 64),
              (15, 40, 30, 64), (16, 120, 20, 64), (17, 70, 35, 64)]
     chunks = [synth.make_ont_chunk(seed=s, region_bp=n * 500, n_sites=n, coverage=c) for s, n, c, _ in specs]
     pd = _params(maxCoverageDepth=64)
     params = capi.Params.from_reference_names(pd)
     dchunks = [capi.DeviceChunk.from_chunk(gpu_ctx, c) for c in chunks]
-    got, st = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
+    gpu_ctx.set_phase_groups(2)
+    try:
+        got, st = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
+    finally:
+        gpu_ctx.set_phase_groups(0)
     assert st.resident == 1 and st.levels > 0 and st.cells > 0
     for chunk, dchunk, g in zip(chunks, dchunks, got):
         oc = orc.OracleChunk(chunk)
