@@ -21,6 +21,11 @@ def short(n):
     return n.split("(")[0].replace("void ", "")
 
 
+# the kernels of bench.py's replay leg (their launches repeat with identical grids); the kernels of the end-to-end steps are
+# listed level by level in pipeline_levels_*.txt instead
+REPLAY = {"mrp_sweep_i32_kernel", "mrp_emission_kernel", "mrp_pack_kernel", "mrp_planes_kernel", "mrp_emission_general_kernel"}
+
+
 def stats(d):
     st = rows_of(d, "*kernel_stats.csv")
     if st:
@@ -33,9 +38,9 @@ def stats(d):
     for r in tr:
         if "mrp_" in r["Kernel_Name"]:
             by[(short(r["Kernel_Name"]), int(r["Grid_Size_X"]), r["Workgroup_Size_X"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6)
-    print("dispatches with the same (kernel, grid) and a grid of at least 100000 work-items, 3 to 64 calls (replay launches, steps of the timed region):")
+    print("replay launches (kernels of the replay leg, same grid in every launch: at least 20 calls, grid of at least 100000 work-items):")
     for (name, g, wg), v in sorted(by.items(), key=lambda kv: (kv[0][0], -kv[0][1])):
-        if g >= 100000 and 3 <= len(v) <= 64:
+        if g >= 100000 and 20 <= len(v) <= 64 and name in REPLAY:
             print(f"  {name:34s} grid {g:>10d} wg {wg:>4s} calls {len(v):3d} avg {sum(v) / len(v):8.3f} ms  min {min(v):8.3f}  max {max(v):8.3f}")
 
 
@@ -53,7 +58,7 @@ def pmc(d):
     print("counters, mean per dispatch (dispatches with the same kernel and grid, grid of at least 100000 work-items):")
     for (name, g, wg), dd in sorted(by.items(), key=lambda kv: (kv[0][0], -kv[0][1])):
         n = len(next(iter(dd.values())))
-        if g >= 100000 and n <= 64:
+        if g >= 100000 and n <= 64 and ((name in REPLAY and n >= 4) or (name == "mrp_cross_emit_kernel" and g > 5000000)):
             print(f"  {name:34s} grid {g:>10d} wg {wg:>4s} n={n:2d}: " + ", ".join(f"{c}={sum(v) / len(v):.5g}" for c, v in sorted(dd.items())))
 
 
