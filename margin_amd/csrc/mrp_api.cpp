@@ -505,12 +505,17 @@ int mrp_batch_add_impl(mrp_batch *b, const mrp_hmm_job *job, bool resident, int6
  * mrp_pool_run(n, grain, fn, arg) calls fn(i, arg) for every i in [0, n) on the calling thread and the pool's workers and
  * returns when all are done.  The resident pipeline issues ~50 short parallel loops per call; creating and joining 15
  * threads for each of them cost more than many of the loops.  Several callers may be inside at once (the concurrent
- * halves of mrp_phase_reads_many): jobs queue up, a worker serves the oldest job that still has indices to hand out. */
+ * batches of mrp_phase_reads_many): jobs queue up, a worker serves the job of the most urgent caller that still has indices
+ * to hand out (mrp_pool_set_priority: batch 0 before batch 1 ...: the batches then leave their host-only phases one after
+ * the other instead of all together, and the device has work while the later ones are still being prepared), the oldest
+ * among equals. */
 namespace {
+thread_local int t_pool_priority = 0;
 struct PoolJob {
     void (*fn)(int64_t, void *);
     void *arg;
     int64_t n, grain;
+    int prio = 0;
     std::atomic<int64_t> next{0}, done{0};
     int active = 0; /* workers currently holding the pointer (under Pool::mu) */
 };
@@ -534,7 +539,7 @@ struct Pool {
         for (;;) {
             PoolJob *j = nullptr;
             for (PoolJob *q : jobs)
-                if (q->next.load() < q->n) { j = q; break; }
+                if (q->next.load() < q->n && (!j || q->prio < j->prio)) j = q;
             if (!j) {
                 if (stop) return;
                 cv_work.wait(lk);
@@ -578,7 +583,7 @@ extern "C" void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void 
     Pool &P = pool();
     P.ensure(mrp_host_threads() - 1);
     PoolJob j;
-    j.fn = fn; j.arg = arg; j.n = n; j.grain = grain;
+    j.fn = fn; j.arg = arg; j.n = n; j.grain = grain; j.prio = t_pool_priority;
     {
         std::lock_guard<std::mutex> lk(P.mu);
         P.jobs.push_back(&j);
@@ -589,6 +594,8 @@ extern "C" void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void 
     P.cv_done.wait(lk, [&] { return j.done.load() >= j.n && j.active == 0; });
     P.jobs.erase(std::find(P.jobs.begin(), P.jobs.end(), &j));
 }
+
+extern "C" void mrp_pool_set_priority(int p) { t_pool_priority = p; }
 
 static std::atomic<int> g_host_threads{0};
 int mrp_host_threads(void) {

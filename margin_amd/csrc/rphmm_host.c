@@ -2025,12 +2025,14 @@ typedef struct {
     const mrp_params *params;
     mrp_phase_result **out;
     mrp_phase_many_stats stats;
-    int rc;
+    int rc, index;
     char err[256];
 } phase_group;
 static void *phase_group_main(void *p) {
     phase_group *g = p;
+    mrp_pool_set_priority(g->index); /* batch 0's host loops first: the batches reach their device-heavy levels one after the other */
     g->rc = phase_many_resident(g->ctx, g->n, g->chunks, g->reads, g->n_reads, g->params, g->out, &g->stats);
+    mrp_pool_set_priority(0);
     if (g->rc != MRP_OK) snprintf(g->err, sizeof(g->err), "%s", mrp_last_error());
     return NULL;
 }
@@ -2058,6 +2060,7 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
         int started[8] = {0};
         for (int g = 0; g < G; g++) {
             phase_group *q = &grp[g];
+            q->index = g;
             q->ctx = g == 0 ? ctx : mrp_context_sibling(ctx, g - 1);
             q->params = params;
             q->n = (n_chunks - g + G - 1) / G;

@@ -24,6 +24,13 @@ for s, e in iv[1:]:
     else:
         cur_e = max(cur_e, e)
 busy += cur_e - cur_s
+# idle gaps of the device inside the call (longer than 0.3 ms), relative to the first kernel
+gaps, ce = [], iv[0][1]
+for s_, e_ in iv[1:]:
+    if s_ > ce and s_ - ce > 300000:
+        gaps.append(((ce - t0) / 1e6, (s_ - ce) / 1e6))
+    ce = max(ce, e_)
+print("idle gaps > 0.3 ms (at ms, length ms):", [(round(a, 1), round(b, 2)) for a, b in gaps])
 tot = {}
 for r in sel:
     n = r["Kernel_Name"].split("(")[0].replace("void ", "")
