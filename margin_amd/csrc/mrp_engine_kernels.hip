@@ -1601,10 +1601,24 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, con
 __global__ void __launch_bounds__(256) mrp_compact_kernel(MrpBatchDev d, const CrossCol *__restrict__ ccols, const PruneHmm *__restrict__ hmms,
                                                           const int32_t *__restrict__ col_hmm, int64_t n_cols, PruneParams p,
                                                           PruneScratch sc) {
+    __shared__ uint32_t km_all[4][2 * PRUNE_SP]; /* per wave: the kept merge cells after and before the column (ascending) */
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / WAVE));
+    uint32_t *km_next = km_all[wave], *km_prev = km_all[wave] + PRUNE_SP;
     const int S = p.S;
     const int64_t stride = (int64_t) gridDim.x * (blockDim.x / WAVE);
+    /* number of entries below x in an ascending list of n <= 128 entries */
+    auto rank_of = [&](const uint32_t *list, int n, uint32_t x) -> uint32_t {
+        int lo = 0, hi = n; /* first index with list[index] >= x */
+#pragma unroll
+        for (int step = 0; step < 8; step++) {
+            if (lo < hi) {
+                const int mid = (lo + hi) >> 1;
+                if (list[mid] < x) lo = mid + 1; else hi = mid;
+            }
+        }
+        return (uint32_t) lo;
+    };
     for (int64_t lcol = (int64_t) blockIdx.x * (blockDim.x / WAVE) + wave; lcol < n_cols; lcol += stride) {
         const PruneHmm h = k_load(hmms + col_hmm[lcol]);
         const int k = (int) (lcol - h.col0);
@@ -1619,14 +1633,24 @@ __global__ void __launch_bounds__(256) mrp_compact_kernel(MrpBatchDev d, const C
         const int nk = sc.n_kept[lcol];
         const int nm = k + 1 < K ? sc.n_keptm[lcol] : 0;
         const int nmp = k > 0 ? sc.n_keptm[lcol - 1] : 0;
+        /* filterMergeCells keeps the merge cells in their original relative order: a merge cell's new index is the number of
+         * kept merge cells before it, i.e. its position in the (ascending) kept list */
+        {   /* the kept lists are in posterior order (hmm.c:1090); sorted by merge cell index here, 128 keys per wave in registers */
+            uint32_t a0 = lane < nm ? (uint32_t) sc.keptm[lcol * S + lane] : 0xFFFF0000u + (uint32_t) lane;
+            uint32_t a1 = lane + WAVE < nm ? (uint32_t) sc.keptm[lcol * S + lane + WAVE] : 0xFFFF0040u + (uint32_t) lane;
+            uint32_t b0 = lane < nmp ? (uint32_t) sc.keptm[(lcol - 1) * S + lane] : 0xFFFF0000u + (uint32_t) lane;
+            uint32_t b1 = lane + WAVE < nmp ? (uint32_t) sc.keptm[(lcol - 1) * S + lane + WAVE] : 0xFFFF0040u + (uint32_t) lane;
+            if (nm > 1) wave_bitonic_sort128(a0, a1, lane);
+            if (nmp > 1) wave_bitonic_sort128(b0, b1, lane);
+            km_next[lane] = a0; km_next[lane + WAVE] = a1;
+            km_prev[lane] = b0; km_prev[lane + WAVE] = b1;
+        }
+        wave_lds_fence();
         for (int i = lane; i < nk; i += WAVE) {
             const uint32_t c = sc.kept[lcol * S + i];
             const uint32_t np = sc.kept_np[lcol * S + i];
             const uint32_t nx = np & 0xFFFFu, pv = np >> 16;
-            /* filterMergeCells keeps the merge cells in their original relative order */
-            uint32_t new_next = 0, new_prev = 0;
-            for (int j = 0; j < nm; j++) new_next += sc.keptm[lcol * S + j] < nx ? 1u : 0u;
-            for (int j = 0; j < nmp; j++) new_prev += sc.keptm[(lcol - 1) * S + j] < pv ? 1u : 0u;
+            const uint32_t new_next = rank_of(km_next, nm, nx), new_prev = rank_of(km_prev, nmp, pv);
             uint64_t part;
             if (d.partition) part = d.partition[col.cell_off + c];
             else {
@@ -1641,6 +1665,7 @@ __global__ void __launch_bounds__(256) mrp_compact_kernel(MrpBatchDev d, const C
             h.out_n_cells[k] = nk;
             h.out_n_merge[k] = nm;
         }
+        wave_lds_fence(); /* the lists are rewritten for the wave's next column */
     }
 }
 
