@@ -235,6 +235,17 @@ int mrp_hmm_forward_backward(mrp_context *ctx, const mrp_chunk *chunk, mrp_hmm *
 int mrp_hmm_prune(mrp_hmm *hmm, const mrp_params *params);
 /* stRPHmm_forwardTraceBack (hmm.c:165-219): cell index (within its column) per column. */
 int mrp_hmm_forward_trace_back(const mrp_hmm *hmm, int32_t *cell_index_per_column);
+/* stRPHmm_split (hmm.c:1231-1300): hmm keeps [refStart, split_point), *suffix_out receives the rest (same reads array as
+ * the one the hmm was built from).  The column holding the split point is cut in two; results of a sweep are dropped.
+ * MRP_ERR_ARG where the reference aborts (split point outside (refStart, refStart + refLength)). */
+int mrp_hmm_split(const mrp_chunk *chunk, const mrp_read *reads, int64_t n_reads, mrp_hmm *hmm, int32_t split_point,
+                  mrp_hmm **suffix_out);
+/* stRPHMM_splitWherePhasingIsUncertain (hmm.c:1322-1383): forward/backward on the device, trace back, predicted
+ * haplotypes; between consecutive heterozygous sites spanned by fewer than
+ * min_read_coverage_to_support_phasing_between_heterozygous_sites reads the hmm is cut half way.  Returns a malloc'd array
+ * whose first entry is the (shortened) input hmm; the caller owns all of them. */
+int mrp_hmm_split_where_phasing_is_uncertain(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *reads, int64_t n_reads,
+                                             mrp_hmm *hmm, const mrp_params *params, mrp_hmm ***hmms_out, int64_t *n_out);
 
 /* stGenomeFragment (inc/margin.h:482-520) + read partition, as plain arrays. */
 typedef struct mrp_phase_result {

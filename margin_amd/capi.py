@@ -23,7 +23,7 @@ FLAG_INCLUDE_ANCESTOR_SUB_PROB = 2
 #: every symbol include/margin_rphmm.h declares (checked by the CPU test-suite)
 EXPORTED_SYMBOLS = [
     "mrp_last_error", "mrp_version", "mrp_device_count", "mrp_context_create", "mrp_context_destroy",
-    "mrp_context_synchronize", "mrp_context_set_phase_groups", "mrp_set_host_threads", "mrp_chunk_create", "mrp_chunk_destroy", "mrp_fb_run", "mrp_batch_create",
+    "mrp_context_synchronize", "mrp_hmm_split", "mrp_hmm_split_where_phasing_is_uncertain", "mrp_context_set_phase_groups", "mrp_set_host_threads", "mrp_chunk_create", "mrp_chunk_destroy", "mrp_fb_run", "mrp_batch_create",
     "mrp_batch_add", "mrp_batch_upload", "mrp_batch_launch", "mrp_batch_download", "mrp_batch_destroy",
     "mrp_batch_stats", "mrp_count_bit_vectors", "mrp_emissions", "mrp_get_rp_hmms", "mrp_hmm_destroy", "mrp_free",
     "mrp_hmm_view", "mrp_hmm_forward_backward", "mrp_hmm_prune", "mrp_hmm_forward_trace_back", "mrp_phase_reads",
@@ -237,6 +237,8 @@ def load():
     L.mrp_hmm_forward_backward.argtypes = [vp, vp, vp, P(Params), vp]
     L.mrp_hmm_prune.argtypes = [vp, P(Params)]
     L.mrp_hmm_forward_trace_back.argtypes = [vp, vp]
+    L.mrp_hmm_split.argtypes = [vp, P(ReadRec), i64, vp, i32, P(vp)]
+    L.mrp_hmm_split_where_phasing_is_uncertain.argtypes = [vp, vp, P(ReadRec), i64, vp, P(Params), P(P(vp)), P(i64)]
     L.mrp_phase_reads.argtypes = [vp, vp, P(ReadRec), i64, P(Params), vp, P(P(PhaseResult))]
     L.mrp_phase_result_destroy.argtypes = [P(PhaseResult)]
     L.mrp_phase_result_destroy.restype = None
@@ -531,6 +533,26 @@ def hmm_destroy(h):
 
 def hmm_forward_backward(ctx: Context, dchunk: DeviceChunk, h, params: Params):
     _check(load().mrp_hmm_forward_backward(ctx.h, dchunk.h, h, C.byref(params), None))
+
+
+def hmm_split(dchunk: DeviceChunk, chunk, h, split_point: int):
+    """mrp_hmm_split: h keeps the prefix, returns the suffix hmm."""
+    recs, _keep = read_records(chunk)
+    out = C.c_void_p()
+    _check(load().mrp_hmm_split(dchunk.h, recs, len(chunk.reads), h, int(split_point), C.byref(out)))
+    return out
+
+
+def hmm_split_where_phasing_is_uncertain(ctx: Context, dchunk: DeviceChunk, chunk, h, params: Params):
+    """mrp_hmm_split_where_phasing_is_uncertain: list of hmm handles, the first one is h itself."""
+    L = load()
+    recs, _keep = read_records(chunk)
+    out = C.POINTER(C.c_void_p)()
+    n_out = C.c_int64(0)
+    _check(L.mrp_hmm_split_where_phasing_is_uncertain(ctx.h, dchunk.h, recs, len(chunk.reads), h, C.byref(params), C.byref(out), C.byref(n_out)))
+    hmms = [C.c_void_p(out[i]) for i in range(n_out.value)]
+    L.mrp_free(out)
+    return hmms
 
 
 def hmm_forward_trace_back(h, n_columns: int) -> np.ndarray:

@@ -1015,6 +1015,143 @@ int mrp_hmm_forward_trace_back(const mrp_hmm *h, int32_t *path) {
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* split (hmm.c:1192-1383)                                                                      */
+/* ------------------------------------------------------------------------------------------ */
+/* columns [k0, k1) of src appended to dst; the first one may start later, the last one end earlier (stRPColumn_split
+ * column.c:86-101 leaves both halves with the same cells and reads) */
+static void hmm_append_columns(const world *w, mrp_hmm *dst, const mrp_hmm *src, int64_t k0, int64_t k1, int32_t first_start,
+                               int32_t last_end) {
+    for (int64_t k = k0; k < k1; k++) {
+        int32_t start = src->col_start.a[k], end = start + src->col_len.a[k];
+        if (k == k0 && first_start > start) start = first_start;
+        if (k == k1 - 1 && last_end < end) end = last_end;
+        hmm_begin_column(dst, w, start, end - start, src->col_depth.a[k], src->col_reads.a + src->read_off.a[k]);
+        for (int64_t c = src->cell_off.a[k]; c < src->cell_off.a[k + 1]; c++) {
+            hmm_add_cell(dst, src->part.a[c], k == k0 ? 0u : src->prev.a[c]);
+            dst->next.a[dst->next.n - 1] = k == k1 - 1 ? 0u : src->next.a[c];
+        }
+        hmm_end_column(dst);
+        if (k + 1 < k1) {
+            hmm_begin_merge(dst, src->mask_from.a[k], src->mask_to.a[k]);
+            for (int64_t m = src->mcell_off.a[k]; m < src->mcell_off.a[k + 1]; m++) { VEC_PUSH(dst->mfrom, src->mfrom.a[m]); VEC_PUSH(dst->mto, src->mto.a[m]); }
+            hmm_end_merge(dst);
+        }
+    }
+}
+/* h takes the arrays of `from` (which is consumed); h's own bookkeeping as an allocation stays */
+static void hmm_take(mrp_hmm *h, mrp_hmm *from) {
+    void *arrays[] = {h->reads.a, h->col_start.a, h->col_len.a, h->col_depth.a, h->cell_off.a, h->read_off.a, h->col_reads.a,
+                      h->read_byte_off.a, h->part.a, h->next.a, h->prev.a, h->mask_from.a, h->mask_to.a, h->mcell_off.a,
+                      h->mfrom.a, h->mto.a};
+    for (size_t i = 0; i < sizeof(arrays) / sizeof(arrays[0]); i++) hmm_free_array(h, arrays[i]);
+    hmm_free_results(h);
+    h->ref_start = from->ref_start; h->ref_length = from->ref_length; h->max_depth = from->max_depth;
+    h->reads = from->reads; h->col_start = from->col_start; h->col_len = from->col_len; h->col_depth = from->col_depth;
+    h->cell_off = from->cell_off; h->read_off = from->read_off; h->col_reads = from->col_reads; h->read_byte_off = from->read_byte_off;
+    h->part = from->part; h->next = from->next; h->prev = from->prev; h->mask_from = from->mask_from; h->mask_to = from->mask_to;
+    h->mcell_off = from->mcell_off; h->mfrom = from->mfrom; h->mto = from->mto;
+    free(from);
+}
+/* stRPHmm_split hmm.c:1231-1300: h keeps [refStart, split_point), the returned hmm holds the rest.  The column that
+ * contains the split point is cut in two (both halves keep its cells); the merge column in front of the suffix goes. */
+static mrp_hmm *hmm_split(const world *w, mrp_hmm *h, int32_t sp) {
+    const int64_t K = hmm_K(h);
+    int64_t ks = 0; /* getColumn :1192-1209 */
+    while (ks < K && sp >= h->col_start.a[ks] + h->col_len.a[ks]) ks++;
+    const int inside = sp > h->col_start.a[ks];
+    mrp_hmm *L = hmm_new(), *R = hmm_new();
+    for (int64_t i = 0; i < h->reads.n; i++) { /* :1247-1262 */
+        const mrp_read *r = &w->reads[h->reads.a[i]];
+        if (r->ref_start < sp) VEC_PUSH(L->reads, h->reads.a[i]);
+        if (r->ref_start + r->length > sp) VEC_PUSH(R->reads, h->reads.a[i]);
+    }
+    hmm_append_columns(w, L, h, 0, inside ? ks + 1 : ks, h->col_start.a[0], sp);
+    hmm_append_columns(w, R, h, ks, K, sp, h->col_start.a[K - 1] + h->col_len.a[K - 1]);
+    L->ref_start = h->ref_start; L->ref_length = sp - h->ref_start;
+    R->ref_start = sp; R->ref_length = h->ref_start + h->ref_length - sp;
+    hmm_take(h, L);
+    return R;
+}
+static int world_host(world *w, const mrp_chunk *chunk, const mrp_read *reads, int64_t n_reads) {
+    if (!chunk || (n_reads > 0 && !reads)) return mrp_set_error(MRP_ERR_ARG, "NULL argument");
+    memset(w, 0, sizeof(*w));
+    w->chunk = chunk; w->reads = reads; w->n_reads = n_reads;
+    mrp_chunk_host_view(chunk, &w->ch);
+    return check_reads(w, reads, n_reads);
+}
+static int hmm_reads_known(const mrp_hmm *h, int64_t n_reads) {
+    for (int64_t i = 0; i < h->reads.n; i++) if (h->reads.a[i] < 0 || h->reads.a[i] >= n_reads) return 0;
+    return 1;
+}
+int mrp_hmm_split(const mrp_chunk *chunk, const mrp_read *reads, int64_t n_reads, mrp_hmm *hmm, int32_t split_point,
+                  mrp_hmm **suffix_out) {
+    if (!hmm || !suffix_out || hmm->resident) return mrp_set_error(MRP_ERR_ARG, "mrp_hmm_split: bad arguments");
+    if (split_point <= hmm->ref_start) return mrp_set_error(MRP_ERR_ARG, "The split point is at or before the start of the reference interval");
+    if (split_point >= hmm->ref_start + hmm->ref_length) return mrp_set_error(MRP_ERR_ARG, "The split point is after the last position of the reference interval");
+    world w;
+    int rc = world_host(&w, chunk, reads, n_reads);
+    if (rc != MRP_OK) return rc;
+    if (!hmm_reads_known(hmm, n_reads)) return mrp_set_error(MRP_ERR_ARG, "mrp_hmm_split: the hmm names reads beyond n_reads");
+    *suffix_out = hmm_split(&w, hmm, split_point);
+    return MRP_OK;
+}
+
+static void genome_fragment(const world *w, mrp_phase_result *g, const mrp_hmm *h, const uint64_t *chosen, int64_t max_iterations);
+static mrp_phase_result *result_new(int32_t ref_start, int32_t length, int64_t n_reads);
+/* sitesLinkageIsWellSupported hmm.c:1302-1320: reads shared by the columns that hold the two sites */
+static int sites_linkage_well_supported(const mrp_hmm *h, const mrp_params *params, int32_t left, int32_t right) {
+    const int64_t K = hmm_K(h);
+    int64_t kl = 0, kr;
+    while (kl < K - 1 && left >= h->col_start.a[kl] + h->col_len.a[kl]) kl++;
+    kr = kl;
+    while (kr < K - 1 && right >= h->col_start.a[kr] + h->col_len.a[kr]) kr++;
+    const int32_t *a = h->col_reads.a + h->read_off.a[kl], *b = h->col_reads.a + h->read_off.a[kr];
+    int64_t common = 0;
+    for (int32_t i = 0; i < h->col_depth.a[kl]; i++)
+        for (int32_t j = 0; j < h->col_depth.a[kr]; j++)
+            if (a[i] == b[j]) { common++; break; }
+    return common >= params->min_read_coverage_to_support_phasing_between_heterozygous_sites;
+}
+/* stRPHMM_splitWherePhasingIsUncertain hmm.c:1322-1383: sweep, trace back, predicted haplotypes; between two consecutive
+ * heterozygous sites that too few reads span, the hmm is cut half way.  The input hmm becomes the first of the list. */
+int mrp_hmm_split_where_phasing_is_uncertain(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *reads, int64_t n_reads,
+                                             mrp_hmm *hmm, const mrp_params *params, mrp_hmm ***hmms_out, int64_t *n_out) {
+    if (!hmm || !params || !hmms_out || !n_out || hmm->resident) return mrp_set_error(MRP_ERR_ARG, "mrp_hmm_split_where_phasing_is_uncertain: bad arguments");
+    world w;
+    int rc = world_init(&w, ctx, chunk, reads, n_reads, NULL);
+    if (rc != MRP_OK) return rc;
+    if (!hmm_reads_known(hmm, n_reads)) return mrp_set_error(MRP_ERR_ARG, "the hmm names reads beyond n_reads");
+    mrp_hmm *one = hmm;
+    rc = sweep_many(&w, &one, 1, params);
+    if (rc != MRP_OK) return rc;
+    const int64_t K = hmm_K(hmm);
+    int32_t *path = xmalloc(sizeof(int32_t) * (size_t) K);
+    rc = mrp_hmm_forward_trace_back(hmm, path);
+    if (rc != MRP_OK) { free(path); return rc; }
+    uint64_t *chosen = xmalloc(sizeof(uint64_t) * (size_t) K);
+    for (int64_t k = 0; k < K; k++) chosen[k] = hmm->part.a[hmm->cell_off.a[k] + path[k]];
+    mrp_phase_result *g = result_new(hmm->ref_start, hmm->ref_length, n_reads);
+    genome_fragment(&w, g, hmm, chosen, 0); /* stGenomeFragment_construct only, :1330 */
+    hmm_vec out = {0};
+    int32_t prev_het = -1;
+    for (int32_t i = 0; i < g->length; i++) {
+        if (g->haplotype_string1[i] == g->haplotype_string2[i]) continue;
+        const int32_t site = g->ref_start + i;
+        if (prev_het >= 0 && !sites_linkage_well_supported(hmm, params, prev_het, site)) {
+            mrp_hmm *right = hmm_split(&w, hmm, prev_het + (site - prev_het + 1) / 2); /* :1361 */
+            VEC_PUSH(out, hmm);
+            hmm = right;
+        }
+        prev_het = site;
+    }
+    VEC_PUSH(out, hmm);
+    free(path); free(chosen); mrp_phase_result_destroy(g);
+    *hmms_out = out.a;
+    *n_out = out.n;
+    return MRP_OK;
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* genome fragment (emissions.c:246-343, genomeFragment.c)                                     */
 /* ------------------------------------------------------------------------------------------ */
 static mrp_phase_result *result_new(int32_t ref_start, int32_t length, int64_t n_reads) {

@@ -101,6 +101,7 @@ def lib():
         "orc_hmm_prune": (None, [P(Hmm)]),
         "orc_hmm_forwardTraceBack": (P(vp), [P(Hmm), P(i64)]),
         "orc_hmm_splitWherePhasingIsUncertain": (P(P(Hmm)), [P(Hmm), P(i64)]),
+        "orc_hmm_split": (P(Hmm), [P(Hmm), i64]),
         "orc_getRPHmms": (P(P(Hmm)), [P(vp), i64, P(Params), P(i64)]),
         "orc_filterReadsByCoverageDepth": (None, [P(vp), i64, P(Params), P(vp), P(i64), P(vp), P(i64)]),
         "orc_tilingPathCount": (i64, [P(vp), i64, P(Params)]),

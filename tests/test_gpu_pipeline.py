@@ -90,3 +90,58 @@ def test_unit_test_shape_sum_mode_pipeline(gpu_ctx, orc):
         capi.hmm_destroy(hg)
     dchunk.close()
     oc.close()
+
+
+def test_split_where_phasing_is_uncertain_matches_oracle(gpu_ctx, orc):
+    """stRPHMM_splitWherePhasingIsUncertain (hmm.c:1322-1383; the reference's system test runs it with
+    splitHmmsWherePhasingUncertain, tests/stRPHmmTest.c:254-263) and stRPHmm_split (hmm.c:1231-1300): the pieces of every hmm
+    of getRPHmms -- intervals, read lists, the cut column on both sides, cells, transitions, merge cells -- equal the oracle's."""
+    import ctypes as C
+    chunk = synth.make_unit_test_chunk(77, 200, 10, 10, 40, 0.05)
+    pd = synth.unit_test_params(max_partitions=50, max_not_sum=1, min_cov=15)
+    oc = orc.OracleChunk(chunk)
+    oparams = orc.make_params(pd)
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    params = capi.Params.from_reference_names(pd)
+    ref = oc.get_rp_hmms(oparams)
+    got = capi.get_rp_hmms(gpu_ctx, dchunk, chunk, params)
+    assert len(ref) == len(got)
+    L = orc.lib()
+    n_pieces = 0
+    for hr, hg in zip(ref, got):
+        n = C.c_int64(0)
+        parts = L.orc_hmm_splitWherePhasingIsUncertain(hr, C.byref(n))
+        orc.check_error()
+        mine = capi.hmm_split_where_phasing_is_uncertain(gpu_ctx, dchunk, chunk, hg, params)
+        assert len(mine) == n.value
+        for i in range(n.value):
+            fr, fg = orc.flatten(parts[i], oc.pool_off), capi.hmm_to_flat(mine[i])
+            assert_same_hmm(fr, fg, values=False)
+            n_pieces += 1
+        # one more cut of the first piece, in the middle of one of its columns when it has one longer than a site
+        f0 = capi.hmm_to_flat(mine[0])
+        starts, lens = np.asarray(f0["col_ref_start"]), np.asarray(f0["col_length"])
+        wide = np.nonzero(lens > 1)[0]
+        if f0["ref_length"] > 1:
+            sp = int(starts[wide[0]] + 1) if wide.size else int(f0["ref_start"] + 1)
+            right_o = L.orc_hmm_split(parts[0], sp)
+            orc.check_error()
+            right_g = capi.hmm_split(dchunk, chunk, mine[0], sp)
+            assert_same_hmm(orc.flatten(parts[0], oc.pool_off), capi.hmm_to_flat(mine[0]), values=False)
+            assert_same_hmm(orc.flatten(right_o, oc.pool_off), capi.hmm_to_flat(right_g), values=False)
+            L.orc_hmm_destruct(right_o, 1)
+            capi.hmm_destroy(right_g)
+        for i in range(n.value):
+            L.orc_hmm_destruct(parts[i], 1)
+            capi.hmm_destroy(mine[i])
+        L.free(parts)
+    assert n_pieces > len(ref)  # the parameters of the system test do cut
+    with pytest.raises(capi.MrpError):
+        h = capi.get_rp_hmms(gpu_ctx, dchunk, chunk, params)
+        try:
+            capi.hmm_split(dchunk, chunk, h[0], int(capi.hmm_to_flat(h[0])["ref_start"]))
+        finally:
+            for x in h:
+                capi.hmm_destroy(x)
+    dchunk.close()
+    oc.close()
