@@ -120,3 +120,29 @@ def test_profile_byte_encoding_of_generator():
         b = c.pool[r.pool_off:r.pool_off + r.nbytes].reshape(-1, 2)
         assert (b.min(axis=1) == 0).all()
     assert c.units == sum(r.length for r in c.reads)
+
+
+def test_parameters_are_the_reference_shipped_values():
+    """The parameters every parity test and bench run uses are the reference's shipped ones (data fixture extracted from
+    params/base_params.json and the two configuration files BASELINE.json names, tests/golden/make_params_fixture.py):
+    the stRPHmm parameters of the 'phase' block, untouched by the haplotag (ONT r9.4) and phase_vcf (HiFi) overrides, and the
+    pair-HMM of the alignment step."""
+    import json
+    import os
+    from margin_amd import synth
+    fx = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "reference_params.json")))
+    shipped = synth.shipped_phase_params()
+    for k, v in shipped.items():
+        if k == "includeAncestorSubProb":  # not a file parameter: parser.c:30 default true, switched by bubbleGraph.c:2733/2748
+            assert v == 1
+            continue
+        assert k in fx["phase"], k
+        assert float(fx["phase"][k]) == float(v), (k, fx["phase"][k], v)
+    for name, ov in fx["overrides"].items():
+        assert not (set(ov) & set(shipped)), (name, set(ov) & set(shipped))  # the configs do not override an stRPHmm parameter
+    typ, tr, em = synth.margin_phase_pair_hmm_arrays()
+    h = fx["hmmForwardStrandReadGivenReference"]
+    assert typ == h["type"] and list(tr) == h["transitions"] and list(em) == h["emissions"]
+    # the phase set rules' defaults (vcf.c:869-953) the frame tests run with
+    assert fx["phase"]["phasesetMaxDiscordantRatio"] == 0.5 and fx["phase"]["phasesetMinSpanningReads"] == 1
+    assert fx["phase"]["referenceExpansionForSmallVariants"] == 12 and fx["phase"]["referenceExpansionForStructuralVariants"] == 512
