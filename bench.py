@@ -104,6 +104,9 @@ def main():
     n_chunks = args.chunks * (n_gpus if single_process_multi else 1)
     cpu_share = max(1, (os.cpu_count() or 8) // max(1, world))
     n_threads = args.threads or min(16, cpu_share, n_chunks)
+    # the library's worker pool: this rank's share of the node's cores (16 per device it drives)
+    host_threads = max(1, min(16 * (n_gpus if single_process_multi else 1), cpu_share))
+    capi.load().mrp_set_host_threads(host_threads)
     seeds = sharding.chunk_seeds(rank, n_chunks)
 
     t0 = time.time()
@@ -150,7 +153,7 @@ def main():
                chunks_per_gpu=args.chunks, units_per_gpu=int(units) // (n_gpus if single_process_multi else 1),
                parallelism=(f"1 process, {n_gpus} devices, host work queue (mrp_queue_phase_chunks), no collectives" if single_process_multi else
                             f"{world} process(es), one per GPU, chunks sharded by rank, no collectives"),
-               host_threads=min(16, os.cpu_count() or 1), synth_s=t_synth)
+               host_threads=host_threads, synth_s=t_synth)
     out = dict(metric="het-sites x reads phased/sec (30x ONT synthetic chunks, end to end: every merge level + final sweep)",
                value=value, unit="het-site-reads/s", n_gpus=n_gpus, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int32", data="synthetic", config=cfg)
