@@ -21,8 +21,8 @@ python3 $R/tools/r02_summary.py pmc $O/t_sq > $O/pmc_sq.txt
 # 4. the levels of the resident pipeline: one batch (per-dispatch listing), four concurrent batches (device occupancy)
 MRP_PHASE_GROUPS=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/t_lv -o t -- python3 $R/tools/pipeline_probe.py --chunks 96 --repeat 3 --check-host 0 > $O/probe_96_g1.log 2>&1 || exit 1
 python3 $R/tools/trace_levels.py $O/t_lv > $O/pipeline_levels_96chunks_1batch.txt
-MRP_PHASE_GROUPS=4 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/t_g4 -o t -- python3 $R/tools/pipeline_probe.py --chunks 192 --repeat 3 --check-host 0 > $O/probe_192_g4.log 2>&1 || exit 1
-python3 $R/tools/trace_busy.py $O/t_g4 4 > $O/pipeline_busy_192chunks_4batches.txt
-grep "^run" $O/probe_96_g1.log $O/probe_192_g4.log > $O/probe_runs.txt
+MRP_PHASE_GROUPS=4 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/t_g4 -o t -- python3 $R/tools/pipeline_probe.py --chunks 288 --repeat 3 --check-host 0 > $O/probe_288_g4.log 2>&1 || exit 1
+python3 $R/tools/trace_busy.py $O/t_g4 4 > $O/pipeline_busy_288chunks_4batches.txt
+grep "^run" $O/probe_96_g1.log $O/probe_288_g4.log > $O/probe_runs.txt
 rm -rf $O/t_stats $O/t_FETCH_SIZE $O/t_WRITE_SIZE $O/t_sq $O/t_lv $O/t_g4
 ls -la $O
