@@ -1015,6 +1015,9 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
          * Every role runs its own loop over the columns (the registers of one role are not live in the others); all of them
          * pass the same barriers: one after the prologue, one per column, one before the last merge list. */
         if (wave == 0) {
+            /* the chain wave goes first whenever it can issue: alone on the device that changes nothing (its SIMD's helper
+             * waves are parked), beside the kernels of other batches on the same CU it is worth ~2 % of a call */
+            __builtin_amdgcn_s_setprio(3);
             if (lane == 0) {
                 kml[0] = 0u;   /* column 0: every cell is "linked" (one virtual merge cell in front of it) */
                 sh[40] = 1u;
