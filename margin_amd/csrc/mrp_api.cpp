@@ -183,6 +183,9 @@ int mrp_chunk_create(mrp_context *ctx, int64_t n_sites, const uint32_t *allele_n
         }
     }
     ch->allele_offset[n_sites] = (uint32_t) off;
+    ch->same_until.resize((size_t) n_sites);
+    for (int64_t i = n_sites - 1; i >= 0; i--)
+        ch->same_until[(size_t) i] = (i + 1 < n_sites && allele_number[i + 1] == allele_number[i]) ? ch->same_until[(size_t) i + 1] : (int32_t) (i + 1);
     ch->sub_offset[n_sites] = (uint32_t) soff;
     std::vector<uint16_t> &sub = ch->sub, &prior = ch->prior;
     sub.assign(soff, 0);
@@ -509,13 +512,18 @@ int mrp_batch_add_impl(mrp_batch *b, const mrp_hmm_job *job, bool resident, int6
  * to hand out (mrp_pool_set_priority: batch 0 before batch 1 ...: the batches then leave their host-only phases one after
  * the other instead of all together, and the device has work while the later ones are still being prepared), the oldest
  * among equals. */
+std::atomic<long long> g_pool_task_cpu_ns{0};
+std::atomic<long long> g_pool_tag_cpu_ns[16];
+extern "C" long long mrp_pool_task_cpu_ns(void) { return g_pool_task_cpu_ns.load(); }
+extern "C" long long mrp_pool_tag_cpu_ns(int tag) { return g_pool_tag_cpu_ns[tag & 15].load(); }
 namespace {
 thread_local int t_pool_priority = 0;
+thread_local int t_pool_tag = 0;
 struct PoolJob {
     void (*fn)(int64_t, void *);
     void *arg;
     int64_t n, grain;
-    int prio = 0;
+    int prio = 0, tag = 0;
     std::atomic<int64_t> next{0}, done{0};
     int active = 0; /* workers currently holding the pointer (under Pool::mu) */
 };
@@ -526,6 +534,13 @@ struct Pool {
     std::vector<std::thread> workers;
     bool stop = false;
     static void run_chunks(PoolJob *j) {
+        struct Acc { /* MRP_TIMING: thread CPU spent inside pool tasks */
+            timespec a;
+            int tag;
+            Acc(int t) : tag(t) { clock_gettime(CLOCK_THREAD_CPUTIME_ID, &a); }
+            ~Acc() { timespec b; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &b); const long long d = (b.tv_sec - a.tv_sec) * 1000000000ll + (b.tv_nsec - a.tv_nsec);
+                     g_pool_task_cpu_ns.fetch_add(d); g_pool_tag_cpu_ns[tag & 15].fetch_add(d); }
+        } acc(j->tag);
         for (;;) {
             const int64_t lo = j->next.fetch_add(j->grain);
             if (lo >= j->n) return;
@@ -583,7 +598,7 @@ extern "C" void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void 
     Pool &P = pool();
     P.ensure(mrp_host_threads() - 1);
     PoolJob j;
-    j.fn = fn; j.arg = arg; j.n = n; j.grain = grain; j.prio = t_pool_priority;
+    j.fn = fn; j.arg = arg; j.n = n; j.grain = grain; j.prio = t_pool_priority; j.tag = t_pool_tag;
     {
         std::lock_guard<std::mutex> lk(P.mu);
         P.jobs.push_back(&j);
@@ -596,6 +611,7 @@ extern "C" void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void 
 }
 
 extern "C" void mrp_pool_set_priority(int p) { t_pool_priority = p; }
+extern "C" void mrp_pool_set_tag(int t) { t_pool_tag = t; } /* MRP_TIMING: which loop the CPU time of the pool tasks is booked to */
 
 static std::atomic<int> g_host_threads{0};
 int mrp_host_threads(void) {

@@ -33,6 +33,7 @@
 #include <vector>
 
 #include "mrp_engine.h"
+extern "C" void mrp_pool_set_tag(int t);
 #include "mrp_internal.h"
 
 #define ENG_TRY(expr)                                                                                          \
@@ -341,7 +342,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     /* pass 1 (parallel): allele slots per hmm, static bounds, validity */
     struct Bound { int64_t slots, cells, merge; int32_t max_cells, max_merge; int64_t cost; int bad; };
     std::vector<Bound> bd((size_t) n);
-    mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
+    mrp_pool_set_tag(7); mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
         const mrp_xhmm &h = x[i];
         const mrp_chunk *ch = h.chunk;
         const bool anc = (h.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
@@ -415,7 +416,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     tm[tmi++] = eng_now();
     /* pass 2 (parallel): the plan */
     std::vector<int32_t> n_planes_of((size_t) n, 0);
-    mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
+    mrp_pool_set_tag(8); mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
         mrp_xhmm &h = x[i];
         int32_t planes_here = 0;
         const mrp_chunk *ch = h.chunk;
@@ -434,9 +435,8 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
             o.n_slots = (int32_t) (ch->allele_offset[o.site_start + o.n_sites] - ch->allele_offset[o.site_start]);
             s_off += o.n_slots;
             o.chunk = chunk_index[(size_t) i];
-            int32_t uniform = (int32_t) ch->allele_number[o.site_start];
-            for (int s2 = 1; s2 < o.n_sites; s2++)
-                if ((int32_t) ch->allele_number[o.site_start + s2] != uniform) uniform = 0;
+            /* one allele count for all the column's sites? (per-chunk run lengths, built with the chunk) */
+            const int32_t uniform = ch->same_until[(size_t) o.site_start] >= o.site_start + o.n_sites ? (int32_t) ch->allele_number[o.site_start] : 0;
             o.uniform_alleles = uniform;
             o.d1 = c.d1; o.d2 = c.d2; o.out_a = c.out_a; o.out_b = c.out_b;
             o.out_a_paired = c.out_a_paired; o.out_b_paired = c.out_b_paired;
@@ -469,7 +469,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
             n_plane += n_planes_of[(size_t) i];
             n_pack += x[i].n_cols - n_planes_of[(size_t) i];
         }
-        mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
+        mrp_pool_set_tag(9); mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
             int64_t a = plane0[(size_t) i], c2 = pack0[(size_t) i];
             for (int64_t c = col0[(size_t) i]; c < col0[(size_t) i + 1]; c++) {
                 if (plan[c].need_planes) plane_list[a++] = (int32_t) c;
@@ -517,7 +517,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         std::vector<PruneHmm> sorted((size_t) n);
         for (int64_t j = 0; j < n; j++) { sorted[(size_t) j] = ph[L->perm[(size_t) j]]; pos[(size_t) L->perm[(size_t) j]] = (int32_t) j; }
         memcpy(ph, sorted.data(), sizeof(PruneHmm) * (size_t) n);
-        mrp_parallel_for(n, std::max<int64_t>(1, n / 64), [&](int64_t i) {
+        mrp_pool_set_tag(10); mrp_parallel_for(n, std::max<int64_t>(1, n / 64), [&](int64_t i) {
             for (int64_t c = col0[(size_t) i]; c < col0[(size_t) i + 1]; c++) col_hmm[c] = pos[(size_t) i];
         });
     }

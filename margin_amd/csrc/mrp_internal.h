@@ -206,6 +206,7 @@ struct mrp_chunk {
     mrp_context *ctx = nullptr;
     int64_t n_sites = 0, pool_bytes = 0;
     std::vector<uint32_t> allele_number, allele_offset, sub_offset;
+    std::vector<int32_t> same_until; /* [n_sites] first site after i whose allele count differs from site i's (n_sites if none) */
     std::vector<uint16_t> sub, prior; /* host copies for the structural code (rphmm_host.c) */
     std::vector<uint8_t> pool;
     uint32_t max_sub = 0, max_prior = 0;

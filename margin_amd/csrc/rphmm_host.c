@@ -36,22 +36,66 @@ static void parallel_for(int64_t n, par_fn fn, void *arg) { mrp_pool_run(n, 1, f
 /* ------------------------------------------------------------------------------------------ */
 /* helpers                                                                                     */
 /* ------------------------------------------------------------------------------------------ */
+/* Scratch arena of the calling thread.  One merge of the resident pipeline (r_prepare_merge) makes some thirty small
+ * allocations that all die before it returns -- component lists, tiling paths, piece lists -- and a call makes 10^5 merges on
+ * 16 threads: a quarter of the host CPU time of a call went into malloc/free.  While the arena is switched on, xmalloc /
+ * xcalloc / xrealloc (hence VEC_PUSH) bump-allocate from it; free() of such a pointer is a no-op (this file's free() checks
+ * the range), the arena is rewound when the merge is done.  What outlives the merge (shadows, the result path, the garbage
+ * list) is allocated with the arena switched off.  A block never changes threads while the arena owns it. */
+typedef struct { char *base; size_t cap, used; int active; } tl_arena;
+static __thread tl_arena t_ar;
+static pthread_key_t ar_key;
+static pthread_once_t ar_once = PTHREAD_ONCE_INIT;
+static void ar_release(void *p) { free(p); }
+static void ar_make_key(void) { (void) pthread_key_create(&ar_key, ar_release); }
+static inline int ar_owns(const void *p) { return t_ar.base && (const char *) p >= t_ar.base && (const char *) p < t_ar.base + t_ar.cap; }
+static void *ar_alloc(size_t n) {
+    if (!t_ar.base) {
+        (void) pthread_once(&ar_once, ar_make_key);
+        t_ar.cap = (size_t) 8 << 20;
+        t_ar.base = malloc(t_ar.cap);
+        if (!t_ar.base) { t_ar.cap = 0; return NULL; }
+        (void) pthread_setspecific(ar_key, t_ar.base); /* freed when the thread ends */
+    }
+    n = (n + 15) & ~(size_t) 15;
+    if (t_ar.used + n + 16 > t_ar.cap) return NULL; /* does not fit: the caller takes it from the heap */
+    char *q = t_ar.base + t_ar.used;
+    *(size_t *) q = n;
+    t_ar.used += n + 16;
+    return q + 16;
+}
+static inline void ar_on(void) { t_ar.active = 1; }
+static inline void ar_off(void) { t_ar.active = 0; }
+static inline void ar_rewind(void) { t_ar.used = 0; t_ar.active = 0; }
+
 static void *xmalloc(size_t n) { /* like st_malloc: out of memory is fatal */
+    if (t_ar.active) { void *a = ar_alloc(n ? n : 1); if (a) return a; }
     void *p = malloc(n ? n : 1);
     if (!p) { fprintf(stderr, "margin_rphmm: out of host memory\n"); abort(); }
     return p;
 }
 static void *xcalloc(size_t n, size_t s) {
+    if (t_ar.active) { void *a = ar_alloc((n ? n : 1) * (s ? s : 1)); if (a) { memset(a, 0, (n ? n : 1) * (s ? s : 1)); return a; } }
     void *p = calloc(n ? n : 1, s ? s : 1);
     if (!p) { fprintf(stderr, "margin_rphmm: out of host memory\n"); abort(); }
     return p;
 }
 static void *xrealloc(void *q, size_t n) {
+    if (q && ar_owns(q)) { /* grows inside the arena (or moves to the heap when the arena is full or off) */
+        const size_t old = *(size_t *) ((char *) q - 16);
+        if (n <= old) return q;
+        void *p = xmalloc(n);
+        memcpy(p, q, old);
+        return p;
+    }
+    if (!q) return xmalloc(n);
     void *p = realloc(q, n ? n : 1);
     if (!p) { fprintf(stderr, "margin_rphmm: out of host memory\n"); abort(); }
     return p;
 }
 void mrp_free(void *p) { free(p); }
+static inline void tl_free(void *p) { if (p && !ar_owns(p)) free(p); }
+#define free(p) tl_free(p) /* from here on: a block of the thread's scratch arena is not given to the heap */
 
 #define VEC(T) struct { T *a; int64_t n, cap; }
 #define VEC_PUSH(v, x)                                                                        \
@@ -1440,7 +1484,7 @@ static mrp_hmm *r_shadow_new(int64_t K, int64_t D, int64_t n_reads, int with_xco
     h->cell_off.a[0] = 0; h->cell_off.n = 1;
     h->read_off.a[0] = 0; h->read_off.n = 1;
     h->mcell_off.a[0] = 0; h->mcell_off.n = 1;
-    if (with_xcols) { h->xcols = (mrp_xcol *) (blk + o_xcols); memset(h->xcols, 0, sizeof(mrp_xcol) * (size_t) K); }
+    if (with_xcols) h->xcols = (mrp_xcol *) (blk + o_xcols); /* every field is written by r_cross_shadow */
     return h;
 }
 
@@ -1583,7 +1627,11 @@ static int r_cross_shadow(const world *w, const piece_vec *A, const piece_vec *B
             h->mask_from.a[s] = c->mask_from;
             h->mask_to.a[s] = c->mask_to;
             h->mcell_off.a[s + 1] = 0;
+        } else { /* no merge column after the last column */
+            c->out_a = c->out_b = MRP_CONN_NONE; c->a_nmerge = c->b_nmerge = NULL; c->out_a_paired = c->out_b_paired = 0;
+            c->mask_from = c->mask_to = 0;
         }
+        c->pad[0] = c->pad[1] = 0;
     }
     h->col_start.n = h->col_len.n = h->col_depth.n = n;
     h->col_reads.n = h->read_byte_off.n = D;
@@ -1597,18 +1645,23 @@ static int r_cross_shadow(const world *w, const piece_vec *A, const piece_vec *B
 /* mergeTwoTilingPaths coordination.c:263-339, structure only: the overlap components that need a cross
  * product are appended to xs (and, unpruned, to res); the others pass through */
 static int64_t g_ns[6]; /* MRP_TIMING: components, tiling paths, pieces, cross shadow, destroy, other */
-#define T_ADD(slot, t0) __atomic_fetch_add(&g_ns[slot], (int64_t) ((now_ms() - (t0)) * 1e6), __ATOMIC_RELAXED)
+static double tcpu_ms(void) { struct timespec t; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t); return 1e3 * (double) t.tv_sec + 1e-6 * (double) t.tv_nsec; }
+#define T_ADD(slot, t0) __atomic_fetch_add(&g_ns[slot], (int64_t) ((tcpu_ms() - (t0)) * 1e6), __ATOMIC_RELAXED)
 static int r_prepare_merge(const world *w, hmm_vec *tp1, hmm_vec *tp2, hmm_vec *res, xbuild_vec *xs, hmm_vec *garbage) {
-    double tq = now_ms();
+    double tq = tcpu_ms();
+    ar_on();
     comp_vec comps = overlapping_components(w, tp1, tp2);
+    ar_off();
     T_ADD(0, tq);
     free(tp1->a); free(tp1); free(tp2->a); free(tp2);
     int rc = MRP_OK;
     for (int64_t i = 0; i < comps.n; i++) {
         component *comp = comps.a[i];
         if (rc == MRP_OK) {
-            tq = now_ms();
+            tq = tcpu_ms();
+            ar_on();
             path_vec sub = tiling_paths_from(w, comp->members.a, comp->members.n);
+            ar_off();
             T_ADD(1, tq);
             if (sub.n == 2) {
                 hmm_vec *a = sub.a[0], *b = sub.a[1];
@@ -1617,13 +1670,15 @@ static int r_prepare_merge(const world *w, hmm_vec *tp1, hmm_vec *tp2, hmm_vec *
                 int32_t Eb = b->a[b->n - 1]->ref_start + b->a[b->n - 1]->ref_length;
                 int32_t E = Ea > Eb ? Ea : Eb;
                 piece_vec pa = {0}, pb = {0}, qa = {0}, qb = {0};
-                tq = now_ms();
+                tq = tcpu_ms();
+                ar_on();
                 pieces_of_path(a, S, E, &pa);
                 pieces_of_path(b, S, E, &pb);
                 align_pieces(&pa, &pb, &qa, &qb);
+                ar_off();
                 T_ADD(2, tq);
                 xbuild xb = {0};
-                tq = now_ms();
+                tq = tcpu_ms();
                 rc = r_cross_shadow(w, &qa, &qb, a, b, S, E, &xb);
                 T_ADD(3, tq);
                 free(pa.a); free(pb.a); free(qa.a); free(qb.a);
@@ -1643,6 +1698,7 @@ static int r_prepare_merge(const world *w, hmm_vec *tp1, hmm_vec *tp2, hmm_vec *
         free(comp->members.a); free(comp);
     }
     free(comps.a);
+    ar_rewind(); /* every temporary of this merge is gone */
     return rc;
 }
 
@@ -1783,7 +1839,7 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
         n_items = 0;
         for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > 0 && lvl[i] == h && !t->a[i].w->failed) { items[n_items].t = t; items[n_items].node = i; n_items++; }
         /* the merges of a level touch disjoint nodes: structure in parallel, device work as one batch */
-        parallel_for(n_items, level_prepare, items);
+        mrp_pool_set_tag(1); parallel_for(n_items, level_prepare, items); mrp_pool_set_tag(0);
         const double ta = now_ms();
         int64_t n_x = 0;
         for (int64_t i = 0; i < n_items; i++) {
@@ -1818,7 +1874,7 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
             x->stride = mrp_engine_stride(e);
             x->d_part = xh[i].d_part; x->d_np = xh[i].d_np; x->d_ncells = xh[i].d_ncells; x->d_nmerge = xh[i].d_nmerge;
         }
-        if (rc == MRP_OK) parallel_for(n_items, level_finish, items);
+        mrp_pool_set_tag(2); if (rc == MRP_OK) parallel_for(n_items, level_finish, items); mrp_pool_set_tag(0);
         for (int64_t i = 0; i < n_items; i++) t->a[items[i].node].path = items[i].res;
         const double t1 = now_ms();
         /* the wait for level h - 1, then level h goes to the device */
@@ -1827,7 +1883,7 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
         level_run_settle(&prev, rc == MRP_OK);
         /* while the device works: drop the parents' shadows */
         const double t2 = now_ms();
-        parallel_for(n_items, level_drop_garbage, items);
+        mrp_pool_set_tag(3); parallel_for(n_items, level_drop_garbage, items); mrp_pool_set_tag(0);
         T_ADD(4, t2);
         g_t_prepare += t1 - t0; g_t_level += now_ms() - t1;
         if (getenv("MRP_TIMING"))
@@ -2058,7 +2114,7 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
     for (int q = 0; q < 6; q++) __atomic_store_n(&g_ns[q], 0, __ATOMIC_RELAXED); /* (diagnostics shared by the concurrent halves) */
     many_ctl ctl = {st, ctx, chunks, reads, n_reads, params, &pc, e, &tree, out, NULL, 0};
     tt[3] = tt[2] = 0;
-    parallel_for(n_chunks, many_setup, &ctl);
+    mrp_pool_set_tag(4); parallel_for(n_chunks, many_setup, &ctl); mrp_pool_set_tag(0);
     for (int64_t c = 0; c < n_chunks; c++) { /* splice the chunks' subtrees into one tree */
         many_state *m = &st[c];
         if (m->rc != MRP_OK && rc == MRP_OK) rc = mrp_set_error(m->rc, "%s", m->err);
@@ -2084,7 +2140,7 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
     if (rc == MRP_OK) {
         ctl.final_flags = sweep_flags(&pc);
         ctl.xfinal = xcalloc((size_t) n_chunks + 1, sizeof(*ctl.xfinal));
-        parallel_for(n_chunks, many_final_shadow, &ctl);
+        mrp_pool_set_tag(5); parallel_for(n_chunks, many_final_shadow, &ctl); mrp_pool_set_tag(0);
         mrp_xhmm *xh = xcalloc((size_t) n_chunks + 1, sizeof(*xh));
         int64_t nj = 0;
         for (int64_t c = 0; c < n_chunks; c++) {
@@ -2110,7 +2166,7 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
     }
     tt[4] = now_ms();
     if (rc == MRP_OK) {
-        parallel_for(n_chunks, many_finish, &ctl);
+        mrp_pool_set_tag(6); parallel_for(n_chunks, many_finish, &ctl); mrp_pool_set_tag(0);
         for (int64_t c = 0; c < n_chunks; c++)
             if (st[c].rc != MRP_OK && rc == MRP_OK) rc = mrp_set_error(st[c].rc, "%s", st[c].err);
     }
@@ -2165,11 +2221,20 @@ typedef struct {
     int rc, index;
     char err[256];
 } phase_group;
+long long mrp_pool_task_cpu_ns(void);
+static double thread_cpu_ms(void) { struct timespec t; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t); return 1e3 * t.tv_sec + 1e-6 * t.tv_nsec; }
 static void *phase_group_main(void *p) {
     phase_group *g = p;
+    const double cpu0 = thread_cpu_ms();
+    const long long pool0 = mrp_pool_task_cpu_ns();
     mrp_pool_set_priority(g->index); /* batch 0's host loops first: the batches reach their device-heavy levels one after the other */
     g->rc = phase_many_resident(g->ctx, g->n, g->chunks, g->reads, g->n_reads, g->params, g->out, &g->stats);
     mrp_pool_set_priority(0);
+    if (getenv("MRP_TIMING")) {
+        fprintf(stderr, "  batch %d: cpu of its own thread %.1f ms; pool tasks (all batches, while it ran) %.1f ms; cumulative by loop:", g->index, thread_cpu_ms() - cpu0, (mrp_pool_task_cpu_ns() - pool0) * 1e-6);
+        for (int t = 0; t < 12; t++) fprintf(stderr, " %d:%.0f", t, mrp_pool_tag_cpu_ns(t) * 1e-6);
+        fprintf(stderr, "\n");
+    }
     if (g->rc != MRP_OK) snprintf(g->err, sizeof(g->err), "%s", mrp_last_error());
     return NULL;
 }

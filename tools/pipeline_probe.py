@@ -66,10 +66,10 @@ def main():
                   f"{[round(x[1].device_ms, 1) for x in res]}", flush=True)
     for r in range(args.repeat):
         last = r + 1 == args.repeat
-        t0 = time.perf_counter()
+        t0, c0 = time.perf_counter(), time.process_time()
         got, st = capi.phase_reads_many(ctx, dchunks, chunks, params, convert=last)
-        dt = time.perf_counter() - t0
-        print(f"run {r}: {dt * 1e3:.1f} ms wall, {units / dt:.3e} units/s, resident={st.resident} levels={st.levels} hmms={st.hmms} "
+        dt, cpu = time.perf_counter() - t0, time.process_time() - c0
+        print(f"run {r}: {dt * 1e3:.1f} ms wall, {units / dt:.3e} units/s, host cpu {cpu * 1e3:.0f} ms, resident={st.resident} levels={st.levels} hmms={st.hmms} "
               f"cols={st.columns} cells={st.cells} device_ms={st.device_ms:.2f} (cross {st.cross_ms:.2f} sweep {st.sweep_ms:.2f} "
               f"prune {st.prune_ms:.2f})", flush=True)
     for i in range(min(args.check_host, args.chunks)):
