@@ -177,6 +177,7 @@ int mrp_chunk_create(mrp_context *ctx, int64_t n_sites, const uint32_t *allele_n
         }
         off += A;
         soff += A * A;
+        ch->max_alleles = std::max<uint32_t>(ch->max_alleles, (uint32_t) A);
         if (off > 0xFFFFFFFFull || soff > 0xFFFFFFFFull) {
             delete ch;
             return fail(MRP_ERR_ARG, "allele tables exceed 32-bit offsets");
@@ -199,10 +200,12 @@ int mrp_chunk_create(mrp_context *ctx, int64_t n_sites, const uint32_t *allele_n
     /* from the context's caching allocator: a work queue creates and destroys a batch of chunks per call */
     ch->d_allele_number.pool = ch->d_allele_offset.pool = ch->d_sub_offset.pool = &ctx->pool;
     ch->d_sub.pool = ch->d_prior.pool = &ctx->pool;
+    ch->d_same_until.pool = &ctx->pool;
     ch->d_pool.pool = &ctx->pool;
     hipError_t e = ch->d_allele_number.upload(ch->allele_number, s);
     if (e == hipSuccess) e = ch->d_allele_offset.upload(ch->allele_offset, s);
     if (e == hipSuccess) e = ch->d_sub_offset.upload(ch->sub_offset, s);
+    if (e == hipSuccess) e = ch->d_same_until.upload(ch->same_until, s);
     if (e == hipSuccess) e = ch->d_sub.upload(sub, s);
     if (e == hipSuccess) e = ch->d_prior.upload(prior, s);
     if (e == hipSuccess) e = ch->d_pool.alloc((size_t) pool_bytes);
@@ -219,6 +222,7 @@ int mrp_chunk_create(mrp_context *ctx, int64_t n_sites, const uint32_t *allele_n
     ch->dev.sub = ch->d_sub.p;
     ch->dev.prior = ch->d_prior.p;
     ch->dev.pool = ch->d_pool.p;
+    ch->dev.same_until = ch->d_same_until.p;
     *out = ch;
     return MRP_OK;
 }

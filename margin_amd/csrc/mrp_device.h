@@ -22,6 +22,7 @@ struct DevChunk {
     const uint16_t *sub;           /* substitutionLogProbs */
     const uint16_t *prior;         /* allelePriorLogProbs, indexed by allele_offset */
     const uint8_t *pool;           /* profile bytes */
+    const int32_t *same_until;     /* [n_sites] first site after i whose allele count differs from site i's */
 };
 
 struct DevCol {

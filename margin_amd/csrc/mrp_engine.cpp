@@ -43,10 +43,12 @@ extern "C" void mrp_pool_set_tag(int t);
     } while (0)
 
 namespace {
-struct Segment { /* the pruned hmms produced by one level */
+struct Segment { /* the pruned hmms produced by one level, and their column structure (read by the levels above) */
     DevBuf<uint64_t> part;
     DevBuf<uint32_t> np;
     DevBuf<int32_t> n_cells, n_merge;
+    DevBuf<ResCol> cols;
+    DevBuf<int64_t> rbo;
 };
 
 /* page-locked, grow-only host buffer: source of the asynchronous uploads of a staged level */
@@ -72,6 +74,9 @@ struct mrp_engine_level_state {
     std::unique_ptr<Segment> seg;
     /* static description, device side */
     DevBuf<PlanCol> d_plan;
+    DevBuf<XDesc> d_xd;
+    DevBuf<mrp_xpar> d_par;
+    DevBuf<int32_t> d_cstart, d_croff;
     DevBuf<PlanHmm> d_phmm;
     DevBuf<uint16_t> d_dims;
     DevBuf<LayoutTot> d_tot;
@@ -90,6 +95,8 @@ struct mrp_engine_level_state {
     double *fb = nullptr;
     std::vector<int32_t> perm; /* position in the (sorted) PruneHmm array -> index into x */
     bool final_level = false;
+    bool any_pack = true, any_planes = true; /* columns for the byte packing kernel / the bit plane kernel */
+    int seg_id = -1;
     bool fused = false; /* cross product and emission in one kernel, no partition array (merge levels, no ancestor model) */
     unsigned long long clk[12] = {0};
     mrp_xhmm *x = nullptr;
@@ -114,6 +121,11 @@ struct mrp_engine {
     DevBuf<uint32_t> leaf_np;
     DevBuf<int32_t> leaf_count;
     std::vector<std::unique_ptr<Segment>> segments;
+    /* every staged level gets a segment number; its arrays are listed here (host copy + device table) for the levels above */
+    static constexpr int MAX_SEGS = 64;
+    SegDev segtab[MAX_SEGS] = {};
+    int n_segs = 0;
+    DevBuf<SegDev> d_segs;
     mrp_engine_stats stats{};
     mrp_engine_level_state *staged = nullptr;  /* staged, not launched */
     mrp_engine_level_state *running = nullptr; /* launched, not ended */
@@ -140,7 +152,7 @@ static void level_retire(mrp_engine *e, mrp_engine_level_state *L) {
         L->b = nullptr;
     }
     L->seg.reset();
-    L->d_plan.release(); L->d_phmm.release(); L->d_dims.release(); L->d_tot.release(); L->d_base.release(); L->d_totals.release();
+    L->d_plan.release(); L->d_xd.release(); L->d_par.release(); L->d_cstart.release(); L->d_croff.release(); L->d_phmm.release(); L->d_dims.release(); L->d_tot.release(); L->d_base.release(); L->d_totals.release();
     L->d_cc.release(); L->d_ph.release(); L->d_col_hmm.release(); L->d_nkept.release(); L->d_nkeptm.release(); L->d_err.release();
     L->d_err_hmm.release(); L->d_kept.release(); L->d_keptm.release(); L->d_kept_np.release();
     L->perm.clear();
@@ -188,6 +200,7 @@ int mrp_engine_create(mrp_context *ctx, const mrp_params *params, mrp_engine **o
     e->leaf_part.pool = &ctx->pool;
     e->leaf_np.pool = &ctx->pool;
     e->leaf_count.pool = &ctx->pool;
+    e->d_segs.pool = &ctx->pool;
     {   /* what the last engine of this context left behind */
         std::lock_guard<std::mutex> lock(ctx->sibling_mu);
         if (ctx->spare_batch) { e->spare.push_back(ctx->spare_batch); ctx->spare_batch = nullptr; }
@@ -198,6 +211,7 @@ int mrp_engine_create(mrp_context *ctx, const mrp_params *params, mrp_engine **o
     hipError_t he = e->leaf_part.alloc(4);
     if (he == hipSuccess) he = e->leaf_np.alloc(4);
     if (he == hipSuccess) he = e->leaf_count.alloc(4);
+    if (he == hipSuccess) he = e->d_segs.alloc(mrp_engine::MAX_SEGS);
     const uint64_t lp[4] = {1, 0, 0, 0}; /* stRPHmm_construct hmm.c:97-133 */
     const uint32_t ln[4] = {0, 0, 0, 0};
     const int32_t lc[4] = {2, 0, 0, 0};  /* its single column has two cells */
@@ -244,10 +258,13 @@ extern "C" {
 
 int32_t mrp_engine_stride(const mrp_engine *e) { return e->pp.S; }
 
-void mrp_engine_leaf(const mrp_engine *e, const uint64_t **part, const uint32_t **np, const int32_t **n_cells) {
-    *part = e->leaf_part.p;
-    *np = e->leaf_np.p;
-    *n_cells = e->leaf_count.p;
+int mrp_engine_locate(const mrp_engine *e, int32_t seg, int64_t col0, const uint64_t **part, const uint32_t **np,
+                      const int32_t **n_cells, const int32_t **n_merge) {
+    if (!e || seg >= e->n_segs) return mrp_set_error(MRP_ERR_ARG, "mrp_engine_locate: no segment %d", seg);
+    if (seg < 0) { *part = e->leaf_part.p; *np = e->leaf_np.p; *n_cells = e->leaf_count.p; *n_merge = nullptr; return MRP_OK; }
+    const SegDev &sg = e->segtab[seg];
+    *part = sg.part + col0 * e->pp.S; *np = sg.np + col0 * e->pp.S; *n_cells = sg.n_cells + col0; *n_merge = sg.n_merge + col0;
+    return MRP_OK;
 }
 
 void mrp_engine_get_stats(const mrp_engine *e, mrp_engine_stats *out) { *out = e->stats; }
@@ -267,10 +284,6 @@ int mrp_engine_sync(mrp_engine *e) {
 
 }  /* extern "C" */
 
-/* static upper bound of the cells one side contributes to a cross product column: a pruned column has at most S cells,
- * and never more than the bipartitions of its reads */
-static inline int64_t side_bound(int depth, int S) { return depth >= 7 ? S : std::min<int64_t>(S, (int64_t) 1 << depth); }
-
 /* ---- stage: the static description of a level, built and uploaded while the level before runs ---- */
 static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) {
     if (!e || n < 0 || (n > 0 && !x)) return mrp_set_error(MRP_ERR_ARG, "mrp_engine_level: bad arguments");
@@ -280,6 +293,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     ENG_TRY(hipSetDevice(ctx->device));
     hipStream_t cs = ctx->pre; /* copy stream: nothing here depends on the kernels in flight */
     const int S = e->pp.S;
+    if (e->n_segs >= mrp_engine::MAX_SEGS) return mrp_set_error(MRP_ERR_UNSUPPORTED, "more than %d levels", mrp_engine::MAX_SEGS);
     std::unique_ptr<mrp_engine_level_state> L;
     if (!e->spare_levels.empty()) { L.reset(e->spare_levels.back()); e->spare_levels.pop_back(); }
     else L.reset(new (std::nothrow) mrp_engine_level_state());
@@ -299,23 +313,6 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
 
     double tm[8]; int tmi = 0;
     tm[tmi++] = eng_now();
-    /* sizes that do not depend on counts */
-    std::vector<int64_t> col0((size_t) n + 1), read0((size_t) n + 1), slot0((size_t) n + 1);
-    int64_t total_cols = 0, total_reads = 0, total_slots = 0;
-    for (int64_t i = 0; i < n; i++) {
-        const mrp_xhmm &h = x[i];
-        if (h.n_cols < 1 || !h.cols || !h.col_ref_start || !h.col_length || !h.col_depth || !h.col_read_off || !h.chunk)
-            return mrp_set_error(MRP_ERR_ARG, "mrp_engine_level: bad hmm %lld", (long long) i);
-        if (h.chunk->ctx->device != ctx->device) return mrp_set_error(MRP_ERR_ARG, "chunk missing or on a different device");
-        col0[(size_t) i] = total_cols; read0[(size_t) i] = total_reads;
-        total_cols += h.n_cols;
-        total_reads += h.col_read_off[h.n_cols];
-    }
-    col0[(size_t) n] = total_cols;
-    if (total_cols > 0x7FFFFFFFll) return mrp_set_error(MRP_ERR_UNSUPPORTED, "level with %lld columns", (long long) total_cols);
-    L->total_cols = total_cols;
-    L->n_reads = total_reads;
-
     if (e->spare.empty()) {
         mrp_batch *nb = nullptr;
         int rc = mrp_batch_create(ctx, &nb);
@@ -327,166 +324,131 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     }
     mrp_batch *b = L->b;
     b->resident = true;
-    /* chunk table */
+    /* per hmm: where its columns, reads, allele slots and parents start; chunk table; range checks against the static bounds */
+    std::vector<int64_t> col0((size_t) n + 1), read0((size_t) n + 1), slot0((size_t) n + 1), par0((size_t) n + 1), cost((size_t) n);
     std::vector<int32_t> chunk_index((size_t) n);
+    int64_t total_cols = 0, total_reads = 0, total_slots = 0, total_par = 0;
+    bool all_planes = true, no_planes = fused;
     for (int64_t i = 0; i < n; i++) {
-        const mrp_chunk *ch = x[i].chunk;
+        const mrp_xhmm &h = x[i];
+        if (h.n_cols < 1 || !h.col_start || !h.col_read_off || !h.chunk || h.n_a < 0 || h.n_b < 0 || (h.n_a + h.n_b > 0 && !h.par) ||
+            h.ref_start < 0 || h.ref_end <= h.ref_start || h.ref_end > h.chunk->n_sites)
+            return mrp_set_error(MRP_ERR_ARG, "mrp_engine_level: bad hmm %lld", (long long) i);
+        const mrp_chunk *ch = h.chunk;
+        if (ch->ctx->device != ctx->device) return mrp_set_error(MRP_ERR_ARG, "chunk missing or on a different device");
         int idx = -1;
         if (!b->chunks.empty() && b->chunks.back() == ch) idx = (int) b->chunks.size() - 1;
         for (size_t c = 0; idx < 0 && c < b->chunks.size(); c++)
             if (b->chunks[c] == ch) idx = (int) c;
         if (idx < 0) { idx = (int) b->chunks.size(); b->chunks.push_back(ch); }
         chunk_index[(size_t) i] = idx;
-    }
-    tm[tmi++] = eng_now();
-    /* pass 1 (parallel): allele slots per hmm, static bounds, validity */
-    struct Bound { int64_t slots, cells, merge; int32_t max_cells, max_merge; int64_t cost; int bad; };
-    std::vector<Bound> bd((size_t) n);
-    mrp_pool_set_tag(7); mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
-        const mrp_xhmm &h = x[i];
-        const mrp_chunk *ch = h.chunk;
         const bool anc = (h.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
-        Bound q{0, 0, 0, 1, 1, 0, 0};
-        for (int k = 0; k < h.n_cols && !q.bad; k++) {
-            const mrp_xcol &c = h.cols[k];
-            const int32_t st = h.col_ref_start[k], ln = h.col_length[k], dp = h.col_depth[k];
-            if (ln < 1 || st < 0 || (int64_t) st + ln > ch->n_sites || dp < 0 || dp > MRP_MAX_READ_PARTITIONING_DEPTH ||
-                h.col_read_off[k + 1] - h.col_read_off[k] != dp || (int) c.d1 + (int) c.d2 != dp) { q.bad = 1; break; }
-            q.slots += ch->allele_offset[st + ln] - ch->allele_offset[st];
-            const int64_t C = side_bound(c.d1, S) * side_bound(c.d2, S);
-            q.cells += C;
-            q.max_cells = (int32_t) std::max<int64_t>(q.max_cells, C);
-            if (k + 1 < h.n_cols) {
-                const int64_t Ma = c.out_a == MRP_CONN_ZERO ? 1 : side_bound(c.d1, S), Mb = c.out_b == MRP_CONN_ZERO ? 1 : side_bound(c.d2, S);
-                q.merge += Ma * Mb;
-                q.max_merge = (int32_t) std::max<int64_t>(q.max_merge, Ma * Mb);
-            }
-            int64_t per_site = 255ll * dp;
-            if (anc) {
-                per_site += 2ll * ch->max_sub + ch->max_prior;
-                for (int s2 = 0; s2 < ln; s2++)
-                    if (ch->allele_number[st + s2] > MRP_MAX_ALLELES) q.bad = 2;
-            }
-            q.cost += per_site * ln;
-        }
-        bd[(size_t) i] = q;
-    });
-    for (int64_t i = 0; i < n; i++) {
-        const Bound &q = bd[(size_t) i];
-        if (q.bad == 1) return mrp_set_error(MRP_ERR_ARG, "device-resident hmm %lld: inconsistent column description", (long long) i);
-        if (q.bad == 2 || q.max_cells > MRP_PRUNE_MAX_CELLS || q.max_merge > MRP_PRUNE_MAX_CELLS || q.cells >= (1ll << 30) || q.cost >= (1ll << 30))
+        if (!anc) all_planes = false; /* (a column without the ancestor model needs bit planes only if its allele counts differ) */
+        int64_t cb = 255ll * h.depth_sites;
+        if (anc) cb += (2ll * ch->max_sub + ch->max_prior) * (int64_t) (h.ref_end - h.ref_start);
+        cost[(size_t) i] = cb;
+        if ((anc && ch->max_alleles > MRP_MAX_ALLELES) || h.bound_max_cells > MRP_PRUNE_MAX_CELLS || h.bound_max_merge > MRP_PRUNE_MAX_CELLS ||
+            h.bound_cells >= (1ll << 30) || cb >= (1ll << 30))
             return mrp_set_error(MRP_ERR_UNSUPPORTED, "device-resident hmm %lld is outside the kernels' range", (long long) i);
-        slot0[(size_t) i] = total_slots;
-        total_slots += q.slots;
+        col0[(size_t) i] = total_cols; read0[(size_t) i] = total_reads; slot0[(size_t) i] = total_slots; par0[(size_t) i] = total_par;
+        total_cols += h.n_cols;
+        total_reads += h.col_read_off[h.n_cols];
+        total_slots += ch->allele_offset[(size_t) h.ref_end] - ch->allele_offset[(size_t) h.ref_start];
+        total_par += h.n_a + h.n_b;
     }
+    col0[(size_t) n] = total_cols;
+    if (total_cols > 0x7FFFFFFFll) return mrp_set_error(MRP_ERR_UNSUPPORTED, "level with %lld columns", (long long) total_cols);
+    L->total_cols = total_cols;
+    L->n_reads = total_reads;
     L->n_slots = total_slots;
 
     tm[tmi++] = eng_now();
-    /* the level's output: the pruned hmms, fixed stride (the final level keeps one traced-back cell per column) */
+    /* the level's output: the pruned hmms, fixed stride (the final level keeps one traced-back cell per column), and the
+     * column structure the levels above will look up */
     L->seg.reset(new (std::nothrow) Segment());
     if (!L->seg) return mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
     Segment *seg = L->seg.get();
     DevPool *pl = &ctx->pool;
-    seg->part.pool = pl; seg->np.pool = pl; seg->n_cells.pool = seg->n_merge.pool = pl;
+    seg->part.pool = pl; seg->np.pool = pl; seg->n_cells.pool = seg->n_merge.pool = pl; seg->cols.pool = pl; seg->rbo.pool = pl;
     const int64_t out_stride = final_level ? 1 : S;
     ENG_TRY(seg->part.alloc((size_t) (total_cols * out_stride)));
     ENG_TRY(seg->np.alloc((size_t) (final_level ? 1 : total_cols * S)));
     ENG_TRY(seg->n_cells.alloc((size_t) total_cols));
     ENG_TRY(seg->n_merge.alloc((size_t) total_cols));
+    ENG_TRY(seg->cols.alloc((size_t) total_cols));
+    ENG_TRY(seg->rbo.alloc((size_t) total_reads));
+    const int seg_id = e->n_segs++;
+    L->seg_id = seg_id;
+    SegDev &sd = e->segtab[seg_id];
+    sd.part = seg->part.p; sd.np = seg->np.p; sd.n_cells = seg->n_cells.p; sd.n_merge = seg->n_merge.p; sd.cols = seg->cols.p; sd.rbo = seg->rbo.p;
 
     /* host staging: one page-locked block holding every array that is uploaded */
     auto al = [](size_t v) { return (v + 63) & ~(size_t) 63; };
-    const size_t o_plan = 0, o_phmm = o_plan + al(sizeof(PlanCol) * (size_t) total_cols), o_ph = o_phmm + al(sizeof(PlanHmm) * (size_t) n),
-                 o_colhmm = o_ph + al(sizeof(PruneHmm) * (size_t) n), o_rbo = o_colhmm + al(4 * (size_t) total_cols),
-                 o_pack = o_rbo + al(8 * (size_t) total_reads), o_plane = o_pack + al(4 * (size_t) total_cols),
-                 o_ow = o_plane + al(4 * (size_t) total_cols), o_om = o_ow + al(4 * (size_t) n), o_on = o_om + al(4 * (size_t) n),
-                 o_chunks = o_on + al(4 * (size_t) n), o_end = o_chunks + al(sizeof(DevChunk) * b->chunks.size());
+    const size_t o_xd = 0, o_par = o_xd + al(sizeof(XDesc) * (size_t) n), o_cstart = o_par + al(sizeof(mrp_xpar) * (size_t) total_par),
+                 o_croff = o_cstart + al(4 * ((size_t) total_cols + 1)), o_phmm = o_croff + al(4 * (size_t) total_cols),
+                 o_ph = o_phmm + al(sizeof(PlanHmm) * (size_t) n), o_ow = o_ph + al(sizeof(PruneHmm) * (size_t) n), o_om = o_ow + al(4 * (size_t) n),
+                 o_on = o_om + al(4 * (size_t) n), o_chunks = o_on + al(4 * (size_t) n), o_seg = o_chunks + al(sizeof(DevChunk) * b->chunks.size()),
+                 o_end = o_seg + al(sizeof(SegDev));
     ENG_TRY(L->stage.reserve(o_end));
     char *hb = (char *) L->stage.p;
-    PlanCol *plan = (PlanCol *) (hb + o_plan);
+    XDesc *xd = (XDesc *) (hb + o_xd);
+    mrp_xpar *par = (mrp_xpar *) (hb + o_par);
+    int32_t *cstart = (int32_t *) (hb + o_cstart), *croff = (int32_t *) (hb + o_croff);
     PlanHmm *phmm = (PlanHmm *) (hb + o_phmm);
     PruneHmm *ph = (PruneHmm *) (hb + o_ph);
-    int32_t *col_hmm = (int32_t *) (hb + o_colhmm);
-    int64_t *rbo = (int64_t *) (hb + o_rbo);
-    int32_t *pack_list = (int32_t *) (hb + o_pack), *plane_list = (int32_t *) (hb + o_plane);
     int32_t *ord_w = (int32_t *) (hb + o_ow), *ord_m = (int32_t *) (hb + o_om), *ord_n = (int32_t *) (hb + o_on);
     DevChunk *hchunks = (DevChunk *) (hb + o_chunks);
     for (size_t c = 0; c < b->chunks.size(); c++) hchunks[c] = b->chunks[c]->dev;
+    *(SegDev *) (hb + o_seg) = sd;
 
     tm[tmi++] = eng_now();
-    /* pass 2 (parallel): the plan */
-    std::vector<int32_t> n_planes_of((size_t) n, 0);
+    /* the prune kernel walks one hmm per workgroup, its columns one after the other: longest hmms first */
+    L->perm.resize((size_t) n);
+    std::vector<int32_t> pos((size_t) n);
+    {   /* stable counting sort by descending number of columns */
+        int32_t max_cols = 1;
+        for (int64_t i = 0; i < n; i++) max_cols = std::max(max_cols, x[i].n_cols);
+        std::vector<int64_t> at((size_t) max_cols + 2, 0);
+        for (int64_t i = 0; i < n; i++) at[(size_t) (max_cols - x[i].n_cols) + 1]++;
+        for (size_t q = 1; q < at.size(); q++) at[q] += at[q - 1];
+        for (int64_t i = 0; i < n; i++) L->perm[(size_t) at[(size_t) (max_cols - x[i].n_cols)]++] = (int32_t) i;
+        for (int64_t j = 0; j < n; j++) pos[(size_t) L->perm[(size_t) j]] = (int32_t) j;
+    }
+    /* per hmm records and the 8 bytes per column the host contributes (parallel) */
     mrp_pool_set_tag(8); mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
         mrp_xhmm &h = x[i];
-        int32_t planes_here = 0;
-        const mrp_chunk *ch = h.chunk;
         const int K = h.n_cols;
-        const bool anc = (h.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
         const int64_t colbase = col0[(size_t) i];
-        int64_t s_off = slot0[(size_t) i];
-        for (int k = 0; k < K; k++) {
-            const mrp_xcol &c = h.cols[k];
-            PlanCol &o = plan[colbase + k];
-            o.a_part = c.a_part; o.b_part = c.b_part; o.a_np = c.a_np; o.b_np = c.b_np;
-            o.a_ncells = c.a_ncells; o.b_ncells = c.b_ncells; o.a_nmerge = c.a_nmerge; o.b_nmerge = c.b_nmerge;
-            o.read_off = read0[(size_t) i] + h.col_read_off[k];
-            o.slot_off = s_off;
-            o.site_start = h.col_ref_start[k]; o.n_sites = h.col_length[k]; o.depth = h.col_depth[k];
-            o.n_slots = (int32_t) (ch->allele_offset[o.site_start + o.n_sites] - ch->allele_offset[o.site_start]);
-            s_off += o.n_slots;
-            o.chunk = chunk_index[(size_t) i];
-            /* one allele count for all the column's sites? (per-chunk run lengths, built with the chunk) */
-            const int32_t uniform = ch->same_until[(size_t) o.site_start] >= o.site_start + o.n_sites ? (int32_t) ch->allele_number[o.site_start] : 0;
-            o.uniform_alleles = uniform;
-            o.d1 = c.d1; o.d2 = c.d2; o.out_a = c.out_a; o.out_b = c.out_b;
-            o.out_a_paired = c.out_a_paired; o.out_b_paired = c.out_b_paired;
-            o.need_planes = (!fused && (uniform == 0 || anc)) ? 1 : 0; /* bit planes: the general emission kernel only */
-            planes_here += o.need_planes;
-            o.last = k + 1 == K ? 1 : 0;
-            o.pad = 0;
-        }
+        XDesc &d = xd[i];
+        d.col0 = colbase; d.read0 = read0[(size_t) i]; d.slot0 = slot0[(size_t) i]; d.par0 = par0[(size_t) i];
+        d.ref_start = h.ref_start; d.ref_end = h.ref_end; d.n_cols = K; d.n_a = h.n_a; d.n_b = h.n_b;
+        d.chunk = chunk_index[(size_t) i]; d.flags = h.flags; d.prune_pos = pos[(size_t) i];
+        if (h.n_a + h.n_b > 0) memcpy(par + par0[(size_t) i], h.par, sizeof(mrp_xpar) * (size_t) (h.n_a + h.n_b));
+        memcpy(cstart + colbase, h.col_start, sizeof(int32_t) * (size_t) K);
+        memcpy(croff + colbase, h.col_read_off, sizeof(int32_t) * (size_t) K);
         PlanHmm &p = phmm[i];
-        p.col0 = colbase; p.n_cols = K; p.flags = h.flags; p.cost_bound = bd[(size_t) i].cost;
-        if (h.col_read_off[K] > 0) memcpy(rbo + read0[(size_t) i], h.read_byte_off, sizeof(int64_t) * (size_t) h.col_read_off[K]);
-        PruneHmm &q = ph[i];
+        p.col0 = colbase; p.n_cols = K; p.flags = h.flags; p.cost_bound = cost[(size_t) i];
+        PruneHmm &q = ph[pos[(size_t) i]];
         q.col0 = colbase; q.n_cols = K; q.hmm_index = (int32_t) i;
         q.out_part = seg->part.p + colbase * out_stride;
         q.out_np = final_level ? seg->np.p : seg->np.p + colbase * S;
         q.out_n_cells = seg->n_cells.p + colbase;
         q.out_n_merge = seg->n_merge.p + colbase;
-        h.d_part = q.out_part; h.d_np = q.out_np; h.d_ncells = q.out_n_cells; h.d_nmerge = q.out_n_merge;
+        h.seg = seg_id; h.col0 = colbase;
         h.err = 0;
-        n_planes_of[(size_t) i] = planes_here;
     });
+    cstart[total_cols] = 0;
     tm[tmi++] = eng_now();
-    /* packing lists (columns of the fast emission path / those that need bit planes): positions by a prefix sum over the
-     * hmms, filled in parallel */
-    int64_t n_pack = 0, n_plane = 0;
-    {
-        std::vector<int64_t> plane0((size_t) n + 1), pack0((size_t) n + 1);
-        for (int64_t i = 0; i < n; i++) {
-            plane0[(size_t) i] = n_plane; pack0[(size_t) i] = n_pack;
-            n_plane += n_planes_of[(size_t) i];
-            n_pack += x[i].n_cols - n_planes_of[(size_t) i];
-        }
-        mrp_pool_set_tag(9); mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
-            int64_t a = plane0[(size_t) i], c2 = pack0[(size_t) i];
-            for (int64_t c = col0[(size_t) i]; c < col0[(size_t) i + 1]; c++) {
-                if (plan[c].need_planes) plane_list[a++] = (int32_t) c;
-                else pack_list[c2++] = (int32_t) c;
-            }
-        });
-    }
     /* launch classes of the recursion kernel, from the static bounds; largest first inside a class */
     b->order_wide.clear(); b->order_mid.clear(); b->order_narrow.clear(); b->order_f64.clear(); b->order_lse.clear(); b->order_lse_big.clear(); b->order_gen.clear();
     b->max_merge_wide = b->max_merge_mid = b->max_merge_narrow = 1;
     {
         std::vector<std::pair<int64_t, int32_t>> wide, mid, narrow;
         for (int64_t i = 0; i < n; i++) {
-            const Bound &q = bd[(size_t) i];
-            if (q.max_cells <= 256) narrow.push_back({-q.cells, (int32_t) i});
-            else if (q.max_merge <= 4096) mid.push_back({-q.cells, (int32_t) i});
-            else wide.push_back({-q.cells, (int32_t) i});
+            const mrp_xhmm &q = x[i];
+            if (q.bound_max_cells <= 256) narrow.push_back({-q.bound_cells, (int32_t) i});
+            else if (q.bound_max_merge <= 4096) mid.push_back({-q.bound_cells, (int32_t) i});
+            else wide.push_back({-q.bound_cells, (int32_t) i});
         }
         auto plan_class = [&](std::vector<std::pair<int64_t, int32_t>> &v, std::vector<int32_t> &order, int32_t *dst, int *mm) {
             std::sort(v.begin(), v.end());
@@ -494,7 +456,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
             for (size_t j = 0; j < v.size(); j++) {
                 order.push_back(v[j].second);
                 dst[j] = v[j].second;
-                m = std::max(m, bd[(size_t) v[j].second].max_merge);
+                m = std::max(m, std::max(1, x[v[j].second].bound_max_merge));
             }
             *mm = m;
         };
@@ -502,67 +464,64 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         plan_class(mid, b->order_mid, ord_m, &b->max_merge_mid);
         plan_class(narrow, b->order_narrow, ord_n, &b->max_merge_narrow);
     }
-    /* the prune kernel walks one hmm per workgroup, its columns one after the other: longest hmms first */
-    {
-        L->perm.resize((size_t) n);
-        std::vector<int32_t> pos((size_t) n);
-        {   /* stable counting sort by descending number of columns */
-            int32_t max_cols = 1;
-            for (int64_t i = 0; i < n; i++) max_cols = std::max(max_cols, x[i].n_cols);
-            std::vector<int64_t> at((size_t) max_cols + 2, 0);
-            for (int64_t i = 0; i < n; i++) at[(size_t) (max_cols - x[i].n_cols) + 1]++;
-            for (size_t q = 1; q < at.size(); q++) at[q] += at[q - 1];
-            for (int64_t i = 0; i < n; i++) L->perm[(size_t) at[(size_t) (max_cols - x[i].n_cols)]++] = (int32_t) i;
-        }
-        std::vector<PruneHmm> sorted((size_t) n);
-        for (int64_t j = 0; j < n; j++) { sorted[(size_t) j] = ph[L->perm[(size_t) j]]; pos[(size_t) L->perm[(size_t) j]] = (int32_t) j; }
-        memcpy(ph, sorted.data(), sizeof(PruneHmm) * (size_t) n);
-        mrp_pool_set_tag(10); mrp_parallel_for(n, std::max<int64_t>(1, n / 64), [&](int64_t i) {
-            for (int64_t c = col0[(size_t) i]; c < col0[(size_t) i + 1]; c++) col_hmm[c] = pos[(size_t) i];
-        });
-    }
     PruneParams &pp = L->pp;
     pp = e->pp;
     pp.max_cells = 1; pp.max_merge = 1;
     for (int64_t i = 0; i < n; i++) {
-        pp.max_cells = std::max(pp.max_cells, bd[(size_t) i].max_cells);
-        pp.max_merge = std::max(pp.max_merge, bd[(size_t) i].max_merge);
+        pp.max_cells = std::max(pp.max_cells, x[i].bound_max_cells);
+        pp.max_merge = std::max(pp.max_merge, x[i].bound_max_merge);
     }
     pp.pad = (e->params.reserved & 1) && e->stats.levels + (e->running ? 1 : 0) == 1 ? 1 : 0; /* test hook, see mrp_params.reserved */
 
     tm[tmi++] = eng_now();
-    /* device side of the description + the descriptor arrays the layout kernels fill */
+    /* device side of the description + the descriptor arrays the structure and layout kernels fill */
     b->bind_pool(pl);
-    L->d_plan.pool = pl; L->d_phmm.pool = pl; L->d_dims.pool = pl; L->d_tot.pool = pl; L->d_base.pool = pl; L->d_totals.pool = pl;
+    L->d_plan.pool = pl; L->d_xd.pool = pl; L->d_par.pool = pl; L->d_cstart.pool = L->d_croff.pool = pl;
+    L->d_phmm.pool = pl; L->d_dims.pool = pl; L->d_tot.pool = pl; L->d_base.pool = pl; L->d_totals.pool = pl;
     L->d_cc.pool = pl; L->d_ph.pool = pl; L->d_col_hmm.pool = L->d_nkept.pool = L->d_nkeptm.pool = L->d_err.pool = L->d_err_hmm.pool = pl;
     L->d_kept.pool = L->d_keptm.pool = pl; L->d_kept_np.pool = pl;
-    ENG_TRY(L->d_plan.alloc((size_t) total_cols)); ENG_TRY(L->d_phmm.alloc((size_t) n)); ENG_TRY(L->d_dims.alloc(4 * (size_t) total_cols));
+    ENG_TRY(L->d_plan.alloc((size_t) total_cols)); ENG_TRY(L->d_xd.alloc((size_t) n)); ENG_TRY(L->d_par.alloc((size_t) total_par));
+    ENG_TRY(L->d_cstart.alloc((size_t) total_cols + 1)); ENG_TRY(L->d_croff.alloc((size_t) total_cols));
+    ENG_TRY(L->d_phmm.alloc((size_t) n)); ENG_TRY(L->d_dims.alloc(4 * (size_t) total_cols));
     ENG_TRY(L->d_tot.alloc((size_t) n)); ENG_TRY(L->d_base.alloc((size_t) n)); ENG_TRY(L->d_totals.alloc(8));
     ENG_TRY(L->d_cc.alloc((size_t) total_cols)); ENG_TRY(L->d_ph.alloc((size_t) n)); ENG_TRY(L->d_col_hmm.alloc((size_t) total_cols));
     ENG_TRY(L->d_err.alloc(64)); ENG_TRY(L->d_err_hmm.alloc((size_t) n));
     ENG_TRY(b->d_hmms.alloc((size_t) n)); ENG_TRY(b->d_cols.alloc((size_t) total_cols)); ENG_TRY(b->d_scols.alloc((size_t) total_cols));
     ENG_TRY(b->d_pcols.alloc((size_t) total_cols)); ENG_TRY(b->d_tilecols.alloc((size_t) total_cols));
-    ENG_TRY(b->d_chunks.alloc(b->chunks.size())); ENG_TRY(b->d_read_byte_off.alloc((size_t) total_reads));
-    ENG_TRY(b->d_pack_list.alloc((size_t) n_pack)); ENG_TRY(b->d_plane_list.alloc((size_t) n_plane));
+    ENG_TRY(b->d_chunks.alloc(b->chunks.size()));
     ENG_TRY(b->d_order_wide.alloc(b->order_wide.size())); ENG_TRY(b->d_order_mid.alloc(b->order_mid.size()));
     ENG_TRY(b->d_order_narrow.alloc(b->order_narrow.size())); ENG_TRY(b->d_order_f64.alloc(1));
     auto up = [&](void *dst, const void *src, size_t bytes) -> hipError_t {
         return bytes ? hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, cs) : hipSuccess;
     };
-    ENG_TRY(up(L->d_plan.p, plan, sizeof(PlanCol) * (size_t) total_cols));
+    ENG_TRY(up(L->d_xd.p, xd, sizeof(XDesc) * (size_t) n));
+    ENG_TRY(up(L->d_par.p, par, sizeof(mrp_xpar) * (size_t) total_par));
+    ENG_TRY(up(L->d_cstart.p, cstart, 4 * ((size_t) total_cols + 1)));
+    ENG_TRY(up(L->d_croff.p, croff, 4 * (size_t) total_cols));
     ENG_TRY(up(L->d_phmm.p, phmm, sizeof(PlanHmm) * (size_t) n));
     ENG_TRY(up(L->d_ph.p, ph, sizeof(PruneHmm) * (size_t) n));
-    ENG_TRY(up(L->d_col_hmm.p, col_hmm, 4 * (size_t) total_cols));
-    ENG_TRY(up(b->d_read_byte_off.p, rbo, 8 * (size_t) total_reads));
-    ENG_TRY(up(b->d_pack_list.p, pack_list, 4 * (size_t) n_pack));
-    ENG_TRY(up(b->d_plane_list.p, plane_list, 4 * (size_t) n_plane));
     ENG_TRY(up(b->d_order_wide.p, ord_w, 4 * b->order_wide.size()));
     ENG_TRY(up(b->d_order_mid.p, ord_m, 4 * b->order_mid.size()));
     ENG_TRY(up(b->d_order_narrow.p, ord_n, 4 * b->order_narrow.size()));
     ENG_TRY(up(b->d_chunks.p, hchunks, sizeof(DevChunk) * b->chunks.size()));
+    ENG_TRY(up(e->d_segs.p + seg_id, hb + o_seg, sizeof(SegDev)));
     ENG_TRY(hipMemsetAsync(L->d_err.p, 0, 256, cs));
     ENG_TRY(hipMemsetAsync(L->d_err_hmm.p, 0, sizeof(int32_t) * (size_t) n, cs));
+    {   /* the columns of the level, one thread each: parents, connectors, reads, allele slots (also on the copy stream: the
+         * tables it reads were written by the structure kernels of the levels below, on the same stream) */
+        StructureIn si{};
+        si.xd = L->d_xd.p; si.n_hmms = n; si.n_cols = total_cols; si.par = L->d_par.p; si.col_start = L->d_cstart.p; si.col_roff = L->d_croff.p;
+        si.segs = e->d_segs.p; si.chunks = b->d_chunks.p;
+        si.leaf_part = e->leaf_part.p; si.leaf_np = e->leaf_np.p; si.leaf_count = e->leaf_count.p;
+        si.stride = S; si.fused = fused ? 1 : 0;
+        si.plan = L->d_plan.p; si.cols = seg->cols.p; si.rbo = seg->rbo.p; si.col_hmm = L->d_col_hmm.p;
+        si.err = L->d_err.p; si.err_hmm = L->d_err_hmm.p;
+        ENG_TRY(mrp_launch_structure(si, cs));
+    }
     ENG_TRY(hipEventRecord(L->uploaded, cs));
+    /* which of the two packing kernels has columns to look at (they filter by PlaneCol.need_planes) */
+    L->any_pack = !all_planes;
+    L->any_planes = !no_planes;
     /* results come back into a second page-locked block */
     {
         const size_t cols8 = ((size_t) total_cols + 1) & ~(size_t) 1, n8 = ((size_t) n + 1) & ~(size_t) 1;
@@ -579,8 +538,8 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     b->stats.n_columns = total_cols;
     L->t_staged = eng_now();
     if (getenv("MRP_TIMING"))
-        fprintf(stderr, "      stage: sizes+chunks %.2f ms, bounds %.2f, segment+staging %.2f, plan %.2f, lists+classes+order %.2f, allocs+uploads %.2f\n", tm[1] - tm[0],
-                tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], tm[5] - tm[4], L->t_staged - tm[5]);
+        fprintf(stderr, "      stage: offsets+chunks %.2f ms, segment+staging %.2f, records %.2f, classes %.2f, allocs+uploads %.2f\n", tm[1] - tm[0],
+                tm[2] - tm[1], tm[3] - tm[2], tm[4] - tm[3], L->t_staged - tm[4]);
     e->staged = L.release();
     return MRP_OK;
 }
@@ -685,10 +644,10 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
     ENG_TRY(b->d_total.alloc((size_t) total_cols)); ENG_TRY(b->d_hmm_fb.alloc(2 * (size_t) n));
     MrpBatchDev &d = b->dev;
     d = MrpBatchDev{};
-    d.hmms = b->d_hmms.p; d.cols = b->d_cols.p; d.chunks = b->d_chunks.p; d.read_byte_off = b->d_read_byte_off.p;
+    d.hmms = b->d_hmms.p; d.cols = b->d_cols.p; d.chunks = b->d_chunks.p; d.read_byte_off = L->seg->rbo.p;
     d.partition = b->d_partition.p; d.scols = b->d_scols.p; d.pcols = b->d_pcols.p;
-    d.pack_list = b->d_pack_list.p; d.plane_list = b->d_plane_list.p;
-    d.n_pack_list = (int64_t) b->d_pack_list.n; d.n_plane_list = (int64_t) b->d_plane_list.n;
+    d.pack_list = nullptr; d.plane_list = nullptr; d.list_filter = 1; /* every column, filtered by PlaneCol.need_planes */
+    d.n_pack_list = L->any_pack ? total_cols : 0; d.n_plane_list = L->any_planes ? total_cols : 0;
     d.cell_np = b->d_np.p; d.planes = b->d_planes.p; d.slot_total = b->d_slot_total.p; d.slot_bytes = b->d_slot_bytes.p;
     d.cell_cost = b->d_cost.p; d.cell_f32 = b->d_f32.p; d.cell_b32 = b->d_b32.p; d.merge_f32 = b->d_mf32.p; d.merge_b32 = b->d_mb32.p;
     d.col_total = b->d_total.p; d.hmm_fb = b->d_hmm_fb.p;

@@ -88,6 +88,54 @@ struct LayoutOut {       /* everything the layout kernels write */
     TileCol *tilecols;
     CrossCol *ccols;
 };
+/* ---- column structure of a level, on the device -----------------------------------------------------------------
+ * The columns of a cross product (stRPHmm_fuse + stRPHmm_alignColumns + stRPHmm_createCrossProductOfTwoAlignedHmm,
+ * hmm.c:283-750) depend on read intervals only.  The host decides WHICH hmms are merged (tiling paths, overlap
+ * components: a few hundred intervals per chunk) and merges their column boundaries (4 bytes per column); everything
+ * else a column needs -- which parent column each side is cut from, connector kinds, the column's reads and where their
+ * profile bytes start, allele slots, the PlanCol the layout kernels read -- is derived here, one thread per column,
+ * from the parents' own column tables, which stay in HBM from the level that built them (ResCol). */
+struct ResCol {          /* one column of an hmm that lives in a segment (persistent: its children look it up) */
+    int64_t rbo_off;     /* first entry of the column in the segment's read_byte_off array */
+    int32_t start;       /* first site */
+    uint8_t depth;
+    uint8_t cont;        /* some read of the column goes on into the next column (maskFrom != 0, mergeColumn.c) */
+    uint16_t pad;
+};
+struct SegDev {          /* the arrays of one level's segment */
+    const uint64_t *part;
+    const uint32_t *np;
+    const int32_t *n_cells, *n_merge;
+    const ResCol *cols;
+    const int64_t *rbo;
+};
+struct XDesc {           /* one cross product hmm of the level being described */
+    int64_t col0;        /* first column in the level */
+    int64_t read0;       /* first entry in the level's read_byte_off */
+    int64_t slot0;       /* first allele slot */
+    int64_t par0;        /* first mrp_xpar of tiling path A; path B follows */
+    int32_t ref_start, ref_end;
+    int32_t n_cols, n_a, n_b;
+    int32_t chunk;       /* index into the level's DevChunk table */
+    uint32_t flags;      /* MRP_FLAG_* of the sweep */
+    int32_t prune_pos;   /* position of the hmm in the level's PruneHmm array (-> col_hmm) */
+};
+struct StructureIn {
+    const XDesc *xd; int64_t n_hmms, n_cols;
+    const mrp_xpar *par;
+    const int32_t *col_start;  /* [n_cols] */
+    const int32_t *col_roff;   /* [n_cols] offset of the column's reads within its hmm */
+    const SegDev *segs;
+    const DevChunk *chunks;
+    const uint64_t *leaf_part; const uint32_t *leaf_np; const int32_t *leaf_count; /* the column of a stRPHmm_construct hmm */
+    int32_t stride;            /* cells per column of the resident layout */
+    int32_t fused;             /* cross product and emission in one pass: no column needs bit planes */
+    /* outputs */
+    PlanCol *plan; ResCol *cols; int64_t *rbo; int32_t *col_hmm;
+    int32_t *err, *err_hmm;    /* MRP_ENGINE_ERR_RANGE: a column that no parent column covers consistently */
+};
+hipError_t mrp_launch_structure(const StructureIn &in, hipStream_t stream);
+
 /* plan_dev / hmms_dev: PlanCol [n_cols], PlanHmm [n_hmms]; chunks_dev: the batch's DevChunk table; S: cells a pruned column
  * can have at most (parents' counts are clamped to it, so that a discarded parent cannot blow the level up) */
 hipError_t mrp_launch_layout(const PlanCol *plan_dev, const PlanHmm *hmms_dev, int64_t n_hmms, int64_t n_cols, const DevChunk *chunks_dev,

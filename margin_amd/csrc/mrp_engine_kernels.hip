@@ -528,6 +528,126 @@ hipError_t mrp_launch_cross_emit(const CrossCol *cols_dev, const MrpBatchDev &d,
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* column structure of a level (mrp_engine.h "column structure of a level, on the device")      */
+/* ------------------------------------------------------------------------------------------ */
+/* what one side (tiling path) contributes to the child column [cs, ce): the piece of pieces_of_path / align_pieces of the
+ * reference's stRPHmm_fuse (hmm.c:283-372) and stRPHmm_alignColumns (hmm.c:374-507) that holds cs */
+struct SidePiece {
+    const uint64_t *part; const uint32_t *np; const int32_t *ncells, *nmerge;
+    const int64_t *rbo;      /* the parent column's read_byte_off entries */
+    int64_t leaf_rbo;        /* leaf: the read's pool offset */
+    int32_t delta_site;      /* first site of the parent column (rbo moves on by the alleles between it and cs) */
+    uint8_t depth, out, paired, cont;
+    bool leaf;
+};
+static __device__ SidePiece structure_side(const StructureIn &in, const mrp_xpar *path, int n_path, int32_t ref_end, int32_t cs, int32_t ce,
+                                           int *bad) {
+    SidePiece r;
+    r.part = nullptr; r.np = nullptr; r.ncells = nullptr; r.nmerge = nullptr; r.rbo = nullptr; r.leaf_rbo = 0; r.delta_site = cs;
+    r.depth = 0; r.out = MRP_CONN_ZERO; r.paired = 0; r.cont = 0; r.leaf = false;
+    /* last hmm of the path that starts at or before cs */
+    int lo = 0, hi = n_path;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (path[mid].start <= cs) lo = mid + 1; else hi = mid; }
+    const int pi = lo - 1;
+    if (pi < 0 || cs >= path[pi].end) { /* gap column (hmm.c:335-359, :396-462): one cell, partition 0, depth 0 */
+        const int32_t gap_end = lo < n_path ? path[lo].start : ref_end;
+        if (ce > gap_end) *bad = 1;
+        r.out = ce < gap_end ? MRP_CONN_IDENT : MRP_CONN_ZERO; /* a gap cut in two: the accept-mask connector of a depth-0 column */
+        return r;
+    }
+    const mrp_xpar p = path[pi];
+    if (p.seg < 0) { /* stRPHmm_construct (hmm.c:97-133): one column {1, 0} over the read's sites */
+        if (ce > p.end) *bad = 1;
+        r.part = in.leaf_part; r.np = in.leaf_np; r.ncells = in.leaf_count;
+        r.leaf = true; r.leaf_rbo = p.col0; r.delta_site = p.start; r.depth = 1;
+        r.out = ce < p.end ? MRP_CONN_IDENT : MRP_CONN_ZERO;
+        r.paired = r.out == MRP_CONN_IDENT ? 1 : 0;
+        r.cont = r.paired;
+        return r;
+    }
+    const SegDev sg = in.segs[p.seg];
+    const ResCol *pc = sg.cols + p.col0;
+    int a = 0, b = p.n_cols; /* last column of the parent that starts at or before cs */
+    while (a < b) { const int mid = (a + b) >> 1; if (pc[mid].start <= cs) a = mid + 1; else b = mid; }
+    const int k = a - 1;
+    if (k < 0) { *bad = 1; return r; }
+    const ResCol c = pc[k];
+    const int32_t pe = k + 1 < p.n_cols ? pc[k + 1].start : p.end;
+    if (ce > pe) *bad = 1;
+    const int64_t col = p.col0 + k;
+    r.part = sg.part + col * in.stride; r.np = sg.np + col * in.stride; r.ncells = sg.n_cells + col;
+    r.rbo = sg.rbo + c.rbo_off; r.delta_site = c.start; r.depth = c.depth;
+    if (ce < pe) { r.out = MRP_CONN_IDENT; r.paired = c.depth > 0 ? 1 : 0; }          /* column.c:86-101 */
+    else if (k + 1 < p.n_cols) { r.out = MRP_CONN_REAL; r.paired = c.cont; r.nmerge = sg.n_merge + col; }
+    else { r.out = MRP_CONN_ZERO; r.paired = 0; }                                       /* hmm.c:324-331 */
+    r.cont = r.paired;
+    return r;
+}
+
+__global__ void __launch_bounds__(256) mrp_structure_kernel(StructureIn in) {
+    const int64_t col = (int64_t) blockIdx.x * blockDim.x + threadIdx.x;
+    if (col >= in.n_cols) return;
+    /* the hmm the column belongs to: last one whose first column is at or before col */
+    int64_t lo = 0, hi = in.n_hmms;
+    while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (in.xd[mid].col0 <= col) lo = mid + 1; else hi = mid; }
+    const XDesc x = in.xd[lo - 1];
+    const int k = (int) (col - x.col0);
+    const bool last = k + 1 == x.n_cols;
+    const int32_t cs = in.col_start[col], ce = last ? x.ref_end : in.col_start[col + 1];
+    int bad = (ce <= cs || cs < x.ref_start || ce > x.ref_end) ? 1 : 0;
+    const mrp_xpar *pa = in.par + x.par0, *pb = pa + x.n_a;
+    const SidePiece A = structure_side(in, pa, x.n_a, x.ref_end, cs, ce, &bad);
+    const SidePiece B = structure_side(in, pb, x.n_b, x.ref_end, cs, ce, &bad);
+    const DevChunk ch = in.chunks[x.chunk];
+    const int depth = (int) A.depth + (int) B.depth;
+    if (depth > MRP_MAX_READ_PARTITIONING_DEPTH) bad = 1;
+    const int64_t read_off = x.read0 + in.col_roff[col];
+    if (!bad) { /* the column's reads: side A's then side B's (partitions.c:21-28); profileSeq.c:41-47 */
+        int64_t *dst = in.rbo + read_off;
+        const uint32_t a_cs = ch.allele_offset[cs];
+        if (A.depth) {
+            const int64_t delta = (int64_t) a_cs - (int64_t) ch.allele_offset[A.delta_site];
+            if (A.leaf) dst[0] = A.leaf_rbo + delta;
+            else for (int i = 0; i < A.depth; i++) dst[i] = A.rbo[i] + delta;
+        }
+        if (B.depth) {
+            const int64_t delta = (int64_t) a_cs - (int64_t) ch.allele_offset[B.delta_site];
+            if (B.leaf) dst[A.depth] = B.leaf_rbo + delta;
+            else for (int i = 0; i < B.depth; i++) dst[A.depth + i] = B.rbo[i] + delta;
+        }
+    }
+    PlanCol o;
+    o.a_part = A.part; o.b_part = B.part; o.a_np = A.np; o.b_np = B.np;
+    o.a_ncells = A.ncells; o.b_ncells = B.ncells; o.a_nmerge = A.nmerge; o.b_nmerge = B.nmerge;
+    o.read_off = read_off;
+    o.slot_off = x.slot0 + (int64_t) (ch.allele_offset[cs] - ch.allele_offset[x.ref_start]);
+    o.site_start = cs; o.n_sites = ce - cs; o.depth = bad ? 0 : depth;
+    o.n_slots = (int32_t) (ch.allele_offset[ce] - ch.allele_offset[cs]);
+    o.chunk = x.chunk;
+    const int32_t uniform = ch.same_until[cs] >= ce ? (int32_t) ch.allele_number[cs] : 0;
+    o.uniform_alleles = uniform;
+    o.d1 = bad ? 0 : A.depth; o.d2 = bad ? 0 : B.depth; o.out_a = A.out; o.out_b = B.out;
+    o.out_a_paired = A.paired; o.out_b_paired = B.paired;
+    o.need_planes = (!in.fused && (uniform == 0 || (x.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB))) ? 1 : 0;
+    o.last = last ? 1 : 0;
+    o.pad = 0;
+    if (bad) { o.a_part = nullptr; o.b_part = nullptr; o.a_np = nullptr; o.b_np = nullptr; o.a_ncells = nullptr; o.b_ncells = nullptr;
+               o.a_nmerge = nullptr; o.b_nmerge = nullptr; o.out_a = o.out_b = MRP_CONN_ZERO; o.out_a_paired = o.out_b_paired = 0; }
+    in.plan[col] = o;
+    ResCol rc;
+    rc.rbo_off = read_off; rc.start = cs; rc.depth = (uint8_t) o.depth; rc.cont = last ? 0 : (uint8_t) ((A.cont | B.cont) && !bad); rc.pad = 0;
+    in.cols[col] = rc;
+    in.col_hmm[col] = x.prune_pos;
+    if (bad) { atomicOr(in.err, MRP_ENGINE_ERR_RANGE); atomicOr(in.err_hmm + x.prune_pos, MRP_ENGINE_ERR_RANGE); }
+}
+
+hipError_t mrp_launch_structure(const StructureIn &in, hipStream_t stream) {
+    if (in.n_cols <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mrp_structure_kernel, dim3((unsigned) ((in.n_cols + 255) / 256)), dim3(256), 0, stream, in);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* layout of a level: sizes, offsets and kernel descriptors from the parents' counts           */
 /* ------------------------------------------------------------------------------------------ */
 static __device__ __forceinline__ int32_t layout_count(const int32_t *p, int32_t S) {

@@ -18,6 +18,10 @@ struct MrpBatchDev {
     const int32_t *pack_list;  /* columns of the uniform-allele fast path: packed bytes only (mrp_pack_kernel) */
     const int32_t *plane_list; /* columns that also need the bit planes (general emission path) */
     int64_t n_pack_list, n_plane_list;
+    int32_t list_filter;       /* 1 (levels described on the device, no lists): both kernels scan every column, the pack kernel
+                                * takes those without need_planes, the bit-plane kernel those with it; n_pack_list / n_plane_list
+                                * are then 0 ("no such column") or the number of columns */
+    int32_t pad_filter;
     const uint64_t *partition;
     const uint32_t *cell_np;   /* next | prev << 16 */
     const uint32_t *cell_next; /* only when some hmm has > 65535 merge cells in a column */

@@ -75,7 +75,7 @@ __global__ void __launch_bounds__(256) mrp_planes_kernel(const PlaneCol *__restr
                                                          const int64_t *__restrict__ read_byte_off,
                                                          uint64_t *__restrict__ planes,
                                                          uint32_t *__restrict__ slot_total,
-                                                         uint32_t *__restrict__ slot_bytes) {
+                                                         uint32_t *__restrict__ slot_bytes, int filter) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / WAVE));
     /* Persistent waves striding over the columns.  Per column there are three dependent memory levels
@@ -96,7 +96,8 @@ __global__ void __launch_bounds__(256) mrp_planes_kernel(const PlaneCol *__restr
     const bool active = lane < c.depth;
     const uint8_t *__restrict__ src = c.pool + my_off;
 #define PLANE_U 8
-    for (int s0 = 0; s0 < c.n_slots; s0 += PLANE_U) {
+    const int n_slots_here = (filter && !c.need_planes) ? 0 : c.n_slots; /* filter: the pack kernel handles the other columns */
+    for (int s0 = 0; s0 < n_slots_here; s0 += PLANE_U) {
         uint32_t bytes[PLANE_U];
 #pragma unroll
         for (int u = 0; u < PLANE_U; u++) bytes[u] = (active && s0 + u < c.n_slots) ? src[s0 + u] : 0u;
@@ -140,11 +141,12 @@ __global__ void __launch_bounds__(256) mrp_planes_kernel(const PlaneCol *__restr
  * (4 reads); every load of a lane is independent of the other lanes, nothing is exchanged but the 16-lane sum. */
 __global__ void __launch_bounds__(256) mrp_pack_kernel(const PlaneCol *__restrict__ pcols, const int32_t *__restrict__ list,
                                                        int64_t n_list, const int64_t *__restrict__ read_byte_off,
-                                                       uint32_t *__restrict__ slot_total, uint32_t *__restrict__ slot_bytes) {
+                                                       uint32_t *__restrict__ slot_total, uint32_t *__restrict__ slot_bytes, int filter) {
     const int64_t q = ((int64_t) blockIdx.x * blockDim.x + threadIdx.x) >> 4;
     const int w = threadIdx.x & 15;
     if (q >= n_list) return;
     const PlaneCol c = pcols[list ? list[q] : q];
+    if (filter && c.need_planes) return; /* (all 16 lanes of a column leave together) */
     int64_t off[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
@@ -169,19 +171,19 @@ __global__ void __launch_bounds__(256) mrp_pack_kernel(const PlaneCol *__restric
 hipError_t mrp_launch_planes(const MrpBatchDev &d, hipStream_t stream) {
     if (d.n_cols == 0) return hipSuccess;
     const int waves = 4;
-    const bool split = d.pack_list != nullptr || d.plane_list != nullptr;
+    const bool split = d.pack_list != nullptr || d.plane_list != nullptr || d.list_filter != 0;
     const int64_t n_planes = split ? d.n_plane_list : d.n_cols;
     if (n_planes > 0) {
         int64_t grid = (n_planes + waves - 1) / waves;
         if (grid > MRP_PERSISTENT_GRID) grid = MRP_PERSISTENT_GRID;
         hipLaunchKernelGGL(mrp_planes_kernel, dim3((unsigned) grid), dim3(waves * WAVE), 0, stream, d.pcols,
                            split ? d.plane_list : (const int32_t *) nullptr, n_planes, d.read_byte_off, d.planes, d.slot_total,
-                           d.slot_bytes);
+                           d.slot_bytes, d.list_filter);
     }
     if (split && d.n_pack_list > 0) {
         const int64_t grid = (d.n_pack_list * 16 + 255) / 256;
         hipLaunchKernelGGL(mrp_pack_kernel, dim3((unsigned) grid), dim3(256), 0, stream, d.pcols, d.pack_list, d.n_pack_list,
-                           d.read_byte_off, d.slot_total, d.slot_bytes);
+                           d.read_byte_off, d.slot_total, d.slot_bytes, d.list_filter);
     }
     return hipGetLastError();
 }

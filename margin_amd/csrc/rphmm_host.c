@@ -222,21 +222,6 @@ struct mrp_hmm {
     double *f, *b, *mf, *mb, *total;
     double fwd, bwd;
     int has_results;
-    /* device-resident form (mrp_engine.cpp): no host cell arrays; column k's cells are at
-     * d_part + k * stride, its counts at d_ncells[k] / d_nmerge[k] (merge column after column k): they are not known to
-     * the host while the merge levels run, only their addresses are */
-    int resident, leaf; /* leaf: the single column {1, 0} of stRPHmm_construct, shared by all such hmms */
-    int32_t stride;
-    const uint64_t *d_part;
-    const uint32_t *d_np;
-    const int32_t *d_ncells, *d_nmerge; /* device: cells per column, merge cells of the merge column after it */
-    VEC(int32_t) rc_cells, rc_merge;   /* host copies, fetched only when the hmm is downloaded */
-    /* shadows are one allocation: the struct followed by its exactly sized arrays (and the cross product
-     * descriptors of the level that builds it); arrays outside [this, this + arena_bytes) are malloc'd */
-    size_t arena_bytes;
-    mrp_xcol *xcols;
-    int in_block; /* the struct lives inside a block owned by someone else (the leaves of a run) */
-    int pool_class; /* shadows: size class of the block in the shadow pool (-1: plain malloc), +1; 0 = not from the pool */
 };
 
 static int64_t hmm_K(const mrp_hmm *h) { return h->col_start.n; }
@@ -253,19 +238,15 @@ static void hmm_free_results(mrp_hmm *h) {
     h->f = h->b = h->mf = h->mb = h->total = NULL;
     h->has_results = 0;
 }
-static void hmm_free_array(const mrp_hmm *h, void *p) {
-    if (p && !((const char *) p >= (const char *) h && (const char *) p < (const char *) h + h->arena_bytes)) free(p);
-}
+static void hmm_free_array(const mrp_hmm *h, void *p) { (void) h; free(p); }
 void mrp_hmm_destroy(mrp_hmm *h) {
     if (!h) return;
     void *arrays[] = {h->reads.a, h->col_start.a, h->col_len.a, h->col_depth.a, h->cell_off.a, h->read_off.a, h->col_reads.a,
                       h->read_byte_off.a, h->part.a, h->next.a, h->prev.a, h->mask_from.a, h->mask_to.a, h->mcell_off.a,
-                      h->mfrom.a, h->mto.a, h->rc_cells.a, h->rc_merge.a};
+                      h->mfrom.a, h->mto.a};
     for (size_t i = 0; i < sizeof(arrays) / sizeof(arrays[0]); i++) hmm_free_array(h, arrays[i]);
     hmm_free_results(h);
-    if (h->in_block) return;
-    if (h->pool_class != 0) shadow_release(h, h->pool_class - 1);
-    else free(h);
+    free(h);
 }
 
 /* per-job view of the reads + chunk the structural code works against */
@@ -327,62 +308,13 @@ static mrp_hmm *hmm_from_read(const world *w, int32_t read) {
     return h;
 }
 
-/* stRPHmm_cmpFn hmm.c:67-95 (single reference per chunk; pointer tie-break -> creation order) */
-static int hmm_cmp(const world *w, const mrp_hmm *a, const mrp_hmm *b) {
-    if (a->ref_start != b->ref_start) return a->ref_start > b->ref_start ? 1 : -1;
-    if (a->ref_length != b->ref_length) return b->ref_length > a->ref_length ? 1 : -1;
-    if (a->reads.n > 0 && b->reads.n > 0) {
-        int i = strcmp(w->reads[a->reads.a[0]].name, w->reads[b->reads.a[0]].name);
-        if (i != 0) return i;
-    }
-    return a > b ? 1 : (a < b ? -1 : 0);
-}
-static int hmm_overlap(const mrp_hmm *a, const mrp_hmm *b) { /* hmm.c:1165-1190 */
-    if (a->ref_start > b->ref_start) return hmm_overlap(b, a);
-    return a->ref_start + a->ref_length > b->ref_start;
-}
-
-typedef VEC(mrp_hmm *) hmm_vec;
-
-static const world *g_sort_world; /* qsort context; the pipeline is single-threaded per call */
-static __thread const world *t_sort_world;
-static int hmm_cmp_qsort(const void *a, const void *b) {
-    (void) g_sort_world;
-    return hmm_cmp(t_sort_world, *(mrp_hmm *const *) a, *(mrp_hmm *const *) b);
-}
-static void sort_hmms(const world *w, mrp_hmm **a, int64_t n) {
-    t_sort_world = w;
-    qsort(a, (size_t) n, sizeof(*a), hmm_cmp_qsort);
-}
-
-/* getTilingPaths coordination.c:186-222 (+ :19-55): consumes the array */
-typedef VEC(hmm_vec *) path_vec;
-static path_vec tiling_paths_from(const world *w, mrp_hmm **hmms, int64_t n) {
-    sort_hmms(w, hmms, n);
-    uint8_t *used = xcalloc((size_t) n, 1);
-    path_vec paths = {0};
-    int64_t remaining = n, first = 0;
-    while (remaining > 0) {
-        hmm_vec *tp = xcalloc(1, sizeof(*tp));
-        VEC_PUSH(paths, tp);
-        while (used[first]) first++;
-        int64_t cur = first;
-        VEC_PUSH(*tp, hmms[cur]); used[cur] = 1; remaining--;
-        while (1) {
-            const mrp_hmm *h1 = hmms[cur];
-            int64_t nxt = -1;
-            for (int64_t j = cur + 1; j < n; j++) {
-                if (used[j]) continue;
-                if (h1->ref_start + h1->ref_length <= hmms[j]->ref_start) { nxt = j; break; }
-            }
-            if (nxt < 0) break;
-            VEC_PUSH(*tp, hmms[nxt]); used[nxt] = 1; remaining--;
-            cur = nxt;
-        }
-    }
-    free(used);
-    return paths;
-}
+#define HMM_T mrp_hmm
+#define PFX(x) x
+#define H_NAME_READ(h) ((h)->reads.n > 0 ? (h)->reads.a[0] : -1)
+#include "rphmm_paths.inc"
+#undef HMM_T
+#undef PFX
+#undef H_NAME_READ
 
 /* ------------------------------------------------------------------------------------------ */
 /* fuse + align + cross product in one pass                                                    */
@@ -833,56 +765,6 @@ int mrp_hmm_prune(mrp_hmm *h, const mrp_params *P) {
 /* ------------------------------------------------------------------------------------------ */
 /* coordination.c                                                                              */
 /* ------------------------------------------------------------------------------------------ */
-typedef struct { hmm_vec members; } component;
-typedef VEC(component *) comp_vec;
-
-/* getOverlappingComponents coordination.c:69-184; components in creation order */
-static comp_vec overlapping_components(const world *w, const hmm_vec *tp1, const hmm_vec *tp2) {
-    comp_vec comps = {0};
-    /* component index per hmm of tp1 / tp2 */
-    int64_t *c1 = xmalloc(sizeof(int64_t) * (size_t) (tp1->n + 1)), *c2 = xmalloc(sizeof(int64_t) * (size_t) (tp2->n + 1));
-    for (int64_t i = 0; i < tp1->n; i++) c1[i] = -1;
-    for (int64_t i = 0; i < tp2->n; i++) c2[i] = -1;
-#define NEW_COMP(hmm, slot) do { component *c_ = xcalloc(1, sizeof(component)); VEC_PUSH(c_->members, (hmm)); \
-                                 (slot) = comps.n; VEC_PUSH(comps, c_); } while (0)
-    int64_t j = 0;
-    for (int64_t i = 0; i < tp1->n; i++) {
-        mrp_hmm *h1 = tp1->a[i];
-        int64_t comp = -1, k = 0;
-        while (j + k < tp2->n) {
-            mrp_hmm *h2 = tp2->a[j + k];
-            if (hmm_overlap(h1, h2)) {
-                k++;
-                if (comp < 0) {
-                    comp = c2[j + k - 1];
-                    if (comp < 0) { NEW_COMP(h2, c2[j + k - 1]); comp = c2[j + k - 1]; }
-                    VEC_PUSH(comps.a[comp]->members, h1);
-                    c1[i] = comp;
-                } else {
-                    VEC_PUSH(comps.a[comp]->members, h2);
-                    c2[j + k - 1] = comp;
-                }
-            } else {
-                if (hmm_cmp(w, h1, h2) < 0) {
-                    if (comp < 0) { NEW_COMP(h1, c1[i]); comp = c1[i]; }
-                    break;
-                } else {
-                    if (c2[j + k] < 0) NEW_COMP(h2, c2[j + k]);
-                    j++;
-                }
-            }
-        }
-        if (comp < 0) NEW_COMP(h1, c1[i]);
-    }
-    while (j < tp2->n) {
-        if (c2[j] < 0) NEW_COMP(tp2->a[j], c2[j]);
-        j++;
-    }
-#undef NEW_COMP
-    free(c1); free(c2);
-    return comps;
-}
-
 /* mergeTwoTilingPaths coordination.c:263-339.  All cross products of the call are swept in one
  * device batch (the components are independent), then pruned. */
 static int merge_two_tiling_paths(world *w, hmm_vec *tp1, hmm_vec *tp2, const mrp_params *params, hmm_vec **out) {
@@ -1129,7 +1011,7 @@ static int hmm_reads_known(const mrp_hmm *h, int64_t n_reads) {
 }
 int mrp_hmm_split(const mrp_chunk *chunk, const mrp_read *reads, int64_t n_reads, mrp_hmm *hmm, int32_t split_point,
                   mrp_hmm **suffix_out) {
-    if (!hmm || !suffix_out || hmm->resident) return mrp_set_error(MRP_ERR_ARG, "mrp_hmm_split: bad arguments");
+    if (!hmm || !suffix_out) return mrp_set_error(MRP_ERR_ARG, "mrp_hmm_split: bad arguments");
     if (split_point <= hmm->ref_start) return mrp_set_error(MRP_ERR_ARG, "The split point is at or before the start of the reference interval");
     if (split_point >= hmm->ref_start + hmm->ref_length) return mrp_set_error(MRP_ERR_ARG, "The split point is after the last position of the reference interval");
     world w;
@@ -1160,7 +1042,7 @@ static int sites_linkage_well_supported(const mrp_hmm *h, const mrp_params *para
  * heterozygous sites that too few reads span, the hmm is cut half way.  The input hmm becomes the first of the list. */
 int mrp_hmm_split_where_phasing_is_uncertain(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *reads, int64_t n_reads,
                                              mrp_hmm *hmm, const mrp_params *params, mrp_hmm ***hmms_out, int64_t *n_out) {
-    if (!hmm || !params || !hmms_out || !n_out || hmm->resident) return mrp_set_error(MRP_ERR_ARG, "mrp_hmm_split_where_phasing_is_uncertain: bad arguments");
+    if (!hmm || !params || !hmms_out || !n_out) return mrp_set_error(MRP_ERR_ARG, "mrp_hmm_split_where_phasing_is_uncertain: bad arguments");
     world w;
     int rc = world_init(&w, ctx, chunk, reads, n_reads, NULL);
     if (rc != MRP_OK) return rc;
@@ -1440,250 +1322,300 @@ int mrp_phase_reads(mrp_context *ctx, const mrp_chunk *chunk, const mrp_read *re
 /* device-resident merge                                                     */
 /*                                                                                             */
 /* The same recursion as merge_tiling_paths / merge_two_tiling_paths above, but the hmms never  */
-/* leave HBM: the structural decisions (tiling paths, overlap components, column alignment)     */
-/* depend on read intervals only and are taken here on "shadow" hmms that carry the column      */
-/* structure, per-column cell counts and device pointers; cross product, sweep and prune of     */
-/* every overlap component of a recursion level -- of every chunk and strand handed in -- run    */
-/* as ONE batch of kernels (mrp_engine_level).                                                 */
+/* leave HBM.  The structural decisions depend on read intervals only and are split in two:     */
+/*   host    WHICH hmms are merged -- tiling paths, overlap components (coordination.c:69-339):   */
+/*           a few hundred intervals per chunk and level -- and the merged column BOUNDARIES of   */
+/*           every cross product (two sorted lists per hmm: 8 bytes per column);                 */
+/*   device  everything else a column needs (which parent column each side is cut from, the      */
+/*           connector kinds, the column's reads and where their profile bytes start, allele      */
+/*           slots): mrp_structure_kernel, one thread per column, from the parents' own column    */
+/*           tables, which stay in HBM (mrp_engine.h).                                           */
+/* A "shadow" is what the host keeps of an hmm: interval, reads, column boundaries, and WHERE its */
+/* pruned form will be on the device (segment, first column).  Cross product, sweep and prune    */
+/* of every overlap component of a recursion level -- of every chunk and strand handed in --     */
+/* run as ONE batch of kernels (mrp_engine_level_*).                                            */
 /* ------------------------------------------------------------------------------------------ */
-/* a shadow hmm with K columns, D column reads in total and n_reads reads: one allocation */
-static mrp_hmm *r_shadow_new(int64_t K, int64_t D, int64_t n_reads, int with_xcols, void *place, size_t *bytes_out) {
-#define AL8(x) (((size_t) (x) + 7) & ~(size_t) 7)
-    size_t bytes = AL8(sizeof(mrp_hmm));
-    const size_t o_reads = bytes; bytes += AL8(4 * n_reads);
-    const size_t o_start = bytes; bytes += AL8(4 * K);
-    const size_t o_len = bytes; bytes += AL8(4 * K);
-    const size_t o_depth = bytes; bytes += AL8(4 * K);
-    const size_t o_cell_off = bytes; bytes += AL8(8 * (K + 1));
-    const size_t o_read_off = bytes; bytes += AL8(8 * (K + 1));
-    const size_t o_mcell_off = bytes; bytes += AL8(8 * K);
-    const size_t o_col_reads = bytes; bytes += AL8(4 * D);
-    const size_t o_rbo = bytes; bytes += AL8(8 * D);
-    const size_t o_mask_from = bytes; bytes += AL8(8 * K);
-    const size_t o_mask_to = bytes; bytes += AL8(8 * K);
-    const size_t o_rc_cells = bytes; bytes += AL8(4 * K);
-    const size_t o_rc_merge = bytes; bytes += AL8(4 * K);
-    const size_t o_xcols = bytes; bytes += with_xcols ? AL8(sizeof(mrp_xcol) * (size_t) K) : 0;
-#undef AL8
-    if (bytes_out) *bytes_out = bytes;
-    if (bytes_out && !place) return NULL; /* size query */
-    int cls = 0;
-    char *blk = place ? place : shadow_alloc(bytes, &cls);
-    mrp_hmm *h = (mrp_hmm *) blk;
-    memset(h, 0, sizeof(*h));
-    h->arena_bytes = bytes;
-    h->in_block = place != NULL;
-    h->pool_class = place ? 0 : cls + 1;
-    h->resident = 1;
-#define AT(vec, off, capacity) do { (vec).a = (void *) (blk + (off)); (vec).n = 0; (vec).cap = (capacity); } while (0)
-    AT(h->reads, o_reads, n_reads); AT(h->col_start, o_start, K); AT(h->col_len, o_len, K); AT(h->col_depth, o_depth, K);
-    AT(h->cell_off, o_cell_off, K + 1); AT(h->read_off, o_read_off, K + 1); AT(h->mcell_off, o_mcell_off, K);
-    AT(h->col_reads, o_col_reads, D); AT(h->read_byte_off, o_rbo, D); AT(h->mask_from, o_mask_from, K); AT(h->mask_to, o_mask_to, K);
-    AT(h->rc_cells, o_rc_cells, K); AT(h->rc_merge, o_rc_merge, K);
-#undef AT
-    h->cell_off.a[0] = 0; h->cell_off.n = 1;
-    h->read_off.a[0] = 0; h->read_off.n = 1;
-    h->mcell_off.a[0] = 0; h->mcell_off.n = 1;
-    if (with_xcols) h->xcols = (mrp_xcol *) (blk + o_xcols); /* every field is written by r_cross_shadow */
-    return h;
+typedef struct rhmm {
+    int32_t ref_start, ref_length;
+    int32_t first_read;        /* reads[0]: its name breaks ties in stRPHmm_cmpFn */
+    int32_t n_cols, n_reads;
+    int32_t seg;               /* segment of the engine that holds the pruned hmm; -1: stRPHmm_construct leaf */
+    int64_t col0;              /* first column in the segment; leaf: offset of the read's profile bytes in the pool */
+    int32_t *starts;           /* [n_cols] first site of every column */
+    int32_t *roff;             /* [n_cols + 1] prefix sums of the column depths */
+    int32_t *reads;            /* [n_reads] stRPHmm.profileSeqs; a column's reads are those of them that cover it, in this order */
+    mrp_xpar *par;             /* [n_a + n_b] the two tiling paths it is the cross product of */
+    int32_t n_a, n_b;
+    int64_t bound_cells, bound_merge, depth_sites; /* static bounds, see mrp_xhmm */
+    int32_t bound_max_cells, bound_max_merge;
+    int32_t pool_class;        /* size class of the block in the shadow pool + 1; 0: lives in a block owned by someone else */
+} rhmm;
+
+#define HMM_T rhmm
+#define PFX(x) r_##x
+#define H_NAME_READ(h) ((h)->first_read)
+#include "rphmm_paths.inc"
+#undef HMM_T
+#undef PFX
+#undef H_NAME_READ
+
+static void rhmm_destroy(rhmm *h) {
+    if (h && h->pool_class != 0) shadow_release(h, h->pool_class - 1);
+}
+static void r_free_path(r_hmm_vec *tp, int destroy_hmms) {
+    if (!tp) return;
+    if (destroy_hmms) for (int64_t i = 0; i < tp->n; i++) rhmm_destroy(tp->a[i]);
+    free(tp->a); free(tp);
 }
 
-static mrp_hmm *r_hmm_from_read(const world *w, int32_t read, const mrp_engine *e, void *place) { /* stRPHmm_construct hmm.c:97-133 */
-    mrp_hmm *h = r_shadow_new(1, 1, 1, 0, place, NULL);
+/* stRPHmm_construct (hmm.c:97-133): one column {1, 0} over the read's sites.  All leaves of a chunk live in one block. */
+typedef struct { rhmm h; int32_t starts[1], roff[2], reads[1]; } rleaf;
+static void r_leaf_init(rleaf *l, const world *w, int32_t read) {
     const mrp_read *r = &w->reads[read];
-    h->ref_start = r->ref_start;
-    h->ref_length = r->length;
-    h->reads.a[h->reads.n++] = read;
-    h->col_start.a[0] = r->ref_start; h->col_len.a[0] = r->length; h->col_depth.a[0] = 1;
-    h->col_start.n = h->col_len.n = h->col_depth.n = 1;
-    h->col_reads.a[0] = read; h->col_reads.n = 1;
-    h->read_byte_off.a[0] = read_byte_offset(w, read, r->ref_start); h->read_byte_off.n = 1;
-    h->cell_off.a[1] = 0; h->cell_off.n = 2;
-    h->read_off.a[1] = 1; h->read_off.n = 2;
-    h->max_depth = 1;
-    h->stride = 4;
-    h->leaf = 1;
-    if (e) mrp_engine_leaf(e, &h->d_part, &h->d_np, &h->d_ncells);
-    h->d_nmerge = NULL;
-    h->rc_cells.a[0] = 2; h->rc_cells.n = 1;
-    return h;
+    rhmm *h = &l->h;
+    memset(h, 0, sizeof(*h));
+    h->ref_start = r->ref_start; h->ref_length = r->length; h->first_read = read;
+    h->n_cols = 1; h->n_reads = 1;
+    h->seg = -1; h->col0 = r->pool_offset; /* profileSeq.c:41-47 at the read's first site */
+    l->starts[0] = r->ref_start; l->roff[0] = 0; l->roff[1] = 1; l->reads[0] = read;
+    h->starts = l->starts; h->roff = l->roff; h->reads = l->reads;
+}
+static rleaf *r_leaves_of_chunk(const world *w) {
+    rleaf *lv = xmalloc(sizeof(rleaf) * (size_t) (w->n_reads + 1));
+    for (int64_t i = 0; i < w->n_reads; i++) r_leaf_init(&lv[i], w, (int32_t) i);
+    return lv;
 }
 
-/* filterReadsByCoverageDepth coordination.c:443-488 on shadow leaves (one block for all reads instead of a dozen small
- * allocations per read: the coverage filter looks at every read of a chunk) */
-static void r_filter_reads_by_coverage_depth(const world *w, const mrp_params *params, int32_t *filtered, int64_t *nf,
+/* filterReadsByCoverageDepth coordination.c:443-488 on the chunk's leaves */
+static void r_filter_reads_by_coverage_depth(const world *w, rleaf *leaves, const mrp_params *params, int32_t *filtered, int64_t *nf,
                                              int32_t *discarded, int64_t *nd) {
     const int64_t n = w->n_reads;
-    size_t leaf_bytes = 0;
-    r_shadow_new(1, 1, 1, 0, NULL, &leaf_bytes);
-    char *block = xmalloc(leaf_bytes * (size_t) (n + 1));
-    mrp_hmm **hmms = xmalloc(sizeof(*hmms) * (size_t) (n + 1));
-    for (int64_t i = 0; i < n; i++) hmms[i] = r_hmm_from_read(w, (int32_t) i, NULL, block + leaf_bytes * (size_t) i);
-    path_vec paths = tiling_paths_from(w, hmms, n);
+    rhmm **hmms = xmalloc(sizeof(*hmms) * (size_t) (n + 1));
+    for (int64_t i = 0; i < n; i++) hmms[i] = &leaves[i].h;
+    r_path_vec paths = r_tiling_paths_from(w, hmms, n);
     free(hmms);
     keyed *a = xmalloc(sizeof(keyed) * (size_t) (paths.n + 1)), *t = xmalloc(sizeof(keyed) * (size_t) (paths.n + 1));
     for (int64_t i = 0; i < paths.n; i++) {
         int64_t total = 0;
-        for (int64_t j = 0; j < paths.a[i]->n; j++) total += w->reads[paths.a[i]->a[j]->reads.a[0]].length;
+        for (int64_t j = 0; j < paths.a[i]->n; j++) total += paths.a[i]->a[j]->ref_length;
         a[i].idx = i; a[i].key = (double) total;
     }
     keyed_sort_desc(a, paths.n, t);
     int64_t np = paths.n;
     *nf = 0; *nd = 0;
     while (np > params->max_coverage_depth) {
-        hmm_vec *tp = paths.a[a[--np].idx];
-        for (int64_t j = tp->n - 1; j >= 0; j--) discarded[(*nd)++] = tp->a[j]->reads.a[0];
+        r_hmm_vec *tp = paths.a[a[--np].idx];
+        for (int64_t j = tp->n - 1; j >= 0; j--) discarded[(*nd)++] = tp->a[j]->first_read;
     }
     while (np > 0) {
-        hmm_vec *tp = paths.a[a[--np].idx];
-        for (int64_t j = tp->n - 1; j >= 0; j--) filtered[(*nf)++] = tp->a[j]->reads.a[0];
+        r_hmm_vec *tp = paths.a[a[--np].idx];
+        for (int64_t j = tp->n - 1; j >= 0; j--) filtered[(*nf)++] = tp->a[j]->first_read;
     }
-    for (int64_t i = 0; i < paths.n; i++) free_path(paths.a[i], 0);
-    free(paths.a); free(a); free(t); free(block);
+    for (int64_t i = 0; i < paths.n; i++) r_free_path(paths.a[i], 0);
+    free(paths.a); free(a); free(t);
 }
 
-/* what one side contributes to the connector that leaves piece p: its kind, where the number of its merge cells will be
- * found (REAL connectors; an IDENT connector has one merge cell per cell of the piece, a ZERO connector one) */
-static void r_conn_of(const piece *p, uint8_t *kind, const int32_t **nmerge, uint8_t *paired, uint64_t *mask_from, uint64_t *mask_to) {
-    *nmerge = NULL;
-    switch (p->out) {
-        case CONN_REAL:
-            *kind = MRP_CONN_REAL; *nmerge = p->h->d_nmerge + p->k;
-            *mask_from = p->h->mask_from.a[p->k]; *mask_to = p->h->mask_to.a[p->k];
-            break;
-        case CONN_IDENT: /* column.c:86-101 */
-            *kind = MRP_CONN_IDENT;
-            *mask_from = *mask_to = accept_mask(piece_depth(p));
-            break;
-        case CONN_ZERO: /* hmm.c:324-331 */
-            *kind = MRP_CONN_ZERO; *mask_from = *mask_to = 0;
-            break;
-        default:
-            *kind = MRP_CONN_NONE; *mask_from = *mask_to = 0;
+/* The pieces of a tiling path between S and E, one after the other: a column of one of its hmms, or a gap between two of
+ * them / in front of the first / behind the last (stRPHmm_fuse hmm.c:283-372 and the prefix / suffix gaps of
+ * stRPHmm_alignColumns hmm.c:396-462). */
+typedef struct { const r_hmm_vec *tp; int64_t i; int32_t k, pos, E; } piter;
+typedef struct { int32_t end, depth; uint8_t out; } rpiece; /* out: connector that leaves the piece at its own end */
+static int piter_next(piter *it, rpiece *p) {
+    if (it->i < it->tp->n) {
+        const rhmm *h = it->tp->a[it->i];
+        if (it->k == 0 && h->ref_start > it->pos) { /* gap: depth 0, one cell; (0, 0) merge column behind it (hmm.c:324-345) */
+            p->end = h->ref_start; p->depth = 0; p->out = MRP_CONN_ZERO;
+            it->pos = p->end;
+            return 1;
+        }
+        const int32_t k = it->k;
+        p->end = k + 1 < h->n_cols ? h->starts[k + 1] : h->ref_start + h->ref_length;
+        p->depth = h->roff[k + 1] - h->roff[k];
+        p->out = k + 1 < h->n_cols ? MRP_CONN_REAL : MRP_CONN_ZERO;
+        it->pos = p->end;
+        if (++it->k == h->n_cols) { it->i++; it->k = 0; }
+        return 1;
     }
-    *paired = *mask_from != 0;
+    if (it->pos < it->E) {
+        p->end = it->E; p->depth = 0; p->out = MRP_CONN_ZERO;
+        it->pos = it->E;
+        return 1;
+    }
+    return 0;
 }
 
-typedef struct { mrp_hmm *x; mrp_xcol *cols; const world *w; } xbuild;
-typedef VEC(xbuild) xbuild_vec;
-
-/* the column structure of stRPHmm_createCrossProductOfTwoAlignedHmm (hmm.c:534-750) over two aligned
- * piece lists; the cells are produced on the device from the mrp_xcol descriptors */
-static int r_cross_shadow(const world *w, const piece_vec *A, const piece_vec *B, const hmm_vec *tpA, const hmm_vec *tpB,
-                          int32_t S, int32_t E, xbuild *out) {
-    const int64_t n = A->n;
-    int64_t D = 0, n_reads = 0;
-    for (int64_t s = 0; s < n; s++) {
-        const int32_t depth = piece_depth(&A->a[s]) + piece_depth(&B->a[s]);
-        if (depth > MRP_MAX_READ_PARTITIONING_DEPTH)
-            return mrp_set_error(MRP_ERR_ARG, "cross product column depth %d exceeds %d", depth, MRP_MAX_READ_PARTITIONING_DEPTH);
+/* The shadow of stRPHmm_createCrossProductOfTwoAlignedHmm (hmm.c:534-750) of two tiling paths: both are cut at the union
+ * of their column boundaries (hmm.c:476-504, column.c:70-130); per column the host keeps its first site and its depth and
+ * sums up the static bounds the engine sizes its launches with.  b may be empty: stRPHmm_fuse of path a alone. */
+static int r_cross_build(const world *w, const r_hmm_vec *a, const r_hmm_vec *b, int32_t S, int32_t E, int32_t stride, rhmm **out) {
+    (void) w;
+    int64_t cap = 2, n_reads = 0;
+    for (int64_t i = 0; i < a->n; i++) { cap += a->a[i]->n_cols + 1; n_reads += a->a[i]->n_reads; }
+    for (int64_t i = 0; i < b->n; i++) { cap += b->a[i]->n_cols + 1; n_reads += b->a[i]->n_reads; }
+    const size_t o_starts = (sizeof(rhmm) + 7) & ~(size_t) 7, o_roff = o_starts + 4 * (size_t) cap, o_reads = o_roff + 4 * (size_t) (cap + 1),
+                 o_par = (o_reads + 4 * (size_t) n_reads + 7) & ~(size_t) 7, bytes = o_par + sizeof(mrp_xpar) * (size_t) (a->n + b->n);
+    int cls = 0;
+    char *blk = shadow_alloc(bytes, &cls);
+    rhmm *h = (rhmm *) blk;
+    memset(h, 0, sizeof(*h));
+    h->pool_class = cls + 1;
+    h->starts = (int32_t *) (blk + o_starts); h->roff = (int32_t *) (blk + o_roff); h->reads = (int32_t *) (blk + o_reads);
+    h->par = (mrp_xpar *) (blk + o_par);
+    h->ref_start = S; h->ref_length = E - S; h->seg = -2; /* set when its level is staged */
+    h->n_a = (int32_t) a->n; h->n_b = (int32_t) b->n;
+    {   /* stRPHmm.profileSeqs: path A's reads, then path B's (hmm.c:559-566); the parents as the device will look them up */
+        int32_t *rd = h->reads;
+        mrp_xpar *pr = h->par;
+        const r_hmm_vec *side[2] = {a, b};
+        for (int q = 0; q < 2; q++)
+            for (int64_t i = 0; i < side[q]->n; i++) {
+                const rhmm *p = side[q]->a[i];
+                memcpy(rd, p->reads, sizeof(int32_t) * (size_t) p->n_reads);
+                rd += p->n_reads;
+                pr->start = p->ref_start; pr->end = p->ref_start + p->ref_length; pr->n_cols = p->n_cols; pr->seg = p->seg; pr->col0 = p->col0;
+                pr++;
+            }
+        h->n_reads = (int32_t) n_reads;
+        h->first_read = n_reads > 0 ? h->reads[0] : -1;
+    }
+    piter ia = {a, 0, 0, S, E}, ib = {b, 0, 0, S, E};
+    rpiece pa, pb;
+    if (!piter_next(&ia, &pa) || !piter_next(&ib, &pb)) { rhmm_destroy(h); return mrp_set_error(MRP_ERR_ARG, "cross product of an empty interval"); }
+    int32_t pos = S, n = 0;
+    int64_t D = 0;
+    int rc = MRP_OK;
+    for (;;) {
+        const int32_t end = pa.end < pb.end ? pa.end : pb.end;
+        const int32_t d1 = pa.depth, d2 = pb.depth, depth = d1 + d2;
+        if (depth > MRP_MAX_READ_PARTITIONING_DEPTH) {
+            rc = mrp_set_error(MRP_ERR_ARG, "cross product column depth %d exceeds %d", depth, MRP_MAX_READ_PARTITIONING_DEPTH);
+            break;
+        }
+        if (n >= cap || end <= pos) { rc = mrp_set_error(MRP_ERR_ARG, "cross product: inconsistent tiling paths"); break; }
+        h->starts[n] = pos;
+        h->roff[n] = (int32_t) D;
         D += depth;
-    }
-    for (int64_t i = 0; i < tpA->n; i++) n_reads += tpA->a[i]->reads.n;
-    for (int64_t i = 0; i < tpB->n; i++) n_reads += tpB->a[i]->reads.n;
-    mrp_hmm *h = r_shadow_new(n, D, n_reads, 1, NULL, NULL);
-    h->ref_start = S; h->ref_length = E - S;
-    for (int64_t i = 0; i < tpA->n; i++) { memcpy(h->reads.a + h->reads.n, tpA->a[i]->reads.a, sizeof(int32_t) * (size_t) tpA->a[i]->reads.n); h->reads.n += tpA->a[i]->reads.n; }
-    for (int64_t i = 0; i < tpB->n; i++) { memcpy(h->reads.a + h->reads.n, tpB->a[i]->reads.a, sizeof(int32_t) * (size_t) tpB->a[i]->reads.n); h->reads.n += tpB->a[i]->reads.n; }
-    mrp_xcol *xc = h->xcols;
-    int64_t d_off = 0;
-    for (int64_t s = 0; s < n; s++) {
-        const piece *side[2] = {&A->a[s], &B->a[s]};
-        const piece *pa = side[0], *pb = side[1];
-        const int32_t d1 = piece_depth(pa), d2 = piece_depth(pb), depth = d1 + d2;
-        h->col_start.a[s] = pa->start; h->col_len.a[s] = pa->len; h->col_depth.a[s] = depth;
-        if (depth > h->max_depth) h->max_depth = depth;
-        /* the column's reads: side A's then side B's; their profile bytes start where the parent column's do,
-         * moved on by the alleles between the parent column's first site and the piece's (profileSeq.c:41-47) */
-        for (int q = 0; q < 2; q++) {
-            const piece *p = side[q];
-            const int32_t d = piece_depth(p);
-            if (d == 0) continue;
-            const int64_t ro = p->h->read_off.a[p->k];
-            const int64_t delta = (int64_t) w->ch.allele_offset[p->start] - (int64_t) w->ch.allele_offset[p->h->col_start.a[p->k]];
-            memcpy(h->col_reads.a + d_off, p->h->col_reads.a + ro, sizeof(int32_t) * (size_t) d);
-            const int64_t *src = p->h->read_byte_off.a + ro;
-            int64_t *dst = h->read_byte_off.a + d_off;
-            for (int32_t i = 0; i < d; i++) dst[i] = src[i] + delta;
-            d_off += d;
+        const int64_t C = mrp_side_bound(d1, stride) * mrp_side_bound(d2, stride);
+        h->bound_cells += C;
+        if (C > h->bound_max_cells) h->bound_max_cells = (int32_t) C;
+        h->depth_sites += (int64_t) depth * (end - pos);
+        if (end < E) { /* merge column hmm.c:686-740: a piece that is cut leaves through an accept-mask connector (column.c:86-101) */
+            const uint8_t oa = pa.end > end ? MRP_CONN_IDENT : pa.out, ob = pb.end > end ? MRP_CONN_IDENT : pb.out;
+            const int64_t Ma = oa == MRP_CONN_ZERO ? 1 : mrp_side_bound(d1, stride), Mb = ob == MRP_CONN_ZERO ? 1 : mrp_side_bound(d2, stride);
+            h->bound_merge += Ma * Mb;
+            if (Ma * Mb > h->bound_max_merge) h->bound_max_merge = (int32_t) (Ma * Mb);
         }
-        h->read_off.a[s + 1] = d_off;
-        h->cell_off.a[s + 1] = 0;
-        mrp_xcol *c = &xc[s];
-        c->a_part = pa->h ? pa->h->d_part + (int64_t) pa->k * pa->h->stride : NULL;
-        c->a_np = pa->h ? pa->h->d_np + (int64_t) pa->k * pa->h->stride : NULL;
-        c->b_part = pb->h ? pb->h->d_part + (int64_t) pb->k * pb->h->stride : NULL;
-        c->b_np = pb->h ? pb->h->d_np + (int64_t) pb->k * pb->h->stride : NULL;
-        c->a_ncells = pa->h ? pa->h->d_ncells + pa->k : NULL;
-        c->b_ncells = pb->h ? pb->h->d_ncells + pb->k : NULL;
-        c->d1 = (uint8_t) d1; c->d2 = (uint8_t) d2;
-        if (s + 1 < n) { /* merge column hmm.c:686-740 */
-            uint64_t fa, ta, fb, tb;
-            r_conn_of(pa, &c->out_a, &c->a_nmerge, &c->out_a_paired, &fa, &ta);
-            r_conn_of(pb, &c->out_b, &c->b_nmerge, &c->out_b_paired, &fb, &tb);
-            const int32_t d1n = piece_depth(&A->a[s + 1]);
-            c->mask_from = merge_bits(fa, fb, d1);
-            c->mask_to = merge_bits(ta, tb, d1n);
-            h->mask_from.a[s] = c->mask_from;
-            h->mask_to.a[s] = c->mask_to;
-            h->mcell_off.a[s + 1] = 0;
-        } else { /* no merge column after the last column */
-            c->out_a = c->out_b = MRP_CONN_NONE; c->a_nmerge = c->b_nmerge = NULL; c->out_a_paired = c->out_b_paired = 0;
-            c->mask_from = c->mask_to = 0;
-        }
-        c->pad[0] = c->pad[1] = 0;
+        n++;
+        pos = end;
+        if (pos >= E) break;
+        if (pa.end == end && !piter_next(&ia, &pa)) { rc = mrp_set_error(MRP_ERR_ARG, "cross product: tiling path A ends early"); break; }
+        if (pb.end == end && !piter_next(&ib, &pb)) { rc = mrp_set_error(MRP_ERR_ARG, "cross product: tiling path B ends early"); break; }
     }
-    h->col_start.n = h->col_len.n = h->col_depth.n = n;
-    h->col_reads.n = h->read_byte_off.n = D;
-    h->read_off.n = h->cell_off.n = n + 1;
-    h->mcell_off.n = n;
-    h->mask_from.n = h->mask_to.n = n - 1;
-    out->x = h; out->cols = xc; out->w = w;
+    if (rc == MRP_OK && D > 0x7FFFFFFFll) rc = mrp_set_error(MRP_ERR_UNSUPPORTED, "cross product with %lld column reads", (long long) D);
+    if (rc != MRP_OK) { rhmm_destroy(h); return rc; }
+    h->roff[n] = (int32_t) D;
+    h->n_cols = n;
+    if (h->bound_max_cells < 1) h->bound_max_cells = 1;
+    if (h->bound_max_merge < 1) h->bound_max_merge = 1;
+    *out = h;
     return MRP_OK;
 }
 
+/* A shadow as an ordinary flat hmm WITHOUT cells: column intervals, the reads of every column in bit order and where their
+ * profile bytes start (profileSeq.c:41-47), and -- with_masks -- the masks of the merge columns (the reads of a column that
+ * go on into the next one, in the bit positions of either column: what hmm.c:686-700 computes by merging the parents'
+ * masks).  A column's reads are the hmm's reads that cover it, in the order of stRPHmm.profileSeqs: side A's reads precede
+ * side B's in both (partitions.c:21-28, hmm.c:559-566), recursively. */
+static mrp_hmm *r_expand(const world *w, const rhmm *x, int with_masks) {
+    mrp_hmm *h = hmm_new();
+    const int64_t K = x->n_cols, D = x->roff[K];
+    h->ref_start = x->ref_start; h->ref_length = x->ref_length;
+    VEC_RESERVE(h->reads, x->n_reads);
+    memcpy(h->reads.a, x->reads, sizeof(int32_t) * (size_t) x->n_reads); h->reads.n = x->n_reads;
+    VEC_RESERVE(h->col_start, K); VEC_RESERVE(h->col_len, K); VEC_RESERVE(h->col_depth, K);
+    VEC_RESERVE(h->read_off, K + 1); VEC_RESERVE(h->cell_off, K + 1);
+    VEC_RESERVE(h->col_reads, D + 1); VEC_RESERVE(h->read_byte_off, D + 1);
+    const int32_t E = x->ref_start + x->ref_length;
+    h->read_off.n = 0; h->cell_off.n = 0;
+    for (int64_t k = 0; k < K; k++) {
+        h->col_start.a[k] = x->starts[k];
+        h->col_len.a[k] = (k + 1 < K ? x->starts[k + 1] : E) - x->starts[k];
+        h->col_depth.a[k] = x->roff[k + 1] - x->roff[k];
+        if (h->col_depth.a[k] > h->max_depth) h->max_depth = h->col_depth.a[k];
+        h->read_off.a[k] = x->roff[k];
+        h->cell_off.a[k] = 0;
+    }
+    h->read_off.a[K] = D; h->cell_off.a[K] = 0;
+    h->col_start.n = h->col_len.n = h->col_depth.n = K;
+    h->read_off.n = h->cell_off.n = K + 1;
+    h->col_reads.n = h->read_byte_off.n = D;
+    int32_t *fill = xmalloc(sizeof(int32_t) * (size_t) (K + 1));
+    memcpy(fill, x->roff, sizeof(int32_t) * (size_t) (K + 1));
+    int ok = 1;
+    for (int64_t i = 0; i < x->n_reads && ok; i++) {
+        const int32_t rd = x->reads[i];
+        const mrp_read *r = &w->reads[rd];
+        int64_t lo = 0, hi = K; /* the column that starts where the read does */
+        while (lo < hi) { const int64_t mid = (lo + hi) >> 1; if (x->starts[mid] < r->ref_start) lo = mid + 1; else hi = mid; }
+        if (lo >= K || x->starts[lo] != r->ref_start) { ok = 0; break; }
+        for (int64_t k = lo; k < K && x->starts[k] < r->ref_start + r->length; k++) {
+            if (fill[k] >= x->roff[k + 1]) { ok = 0; break; }
+            h->col_reads.a[fill[k]] = rd;
+            h->read_byte_off.a[fill[k]] = read_byte_offset(w, rd, x->starts[k]);
+            fill[k]++;
+        }
+    }
+    for (int64_t k = 0; k < K && ok; k++) if (fill[k] != x->roff[k + 1]) ok = 0;
+    free(fill);
+    if (!ok) { mrp_hmm_destroy(h); mrp_set_error(MRP_ERR_ARG, "shadow hmm: the column depths do not match the reads' intervals"); return NULL; }
+    if (with_masks)
+        for (int64_t k = 0; k + 1 < K; k++) {
+            uint64_t mf = 0, mt = 0;
+            const int32_t cut = x->starts[k + 1];
+            const int32_t *ra = h->col_reads.a + h->read_off.a[k], *rb = h->col_reads.a + h->read_off.a[k + 1];
+            for (int32_t i = 0; i < h->col_depth.a[k]; i++) if (w->reads[ra[i]].ref_start + w->reads[ra[i]].length > cut) mf |= (uint64_t) 1 << i;
+            for (int32_t i = 0; i < h->col_depth.a[k + 1]; i++) if (w->reads[rb[i]].ref_start < cut) mt |= (uint64_t) 1 << i;
+            VEC_PUSH(h->mask_from, mf); VEC_PUSH(h->mask_to, mt);
+        }
+    return h;
+}
+
+typedef struct { rhmm *x; const world *w; } xbuild;
+typedef VEC(xbuild) xbuild_vec;
+
 /* mergeTwoTilingPaths coordination.c:263-339, structure only: the overlap components that need a cross
  * product are appended to xs (and, unpruned, to res); the others pass through */
-static int64_t g_ns[6]; /* MRP_TIMING: components, tiling paths, pieces, cross shadow, destroy, other */
+static int64_t g_ns[6]; /* MRP_TIMING: components, tiling paths, cross shadows, destroy */
 static double tcpu_ms(void) { struct timespec t; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t); return 1e3 * (double) t.tv_sec + 1e-6 * (double) t.tv_nsec; }
 #define T_ADD(slot, t0) __atomic_fetch_add(&g_ns[slot], (int64_t) ((tcpu_ms() - (t0)) * 1e6), __ATOMIC_RELAXED)
-static int r_prepare_merge(const world *w, hmm_vec *tp1, hmm_vec *tp2, hmm_vec *res, xbuild_vec *xs, hmm_vec *garbage) {
+static int r_prepare_merge(const world *w, int32_t stride, r_hmm_vec *tp1, r_hmm_vec *tp2, r_hmm_vec *res, xbuild_vec *xs, r_hmm_vec *garbage) {
     double tq = tcpu_ms();
     ar_on();
-    comp_vec comps = overlapping_components(w, tp1, tp2);
+    r_comp_vec comps = r_overlapping_components(w, tp1, tp2);
     ar_off();
     T_ADD(0, tq);
     free(tp1->a); free(tp1); free(tp2->a); free(tp2);
     int rc = MRP_OK;
     for (int64_t i = 0; i < comps.n; i++) {
-        component *comp = comps.a[i];
+        r_component *comp = comps.a[i];
         if (rc == MRP_OK) {
             tq = tcpu_ms();
             ar_on();
-            path_vec sub = tiling_paths_from(w, comp->members.a, comp->members.n);
+            r_path_vec sub = r_tiling_paths_from(w, comp->members.a, comp->members.n);
             ar_off();
             T_ADD(1, tq);
             if (sub.n == 2) {
-                hmm_vec *a = sub.a[0], *b = sub.a[1];
+                r_hmm_vec *a = sub.a[0], *b = sub.a[1];
                 int32_t S = a->a[0]->ref_start < b->a[0]->ref_start ? a->a[0]->ref_start : b->a[0]->ref_start;
                 int32_t Ea = a->a[a->n - 1]->ref_start + a->a[a->n - 1]->ref_length;
                 int32_t Eb = b->a[b->n - 1]->ref_start + b->a[b->n - 1]->ref_length;
                 int32_t E = Ea > Eb ? Ea : Eb;
-                piece_vec pa = {0}, pb = {0}, qa = {0}, qb = {0};
+                xbuild xb = {NULL, w};
                 tq = tcpu_ms();
-                ar_on();
-                pieces_of_path(a, S, E, &pa);
-                pieces_of_path(b, S, E, &pb);
-                align_pieces(&pa, &pb, &qa, &qb);
-                ar_off();
+                rc = r_cross_build(w, a, b, S, E, stride, &xb.x);
                 T_ADD(2, tq);
-                xbuild xb = {0};
-                tq = tcpu_ms();
-                rc = r_cross_shadow(w, &qa, &qb, a, b, S, E, &xb);
-                T_ADD(3, tq);
-                free(pa.a); free(pb.a); free(qa.a); free(qb.a);
                 /* the parents' shadows are no longer needed; their cells stay in the engine's segments */
-                /* (freed by the caller's thread while the device works: cross-thread frees contend in malloc) */
+                /* (freed by the caller's thread while the device works) */
                 for (int64_t t = 0; t < a->n; t++) VEC_PUSH(*garbage, a->a[t]);
                 for (int64_t t = 0; t < b->n; t++) VEC_PUSH(*garbage, b->a[t]);
                 if (rc == MRP_OK) { VEC_PUSH(*xs, xb); VEC_PUSH(*res, xb.x); }
@@ -1707,11 +1639,11 @@ typedef struct {
     int left, right;   /* children (node indices) or -1 */
     int height;        /* 0: a tiling path as it is; h > 0: merged at level h */
     const world *w;
-    hmm_vec *path;     /* the node's tiling path once its level is done (owned) */
+    r_hmm_vec *path;   /* the node's tiling path once its level is done (owned) */
 } rnode;
 typedef VEC(rnode) rnode_vec;
 
-static int r_leaf_node(rnode_vec *t, const world *w, hmm_vec *path) {
+static int r_leaf_node(rnode_vec *t, const world *w, r_hmm_vec *path) {
     rnode nd = {-1, -1, 0, w, path};
     VEC_PUSH(*t, nd);
     return (int) t->n - 1;
@@ -1722,32 +1654,23 @@ static int r_merge_node(rnode_vec *t, const world *w, int l, int r) {
     VEC_PUSH(*t, nd);
     return (int) t->n - 1;
 }
-static int r_tree_of_paths(rnode_vec *t, const world *w, hmm_vec **paths, int64_t n) {
-    if (n == 0) return r_leaf_node(t, w, xcalloc(1, sizeof(hmm_vec)));
+static int r_tree_of_paths(rnode_vec *t, const world *w, r_hmm_vec **paths, int64_t n) {
+    if (n == 0) return r_leaf_node(t, w, xcalloc(1, sizeof(r_hmm_vec)));
     if (n == 1) return r_leaf_node(t, w, paths[0]);
     if (n == 2) return r_merge_node(t, w, r_leaf_node(t, w, paths[0]), r_leaf_node(t, w, paths[1]));
     const int l = r_tree_of_paths(t, w, paths, n / 2);
     const int r = r_tree_of_paths(t, w, paths + n / 2, n - n / 2);
     return r_merge_node(t, w, l, r);
 }
-/* getRPHmms coordination.c:490-516 as a subtree; returns the root node or -1 */
-typedef VEC(void *) block_vec;
-static int r_tree_of_reads(rnode_vec *t, const world *w, const mrp_engine *e, const int32_t *read_index, int64_t n,
-                           const mrp_params *params, block_vec *blocks) {
-    mrp_hmm **hmms = xmalloc(sizeof(*hmms) * (size_t) (n + 1));
-    char *block = NULL;
-    size_t leaf_bytes = 0;
-    if (blocks && n > 0) { /* all leaves of the problem in one allocation, owned by the caller */
-        r_shadow_new(1, 1, 1, 0, NULL, &leaf_bytes);
-        block = xmalloc(leaf_bytes * (size_t) n);
-        VEC_PUSH(*blocks, block);
-    }
-    for (int64_t i = 0; i < n; i++) hmms[i] = r_hmm_from_read(w, read_index[i], e, block ? block + leaf_bytes * (size_t) i : NULL);
-    path_vec paths = tiling_paths_from(w, hmms, n);
+/* getRPHmms coordination.c:490-516 as a subtree over the chunk's leaves; returns the root node or -1 */
+static int r_tree_of_reads(rnode_vec *t, const world *w, rleaf *leaves, const int32_t *read_index, int64_t n, const mrp_params *params) {
+    rhmm **hmms = xmalloc(sizeof(*hmms) * (size_t) (n + 1));
+    for (int64_t i = 0; i < n; i++) hmms[i] = &leaves[read_index[i]].h;
+    r_path_vec paths = r_tiling_paths_from(w, hmms, n);
     free(hmms);
     if (paths.n > MRP_MAX_READ_PARTITIONING_DEPTH || paths.n > params->max_coverage_depth) { /* :500-504 */
         const int64_t np = paths.n;
-        for (int64_t i = 0; i < paths.n; i++) free_path(paths.a[i], 1);
+        for (int64_t i = 0; i < paths.n; i++) r_free_path(paths.a[i], 0);
         free(paths.a);
         mrp_set_error(MRP_ERR_ARG, "Coverage depth: read depth of %lld exceeds hard maximum of %d with configured maximum of %lld",
                       (long long) np, MRP_MAX_READ_PARTITIONING_DEPTH, (long long) params->max_coverage_depth);
@@ -1759,7 +1682,7 @@ static int r_tree_of_reads(rnode_vec *t, const world *w, const mrp_engine *e, co
 }
 
 static void r_free_tree(rnode_vec *t) {
-    for (int64_t i = 0; i < t->n; i++) free_path(t->a[i].path, 1);
+    for (int64_t i = 0; i < t->n; i++) r_free_path(t->a[i].path, 1);
     free(t->a);
     t->a = NULL; t->n = t->cap = 0;
 }
@@ -1769,9 +1692,10 @@ static __thread double g_t_prepare, g_t_level; /* MRP_TIMING diagnostics of the 
 typedef struct {
     rnode_vec *t;
     int64_t node;
-    hmm_vec *res;
+    int32_t stride;
+    r_hmm_vec *res;
     xbuild_vec xs;
-    hmm_vec garbage;
+    r_hmm_vec garbage;
     int rc;
     char err[256];
 } level_item;
@@ -1779,14 +1703,14 @@ static void level_prepare(int64_t i, void *arg) {
     level_item *it = &((level_item *) arg)[i];
     rnode *nd = &it->t->a[it->node];
     it->res = xcalloc(1, sizeof(*it->res));
-    hmm_vec *l = it->t->a[nd->left].path, *r = it->t->a[nd->right].path;
+    r_hmm_vec *l = it->t->a[nd->left].path, *r = it->t->a[nd->right].path;
     it->t->a[nd->left].path = NULL; it->t->a[nd->right].path = NULL;
-    it->rc = r_prepare_merge(nd->w, l, r, it->res, &it->xs, &it->garbage);
+    it->rc = r_prepare_merge(nd->w, it->stride, l, r, it->res, &it->xs, &it->garbage);
     if (it->rc != MRP_OK) snprintf(it->err, sizeof(it->err), "%s", mrp_last_error());
 }
 static void level_drop_garbage(int64_t i, void *arg) { /* the parents' shadows of one merge */
     level_item *it = &((level_item *) arg)[i];
-    for (int64_t j = 0; j < it->garbage.n; j++) mrp_hmm_destroy(it->garbage.a[j]);
+    for (int64_t j = 0; j < it->garbage.n; j++) rhmm_destroy(it->garbage.a[j]);
     free(it->garbage.a);
     it->garbage.a = NULL;
     it->garbage.n = 0;
@@ -1794,7 +1718,17 @@ static void level_drop_garbage(int64_t i, void *arg) { /* the parents' shadows o
 static void level_finish(int64_t i, void *arg) {
     level_item *it = &((level_item *) arg)[i];
     rnode *nd = &it->t->a[it->node];
-    sort_hmms(nd->w, it->res->a, it->res->n); /* coordination.c:336 */
+    r_sort_hmms(nd->w, it->res->a, it->res->n); /* coordination.c:336 */
+}
+/* a shadow as the engine is told about it */
+static void r_describe(const world *w, const rhmm *x, uint32_t flags, mrp_xhmm *d) {
+    memset(d, 0, sizeof(*d));
+    d->chunk = w->chunk; d->flags = flags;
+    d->ref_start = x->ref_start; d->ref_end = x->ref_start + x->ref_length;
+    d->n_cols = x->n_cols; d->n_a = x->n_a; d->n_b = x->n_b; d->par = x->par;
+    d->col_start = x->starts; d->col_read_off = x->roff;
+    d->bound_cells = x->bound_cells; d->bound_merge = x->bound_merge; d->depth_sites = x->depth_sites;
+    d->bound_max_cells = x->bound_max_cells; d->bound_max_merge = x->bound_max_merge;
 }
 /* what the host keeps of a level while it is on the device */
 typedef struct {
@@ -1825,10 +1759,11 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
         if (t->a[i].left >= 0) { lvl[t->a[i].left] = lvl[i] - 1; lvl[t->a[i].right] = lvl[i] - 1; }
     }
     const uint32_t flags = sweep_flags(params);
+    const int32_t stride = mrp_engine_stride(e);
     int rc = MRP_OK;
-    /* The host's part of level h -- structure of the merged hmms, their description for the device -- needs nothing the
-     * device computes (only the ADDRESSES of level h - 1's results, fixed when that level was staged): it is done while
-     * level h - 1 runs.  The one wait per level is inside mrp_engine_level_launch. */
+    /* The host's part of level h -- which hmms are merged, their column boundaries -- needs nothing the device computes
+     * (only WHERE level h - 1's results are, fixed when that level was staged): it is done while level h - 1 runs.  The one
+     * wait per level is inside mrp_engine_level_launch. */
     level_run prev = {0};
     for (int h = 1; h <= max_h && rc == MRP_OK; h++) {
         const double t0 = now_ms();
@@ -1837,9 +1772,9 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
         if (n_items == 0) continue;
         level_item *items = xcalloc((size_t) n_items + 1, sizeof(*items));
         n_items = 0;
-        for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > 0 && lvl[i] == h && !t->a[i].w->failed) { items[n_items].t = t; items[n_items].node = i; n_items++; }
+        for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > 0 && lvl[i] == h && !t->a[i].w->failed) { items[n_items].t = t; items[n_items].node = i; items[n_items].stride = stride; n_items++; }
         /* the merges of a level touch disjoint nodes: structure in parallel, device work as one batch */
-        mrp_pool_set_tag(1); parallel_for(n_items, level_prepare, items); mrp_pool_set_tag(0);
+        mrp_pool_set_tag(1); mrp_pool_run(n_items, n_items > 4096 ? 16 : 1, level_prepare, items); mrp_pool_set_tag(0);
         const double ta = now_ms();
         int64_t n_x = 0;
         for (int64_t i = 0; i < n_items; i++) {
@@ -1855,26 +1790,15 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
             items[i].xs.a = NULL;
         }
         for (int64_t i = 0; i < n_x; i++) {
-            mrp_hmm *x = xb[i].x;
-            const int64_t K = hmm_K(x);
-            xh[i].chunk = xb[i].w->chunk;
-            xh[i].n_cols = (int32_t) K;
-            xh[i].flags = flags;
-            xh[i].cols = xb[i].cols;
-            xh[i].col_ref_start = x->col_start.a; xh[i].col_length = x->col_len.a; xh[i].col_depth = x->col_depth.a;
-            xh[i].col_read_off = x->read_off.a; xh[i].read_byte_off = x->read_byte_off.a;
+            r_describe(xb[i].w, xb[i].x, flags, &xh[i]);
             ((world *) xb[i].w)->n_sweeps += 1; /* coordination.c:312: one forward/backward per overlap component */
         }
         const double tb = now_ms();
         if (rc == MRP_OK) rc = mrp_engine_level_stage(e, n_x, xh);
         const double tc = now_ms();
         /* where the level's results will be is known from here on: the next level can be described against them */
-        for (int64_t i = 0; i < n_x && rc == MRP_OK; i++) {
-            mrp_hmm *x = xb[i].x;
-            x->stride = mrp_engine_stride(e);
-            x->d_part = xh[i].d_part; x->d_np = xh[i].d_np; x->d_ncells = xh[i].d_ncells; x->d_nmerge = xh[i].d_nmerge;
-        }
-        mrp_pool_set_tag(2); if (rc == MRP_OK) parallel_for(n_items, level_finish, items); mrp_pool_set_tag(0);
+        for (int64_t i = 0; i < n_x && rc == MRP_OK; i++) { xb[i].x->seg = xh[i].seg; xb[i].x->col0 = xh[i].col0; }
+        mrp_pool_set_tag(2); if (rc == MRP_OK) mrp_pool_run(n_items, n_items > 4096 ? 16 : 1, level_finish, items); mrp_pool_set_tag(0);
         for (int64_t i = 0; i < n_items; i++) t->a[items[i].node].path = items[i].res;
         const double t1 = now_ms();
         /* the wait for level h - 1, then level h goes to the device */
@@ -1883,8 +1807,8 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
         level_run_settle(&prev, rc == MRP_OK);
         /* while the device works: drop the parents' shadows */
         const double t2 = now_ms();
-        mrp_pool_set_tag(3); parallel_for(n_items, level_drop_garbage, items); mrp_pool_set_tag(0);
-        T_ADD(4, t2);
+        mrp_pool_set_tag(3); mrp_pool_run(n_items, n_items > 4096 ? 16 : 1, level_drop_garbage, items); mrp_pool_set_tag(0);
+        T_ADD(3, t2);
         g_t_prepare += t1 - t0; g_t_level += now_ms() - t1;
         if (getenv("MRP_TIMING"))
             fprintf(stderr, "    host level %d: prepare %.2f ms, gather %.2f, stage %.2f, sort %.2f | launch (waits for the level before) %.2f | settle+garbage %.2f\n",
@@ -1906,40 +1830,49 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
 
 /* resident shadow -> ordinary flat hmm on the host; phase 0 queues the copies, phase 1 (after
  * mrp_engine_sync) unpacks them */
-typedef struct { uint64_t *part; uint32_t *np; } r_staging;
-static int r_download_begin(mrp_engine *e, mrp_hmm *h, r_staging *st) {
-    const int64_t K = hmm_K(h), n = K * h->stride;
+typedef struct { mrp_hmm *h; uint64_t *part; uint32_t *np; int32_t *n_cells, *n_merge; int32_t stride; } r_staging;
+static int r_download_begin(mrp_engine *e, const world *w, const rhmm *x, r_staging *st) {
     memset(st, 0, sizeof(*st));
-    if (h->leaf) return MRP_OK; /* a stRPHmm_construct hmm: nothing to fetch */
+    st->h = r_expand(w, x, 1);
+    if (!st->h) return MRP_ERR_ARG;
+    if (x->seg < 0) return MRP_OK; /* a stRPHmm_construct hmm: nothing to fetch */
+    const int64_t K = x->n_cols;
+    st->stride = mrp_engine_stride(e);
+    const int64_t n = K * st->stride;
+    const uint64_t *d_part; const uint32_t *d_np; const int32_t *d_nc, *d_nm;
+    int rc = mrp_engine_locate(e, x->seg, x->col0, &d_part, &d_np, &d_nc, &d_nm);
+    if (rc != MRP_OK) return rc;
     st->part = xmalloc(sizeof(uint64_t) * (size_t) n);
     st->np = xmalloc(sizeof(uint32_t) * (size_t) n);
-    int rc = mrp_engine_fetch(e, st->part, h->d_part, (int64_t) sizeof(uint64_t) * n);
-    if (rc == MRP_OK) rc = mrp_engine_fetch(e, st->np, h->d_np, (int64_t) sizeof(uint32_t) * n);
-    /* the per-column counts (capacity K in the shadow's arena) */
-    h->rc_cells.n = K; h->rc_merge.n = K;
-    if (rc == MRP_OK) rc = mrp_engine_fetch(e, h->rc_cells.a, h->d_ncells, (int64_t) sizeof(int32_t) * K);
-    if (rc == MRP_OK) rc = mrp_engine_fetch(e, h->rc_merge.a, h->d_nmerge, (int64_t) sizeof(int32_t) * K);
+    st->n_cells = xmalloc(sizeof(int32_t) * (size_t) K);
+    st->n_merge = xmalloc(sizeof(int32_t) * (size_t) K);
+    rc = mrp_engine_fetch(e, st->part, d_part, (int64_t) sizeof(uint64_t) * n);
+    if (rc == MRP_OK) rc = mrp_engine_fetch(e, st->np, d_np, (int64_t) sizeof(uint32_t) * n);
+    if (rc == MRP_OK) rc = mrp_engine_fetch(e, st->n_cells, d_nc, (int64_t) sizeof(int32_t) * K);
+    if (rc == MRP_OK) rc = mrp_engine_fetch(e, st->n_merge, d_nm, (int64_t) sizeof(int32_t) * K);
     return rc;
 }
-static void r_download_end(mrp_hmm *h, r_staging *st) {
+static void r_staging_free(r_staging *st) { free(st->part); free(st->np); free(st->n_cells); free(st->n_merge); memset(st, 0, sizeof(*st)); }
+static mrp_hmm *r_download_end(r_staging *st) {
+    mrp_hmm *h = st->h;
     const int64_t K = hmm_K(h);
     h->cell_off.n = 0; h->mcell_off.n = 0;
     VEC_PUSH(h->cell_off, 0);
     VEC_PUSH(h->mcell_off, 0);
-    if (h->leaf) { /* hmm.c:97-133 */
+    if (!st->part) { /* hmm.c:97-133 */
         hmm_add_cell(h, 1, 0);
         hmm_add_cell(h, 0, 0);
         VEC_PUSH(h->cell_off, h->part.n);
     } else {
         for (int64_t k = 0; k < K; k++) {
-            const int64_t o = k * h->stride;
-            for (int32_t i = 0; i < h->rc_cells.a[k]; i++) {
+            const int64_t o = k * st->stride;
+            for (int32_t i = 0; i < st->n_cells[k]; i++) {
                 hmm_add_cell(h, st->part[o + i], st->np[o + i] >> 16);
                 h->next.a[h->next.n - 1] = st->np[o + i] & 0xFFFFu;
             }
             VEC_PUSH(h->cell_off, h->part.n);
             if (k + 1 < K) {
-                for (int32_t m = 0; m < h->rc_merge.a[k]; m++) { VEC_PUSH(h->mfrom, 0); VEC_PUSH(h->mto, 0); }
+                for (int32_t m = 0; m < st->n_merge[k]; m++) { VEC_PUSH(h->mfrom, 0); VEC_PUSH(h->mto, 0); }
                 VEC_PUSH(h->mcell_off, h->mfrom.n);
             }
         }
@@ -1951,20 +1884,23 @@ static void r_download_end(mrp_hmm *h, r_staging *st) {
                 if (k > 0) h->mto.a[h->mcell_off.a[k - 1] + h->prev.a[c]] = h->part.a[c] & h->mask_to.a[k - 1];
             }
     }
-    free(st->part); free(st->np);
-    h->resident = 0;
-    h->d_part = NULL; h->d_np = NULL; h->d_ncells = NULL; h->d_nmerge = NULL;
+    st->h = NULL;
+    r_staging_free(st);
+    return h;
 }
-static int r_download_path(mrp_engine *e, hmm_vec *tp) {
+static int r_download_path(mrp_engine *e, const world *w, const r_hmm_vec *tp, mrp_hmm ***out) {
     r_staging *st = xcalloc((size_t) tp->n + 1, sizeof(*st));
+    mrp_hmm **res = xcalloc((size_t) tp->n + 1, sizeof(*res));
     int rc = MRP_OK;
-    for (int64_t i = 0; i < tp->n && rc == MRP_OK; i++) rc = r_download_begin(e, tp->a[i], &st[i]);
+    for (int64_t i = 0; i < tp->n && rc == MRP_OK; i++) rc = r_download_begin(e, w, tp->a[i], &st[i]);
     if (rc == MRP_OK) rc = mrp_engine_sync(e);
     for (int64_t i = 0; i < tp->n; i++) {
-        if (rc == MRP_OK) r_download_end(tp->a[i], &st[i]);
-        else { free(st[i].part); free(st[i].np); }
+        if (rc == MRP_OK) res[i] = r_download_end(&st[i]);
+        else { mrp_hmm_destroy(st[i].h); st[i].h = NULL; r_staging_free(&st[i]); }
     }
     free(st);
+    if (rc != MRP_OK) { free(res); res = NULL; }
+    *out = res;
     return rc;
 }
 
@@ -1979,19 +1915,18 @@ int mrp_get_rp_hmms_resident(mrp_context *ctx, const mrp_chunk *chunk, const mrp
     mrp_engine *e = NULL;
     rc = mrp_engine_create(ctx, params, &e);
     if (rc != MRP_OK) return rc;
+    rleaf *leaves = r_leaves_of_chunk(&w);
     rnode_vec tree = {0};
-    const int root = r_tree_of_reads(&tree, &w, e, read_index, n, params, NULL);
+    const int root = r_tree_of_reads(&tree, &w, leaves, read_index, n, params);
     rc = root < 0 ? MRP_ERR_ARG : r_run_tree(e, &tree, params, NULL);
     if (rc == MRP_OK && w.failed) rc = mrp_set_error(MRP_ERR_UNSUPPORTED, "device-resident merge: an hmm outside what the kernels handle (pair order / kept merge cells)");
-    if (rc == MRP_OK) rc = r_download_path(e, tree.a[root].path);
     if (rc == MRP_OK) {
-        hmm_vec *tp = tree.a[root].path;
-        tree.a[root].path = NULL;
-        *n_out = tp->n;
-        *hmms_out = tp->a ? tp->a : xmalloc(sizeof(mrp_hmm *));
-        free(tp);
+        mrp_hmm **res = NULL;
+        rc = r_download_path(e, &w, tree.a[root].path, &res);
+        if (rc == MRP_OK) { *n_out = tree.a[root].path->n; *hmms_out = res; }
     }
     r_free_tree(&tree);
+    free(leaves);
     mrp_engine_destroy(e);
     return rc;
 }
@@ -2003,12 +1938,12 @@ typedef struct {
     int32_t *discarded; int64_t nd;
     int root;            /* node of the joined tiling path (in the chunk's own tree, then in the run's tree) */
     rnode_vec tree;      /* the chunk's subtree while it is being set up */
-    mrp_hmm *hmm;        /* shadow of the fused final hmm */
+    rhmm *hmm;           /* shadow of the fused final hmm */
     int32_t *path;       /* traced-back cell per column */
     uint64_t *chosen;    /* and its partition */
     double fwd, bwd;
     int64_t final_index;
-    block_vec blocks;    /* leaf shadows */
+    rleaf *leaves;       /* leaf shadows of all reads of the chunk */
     int rc;
     char err[256];
 } many_state;
@@ -2035,10 +1970,11 @@ static void many_setup(int64_t c, void *arg) {
     m->rc = world_init(&m->w, ctl->ctx, ctl->chunks[c], ctl->reads[c], ctl->n_reads[c], NULL);
     if (m->rc == MRP_OK && ctl->n_reads[c] > 0) {
         const int64_t nr = ctl->n_reads[c];
+        m->leaves = r_leaves_of_chunk(&m->w);
         int32_t *filtered = xmalloc(sizeof(int32_t) * (size_t) nr);
         m->discarded = xmalloc(sizeof(int32_t) * (size_t) nr);
         int64_t nf;
-        r_filter_reads_by_coverage_depth(&m->w, ctl->params, filtered, &nf, m->discarded, &m->nd); /* :2699 */
+        r_filter_reads_by_coverage_depth(&m->w, m->leaves, ctl->params, filtered, &nf, m->discarded, &m->nd); /* :2699 */
         uint8_t *is_disc = xcalloc((size_t) nr, 1);
         for (int64_t i = 0; i < m->nd; i++) is_disc[m->discarded[i]] = 1;
         int32_t *fwd = xmalloc(sizeof(int32_t) * (size_t) nr), *rev = xmalloc(sizeof(int32_t) * (size_t) nr);
@@ -2047,8 +1983,8 @@ static void many_setup(int64_t c, void *arg) {
             if (is_disc[i]) continue;
             if (ctl->reads[c][i].forward_strand) fwd[nfwd++] = (int32_t) i; else rev[nrev++] = (int32_t) i;
         }
-        const int rf = r_tree_of_reads(&m->tree, &m->w, ctl->e, fwd, nfwd, ctl->pc, &m->blocks);   /* :2736 */
-        const int rr = rf < 0 ? -1 : r_tree_of_reads(&m->tree, &m->w, ctl->e, rev, nrev, ctl->pc, &m->blocks); /* :2740 */
+        const int rf = r_tree_of_reads(&m->tree, &m->w, m->leaves, fwd, nfwd, ctl->pc);   /* :2736 */
+        const int rr = rf < 0 ? -1 : r_tree_of_reads(&m->tree, &m->w, m->leaves, rev, nrev, ctl->pc); /* :2740 */
         if (rf < 0 || rr < 0) m->rc = MRP_ERR_ARG;
         else m->root = r_merge_node(&m->tree, &m->w, rf, rr);                         /* :2745 */
         free(filtered); free(is_disc); free(fwd); free(rev);
@@ -2056,35 +1992,22 @@ static void many_setup(int64_t c, void *arg) {
     if (m->rc != MRP_OK) snprintf(m->err, sizeof(m->err), "%s", mrp_last_error());
 }
 /* stRPHmm_fuse of the joined tiling path (hmm.c:283-372, gap columns :335-359) = its cross product with nothing:
- * the shadow of the final hmm and the descriptors the device builds it from */
+ * the shadow of the final hmm as the device builds it */
 static void many_final_shadow(int64_t c, void *arg) {
     many_ctl *ctl = arg;
     many_state *m = &ctl->st[c];
     if (m->root < 0 || m->rc != MRP_OK || m->w.failed) return;
-    hmm_vec *joined = ctl->tree->a[m->root].path;
+    r_hmm_vec *joined = ctl->tree->a[m->root].path;
     if (joined->n == 0) return;
     const int32_t S = joined->a[0]->ref_start, E = joined->a[joined->n - 1]->ref_start + joined->a[joined->n - 1]->ref_length;
-    piece_vec pa = {0}, pb = {0}, qa = {0}, qb = {0};
-    pieces_of_path(joined, S, E, &pa);
-    piece gap = {NULL, 0, S, E - S, CONN_NONE};
-    VEC_PUSH(pb, gap);
-    align_pieces(&pa, &pb, &qa, &qb);
-    hmm_vec nothing = {0};
-    xbuild xb = {0};
-    m->rc = r_cross_shadow(&m->w, &qa, &qb, joined, &nothing, S, E, &xb);
-    free(pa.a); free(pb.a); free(qa.a); free(qb.a);
-    if (m->rc != MRP_OK) { snprintf(m->err, sizeof(m->err), "%s", mrp_last_error()); return; }
-    m->hmm = xb.x;
-    const int64_t K = hmm_K(m->hmm);
+    r_hmm_vec nothing = {0};
+    m->rc = r_cross_build(&m->w, joined, &nothing, S, E, mrp_engine_stride(ctl->e), &m->hmm);
+    if (m->rc != MRP_OK) { m->hmm = NULL; snprintf(m->err, sizeof(m->err), "%s", mrp_last_error()); return; }
+    const int64_t K = m->hmm->n_cols;
     m->path = xmalloc(sizeof(int32_t) * (size_t) K);
     m->chosen = xmalloc(sizeof(uint64_t) * (size_t) K);
     mrp_xhmm *x = &ctl->xfinal[c];
-    x->chunk = m->w.chunk;
-    x->n_cols = (int32_t) K;
-    x->flags = ctl->final_flags;
-    x->cols = xb.cols;
-    x->col_ref_start = m->hmm->col_start.a; x->col_length = m->hmm->col_len.a; x->col_depth = m->hmm->col_depth.a;
-    x->col_read_off = m->hmm->read_off.a; x->read_byte_off = m->hmm->read_byte_off.a;
+    r_describe(&m->w, m->hmm, ctl->final_flags, x);
     x->n_cells = m->path;
     x->path_part = m->chosen;
     m->w.n_sweeps += 1; /* bubbleGraph.c:2749 */
@@ -2093,7 +2016,12 @@ static void many_finish(int64_t c, void *arg) {
     many_ctl *ctl = arg;
     many_state *m = &ctl->st[c];
     if (m->w.failed) ctl->out[c] = NULL; /* redone by the caller on the hashing path */
-    else if (m->hmm) finish_phase_parts(&m->w, m->hmm, m->chosen, m->fwd, m->bwd, ctl->params, m->discarded, m->nd, &ctl->out[c]);
+    else if (m->hmm) {
+        mrp_hmm *flat = r_expand(&m->w, m->hmm, 0);
+        if (!flat) { m->rc = MRP_ERR_ARG; snprintf(m->err, sizeof(m->err), "%s", mrp_last_error()); return; }
+        finish_phase_parts(&m->w, flat, m->chosen, m->fwd, m->bwd, ctl->params, m->discarded, m->nd, &ctl->out[c]);
+        mrp_hmm_destroy(flat);
+    }
     else ctl->out[c] = result_new(0, 0, ctl->n_reads[c]);
 }
 
@@ -2184,8 +2112,8 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
                         "final sweep %.1f, trace back + genome fragments %.1f\n", tt[1] - tt[0], tt[2] - tt[1], g_t_prepare, g_t_level,
                 tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4]);
     if (timing)
-        fprintf(stderr, "  prepare (summed over threads): components %.1f ms, tiling paths %.1f, pieces %.1f, cross shadow %.1f, destroy %.1f\n",
-                g_ns[0] * 1e-6, g_ns[1] * 1e-6, g_ns[2] * 1e-6, g_ns[3] * 1e-6, g_ns[4] * 1e-6);
+        fprintf(stderr, "  prepare (summed over threads): components %.1f ms, tiling paths %.1f, cross shadows %.1f, garbage %.1f\n",
+                g_ns[0] * 1e-6, g_ns[1] * 1e-6, g_ns[2] * 1e-6, g_ns[3] * 1e-6);
     if (stats) {
         mrp_engine_stats es;
         mrp_engine_get_stats(e, &es);
@@ -2196,9 +2124,9 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
         stats->device_ms = es.device_ms; stats->cross_ms = es.cross_ms; stats->sweep_ms = es.sweep_ms; stats->prune_ms = es.prune_ms;
     }
     const double t_clean = now_ms();
-    for (int64_t c = 0; c < n_chunks; c++) { mrp_hmm_destroy(st[c].hmm); free(st[c].discarded); free(st[c].tree.a); free(st[c].path); free(st[c].chosen); }
+    for (int64_t c = 0; c < n_chunks; c++) { rhmm_destroy(st[c].hmm); free(st[c].discarded); free(st[c].tree.a); free(st[c].path); free(st[c].chosen); }
     r_free_tree(&tree);
-    for (int64_t c = 0; c < n_chunks; c++) { for (int64_t i = 0; i < st[c].blocks.n; i++) free(st[c].blocks.a[i]); free(st[c].blocks.a); }
+    for (int64_t c = 0; c < n_chunks; c++) free(st[c].leaves);
     free(st);
     const double t_eng = now_ms();
     mrp_engine_destroy(e);
@@ -2207,6 +2135,7 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
                 now_ms() - t_eng, now_ms() - t_enter);
     return rc;
 }
+
 
 /* one concurrent batch of mrp_phase_reads_many: while its levels wait for the device, the other batch's host work runs */
 typedef struct {

@@ -44,34 +44,36 @@ void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void *), void *a
 /* ---- device-resident merge levels (mrp_engine.cpp), driven by the structural code of rphmm_host.c ---- */
 typedef struct mrp_engine mrp_engine;
 
-/* one column of a cross product to build on the device (one step of the aligned piece lists).  Nothing in it depends on a
- * forward/backward result: the number of cells of a parent column is not known when the level is described (the level that
- * prunes the parent may still be running), only WHERE it will be found in HBM. */
-typedef struct mrp_xcol {
-    const uint64_t *a_part, *b_part; /* device: cells of each side's column; NULL = gap column */
-    const uint32_t *a_np, *b_np;     /* device: next | prev << 16 of those cells */
-    const int32_t *a_ncells, *b_ncells; /* device: number of cells of each side's column; NULL = 1 (gap column) */
-    const int32_t *a_nmerge, *b_nmerge; /* device: merge cells of the parent's merge column after it (MRP_CONN_REAL connectors only) */
-    uint8_t d1, d2;                  /* depth per side */
-    uint8_t out_a, out_b;            /* connector kinds (MRP_CONN_*) */
-    uint8_t out_a_paired, out_b_paired; /* connector mask != 0: its merge cells come in complement pairs */
-    uint8_t pad[2];
-    uint64_t mask_from, mask_to;     /* masks of the cross product's merge column after this column */
-} mrp_xcol;
+/* One hmm of a tiling path, as a parent of a cross product.  Nothing in it depends on a forward/backward result: the hmm
+ * is named by WHERE its pruned form will be (segment = the level that produces it, first column), which is known as soon as
+ * that level has been staged -- the level itself may still be running. */
+typedef struct mrp_xpar {
+    int32_t start, end;   /* site interval [refStart, refStart + refLength) */
+    int32_t n_cols;
+    int32_t seg;          /* segment of the engine that holds the hmm; -1: a stRPHmm_construct hmm (one column {1, 0}) */
+    int64_t col0;         /* its first column in that segment; seg < 0: offset of the read's profile bytes in the chunk's pool */
+} mrp_xpar;
 
-/* one cross product hmm of a level */
+/* One cross product hmm of a level: stRPHmm_fuse of two tiling paths, stRPHmm_alignColumns and
+ * stRPHmm_createCrossProductOfTwoAlignedHmm (hmm.c:283-750) described by the two paths and the merged column boundaries.
+ * Per column the host supplies 8 bytes; the columns' parents, connectors, reads and allele slots are derived on the device
+ * (mrp_structure_kernel). */
 typedef struct mrp_xhmm {
     const mrp_chunk *chunk;
-    int32_t n_cols;
     uint32_t flags;
-    const mrp_xcol *cols;
-    const int32_t *col_ref_start, *col_length, *col_depth;
-    const int64_t *col_read_off;  /* [n_cols + 1] */
-    const int64_t *read_byte_off;
-    /* results, known as soon as the level is staged: where the pruned hmm will be (resident layout, device) */
-    uint64_t *d_part;
-    uint32_t *d_np;
-    int32_t *d_ncells, *d_nmerge; /* [n_cols] cells per column / merge cells of the merge column after it */
+    int32_t ref_start, ref_end;
+    int32_t n_cols, n_a, n_b;     /* columns; hmms of tiling path A and B (n_b = 0: stRPHmm_fuse of path A alone) */
+    const mrp_xpar *par;          /* [n_a + n_b] path A then path B, each in reference order */
+    const int32_t *col_start;     /* [n_cols] first site of every column (the last one ends at ref_end) */
+    const int32_t *col_read_off;  /* [n_cols + 1] prefix sums of the column depths */
+    /* static bounds (mrp_side_bound per side and column): launch classes and range checks; the exact sizes are computed on
+     * the device from the parents' counts */
+    int64_t bound_cells, bound_merge;
+    int64_t depth_sites;          /* sum over the columns of depth x sites */
+    int32_t bound_max_cells, bound_max_merge;
+    /* results, known as soon as the level is staged: where the pruned hmm will be */
+    int32_t seg;
+    int64_t col0;
     /* mrp_engine_final instead: n_cells[k] = index of the traced-back cell of column k, path_part[k] its
      * partition (host, caller-allocated), and the totals of the final sweep */
     int32_t *n_cells;
@@ -81,6 +83,10 @@ typedef struct mrp_xhmm {
      * the chunk it belongs to has to be redone on the hashing path */
     int32_t err;
 } mrp_xhmm;
+
+/* static upper bound of the cells one side contributes to a cross product column: a pruned column has at most S cells,
+ * and never more than the bipartitions of its reads */
+static inline int64_t mrp_side_bound(int depth, int S) { return depth >= 7 ? S : (((int64_t) 1 << depth) < S ? ((int64_t) 1 << depth) : S); }
 
 typedef struct mrp_engine_stats {
     int64_t levels, hmms, columns, cells, merge_cells;
@@ -93,11 +99,12 @@ typedef struct mrp_engine_stats {
 int mrp_engine_create(mrp_context *ctx, const mrp_params *params, mrp_engine **out);
 void mrp_engine_destroy(mrp_engine *e);
 int32_t mrp_engine_stride(const mrp_engine *e);
-/* the column every stRPHmm_construct hmm consists of (hmm.c:97-133): cells {1, 0}, and its cell count (2) */
-void mrp_engine_leaf(const mrp_engine *e, const uint64_t **part, const uint32_t **np, const int32_t **n_cells);
+/* device arrays of the hmm that starts at column col0 of segment seg (fixed-stride resident layout, mrp_engine.h) */
+int mrp_engine_locate(const mrp_engine *e, int32_t seg, int64_t col0, const uint64_t **part, const uint32_t **np,
+                      const int32_t **n_cells, const int32_t **n_merge);
 /* A level = cross product -> forward/backward -> prune for n independent hmms, in three steps:
- *   stage   host only (description built and uploaded; may run while the level before is still on the device); fills
- *           d_part / d_np / d_ncells / d_nmerge of every x[i];
+ *   stage   host only (description built and uploaded, column structure derived on the copy stream; may run while the level
+ *           before is still on the device); fills seg / col0 of every x[i];
  *   launch  waits for the level before (its x[i].err are set then), lays the level out on the device and queues its kernels;
  *   end     waits for the level and sets its x[i].err.
  * x must stay valid until the level has ended. */
