@@ -134,6 +134,7 @@ void mrp_context_destroy(mrp_context *ctx) {
     for (auto &e : ctx->ev)
         if (e) (void) hipEventDestroy(e);
     if (ctx->fork) (void) hipEventDestroy(ctx->fork);
+    if (ctx->block_ev) (void) hipEventDestroy(ctx->block_ev);
     for (auto &e : ctx->join)
         if (e) (void) hipEventDestroy(e);
     for (auto &st : ctx->aux)

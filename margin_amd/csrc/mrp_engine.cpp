@@ -144,8 +144,8 @@ static void level_retire(mrp_engine *e, mrp_engine_level_state *L) {
     if (!L) return;
     mrp_context *ctx = e->ctx;
     (void) hipSetDevice(ctx->device);
-    (void) hipStreamSynchronize(ctx->stream); /* before the buffers go back to the pool */
-    (void) hipStreamSynchronize(ctx->pre);
+    (void) ctx->wait_stream(ctx->stream); /* before the buffers go back to the pool */
+    (void) ctx->wait_stream(ctx->pre);
     if (L->b) {
         L->b->recycle();
         e->spare.push_back(L->b);
@@ -278,7 +278,7 @@ int mrp_engine_fetch(mrp_engine *e, void *dst, const void *src_dev, int64_t byte
 
 int mrp_engine_sync(mrp_engine *e) {
     ENG_TRY(hipSetDevice(e->ctx->device));
-    ENG_TRY(hipStreamSynchronize(e->ctx->stream));
+    ENG_TRY(e->ctx->wait_stream(e->ctx->stream));
     return MRP_OK;
 }
 
@@ -552,7 +552,7 @@ static int level_finish(mrp_engine *e) {
     mrp_context *ctx = e->ctx;
     int rc = MRP_OK;
     hipError_t se = hipSetDevice(ctx->device);
-    if (se == hipSuccess) se = hipStreamSynchronize(ctx->stream);
+    if (se == hipSuccess) se = ctx->wait_stream(ctx->stream);
     if (se != hipSuccess) rc = mrp_set_error(MRP_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(se));
     if (rc == MRP_OK && getenv("MRP_TIMING")) {
         fprintf(stderr, "  level: %lld hmms %lld cols %lld cells: staged in %.1f ms, launch (layout + totals + queue) %.1f ms\n", (long long) Lp->n,
@@ -626,7 +626,7 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
     /* the one host wait of a level: it also ends the level before (its error flags are in) */
     int rc = level_finish(e);
     if (rc != MRP_OK) return rc;
-    ENG_TRY(hipStreamSynchronize(s));
+    ENG_TRY(ctx->wait_stream(s));
     ctx->pool.reclaim(); /* the blocks of the level before can be reused */
     const int64_t cells = L->totals[0], merge = L->totals[1], tiles_fast = L->totals[2], tiles = L->totals[2] + L->totals[3];
     b->n_cells_total = cells; b->n_merge = merge; b->n_slots = L->n_slots; b->n_tiles_dev = tiles; b->n_fast_tiles = tiles_fast;

@@ -176,6 +176,19 @@ struct mrp_context {
     hipStream_t pre = nullptr; /* copy stream: uploads of a staged level of the resident engine, beside the kernels of the level before */
     hipEvent_t last_emission = nullptr; /* end of the emission kernel of the most recent launch on this context (owned by its batch) */
     hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
+    /* Waiting for a stream without burning a core: hipStreamSynchronize polls (a batch thread of mrp_phase_reads_many spent
+     * 85 % of a call spinning in it); an event created with hipEventBlockingSync makes the waiter sleep until the
+     * interrupt.  One event per context: a context is driven by one host thread at a time. */
+    hipEvent_t block_ev = nullptr;
+    hipError_t wait_stream(hipStream_t s) {
+        if (!block_ev) {
+            hipError_t e = hipEventCreateWithFlags(&block_ev, hipEventBlockingSync | hipEventDisableTiming);
+            if (e != hipSuccess) { block_ev = nullptr; return hipStreamSynchronize(s); }
+        }
+        hipError_t e = hipEventRecord(block_ev, s);
+        if (e != hipSuccess) return e;
+        return hipEventSynchronize(block_ev);
+    }
     DevPool pool;
     int phase_groups = 0; /* concurrent batches of mrp_phase_reads_many (mrp_context_set_phase_groups); 0: chosen by batch size */
     std::vector<mrp_context *> siblings; /* further contexts on the same device (concurrent batches of mrp_phase_reads_many) */

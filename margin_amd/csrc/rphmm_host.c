@@ -1089,7 +1089,8 @@ static mrp_phase_result *result_new(int32_t ref_start, int32_t length, int64_t n
     r->reads_supporting_haplotype1 = xcalloc(n, sizeof(uint64_t)); r->reads_supporting_haplotype2 = xcalloc(n, sizeof(uint64_t));
     r->genotype_probs = xcalloc(n, sizeof(float)); r->haplotype_probs1 = xcalloc(n, sizeof(float));
     r->haplotype_probs2 = xcalloc(n, sizeof(float));
-    r->reads1 = xcalloc((size_t) n_reads + 1, sizeof(int32_t)); r->reads2 = xcalloc((size_t) n_reads + 1, sizeof(int32_t));
+    /* (a read that inconsistent columns put on both sides sits in both lists and may be moved into a list that already holds it) */
+    r->reads1 = xcalloc(2 * (size_t) n_reads + 2, sizeof(int32_t)); r->reads2 = xcalloc(2 * (size_t) n_reads + 2, sizeof(int32_t));
     return r;
 }
 void mrp_phase_result_destroy(mrp_phase_result *r) {
@@ -1102,24 +1103,32 @@ void mrp_phase_result_destroy(mrp_phase_result *r) {
 /* fillInPredictedGenome emissions.c:323-343 for column k with the given partition.  The allele
  * costs are the same integers getLogProbOfAllele returns (sum of the bytes of the reads in the
  * partition), summed directly. */
-static void fill_in_predicted_genome(const world *w, mrp_phase_result *g, const mrp_hmm *h, int64_t k, uint64_t partition) {
+static void fill_in_predicted_genome(const world *w, mrp_phase_result *g, const mrp_hmm *h, int64_t k, uint64_t partition, uint64_t *scratch) {
     const int32_t depth = h->col_depth.a[k];
     const int64_t *off = h->read_byte_off.a + h->read_off.a[k];
     const int32_t start = h->col_start.a[k];
     const uint32_t first_allele = w->ch.allele_offset[start];
-    uint64_t *h1 = xmalloc(sizeof(uint64_t) * 4 * (size_t) w->max_alleles), *h2 = h1 + w->max_alleles, *a1 = h2 + w->max_alleles,
-             *a2 = a1 + w->max_alleles;
+    uint64_t *h1 = scratch, *h2 = h1 + w->max_alleles, *a1 = h2 + w->max_alleles, *a2 = a1 + w->max_alleles; /* [4 * max_alleles] */
     for (int32_t s = 0; s < h->col_len.a[k]; s++) {
         const int32_t site = start + s;
         const uint32_t A = w->ch.allele_number[site], so = w->ch.allele_offset[site] - first_allele;
         const uint16_t *sub = w->ch.sub + w->ch.sub_offset[site], *prior = w->ch.prior + w->ch.allele_offset[site];
-        for (uint32_t a = 0; a < A; a++) {
-            uint64_t x = 0, y = 0;
+        if (A == 2) { /* the common case: both bytes of a read together, no branch on the partition bit */
+            uint64_t t0 = 0, t1 = 0, x0 = 0, x1 = 0; /* totals over the column's reads, and over those in the partition */
             for (int32_t i = 0; i < depth; i++) {
-                const uint64_t v = w->ch.pool[off[i] + so + a];
-                if ((partition >> i) & 1) x += v; else y += v;
+                const uint8_t *b = w->ch.pool + off[i] + so;
+                const uint64_t in = 0 - ((partition >> i) & 1);
+                t0 += b[0]; t1 += b[1];
+                x0 += b[0] & in; x1 += b[1] & in;
             }
-            h1[a] = x; h2[a] = y;
+            h1[0] = x0; h1[1] = x1; h2[0] = t0 - x0; h2[1] = t1 - x1;
+        } else {
+            for (uint32_t a = 0; a < A; a++) { h1[a] = 0; h2[a] = 0; }
+            for (int32_t i = 0; i < depth; i++) {
+                const uint8_t *b = w->ch.pool + off[i] + so;
+                uint64_t *dst = ((partition >> i) & 1) ? h1 : h2;
+                for (uint32_t a = 0; a < A; a++) dst[a] += b[a];
+            }
         }
         for (uint32_t i = 0; i < A; i++) { /* ancestorHapProbabilities emissions.c:156-172 */
             uint64_t x = h1[0] + sub[i * A], y = h2[0] + sub[i * A];
@@ -1150,21 +1159,25 @@ static void fill_in_predicted_genome(const world *w, mrp_phase_result *g, const 
         g->reads_supporting_haplotype1[q] = (uint64_t) __builtin_popcountll(partition);
         g->reads_supporting_haplotype2[q] = (uint64_t) depth - (uint64_t) __builtin_popcountll(partition);
     }
-    free(h1);
 }
-/* getLogProbOfReadGivenHaplotype genomeFragment.c:71-89 */
-static double read_log_prob(const world *w, const uint64_t *hap, int32_t start, int32_t length, int32_t read) {
+/* getLogProbOfReadGivenHaplotype genomeFragment.c:71-89, for both haplotypes in one walk over the read's sites: *x for hap1,
+ * *y for hap2 (each sum in site order, then divided by PROFILE_PROB_SCALAR inc/margin.h:189) */
+static void read_log_prob2(const world *w, const uint64_t *hap1, const uint64_t *hap2, int32_t start, int32_t length, int32_t read, double *x, double *y) {
     const mrp_read *r = &w->reads[read];
-    double total = 0.0;
+    double t1 = 0.0, t2 = 0.0;
     const uint32_t first = w->ch.allele_offset[r->ref_start];
-    for (int32_t i = 0; i < r->length; i++) {
-        const int64_t j = (int64_t) i + r->ref_start - start;
-        if (j >= 0 && j < length) {
-            const uint64_t allele = hap[j];
-            total -= w->ch.pool[r->pool_offset + (w->ch.allele_offset[i + r->ref_start] - first) + allele];
-        }
+    int32_t lo = start - r->ref_start, hi = start + length - r->ref_start;
+    if (lo < 0) lo = 0;
+    if (hi > r->length) hi = r->length;
+    const uint8_t *pool = w->ch.pool + r->pool_offset;
+    const uint32_t *ao = w->ch.allele_offset + r->ref_start;
+    const uint64_t *a1 = hap1 + (r->ref_start - start), *a2 = hap2 + (r->ref_start - start);
+    for (int32_t i = lo; i < hi; i++) {
+        const uint32_t o = ao[i] - first;
+        t1 -= pool[o + a1[i]];
+        t2 -= pool[o + a2[i]];
     }
-    return total / 30.0; /* PROFILE_PROB_SCALAR inc/margin.h:189 */
+    *x = t1 / 30.0; *y = t2 / 30.0;
 }
 
 /* stGenomeFragment_construct genomeFragment.c:40-69 (+ hmm.c:221-248) then
@@ -1176,6 +1189,7 @@ static void genome_fragment(const world *w, mrp_phase_result *g, const mrp_hmm *
      * (a read can be put in both sets by inconsistent columns; set semantics as in the reference) */
     uint8_t *in1 = xcalloc((size_t) w->n_reads + 1, 1), *in2 = xcalloc((size_t) w->n_reads + 1, 1);
     uint64_t *p = xmalloc(sizeof(uint64_t) * (size_t) K);
+    uint64_t *scratch = xmalloc(sizeof(uint64_t) * 4 * (size_t) w->max_alleles);
     for (int64_t k = 0; k < K; k++) {
         p[k] = chosen[k]; /* partition of the traced-back cell of column k */
         const int32_t *cr = h->col_reads.a + h->read_off.a[k];
@@ -1183,23 +1197,25 @@ static void genome_fragment(const world *w, mrp_phase_result *g, const mrp_hmm *
             if ((p[k] >> i) & 1) { if (!in1[cr[i]]) { in1[cr[i]] = 1; g->reads1[g->n_reads1++] = cr[i]; } }
             else { if (!in2[cr[i]]) { in2[cr[i]] = 1; g->reads2[g->n_reads2++] = cr[i]; } }
         }
-        fill_in_predicted_genome(w, g, h, k, p[k]);
+        fill_in_predicted_genome(w, g, h, k, p[k], scratch);
     }
     int64_t iteration = 0;
     uint8_t *m12 = xcalloc((size_t) w->n_reads + 1, 1), *m21 = xcalloc((size_t) w->n_reads + 1, 1);
-    int32_t *n1 = xmalloc(sizeof(int32_t) * (size_t) (w->n_reads + 1)), *n2 = xmalloc(sizeof(int32_t) * (size_t) (w->n_reads + 1));
+    int32_t *n1 = xmalloc(sizeof(int32_t) * (size_t) (2 * w->n_reads + 2)), *n2 = xmalloc(sizeof(int32_t) * (size_t) (2 * w->n_reads + 2));
     while (iteration++ < max_iterations) {
         int64_t c12 = 0, c21 = 0;
         memset(m12, 0, (size_t) w->n_reads + 1); memset(m21, 0, (size_t) w->n_reads + 1);
         for (int64_t i = 0; i < g->n_reads1; i++) { /* :126-151 */
             const int32_t r = g->reads1[i];
-            if (read_log_prob(w, g->haplotype_string1, g->ref_start, g->length, r) <
-                read_log_prob(w, g->haplotype_string2, g->ref_start, g->length, r)) { m12[r] = 1; c12++; }
+            double x, y;
+            read_log_prob2(w, g->haplotype_string1, g->haplotype_string2, g->ref_start, g->length, r, &x, &y);
+            if (x < y) { m12[r] = 1; c12++; }
         }
         for (int64_t i = 0; i < g->n_reads2; i++) {
             const int32_t r = g->reads2[i];
-            if (read_log_prob(w, g->haplotype_string2, g->ref_start, g->length, r) <
-                read_log_prob(w, g->haplotype_string1, g->ref_start, g->length, r)) { m21[r] = 1; c21++; }
+            double x, y;
+            read_log_prob2(w, g->haplotype_string1, g->haplotype_string2, g->ref_start, g->length, r, &x, &y);
+            if (y < x) { m21[r] = 1; c21++; }
         }
         if (c12 + c21 == 0) break;
         int64_t a = 0, b = 0;
@@ -1213,10 +1229,10 @@ static void genome_fragment(const world *w, mrp_phase_result *g, const mrp_hmm *
             const int32_t *cr = h->col_reads.a + h->read_off.a[k];
             for (int32_t i = 0; i < h->col_depth.a[k]; i++) if (m12[cr[i]]) p[k] ^= (uint64_t) 1 << i;
             for (int32_t i = 0; i < h->col_depth.a[k]; i++) if (m21[cr[i]]) p[k] ^= (uint64_t) 1 << i;
-            fill_in_predicted_genome(w, g, h, k, p[k]);
+            fill_in_predicted_genome(w, g, h, k, p[k], scratch);
         }
     }
-    free(in1); free(in2); free(p); free(m12); free(m21); free(n1); free(n2);
+    free(in1); free(in2); free(p); free(m12); free(m21); free(n1); free(n2); free(scratch);
 }
 
 /* filterReadsByCoverageDepth coordination.c:443-488 */
@@ -1253,8 +1269,8 @@ static void finish_phase_parts(world *w, const mrp_hmm *hmm, const uint64_t *cho
     mrp_phase_result *g = result_new(hmm->ref_start, hmm->ref_length, w->n_reads);
     genome_fragment(w, g, hmm, chosen, params->rounds_of_iterative_refinement); /* :2761-2764 */
     for (int64_t i = 0; i < nd; i++) { /* :2772-2779 */
-        const double x = read_log_prob(w, g->haplotype_string1, g->ref_start, g->length, discarded[i]);
-        const double y = read_log_prob(w, g->haplotype_string2, g->ref_start, g->length, discarded[i]);
+        double x, y;
+        read_log_prob2(w, g->haplotype_string1, g->haplotype_string2, g->ref_start, g->length, discarded[i], &x, &y);
         if (x < y) g->reads2[g->n_reads2++] = discarded[i]; else g->reads1[g->n_reads1++] = discarded[i];
     }
     g->hmm_forward = fwd; g->hmm_backward = bwd; g->n_sweeps = w->n_sweeps;
@@ -1387,13 +1403,9 @@ static rleaf *r_leaves_of_chunk(const world *w) {
 }
 
 /* filterReadsByCoverageDepth coordination.c:443-488 on the chunk's leaves */
-static void r_filter_reads_by_coverage_depth(const world *w, rleaf *leaves, const mrp_params *params, int32_t *filtered, int64_t *nf,
+static void r_filter_reads_by_coverage_depth(const world *w, rhmm *const *sorted, const mrp_params *params, int32_t *filtered, int64_t *nf,
                                              int32_t *discarded, int64_t *nd) {
-    const int64_t n = w->n_reads;
-    rhmm **hmms = xmalloc(sizeof(*hmms) * (size_t) (n + 1));
-    for (int64_t i = 0; i < n; i++) hmms[i] = &leaves[i].h;
-    r_path_vec paths = r_tiling_paths_from(w, hmms, n);
-    free(hmms);
+    r_path_vec paths = r_tiling_paths_sorted(sorted, w->n_reads);
     keyed *a = xmalloc(sizeof(keyed) * (size_t) (paths.n + 1)), *t = xmalloc(sizeof(keyed) * (size_t) (paths.n + 1));
     for (int64_t i = 0; i < paths.n; i++) {
         int64_t total = 0;
@@ -1662,12 +1674,10 @@ static int r_tree_of_paths(rnode_vec *t, const world *w, r_hmm_vec **paths, int6
     const int r = r_tree_of_paths(t, w, paths + n / 2, n - n / 2);
     return r_merge_node(t, w, l, r);
 }
-/* getRPHmms coordination.c:490-516 as a subtree over the chunk's leaves; returns the root node or -1 */
-static int r_tree_of_reads(rnode_vec *t, const world *w, rleaf *leaves, const int32_t *read_index, int64_t n, const mrp_params *params) {
-    rhmm **hmms = xmalloc(sizeof(*hmms) * (size_t) (n + 1));
-    for (int64_t i = 0; i < n; i++) hmms[i] = &leaves[read_index[i]].h;
-    r_path_vec paths = r_tiling_paths_from(w, hmms, n);
-    free(hmms);
+/* getRPHmms coordination.c:490-516 as a subtree over leaves given in stRPHmm_cmpFn order (a chunk's leaves are sorted once:
+ * the coverage filter and both strands walk the same order); returns the root node or -1 */
+static int r_tree_of_sorted(rnode_vec *t, const world *w, rhmm *const *hmms, int64_t n, const mrp_params *params) {
+    r_path_vec paths = r_tiling_paths_sorted(hmms, n);
     if (paths.n > MRP_MAX_READ_PARTITIONING_DEPTH || paths.n > params->max_coverage_depth) { /* :500-504 */
         const int64_t np = paths.n;
         for (int64_t i = 0; i < paths.n; i++) r_free_path(paths.a[i], 0);
@@ -1774,7 +1784,7 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
         n_items = 0;
         for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > 0 && lvl[i] == h && !t->a[i].w->failed) { items[n_items].t = t; items[n_items].node = i; items[n_items].stride = stride; n_items++; }
         /* the merges of a level touch disjoint nodes: structure in parallel, device work as one batch */
-        mrp_pool_set_tag(1); mrp_pool_run(n_items, n_items > 4096 ? 16 : 1, level_prepare, items); mrp_pool_set_tag(0);
+        mrp_pool_set_tag(1); mrp_pool_run(n_items, n_items > 512 ? (n_items > 16384 ? 64 : n_items / 256) : 1, level_prepare, items); mrp_pool_set_tag(0);
         const double ta = now_ms();
         int64_t n_x = 0;
         for (int64_t i = 0; i < n_items; i++) {
@@ -1798,7 +1808,7 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
         const double tc = now_ms();
         /* where the level's results will be is known from here on: the next level can be described against them */
         for (int64_t i = 0; i < n_x && rc == MRP_OK; i++) { xb[i].x->seg = xh[i].seg; xb[i].x->col0 = xh[i].col0; }
-        mrp_pool_set_tag(2); if (rc == MRP_OK) mrp_pool_run(n_items, n_items > 4096 ? 16 : 1, level_finish, items); mrp_pool_set_tag(0);
+        mrp_pool_set_tag(2); if (rc == MRP_OK) mrp_pool_run(n_items, n_items > 512 ? (n_items > 16384 ? 64 : n_items / 256) : 1, level_finish, items); mrp_pool_set_tag(0);
         for (int64_t i = 0; i < n_items; i++) t->a[items[i].node].path = items[i].res;
         const double t1 = now_ms();
         /* the wait for level h - 1, then level h goes to the device */
@@ -1807,7 +1817,7 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
         level_run_settle(&prev, rc == MRP_OK);
         /* while the device works: drop the parents' shadows */
         const double t2 = now_ms();
-        mrp_pool_set_tag(3); mrp_pool_run(n_items, n_items > 4096 ? 16 : 1, level_drop_garbage, items); mrp_pool_set_tag(0);
+        mrp_pool_set_tag(3); mrp_pool_run(n_items, n_items > 512 ? (n_items > 16384 ? 64 : n_items / 256) : 1, level_drop_garbage, items); mrp_pool_set_tag(0);
         T_ADD(3, t2);
         g_t_prepare += t1 - t0; g_t_level += now_ms() - t1;
         if (getenv("MRP_TIMING"))
@@ -1917,7 +1927,11 @@ int mrp_get_rp_hmms_resident(mrp_context *ctx, const mrp_chunk *chunk, const mrp
     if (rc != MRP_OK) return rc;
     rleaf *leaves = r_leaves_of_chunk(&w);
     rnode_vec tree = {0};
-    const int root = r_tree_of_reads(&tree, &w, leaves, read_index, n, params);
+    rhmm **picked = xmalloc(sizeof(*picked) * (size_t) (n + 1));
+    for (int64_t i = 0; i < n; i++) picked[i] = &leaves[read_index[i]].h;
+    r_sort_hmms(&w, picked, n);
+    const int root = r_tree_of_sorted(&tree, &w, picked, n, params);
+    free(picked);
     rc = root < 0 ? MRP_ERR_ARG : r_run_tree(e, &tree, params, NULL);
     if (rc == MRP_OK && w.failed) rc = mrp_set_error(MRP_ERR_UNSUPPORTED, "device-resident merge: an hmm outside what the kernels handle (pair order / kept merge cells)");
     if (rc == MRP_OK) {
@@ -1971,23 +1985,29 @@ static void many_setup(int64_t c, void *arg) {
     if (m->rc == MRP_OK && ctl->n_reads[c] > 0) {
         const int64_t nr = ctl->n_reads[c];
         m->leaves = r_leaves_of_chunk(&m->w);
+        /* every getTilingPaths of the chunk (coverage filter, either strand) starts by sorting its hmms with stRPHmm_cmpFn
+         * (coordination.c:186-190): the leaves are sorted once, subsets keep the order */
+        rhmm **sorted = xmalloc(sizeof(*sorted) * (size_t) (nr + 1));
+        for (int64_t i = 0; i < nr; i++) sorted[i] = &m->leaves[i].h;
+        r_sort_hmms(&m->w, sorted, nr);
         int32_t *filtered = xmalloc(sizeof(int32_t) * (size_t) nr);
         m->discarded = xmalloc(sizeof(int32_t) * (size_t) nr);
         int64_t nf;
-        r_filter_reads_by_coverage_depth(&m->w, m->leaves, ctl->params, filtered, &nf, m->discarded, &m->nd); /* :2699 */
+        r_filter_reads_by_coverage_depth(&m->w, sorted, ctl->params, filtered, &nf, m->discarded, &m->nd); /* :2699 */
         uint8_t *is_disc = xcalloc((size_t) nr, 1);
         for (int64_t i = 0; i < m->nd; i++) is_disc[m->discarded[i]] = 1;
-        int32_t *fwd = xmalloc(sizeof(int32_t) * (size_t) nr), *rev = xmalloc(sizeof(int32_t) * (size_t) nr);
+        rhmm **fwd = xmalloc(sizeof(*fwd) * (size_t) (nr + 1)), **rev = xmalloc(sizeof(*rev) * (size_t) (nr + 1));
         int64_t nfwd = 0, nrev = 0;
         for (int64_t i = 0; i < nr; i++) { /* :2705-2716 */
-            if (is_disc[i]) continue;
-            if (ctl->reads[c][i].forward_strand) fwd[nfwd++] = (int32_t) i; else rev[nrev++] = (int32_t) i;
+            const int32_t rd = sorted[i]->first_read;
+            if (is_disc[rd]) continue;
+            if (ctl->reads[c][rd].forward_strand) fwd[nfwd++] = sorted[i]; else rev[nrev++] = sorted[i];
         }
-        const int rf = r_tree_of_reads(&m->tree, &m->w, m->leaves, fwd, nfwd, ctl->pc);   /* :2736 */
-        const int rr = rf < 0 ? -1 : r_tree_of_reads(&m->tree, &m->w, m->leaves, rev, nrev, ctl->pc); /* :2740 */
+        const int rf = r_tree_of_sorted(&m->tree, &m->w, fwd, nfwd, ctl->pc);   /* :2736 */
+        const int rr = rf < 0 ? -1 : r_tree_of_sorted(&m->tree, &m->w, rev, nrev, ctl->pc); /* :2740 */
         if (rf < 0 || rr < 0) m->rc = MRP_ERR_ARG;
         else m->root = r_merge_node(&m->tree, &m->w, rf, rr);                         /* :2745 */
-        free(filtered); free(is_disc); free(fwd); free(rev);
+        free(filtered); free(is_disc); free(fwd); free(rev); free(sorted);
     }
     if (m->rc != MRP_OK) snprintf(m->err, sizeof(m->err), "%s", mrp_last_error());
 }
