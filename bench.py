@@ -16,6 +16,7 @@ Beside it, as evidence for the kernels (not as the headline):
                 `traffic` = HBM bytes of that launch from the committed rocprofv3 PMC pass (profiles/r02/traffic.json);
                 `path` = the algorithmic bytes of all sweeps over the wall time of the real step.
   queue         the same chunks through the host work queue from HOST memory (upload included, PCIe-inclusive rate)
+  shapes        the chunk shapes of BASELINE.json configs[2] (640 x ~130 sites) and configs[4] (HiFi, 2-4 alleles) through the same call
   alignment     the pair-HMM kernel family that produces the profile bytes
   cpu_baseline  the oracle (CPU restatement of the reference) on a bounded sample of the same chunks, N = 1 only
 
@@ -55,7 +56,9 @@ def parse_args():
     ap.add_argument("--no-roofline", action="store_true", help="skip the kernel replay leg (it needs ~20 s of host work to record the sweeps)")
     ap.add_argument("--roofline-steps", type=int, default=20)
     ap.add_argument("--roofline-chunks", type=int, default=96, help="chunks whose sweeps the kernel replay leg records (host work: ~0.2 s per chunk)")
-    ap.add_argument("--queue-runs", type=int, default=2, help="runs of the host-memory work queue leg (0: skip)")
+    ap.add_argument("--queue-runs", type=int, default=3, help="runs of the host-memory work queue leg (0: skip)")
+    ap.add_argument("--queue-batch", type=int, default=0, help="chunks per batch of the queue leg (0: the library's default, 96)")
+    ap.add_argument("--shape-runs", type=int, default=3, help="runs of the configs[2] / configs[4] shape legs (0: skip)")
     ap.add_argument("--align-chunks", type=int, default=4, help="chunks whose read x allele pairs the alignment leg scores (0: skip)")
     ap.add_argument("--align-runs", type=int, default=3)
     ap.add_argument("--sum-chunks", type=int, default=16, help="chunks whose sweeps the log-sum-exp leg replays (0: skip)")
@@ -104,8 +107,9 @@ def main():
     n_chunks = args.chunks * (n_gpus if single_process_multi else 1)
     cpu_share = max(1, (os.cpu_count() or 8) // max(1, world))
     n_threads = args.threads or min(16, cpu_share, n_chunks)
-    # the library's worker pool: this rank's share of the node's cores (16 per device it drives)
-    host_threads = max(1, min(16 * (n_gpus if single_process_multi else 1), cpu_share))
+    # the library's worker pool: this rank's share of the node's cores, at most 16 per device (a work queue gives every
+    # device its own pool of this size)
+    host_threads = max(1, min(16, cpu_share // (n_gpus if single_process_multi else 1)))
     capi.load().mrp_set_host_threads(host_threads)
     seeds = sharding.chunk_seeds(rank, n_chunks)
 
@@ -128,7 +132,7 @@ def main():
     if single_process_multi:
         queue = capi.Queue(list(range(n_gpus)))
         descs = capi.chunk_descs(chunks)
-        step = lambda: queue.phase(chunks, params, chunks_per_batch=max(1, args.chunks // 2), descs=descs, convert=False)[1]
+        step = lambda: queue.phase(chunks, params, chunks_per_batch=args.queue_batch, descs=descs, convert=False)[1]
     else:
         ctx = capi.Context(local_rank)
         ctx.set_phase_groups(args.phase_groups)
@@ -172,19 +176,50 @@ def main():
     if args.queue_runs > 0 and not single_process_multi:
         q = capi.Queue([local_rank])
         descs = capi.chunk_descs(chunks)
-        q.phase(chunks, params, chunks_per_batch=max(1, args.chunks // 2), descs=descs, convert=False)
+        q.phase(chunks, params, chunks_per_batch=args.queue_batch, descs=descs, convert=False)
         barrier()
         t0 = time.perf_counter()
         for _ in range(args.queue_runs):
-            _, qst = q.phase(chunks, params, chunks_per_batch=max(1, args.chunks // 2), descs=descs, convert=False)
+            _, qst = q.phase(chunks, params, chunks_per_batch=args.queue_batch, descs=descs, convert=False)
         barrier()
         q_el = time.perf_counter() - t0
         q_el, q_units = sharding.reduce_elapsed_and_units(dist, q_el, units, device=reduce_dev)
-        out["queue"] = dict(what="mrp_queue_phase_chunks: chunks in host memory, sorted by estimated cost, pulled in batches by one worker per device; "
-                                 "site tables and profile bytes uploaded per batch (PCIe-inclusive)",
+        out["queue"] = dict(what="mrp_queue_phase_chunks: the same chunks from HOST memory (PCIe-inclusive): sorted by estimated cost, pulled in "
+                                 "batches by one worker per device, the next batch's site tables and profile bytes uploaded on a second stream "
+                                 "while the current batch is phased",
                             value=q_units * args.queue_runs / q_el, unit="het-site-reads/s", ms_per_run=1e3 * q_el / args.queue_runs,
-                            batches=int(qst.batches), runs=args.queue_runs)
+                            batches=int(qst.batches), runs=args.queue_runs, vs_resident=(q_units * args.queue_runs / q_el) / value)
         q.close()
+
+    # ---- the shapes of BASELINE.json configs[2] and configs[4] on one GPU (same call, other chunks) ---------------
+    if args.shape_runs > 0 and not single_process_multi:
+        def shape_leg(name, what, make, n):
+            with ThreadPoolExecutor(max_workers=n_threads) as ex:
+                cs = list(ex.map(make, range(n)))
+            for c in cs:
+                capi.read_records(c)
+            dcs = [capi.DeviceChunk.from_chunk(ctx, c) for c in cs]
+            u = float(sum(c.units for c in cs))
+            capi.phase_reads_many(ctx, dcs, cs, params, convert=False)
+            barrier()
+            t1 = time.perf_counter()
+            for _ in range(args.shape_runs):
+                _, sst = capi.phase_reads_many(ctx, dcs, cs, params, convert=False)
+            barrier()
+            el = time.perf_counter() - t1
+            el, u_all = sharding.reduce_elapsed_and_units(dist, el, u, device=reduce_dev)
+            for d_ in dcs:
+                d_.close()
+            out.setdefault("shapes", {})[name] = dict(what=what, chunks_per_gpu=n, value=u_all * args.shape_runs / el, unit="het-site-reads/s",
+                                                     ms_per_call=1e3 * el / args.shape_runs, runs=args.shape_runs, resident=int(sst.resident),
+                                                     fallback_chunks=int(sst.fallback_chunks))
+        shape_leg("configs[2]", "chr20-like: 640 chunks of ~130 het sites (100 kb + margins), 30x ONT reads, one mrp_phase_reads_many call",
+                  lambda s_: synth.make_ont_chunk(seed=50_000 + 1000 * rank + s_, region_bp=130 * 500, n_sites=130, coverage=args.coverage), 640)
+        shape_leg("configs[4]", "HiFi-like: 48 chunks of 2 000 sites, 35x reads N(18 kb, 3 kb), 1 % allele error, 2-4 alleles per site "
+                                "(shipped ONT haplotag parameters; phase_vcf mode differs in I/O only)",
+                  lambda s_: synth.make_ont_chunk(seed=60_000 + 1000 * rank + s_, region_bp=args.sites * 500, n_sites=args.sites, coverage=35.0, median_len=18_000.0,
+                                                  allele_error=0.01, allele_choices=(2, 3, 4), allele_probs=(0.85, 0.1, 0.05), length_model="normal",
+                                                  normal_sd=3000.0), 48)
 
     # ---- kernel evidence: all sweeps of the same chunks replayed as one batch (rank 0) ---------------------------
     if not args.no_roofline and rank == 0 and not single_process_multi:

@@ -59,15 +59,19 @@ int mrp_device_count(void);
 int mrp_context_create(int device, mrp_context **out);
 void mrp_context_destroy(mrp_context *ctx);
 int mrp_context_synchronize(mrp_context *ctx);
+/* Optional, once, BEFORE the process's first HIP call (its own or this library's): asks the ROCm runtime for 16 hardware
+ * queues (GPU_MAX_HW_QUEUES, unless the environment already sets it).  The runtime multiplexes HIP streams onto 4 hardware
+ * queues by default and kernels of streams that share a queue serialize; the concurrent batches of mrp_phase_reads_many
+ * launch on four streams each (96 chunks: 68 ms instead of 82 ms on an MI355X).  Without the call everything works, slower. */
+int mrp_runtime_init(void);
 /* mrp_phase_reads_many splits its chunks into this many interleaved batches that run concurrently on the context and its
  * sibling contexts (one batch's host work beside the others' kernels); 1..8, or 0 (default): one batch per 24 chunks, at
- * most 4.  Every batch launches on four HIP streams; the ROCm runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware
- * queues (4 unless the environment says otherwise) and kernels of streams that share a queue serialize, so the library
- * sets GPU_MAX_HW_QUEUES=16 when it is loaded -- unless the variable is already set, and without effect if the process
- * initialised HIP earlier (then set it in the environment: 96 chunks take 68 ms instead of 82 ms on an MI355X). */
+ * most 4. */
 int mrp_context_set_phase_groups(mrp_context *ctx, int groups);
-/* size of the host worker pool shared by all contexts (structure of the merge levels, descriptors, classification of
- * alignment pairs); default min(16, cores); takes effect for workers not yet started */
+/* size of the host worker pool (structure of the merge levels, descriptors, classification of alignment pairs): the
+ * process-wide pool of contexts used directly, and EACH worker's own pool of a work queue (mrp_queue_*: one pool per device).
+ * Default: min(16, hardware threads) for the process-wide pool, hardware threads / devices (2..16) per queue worker.
+ * Takes effect for pools not yet started. */
 int mrp_set_host_threads(int n);
 
 /*
@@ -294,11 +298,15 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
 /* ---- the chunks of a node's worth of work over its GPUs ---------------------------------------------
  * Replaces the chunk loop of phase.c:276-473 together with its ordering (phase.c:257-263, chunks by estimated depth,
  * largest first) and its schedule ("#pragma omp parallel for schedule(dynamic,1)", :276-279), with devices in the role
- * of the threads: one host thread and one context per entry of devices[] pull the next batch of chunks_per_batch
- * consecutive chunks of that order, upload them (mrp_chunk_create), phase them (mrp_phase_reads_many) and store the
- * results at the chunks' own positions of out[].  Chunks are independent until stitching: no collective, no traffic
- * between devices.  A device may be listed more than once (two workers sharing it). */
+ * of the threads: two host threads ("lanes") per entry of devices[] pull the next batch of chunks_per_batch (0: about 288) consecutive
+ * chunks of that order, phases it (mrp_phase_reads_many) and stores the results at the chunks' own positions of out[];
+ * while a batch is phased the worker's NEXT batch is uploaded on a second stream (site tables + profile bytes, one wait per
+ * batch).  Every worker has its own host thread pool (mrp_set_host_threads per device) and, when the queue drives more than
+ * one device, runs on the CPUs next to its device (/sys/bus/pci/devices/.../local_cpulist; MRP_QUEUE_AFFINITY=0 turns that
+ * off).  Chunks are independent until stitching: no collective, no traffic between devices.  A device may be listed more
+ * than once (two workers sharing it). */
 #define MRP_MAX_QUEUE_DEVICES 16
+#define MRP_QUEUE_DEFAULT_BATCH 288 /* chunks per batch when the caller passes 0 (fewer when the queue is short: one batch per device) */
 typedef struct mrp_chunk_desc {     /* one genome chunk in host memory: what mrp_chunk_create and mrp_phase_reads take */
     int64_t n_sites;
     const uint32_t *allele_number;

@@ -22,7 +22,7 @@ FLAG_INCLUDE_ANCESTOR_SUB_PROB = 2
 
 #: every symbol include/margin_rphmm.h declares (checked by the CPU test-suite)
 EXPORTED_SYMBOLS = [
-    "mrp_last_error", "mrp_version", "mrp_device_count", "mrp_context_create", "mrp_context_destroy",
+    "mrp_last_error", "mrp_version", "mrp_runtime_init", "mrp_device_count", "mrp_context_create", "mrp_context_destroy",
     "mrp_context_synchronize", "mrp_hmm_split", "mrp_hmm_split_where_phasing_is_uncertain", "mrp_context_set_phase_groups", "mrp_set_host_threads", "mrp_chunk_create", "mrp_chunk_destroy", "mrp_fb_run", "mrp_batch_create",
     "mrp_batch_add", "mrp_batch_upload", "mrp_batch_launch", "mrp_batch_download", "mrp_batch_destroy",
     "mrp_batch_stats", "mrp_count_bit_vectors", "mrp_emissions", "mrp_get_rp_hmms", "mrp_hmm_destroy", "mrp_free",
@@ -203,6 +203,8 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise FileNotFoundError(f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
     L = C.CDLL(LIB_PATH)
+    L.mrp_runtime_init.restype = C.c_int
+    L.mrp_runtime_init()  # before the first HIP call of this process (hardware queues for the concurrent batches)
     vp, i64, i32, u32 = C.c_void_p, C.c_int64, C.c_int32, C.c_uint32
     P = C.POINTER
     L.mrp_last_error.restype = C.c_char_p

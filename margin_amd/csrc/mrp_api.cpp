@@ -86,10 +86,13 @@ int mrp_set_error(int code, const char *fmt, ...) {
 const char *mrp_last_error(void) { return g_err; }
 const char *mrp_version(void) { return "margin_rphmm 0.2.0 gfx950"; }
 
-/* Concurrent batches of mrp_phase_reads_many launch on 4 streams each; with the runtime's default of 4 hardware queues their
- * kernels would serialize (include/margin_rphmm.h, mrp_context_set_phase_groups).  Runs when the library is loaded, i.e.
- * before this library's first HIP call; never overrides the user's setting. */
-__attribute__((constructor)) static void mrp_runtime_defaults(void) { (void) setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+/* Concurrent batches of mrp_phase_reads_many launch on 4 streams each; with the ROCm runtime's default of 4 hardware queues
+ * their kernels would serialize (include/margin_rphmm.h).  An explicit call, to be made before the process's first HIP call:
+ * a library that edits its host's environment when it is loaded is a surprise for whoever links it. */
+int mrp_runtime_init(void) {
+    if (setenv("GPU_MAX_HW_QUEUES", "16", 0) != 0) return fail(MRP_ERR_ARG, "mrp_runtime_init: setenv failed");
+    return MRP_OK;
+}
 
 int mrp_device_count(void) {
     int n = 0;
@@ -151,14 +154,15 @@ int mrp_context_synchronize(mrp_context *ctx) {
     return MRP_OK;
 }
 
-int mrp_chunk_create(mrp_context *ctx, int64_t n_sites, const uint32_t *allele_number,
-                     const uint16_t *substitution_log_probs, const uint16_t *allele_prior_log_probs,
-                     const uint8_t *profile_pool, int64_t pool_bytes, mrp_chunk **out) {
+}  /* extern "C" */
+
+/* host half of a chunk: validation, prefix sums, host copies of everything (the caller's arrays may go after the call) */
+static int chunk_host_init(mrp_context *ctx, int64_t n_sites, const uint32_t *allele_number, const uint16_t *substitution_log_probs,
+                           const uint16_t *allele_prior_log_probs, const uint8_t *profile_pool, int64_t pool_bytes, mrp_chunk **out) {
     if (!ctx || !out || n_sites < 0 || pool_bytes < 0 || (n_sites > 0 && !allele_number) ||
         (pool_bytes > 0 && !profile_pool))
         return fail(MRP_ERR_ARG, "mrp_chunk_create: bad arguments");
     *out = nullptr;
-    HIP_TRY(hipSetDevice(ctx->device));
     mrp_chunk *ch = new (std::nothrow) mrp_chunk();
     if (!ch) return fail(MRP_ERR_NOMEM, "out of host memory");
     ch->ctx = ctx;
@@ -197,22 +201,35 @@ int mrp_chunk_create(mrp_context *ctx, int64_t n_sites, const uint32_t *allele_n
     if (allele_prior_log_probs) prior.assign(allele_prior_log_probs, allele_prior_log_probs + off);
     for (uint16_t v : sub) ch->max_sub = std::max<uint32_t>(ch->max_sub, v);
     for (uint16_t v : prior) ch->max_prior = std::max<uint32_t>(ch->max_prior, v);
+    *out = ch;
+    return MRP_OK;
+}
+
+extern "C" {
+int mrp_chunk_create(mrp_context *ctx, int64_t n_sites, const uint32_t *allele_number,
+                     const uint16_t *substitution_log_probs, const uint16_t *allele_prior_log_probs,
+                     const uint8_t *profile_pool, int64_t pool_bytes, mrp_chunk **out) {
+    mrp_chunk *ch = nullptr;
+    int rc = chunk_host_init(ctx, n_sites, allele_number, substitution_log_probs, allele_prior_log_probs, profile_pool, pool_bytes, &ch);
+    if (rc != MRP_OK) return rc;
+    *out = nullptr;
+    hipError_t e = hipSetDevice(ctx->device);
     hipStream_t s = ctx->stream;
-    /* from the context's caching allocator: a work queue creates and destroys a batch of chunks per call */
+    /* from the context's caching allocator */
     ch->d_allele_number.pool = ch->d_allele_offset.pool = ch->d_sub_offset.pool = &ctx->pool;
     ch->d_sub.pool = ch->d_prior.pool = &ctx->pool;
     ch->d_same_until.pool = &ctx->pool;
     ch->d_pool.pool = &ctx->pool;
-    hipError_t e = ch->d_allele_number.upload(ch->allele_number, s);
+    if (e == hipSuccess) e = ch->d_allele_number.upload(ch->allele_number, s);
     if (e == hipSuccess) e = ch->d_allele_offset.upload(ch->allele_offset, s);
     if (e == hipSuccess) e = ch->d_sub_offset.upload(ch->sub_offset, s);
     if (e == hipSuccess) e = ch->d_same_until.upload(ch->same_until, s);
-    if (e == hipSuccess) e = ch->d_sub.upload(sub, s);
-    if (e == hipSuccess) e = ch->d_prior.upload(prior, s);
+    if (e == hipSuccess) e = ch->d_sub.upload(ch->sub, s);
+    if (e == hipSuccess) e = ch->d_prior.upload(ch->prior, s);
     if (e == hipSuccess) e = ch->d_pool.alloc((size_t) pool_bytes);
     if (e == hipSuccess && pool_bytes > 0)
-        e = hipMemcpyAsync(ch->d_pool.p, profile_pool, (size_t) pool_bytes, hipMemcpyHostToDevice, s);
-    if (e == hipSuccess) e = hipStreamSynchronize(s);
+        e = hipMemcpyAsync(ch->d_pool.p, ch->pool.data(), (size_t) pool_bytes, hipMemcpyHostToDevice, s); /* (the chunk's own copy: the caller's may go) */
+    if (e == hipSuccess) e = ctx->wait_stream(s);
     if (e != hipSuccess) {
         delete ch;
         return fail(MRP_ERR_HIP, "chunk upload failed: %s", hipGetErrorString(e));
@@ -227,6 +244,68 @@ int mrp_chunk_create(mrp_context *ctx, int64_t n_sites, const uint32_t *allele_n
     *out = ch;
     return MRP_OK;
 }
+}  /* extern "C" */
+
+/* The chunks of one batch of a work queue, uploaded TOGETHER: every array of every chunk is copied (by the calling thread's
+ * host pool) into one page-locked block, which goes to one device block with one asynchronous copy on the context's stream;
+ * one event ends it.  Nothing is waited for here: the first device work that reads a chunk waits for the event on its stream
+ * (mrp_engine.cpp) or on the host (mrp_chunk::host_wait).  Per chunk this replaces seven allocations and seven pageable
+ * copies (30 ms for 288 chunks) by a share of one. */
+int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *const *descs, mrp_chunk **out, mrp_chunk_block *blk) {
+    if (!ctx || n < 0 || !blk || (n > 0 && (!descs || !out))) return fail(MRP_ERR_ARG, "mrp_chunk_block_create: bad arguments");
+    for (int64_t i = 0; i < n; i++) out[i] = nullptr;
+    HIP_TRY(hipSetDevice(ctx->device));
+    std::vector<int> rcs((size_t) n, MRP_OK);
+    std::vector<std::string> msgs((size_t) n);
+    mrp_parallel_for(n, 4, [&](int64_t i) {
+        const mrp_chunk_desc &c = *descs[i];
+        rcs[(size_t) i] = chunk_host_init(ctx, c.n_sites, c.allele_number, c.substitution_log_probs, c.allele_prior_log_probs, c.profile_pool, c.pool_bytes, &out[i]);
+        if (rcs[(size_t) i] != MRP_OK) msgs[(size_t) i] = mrp_last_error();
+    });
+    int rc = MRP_OK;
+    for (int64_t i = 0; i < n && rc == MRP_OK; i++)
+        if (rcs[(size_t) i] != MRP_OK) rc = fail(rcs[(size_t) i], "%s", msgs[(size_t) i].c_str());
+    auto al = [](size_t v) { return (v + 255) & ~(size_t) 255; };
+    std::vector<size_t> off((size_t) n + 1, 0);
+    for (int64_t i = 0; i < n && rc == MRP_OK; i++) {
+        const mrp_chunk *ch = out[i];
+        off[(size_t) i + 1] = off[(size_t) i] + al(4 * ch->allele_number.size()) + al(4 * ch->allele_offset.size()) + al(4 * ch->sub_offset.size()) +
+                              al(4 * ch->same_until.size()) + al(2 * ch->sub.size()) + al(2 * ch->prior.size()) + al(ch->pool.size());
+    }
+    hipError_t e = hipSuccess;
+    if (rc == MRP_OK) {
+        blk->dev.pool = &ctx->pool;
+        e = blk->host.reserve(off[(size_t) n] + 256);
+        if (e == hipSuccess) e = blk->dev.alloc(off[(size_t) n] + 256);
+        if (e == hipSuccess && !blk->ready) e = hipEventCreateWithFlags(&blk->ready, hipEventBlockingSync | hipEventDisableTiming);
+    }
+    if (rc == MRP_OK && e == hipSuccess) {
+        char *hb = (char *) blk->host.p;
+        uint8_t *db = blk->dev.p;
+        mrp_parallel_for(n, 4, [&](int64_t i) {
+            mrp_chunk *ch = out[i];
+            size_t o = off[(size_t) i];
+            auto put = [&](const void *src, size_t bytes) { const size_t at = o; if (bytes) memcpy(hb + at, src, bytes); o += al(bytes); return db + at; };
+            ch->dev.allele_number = (const uint32_t *) put(ch->allele_number.data(), 4 * ch->allele_number.size());
+            ch->dev.allele_offset = (const uint32_t *) put(ch->allele_offset.data(), 4 * ch->allele_offset.size());
+            ch->dev.sub_offset = (const uint32_t *) put(ch->sub_offset.data(), 4 * ch->sub_offset.size());
+            ch->dev.same_until = (const int32_t *) put(ch->same_until.data(), 4 * ch->same_until.size());
+            ch->dev.sub = (const uint16_t *) put(ch->sub.data(), 2 * ch->sub.size());
+            ch->dev.prior = (const uint16_t *) put(ch->prior.data(), 2 * ch->prior.size());
+            ch->dev.pool = (const uint8_t *) put(ch->pool.data(), ch->pool.size());
+        });
+        if (off[(size_t) n] > 0) e = hipMemcpyAsync(db, hb, off[(size_t) n], hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(blk->ready, ctx->stream);
+        if (e == hipSuccess)
+            for (int64_t i = 0; i < n; i++) { out[i]->ready = blk->ready; out[i]->owns_ready = false; out[i]->ready_pending.store(true); }
+    }
+    if (rc == MRP_OK && e != hipSuccess) rc = fail(MRP_ERR_HIP, "chunk block upload failed: %s", hipGetErrorString(e));
+    if (rc != MRP_OK)
+        for (int64_t i = 0; i < n; i++) { delete out[i]; out[i] = nullptr; }
+    return rc;
+}
+
+extern "C" {
 
 void mrp_chunk_destroy(mrp_chunk *chunk) {
     if (!chunk) return;
@@ -312,6 +391,7 @@ int mrp_batch_add_impl(mrp_batch *b, const mrp_hmm_job *job, bool resident, int6
                          !job->hmm_backward || (K > 1 && (!job->merge_forward || !job->merge_backward))))
         return fail(MRP_ERR_ARG, "hmm job is missing output arrays");
     const mrp_chunk *ch = job->chunk;
+    if (ch->host_wait() != hipSuccess) return fail(MRP_ERR_HIP, "chunk upload failed");
     if (ch->ctx->device != b->ctx->device) return fail(MRP_ERR_ARG, "chunk lives on a different device");
     std::lock_guard<std::mutex> lock(b->mu);
     if (b->stats.n_hmms > 0 && b->resident != resident) return fail(MRP_ERR_ARG, "a batch is either host-fed or device-resident");
@@ -532,12 +612,18 @@ struct PoolJob {
     std::atomic<int64_t> next{0}, done{0};
     int active = 0; /* workers currently holding the pointer (under Pool::mu) */
 };
-struct Pool {
+}  // namespace
+/* One pool serves the process by default (mrp_set_host_threads); a work queue gives every device its own (mrp_queue.cpp:
+ * the reference's axis is "every core works", phase.c:276-279 -- eight devices on one shared pool of sixteen threads would
+ * starve each other), optionally bound to the CPUs next to the device.  A thread posts its loops to the pool it has adopted
+ * (mrp_pool_adopt; the batch threads of mrp_phase_reads_many inherit their caller's). */
+struct mrp_host_pool {
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
     std::vector<PoolJob *> jobs;
     std::vector<std::thread> workers;
     bool stop = false;
+    int fixed_threads = 0; /* 0: the process-wide pool, sized by mrp_host_threads() */
     static void run_chunks(PoolJob *j) {
         struct Acc { /* MRP_TIMING: thread CPU spent inside pool tasks */
             timespec a;
@@ -577,7 +663,7 @@ struct Pool {
         std::lock_guard<std::mutex> lk(mu);
         while ((int) workers.size() < n_workers) workers.emplace_back([this] { worker(); });
     }
-    ~Pool() {
+    ~mrp_host_pool() {
         {
             std::lock_guard<std::mutex> lk(mu);
             stop = true;
@@ -586,6 +672,9 @@ struct Pool {
         for (auto &t : workers) t.join();
     }
 };
+namespace {
+typedef mrp_host_pool Pool;
+thread_local Pool *t_pool_current = nullptr;
 Pool &pool() {
     static Pool *p = new Pool(); /* never destroyed: worker threads must not be joined from a static destructor at exit */
     return *p;
@@ -595,13 +684,14 @@ Pool &pool() {
 extern "C" void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void *), void *arg) {
     if (n <= 0) return;
     if (grain < 1) grain = 1;
-    const int nt = (int) std::min<int64_t>(mrp_host_threads(), (n + grain - 1) / grain);
+    Pool &P = t_pool_current ? *t_pool_current : pool();
+    const int threads = P.fixed_threads > 0 ? P.fixed_threads : mrp_host_threads();
+    const int nt = (int) std::min<int64_t>(threads, (n + grain - 1) / grain);
     if (nt <= 1) {
         for (int64_t i = 0; i < n; i++) fn(i, arg);
         return;
     }
-    Pool &P = pool();
-    P.ensure(mrp_host_threads() - 1);
+    P.ensure(threads - 1);
     PoolJob j;
     j.fn = fn; j.arg = arg; j.n = n; j.grain = grain; j.prio = t_pool_priority; j.tag = t_pool_tag;
     {
@@ -615,10 +705,22 @@ extern "C" void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void 
     P.jobs.erase(std::find(P.jobs.begin(), P.jobs.end(), &j));
 }
 
+/* a pool of its own with `threads` threads (the posting thread counts as one); its workers are created by the first loop
+ * posted to it and inherit the CPU affinity of the thread that posts it */
+mrp_host_pool *mrp_host_pool_create(int threads) {
+    mrp_host_pool *p = new (std::nothrow) mrp_host_pool();
+    if (p) p->fixed_threads = threads < 1 ? 1 : threads;
+    return p;
+}
+void mrp_host_pool_destroy(mrp_host_pool *p) { delete p; }
+extern "C" void *mrp_pool_current(void) { return t_pool_current; }
+extern "C" void mrp_pool_adopt(void *p) { t_pool_current = static_cast<mrp_host_pool *>(p); }
+
 extern "C" void mrp_pool_set_priority(int p) { t_pool_priority = p; }
 extern "C" void mrp_pool_set_tag(int t) { t_pool_tag = t; } /* MRP_TIMING: which loop the CPU time of the pool tasks is booked to */
 
 static std::atomic<int> g_host_threads{0};
+static std::atomic<bool> g_host_threads_set{false};
 int mrp_host_threads(void) {
     int n = g_host_threads.load();
     if (n <= 0) {
@@ -627,9 +729,11 @@ int mrp_host_threads(void) {
     }
     return n;
 }
+int mrp_host_threads_setting(void) { return g_host_threads_set.load() ? g_host_threads.load() : 0; } /* 0: never set */
 int mrp_set_host_threads(int n) {
     if (n < 1 || n > 256) return fail(MRP_ERR_ARG, "mrp_set_host_threads: %d outside 1..256", n);
     g_host_threads.store(n);
+    g_host_threads_set.store(true);
     return MRP_OK;
 }
 int mrp_context_set_phase_groups(mrp_context *ctx, int groups) {
@@ -984,6 +1088,7 @@ int mrp_fb_run(mrp_context *ctx, int64_t n_jobs, const mrp_hmm_job *jobs) {
 static int one_column(mrp_context *ctx, const mrp_chunk *chunk, int32_t first_site, int32_t n_sites, int32_t depth,
                       const int64_t *read_byte_off, DevCol *col) {
     if (!ctx || !chunk || chunk->ctx != ctx) return fail(MRP_ERR_ARG, "bad context/chunk");
+    if (chunk->host_wait() != hipSuccess) return fail(MRP_ERR_HIP, "chunk upload failed");
     if (depth < 0 || depth > MRP_MAX_READ_PARTITIONING_DEPTH || n_sites < 0 || first_site < 0 ||
         (int64_t) first_site + n_sites > chunk->n_sites || (depth > 0 && !read_byte_off))
         return fail(MRP_ERR_ARG, "bad column description");

@@ -51,21 +51,6 @@ struct Segment { /* the pruned hmms produced by one level, and their column stru
     DevBuf<int64_t> rbo;
 };
 
-/* page-locked, grow-only host buffer: source of the asynchronous uploads of a staged level */
-struct PinnedBuf {
-    void *p = nullptr;
-    size_t bytes = 0;
-    ~PinnedBuf() { if (p) (void) hipHostFree(p); }
-    hipError_t reserve(size_t want) {
-        if (want <= bytes) return hipSuccess;
-        if (p) (void) hipHostFree(p);
-        p = nullptr; bytes = 0;
-        const size_t sz = std::max<size_t>(want + want / 4, (size_t) 1 << 20);
-        hipError_t e = hipHostMalloc(&p, sz, hipHostMallocDefault);
-        if (e == hipSuccess) bytes = sz;
-        return e;
-    }
-};
 }  // namespace
 
 /* everything one level keeps between its staging and its completion */
@@ -340,7 +325,12 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         if (!b->chunks.empty() && b->chunks.back() == ch) idx = (int) b->chunks.size() - 1;
         for (size_t c = 0; idx < 0 && c < b->chunks.size(); c++)
             if (b->chunks[c] == ch) idx = (int) c;
-        if (idx < 0) { idx = (int) b->chunks.size(); b->chunks.push_back(ch); }
+        if (idx < 0) {
+            idx = (int) b->chunks.size(); b->chunks.push_back(ch);
+            /* a chunk still being uploaded (work queue): the level's structure kernel and, through L->uploaded, its other
+             * kernels are ordered behind the end of the upload */
+            if (ch->ready_pending.load()) ENG_TRY(hipStreamWaitEvent(cs, ch->ready, 0));
+        }
         chunk_index[(size_t) i] = idx;
         const bool anc = (h.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
         if (!anc) all_planes = false; /* (a column without the ancestor model needs bit planes only if its allele counts differ) */

@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <array>
+#include <atomic>
 #include <functional>
 #include <iterator>
 #include <map>
@@ -228,6 +229,48 @@ struct mrp_chunk {
     DevBuf<uint16_t> d_sub, d_prior;
     DevBuf<uint8_t> d_pool;
     DevChunk dev{};
+    /* a chunk whose uploads were queued but not waited for (a work queue uploads its next batch beside the current one): the
+     * event ends them.  Device work that reads the chunk waits for it on its stream (mrp_engine.cpp) or on the host
+     * (host_wait: the paths that upload on the default path). */
+    mutable hipEvent_t ready = nullptr;
+    bool owns_ready = true; /* false: the event belongs to the block the chunk was uploaded with (mrp_chunk_block) */
+    mutable std::atomic<bool> ready_pending{false};
+    hipError_t host_wait() const {
+        if (!ready_pending.load()) return hipSuccess;
+        const hipError_t e = hipEventSynchronize(ready);
+        if (e == hipSuccess) ready_pending.store(false);
+        return e;
+    }
+    ~mrp_chunk() {
+        if (ready && owns_ready) { (void) hipEventSynchronize(ready); (void) hipEventDestroy(ready); }
+    }
+};
+
+/* page-locked, grow-only host buffer: source of asynchronous uploads */
+struct PinnedBuf {
+    void *p = nullptr;
+    size_t bytes = 0;
+    ~PinnedBuf() { if (p) (void) hipHostFree(p); }
+    hipError_t reserve(size_t want) {
+        if (want <= bytes) return hipSuccess;
+        if (p) (void) hipHostFree(p);
+        p = nullptr; bytes = 0;
+        const size_t sz = std::max<size_t>(want + want / 4, (size_t) 1 << 20);
+        hipError_t e = hipHostMalloc(&p, sz, hipHostMallocDefault);
+        if (e == hipSuccess) bytes = sz;
+        return e;
+    }
+};
+
+/* device + staging storage of the chunks of one batch of a work queue (mrp_chunk_block_create); outlives its chunks and
+ * is reused for the batch after next */
+struct mrp_chunk_block {
+    PinnedBuf host;
+    DevBuf<uint8_t> dev;
+    hipEvent_t ready = nullptr;
+    ~mrp_chunk_block() {
+        if (ready) { (void) hipEventSynchronize(ready); (void) hipEventDestroy(ready); }
+    }
 };
 
 struct JobOut {
@@ -322,6 +365,12 @@ int mrp_batch_add_impl(mrp_batch *b, const mrp_hmm_job *job, bool resident, int6
 extern "C" void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void *), void *arg);
 /* releases what mrp_engine.cpp parked in the context (mrp_context_destroy) */
 void mrp_engine_release_context_cache(mrp_context *ctx);
+int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *const *descs, mrp_chunk **out, mrp_chunk_block *blk);
+int mrp_host_threads_setting(void); /* what mrp_set_host_threads() was given, 0 if it was never called */
+/* host worker pools (mrp_api.cpp) */
+struct mrp_host_pool;
+mrp_host_pool *mrp_host_pool_create(int threads);
+void mrp_host_pool_destroy(mrp_host_pool *p);
 template <class F>
 static inline void mrp_parallel_for(int64_t n, int64_t grain, F f) {
     mrp_pool_run(n, grain, [](int64_t i, void *a) { (*static_cast<F *>(a))(i); }, &f);

@@ -6,7 +6,8 @@
  * "#pragma omp parallel for schedule(dynamic,1)"); chunks are independent until stitching, nothing is exchanged.
  * Here a "thread" is a device: one host thread and one context per device pull the next BATCH of chunks (a batch is
  * what one mrp_phase_reads_many call phases; its chunks share kernel launches), upload them, phase them and write the
- * results at the chunks' positions of the caller's array.  No collective, no device-to-device traffic.
+ * results at the chunks' positions of the caller's array.  No collective, no device-to-device traffic.  The uploads of a
+ * worker's next batch run on a second stream while the current batch is phased; every worker has its own host thread pool.
  */
 #include <hip/hip_runtime.h>
 
@@ -15,12 +16,19 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <numeric>
 #include <string>
 #include <thread>
 #include <vector>
 
+#include <pthread.h>
+#include <sched.h>
+#include <cctype>
+
 #include "mrp_internal.h"
+
+int mrp_queue_threads_per_device(int n_devices);
 
 namespace {
 
@@ -103,7 +111,17 @@ int mrp_queue_dry_run(int32_t n_workers, int64_t n_chunks, const int64_t *cost, 
 
 struct mrp_queue {
     std::vector<int32_t> devices;
-    std::vector<mrp_context *> ctx; /* one per worker, created by the worker on its first batch, kept between calls */
+    /* one worker per device, each with: the context its batches are phased on, a second context on the same device whose
+     * stream carries the uploads of the NEXT batch while the current one is phased, and its own host worker pool -- all
+     * created by the worker on its first batch and kept between calls */
+    std::vector<mrp_context *> ctx, stage_ctx; /* [device * lanes + lane] */
+    std::vector<mrp_host_pool *> pools;        /* [device] */
+    std::vector<mrp_chunk_block *> blocks;     /* [(device * lanes + lane) * 2 + parity] storage of a lane's current / next batch */
+    int threads_per_device = 0;
+    /* Two batches of a device are in flight at a time (two "lanes", each a host thread with its own contexts): a call of
+     * mrp_phase_reads_many begins and ends with host work and latency-bound levels that leave the device half empty;
+     * the other lane's call fills it.  MRP_QUEUE_LANES=1..4 overrides. */
+    int lanes = 2;
 };
 
 int mrp_queue_create(const int32_t *devices, int32_t n_devices, mrp_queue **out) {
@@ -116,23 +134,69 @@ int mrp_queue_create(const int32_t *devices, int32_t n_devices, mrp_queue **out)
     mrp_queue *q = new (std::nothrow) mrp_queue();
     if (!q) return mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
     q->devices.assign(devices, devices + n_devices);
-    q->ctx.assign((size_t) n_devices, nullptr);
+    if (const char *le = getenv("MRP_QUEUE_LANES")) { const int v = atoi(le); if (v >= 1 && v <= 4) q->lanes = v; }
+    q->ctx.assign((size_t) n_devices * (size_t) q->lanes, nullptr);
+    q->stage_ctx.assign((size_t) n_devices * (size_t) q->lanes, nullptr);
+    q->pools.assign((size_t) n_devices, nullptr);
+    q->blocks.assign((size_t) n_devices * (size_t) q->lanes * 2, nullptr);
+    q->threads_per_device = mrp_queue_threads_per_device(n_devices);
     *out = q;
     return MRP_OK;
 }
 
 void mrp_queue_destroy(mrp_queue *q) {
     if (!q) return;
+    for (size_t i = 0; i < q->blocks.size(); i++)
+        if (q->blocks[i]) { (void) hipSetDevice(q->devices[i / (2 * (size_t) q->lanes)]); delete q->blocks[i]; }
+    for (auto *c : q->stage_ctx) mrp_context_destroy(c);
     for (auto *c : q->ctx) mrp_context_destroy(c);
+    for (auto *p : q->pools) mrp_host_pool_destroy(p);
     delete q;
 }
+
+}  /* extern "C" */
+
+/* Host threads a worker gets: every device its own pool (phase.c:276-279 uses every core of the machine; one pool of sixteen
+ * threads shared by eight devices would starve them).  mrp_set_host_threads() is the number PER DEVICE; by default the
+ * machine's hardware threads are split evenly, at most 16 and at least 2 each. */
+int mrp_queue_threads_per_device(int n_devices) {
+    const int hw = (int) std::max(1u, std::thread::hardware_concurrency());
+    const int asked = mrp_host_threads_setting();
+    if (asked > 0) return asked;
+    return std::max(2, std::min(16, hw / std::max(1, n_devices)));
+}
+
+/* The CPUs next to a device (Linux: /sys/bus/pci/devices/<bus id>/local_cpulist), for the worker of that device and every
+ * thread it starts.  Only when a queue drives more than one device, and unless MRP_QUEUE_AFFINITY=0: a worker that reaches
+ * across sockets for every staging copy and descriptor loses a third of its host bandwidth. */
+static bool device_cpuset(int device, cpu_set_t *set) {
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int) sizeof(bus) - 1, device) != hipSuccess) return false;
+    for (char *c = bus; *c; c++) *c = (char) tolower((unsigned char) *c);
+    const std::string path = std::string("/sys/bus/pci/devices/") + bus + "/local_cpulist";
+    FILE *f = fopen(path.c_str(), "r");
+    if (!f) return false;
+    char line[4096] = {0};
+    const bool got = fgets(line, sizeof(line), f) != nullptr;
+    fclose(f);
+    if (!got) return false;
+    CPU_ZERO(set);
+    int n = 0;
+    for (char *tok = strtok(line, ",\n"); tok; tok = strtok(nullptr, ",\n")) {
+        int lo = 0, hi = 0;
+        if (sscanf(tok, "%d-%d", &lo, &hi) == 2) { for (int c = lo; c <= hi && c < CPU_SETSIZE; c++) { CPU_SET(c, set); n++; } }
+        else if (sscanf(tok, "%d", &lo) == 1 && lo < CPU_SETSIZE) { CPU_SET(lo, set); n++; }
+    }
+    return n > 0;
+}
+
+extern "C" {
 
 int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc *chunks, const mrp_params *params, int64_t chunks_per_batch,
                            mrp_phase_result **out, mrp_queue_stats *stats) {
     if (!q || n_chunks < 0 || !params || (n_chunks > 0 && (!chunks || !out))) return mrp_set_error(MRP_ERR_ARG, "mrp_queue_phase_chunks: bad arguments");
     const int n_devices = (int) q->devices.size();
     const int32_t *devices = q->devices.data();
-    std::vector<mrp_context *> &ctx = q->ctx;
     if (stats) { memset(stats, 0, sizeof(*stats)); stats->n_devices = n_devices; }
     for (int64_t i = 0; i < n_chunks; i++) out[i] = nullptr;
     if (n_chunks == 0) return MRP_OK;
@@ -144,46 +208,144 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
             return mrp_set_error(MRP_ERR_ARG, "chunk %lld: bad description", (long long) i);
         for (int64_t r = 0; r < c.n_reads; r++) cost[(size_t) i] += c.reads[r].length;
     }
-    if (chunks_per_batch < 1) chunks_per_batch = 48;
+    const int lanes = q->lanes, n_workers = n_devices * lanes;
+    /* A batch is one mrp_phase_reads_many call.  A call begins and ends with host work and walks its merge levels one after the
+     * other, the top ones bound by per-column latency whatever the number of chunks: large batches amortize that (288 chunks in
+     * one call take 140 ms, in four calls on two lanes 225 ms).  So a short queue is ONE batch per device -- its upload overlaps
+     * the host's setup of the same call -- and a long one is cut into batches of about MRP_QUEUE_DEFAULT_BATCH, their number a
+     * multiple of the number of lanes so that the queue does not end with one lane working alone. */
+    if (chunks_per_batch < 1) {
+        if (n_chunks <= (int64_t) n_devices * (MRP_QUEUE_DEFAULT_BATCH + MRP_QUEUE_DEFAULT_BATCH / 3)) chunks_per_batch = (n_chunks + n_devices - 1) / n_devices;
+        else {
+            const int64_t rounds = (n_chunks + (int64_t) n_workers * MRP_QUEUE_DEFAULT_BATCH - 1) / ((int64_t) n_workers * MRP_QUEUE_DEFAULT_BATCH);
+            chunks_per_batch = (n_chunks + rounds * n_workers - 1) / (rounds * n_workers);
+        }
+        if (chunks_per_batch < 1) chunks_per_batch = 1;
+    }
     const QueuePlan plan = plan_queue(n_chunks, cost.data(), chunks_per_batch);
-    if (stats) stats->batches = (int64_t) plan.batch_off.size() - 1;
+    const int64_t n_batches = (int64_t) plan.batch_off.size() - 1;
+    if (stats) stats->batches = n_batches;
 
-    std::vector<std::string> errs((size_t) n_devices);
-    struct PerDev { int64_t chunks = 0, units = 0, fallback = 0; double busy_ms = 0; };
-    std::vector<PerDev> per((size_t) n_devices);
-    const int rc = run_queue(n_devices, plan, [&](int w, int64_t, int64_t first, int64_t count) {
-        auto t0 = std::chrono::steady_clock::now();
+    std::vector<std::string> errs((size_t) n_workers);
+    struct PerDev { int64_t chunks = 0, units = 0, fallback = 0; double busy_ms = 0, stage_wait_ms = 0; };
+    std::vector<PerDev> per((size_t) n_workers);
+    std::mutex pool_mu;
+    std::atomic<int64_t> next{0};
+    std::atomic<int> status{MRP_OK};
+    const char *aff_env = getenv("MRP_QUEUE_AFFINITY");
+    const bool bind = n_devices > 1 && !(aff_env && aff_env[0] == '0');
+
+    /* the chunks of one batch on the device (uploads queued on the staging context's stream and waited for once) */
+    struct Staged {
+        int64_t batch = -1, first = 0, count = 0;
+        std::vector<mrp_chunk *> dch;
+        int rc = MRP_OK;
+        std::string err;
+    };
+    const bool timing = getenv("MRP_TIMING") != nullptr;
+    const auto t_call = std::chrono::steady_clock::now();
+    auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
+    auto stage = [&](int w, int64_t b, int parity, Staged *st) {
+        const auto ts0 = std::chrono::steady_clock::now();
+        st->batch = b; st->first = plan.batch_off[(size_t) b]; st->count = plan.batch_off[(size_t) b + 1] - st->first;
+        st->dch.assign((size_t) st->count, nullptr);
+        mrp_context *sc = q->stage_ctx[(size_t) w];
+        sc->pool.reclaim(); /* the block of the batch before last was emptied after its call returned */
+        mrp_chunk_block *&blk = q->blocks[(size_t) w * 2 + (size_t) parity];
+        if (!blk) blk = new (std::nothrow) mrp_chunk_block();
+        std::vector<const mrp_chunk_desc *> dl((size_t) st->count);
+        for (int64_t i = 0; i < st->count; i++) dl[(size_t) i] = &chunks[plan.order[(size_t) (st->first + i)]];
+        st->rc = blk ? mrp_chunk_block_create(sc, st->count, dl.data(), st->dch.data(), blk) : mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
+        /* (not waited for: the chunks carry the event that ends the upload, the first device work that reads one waits) */
+        if (st->rc != MRP_OK) st->err = mrp_last_error();
+        if (timing) fprintf(stderr, "  [%7.1f] queue lane %d: batch %lld (%lld chunks) staged in %.1f ms\n", since(), w, (long long) b, (long long) st->count,
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count());
+    };
+    auto drop = [&](Staged *st) {
+        for (auto *c : st->dch) if (c) mrp_chunk_destroy(c);
+        st->dch.clear();
+    };
+    auto work = [&](int w) {
+        auto fail = [&](int rc, const std::string &msg) { errs[(size_t) w] = msg; int expect = MRP_OK; status.compare_exchange_strong(expect, rc); };
+        const int d = w / lanes; /* the device this lane works for */
+        if (bind) { /* before the first thread of this worker is created: they inherit it */
+            cpu_set_t set;
+            if (device_cpuset(devices[d], &set)) (void) pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+        }
         int r = MRP_OK;
-        if (!ctx[(size_t) w]) r = mrp_context_create(devices[w], &ctx[(size_t) w]);
-        std::vector<mrp_chunk *> dch((size_t) count, nullptr);
-        std::vector<const mrp_chunk *> cch((size_t) count);
-        std::vector<const mrp_read *> rd((size_t) count);
-        std::vector<int64_t> nr((size_t) count);
-        std::vector<mrp_phase_result *> res((size_t) count, nullptr);
-        for (int64_t i = 0; i < count && r == MRP_OK; i++) { /* upload: site tables + profile bytes of the batch's chunks */
-            const mrp_chunk_desc &c = chunks[plan.order[(size_t) (first + i)]];
-            r = mrp_chunk_create(ctx[(size_t) w], c.n_sites, c.allele_number, c.substitution_log_probs, c.allele_prior_log_probs, c.profile_pool,
-                                 c.pool_bytes, &dch[(size_t) i]);
-            cch[(size_t) i] = dch[(size_t) i]; rd[(size_t) i] = c.reads; nr[(size_t) i] = c.n_reads;
+        if (!q->ctx[(size_t) w]) r = mrp_context_create(devices[d], &q->ctx[(size_t) w]);
+        if (r == MRP_OK && !q->stage_ctx[(size_t) w]) r = mrp_context_create(devices[d], &q->stage_ctx[(size_t) w]);
+        if (r == MRP_OK) {
+            std::lock_guard<std::mutex> lk(pool_mu);
+            if (!q->pools[(size_t) d]) {
+                q->pools[(size_t) d] = mrp_host_pool_create(q->threads_per_device);
+                if (!q->pools[(size_t) d]) r = mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
+            }
         }
-        mrp_phase_many_stats ps{};
-        if (r == MRP_OK) r = mrp_phase_reads_many(ctx[(size_t) w], count, cch.data(), rd.data(), nr.data(), params, res.data(), &ps);
-        for (int64_t i = 0; i < count; i++) {
-            const int64_t chunk = plan.order[(size_t) (first + i)];
-            if (r == MRP_OK) { out[chunk] = res[(size_t) i]; per[(size_t) w].units += cost[(size_t) chunk]; }
-            if (dch[(size_t) i]) mrp_chunk_destroy(dch[(size_t) i]);
+        if (r != MRP_OK) { fail(r, mrp_last_error()); return; }
+        mrp_pool_adopt(q->pools[(size_t) d]);
+        Staged cur;
+        int parity = 0;
+        {
+            const int64_t b = next.fetch_add(1);
+            if (b >= n_batches) { mrp_pool_adopt(nullptr); return; }
+            stage(w, b, parity, &cur);
         }
-        if (r == MRP_OK) { per[(size_t) w].chunks += count; per[(size_t) w].fallback += ps.resident ? ps.fallback_chunks : count; }
-        else errs[(size_t) w] = mrp_last_error();
-        per[(size_t) w].busy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        return r;
-    }, nullptr);
+        while (cur.batch >= 0) {
+            if (cur.rc != MRP_OK) { fail(cur.rc, cur.err); drop(&cur); break; }
+            if (status.load() != MRP_OK) { drop(&cur); break; }
+            auto t0 = std::chrono::steady_clock::now();
+            /* the next batch of this worker is uploaded while the current one is phased (schedule(dynamic,1), one batch ahead) */
+            Staged nxt;
+            std::thread stager;
+            const int64_t nb = next.fetch_add(1);
+            parity ^= 1;
+            if (nb < n_batches) stager = std::thread([&, nb, parity] { mrp_pool_adopt(q->pools[(size_t) d]); stage(w, nb, parity, &nxt); });
+            const int64_t count = cur.count;
+            std::vector<const mrp_chunk *> cch((size_t) count);
+            std::vector<const mrp_read *> rd((size_t) count);
+            std::vector<int64_t> nr((size_t) count);
+            std::vector<mrp_phase_result *> res((size_t) count, nullptr);
+            for (int64_t i = 0; i < count; i++) {
+                const mrp_chunk_desc &c = chunks[plan.order[(size_t) (cur.first + i)]];
+                cch[(size_t) i] = cur.dch[(size_t) i]; rd[(size_t) i] = c.reads; nr[(size_t) i] = c.n_reads;
+            }
+            mrp_phase_many_stats ps{};
+            r = mrp_phase_reads_many(q->ctx[(size_t) w], count, cch.data(), rd.data(), nr.data(), params, res.data(), &ps);
+            std::string msg = r == MRP_OK ? std::string() : std::string(mrp_last_error());
+            for (int64_t i = 0; i < count; i++) {
+                const int64_t chunk = plan.order[(size_t) (cur.first + i)];
+                if (r == MRP_OK) { out[chunk] = res[(size_t) i]; per[(size_t) w].units += cost[(size_t) chunk]; }
+            }
+            if (r == MRP_OK) { per[(size_t) w].chunks += count; per[(size_t) w].fallback += ps.resident ? ps.fallback_chunks : count; }
+            auto t1 = std::chrono::steady_clock::now();
+            if (timing) fprintf(stderr, "  [%7.1f] queue lane %d: batch %lld phased in %.1f ms\n", since(), w, (long long) cur.batch, std::chrono::duration<double, std::milli>(t1 - t0).count());
+            if (stager.joinable()) stager.join();
+            per[(size_t) w].stage_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+            drop(&cur);
+            if (timing) fprintf(stderr, "  [%7.1f] queue lane %d: chunks dropped\n", since(), w);
+            per[(size_t) w].busy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+            if (r != MRP_OK) { fail(r, msg); drop(&nxt); break; }
+            cur = std::move(nxt);
+        }
+        mrp_pool_adopt(nullptr);
+    };
+    {
+        std::vector<std::thread> th;
+        for (int w = 1; w < n_workers; w++) th.emplace_back(work, w);
+        if (bind) { std::thread t0(work, 0); t0.join(); } /* (the caller's own affinity is left alone) */
+        else work(0);
+        for (auto &t : th) t.join();
+    }
+    const int rc = status.load();
+    if (timing) fprintf(stderr, "  [%7.1f] queue: workers joined\n", since());
     if (stats)
-        for (int d = 0; d < n_devices; d++) {
-            stats->chunks_per_device[d] = per[(size_t) d].chunks;
-            stats->units_per_device[d] = per[(size_t) d].units;
-            stats->busy_ms_per_device[d] = per[(size_t) d].busy_ms;
-            stats->fallback_chunks += per[(size_t) d].fallback;
+        for (int w = 0; w < n_workers; w++) {
+            const int d = w / lanes;
+            stats->chunks_per_device[d] += per[(size_t) w].chunks;
+            stats->units_per_device[d] += per[(size_t) w].units;
+            stats->busy_ms_per_device[d] = std::max(stats->busy_ms_per_device[d], per[(size_t) w].busy_ms);
+            stats->fallback_chunks += per[(size_t) w].fallback;
         }
     if (rc != MRP_OK) {
         for (int64_t i = 0; i < n_chunks; i++) { mrp_phase_result_destroy(out[i]); out[i] = nullptr; }

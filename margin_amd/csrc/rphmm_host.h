@@ -37,6 +37,9 @@ int mrp_context_phase_groups(const mrp_context *ctx);
 /* urgency of the parallel loops the calling thread posts to the host worker pool from now on (smaller = served first) */
 void mrp_pool_set_priority(int p);
 void mrp_pool_set_tag(int t);
+/* the pool the calling thread posts its loops to (NULL: the process-wide one); threads started on behalf of a caller adopt it */
+void *mrp_pool_current(void);
+void mrp_pool_adopt(void *pool);
 long long mrp_pool_tag_cpu_ns(int tag);
 /* fn(i, arg) for every i in [0, n), grain indices at a time, on the caller and the persistent worker pool (mrp_api.cpp) */
 void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void *), void *arg);
