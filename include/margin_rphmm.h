@@ -68,6 +68,11 @@ int mrp_runtime_init(void);
  * sibling contexts (one batch's host work beside the others' kernels); 1..8, or 0 (default): one batch per 24 chunks, at
  * most 4. */
 int mrp_context_set_phase_groups(mrp_context *ctx, int groups);
+/* Test suite only (a private switch, not a parameter: a caller's uninitialised struct field cannot turn it on).  Bit 0, fault
+ * injection: the resident path reports MRP_ENGINE_ERR_MERGE for one hmm of its second level, which must send exactly that
+ * chunk to the hashing path.  Bit 1: the resident merge levels run the separate cross product and emission kernels -- the
+ * path the final level and the ancestor model take -- instead of the one-pass kernel, for A/B parity and timing. */
+int mrp_context_set_test_hooks(mrp_context *ctx, int hooks);
 /* size of the host worker pool (structure of the merge levels, descriptors, classification of alignment pairs): the
  * process-wide pool of contexts used directly, and EACH worker's own pool of a work queue (mrp_queue_*: one pool per device).
  * Default: min(16, hardware threads) for the process-wide pool, hardware threads / devices (2..16) per queue worker.
@@ -196,10 +201,7 @@ typedef struct mrp_params {
     int32_t max_not_sum_transitions;
     int32_t include_inverted_partitions;
     int32_t include_ancestor_sub_prob;
-    int32_t reserved; /* 0.  (Test suite only.  Bit 0, fault injection: the resident path reports MRP_ENGINE_ERR_MERGE for one
-                       * hmm of its second level, which must send exactly that chunk to the hashing path.  Bit 1: the
-                       * resident merge levels run the separate cross product and emission kernels -- the path the final
-                       * level and the ancestor model take -- instead of the one-pass kernel, for A/B parity and timing.) */
+    int32_t reserved; /* must be 0 (the resident path rejects anything else: MRP_ERR_ARG) */
     int64_t min_partitions_in_a_column;
     int64_t max_partitions_in_a_column;
     double min_posterior_probability_for_partition;
@@ -286,11 +288,20 @@ typedef struct mrp_phase_many_stats {
     int32_t fallback_chunks; /* chunks of a resident call that one of the kernels' checks sent to the per-chunk hashing path */
     int64_t levels, hmms, columns, cells, merge_cells; /* of the merge levels */
     double device_ms, cross_ms, sweep_ms, prune_ms;    /* summed HIP-event times of the merge levels */
+    /* resident == 0: why the whole call left the device-resident path (log-sum-exp mode, more partitions per column than
+     * its kernels keep, ...).  The hashing path it takes instead phases one chunk per host thread with a device sweep per merge
+     * level and is two orders of magnitude slower; the first such call of a process also says so on stderr (MRP_QUIET=1
+     * silences it). */
+    char note[160];
 } mrp_phase_many_stats;
 
 /* bubbleGraph_phaseBubbleGraph (bubbleGraph.c:2673-2801) for n_chunks independent chunks in one call: the
  * body of the chunk loop of phase.c:276-473.  Merge levels of all chunks (and both strands) are batched
- * into the same kernel launches.  out[n_chunks] receives one result per chunk; stats may be NULL. */
+ * into the same kernel launches.  out[n_chunks] receives one result per chunk; stats may be NULL.
+ * Parameters outside the resident kernels' range (maxNotSumTransitions = false: the prune ranks doubles; more than 116
+ * partitions per column, the reference's code default is 200, parser.c:22-23) do not fail: every chunk then goes through
+ * mrp_phase_reads, one chunk per host thread -- results identical, throughput that of the hashing path; stats->resident = 0
+ * and stats->note say so. */
 int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *const *chunks, const mrp_read *const *reads,
                          const int64_t *n_reads, const mrp_params *params, mrp_phase_result **out,
                          mrp_phase_many_stats *stats);

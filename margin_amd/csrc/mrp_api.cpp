@@ -64,6 +64,7 @@ mrp_context *mrp_context_sibling(mrp_context *ctx, int i) {
         mrp_context *s = nullptr;
         if (mrp_context_create(ctx->device, &s) != MRP_OK) return nullptr;
         s->phase_groups = 1;
+        s->test_hooks = ctx->test_hooks;
         /* every pool of the family knows the others (out-of-memory retry) */
         std::vector<mrp_context *> family(ctx->siblings);
         family.push_back(ctx);
@@ -742,6 +743,13 @@ int mrp_context_set_phase_groups(mrp_context *ctx, int groups) {
     return MRP_OK;
 }
 int mrp_context_phase_groups(const mrp_context *ctx) { return ctx->phase_groups; }
+int mrp_context_set_test_hooks(mrp_context *ctx, int hooks) {
+    if (!ctx || hooks < 0 || hooks > 3) return fail(MRP_ERR_ARG, "mrp_context_set_test_hooks: bad arguments");
+    ctx->test_hooks = hooks;
+    for (mrp_context *s_ : ctx->siblings) s_->test_hooks = hooks;
+    return MRP_OK;
+}
+int mrp_context_test_hooks(const mrp_context *ctx) { return ctx->test_hooks; }
 
 extern "C" {
 
@@ -773,9 +781,13 @@ int mrp_batch_upload(mrp_batch *b) {
             else wide.push_back({-work, (int32_t) i});
         } else {
             generic.push_back({-work, (int32_t) i});
-            /* sum mode with merge columns that fit LDS: the reproducible log-sum-exp kernel */
-            if (!max_mode && !h.wide_idx && h.max_merge <= MRP_LSE_CUR_LDS_MAX_MERGE) lse.push_back({-work, (int32_t) i});
-            else if (!max_mode && !h.wide_idx && h.max_merge <= MRP_LSE_MAX_MERGE) lse_big.push_back({-work, (int32_t) i});
+            /* sum mode with merge columns that fit LDS: the reproducible log-sum-exp kernel.  Its sums are 64-bit fixed point
+             * in units of 2^-50 with every term <= 1: fewer than 2^14 terms per sum (a column's cells also sum into the
+             * hmm's / column's total), and its reference points are floats: |log p| has to stay below 2^27, where a float
+             * still resolves 8 -- beyond either bound the generic fp64 kernel takes the hmm */
+            const bool lse_ok = !max_mode && !h.wide_idx && h.max_cells < MRP_LSE_MAX_TERMS && h.cost_bound < MRP_LSE_MAX_COST;
+            if (lse_ok && h.max_merge <= MRP_LSE_CUR_LDS_MAX_MERGE) lse.push_back({-work, (int32_t) i});
+            else if (lse_ok && h.max_merge <= MRP_LSE_MAX_MERGE) lse_big.push_back({-work, (int32_t) i});
         }
     }
     auto plan = [&](std::vector<std::pair<int64_t, int32_t>> &v, std::vector<int32_t> &order, int *max_merge) {

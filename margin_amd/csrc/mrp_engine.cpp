@@ -151,6 +151,7 @@ extern "C" {
 int mrp_engine_create(mrp_context *ctx, const mrp_params *params, mrp_engine **out) {
     if (!ctx || !params || !out) return mrp_set_error(MRP_ERR_ARG, "mrp_engine_create: NULL argument");
     *out = nullptr;
+    if (params->reserved != 0) return mrp_set_error(MRP_ERR_ARG, "mrp_params.reserved must be 0");
     if (!params->max_not_sum_transitions)
         return mrp_set_error(MRP_ERR_UNSUPPORTED, "the device-resident merge needs maxNotSumTransitions (integer posteriors)");
     const int64_t lim = std::max<int64_t>(params->min_partitions_in_a_column, params->max_partitions_in_a_column);
@@ -287,7 +288,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     L->x = x;
     L->n = n;
     L->final_level = final_level;
-    L->fused = !final_level && !(e->params.reserved & 2);
+    L->fused = !final_level && !(ctx->test_hooks & 2);
     for (int64_t i = 0; i < n && L->fused; i++)
         if (x[i].flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) L->fused = false;
     const bool fused = L->fused;
@@ -461,7 +462,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         pp.max_cells = std::max(pp.max_cells, x[i].bound_max_cells);
         pp.max_merge = std::max(pp.max_merge, x[i].bound_max_merge);
     }
-    pp.pad = (e->params.reserved & 1) && e->stats.levels + (e->running ? 1 : 0) == 1 ? 1 : 0; /* test hook, see mrp_params.reserved */
+    pp.pad = (ctx->test_hooks & 1) && e->stats.levels + (e->running ? 1 : 0) == 1 ? 1 : 0; /* test hook, see mrp_context_set_test_hooks */
 
     tm[tmi++] = eng_now();
     /* device side of the description + the descriptor arrays the structure and layout kernels fill */
@@ -563,6 +564,9 @@ static int level_finish(mrp_engine *e) {
             if (bits == 0) continue;
             Lp->x[(size_t) Lp->perm[(size_t) j]].err = bits;
             if (bits & (MRP_ENGINE_ERR_STRUCTURE | MRP_ENGINE_ERR_MERGE)) continue;
+            /* an hmm whose chunk already left the resident path at the level before (this level was staged before that was
+             * known): it ran on a discarded parent's arrays, whatever it raised is that parent's */
+            { const mrp_xhmm &xq = Lp->x[(size_t) Lp->perm[(size_t) j]]; if (xq.discarded && *xq.discarded) continue; }
             if (bits & MRP_ENGINE_ERR_POSTERIOR) rc = mrp_set_error(MRP_ERR_ARG, "ERROR: invalid prob (f + b exceeds the column total)");
             else rc = mrp_set_error(MRP_ERR_LOOKUP, "device-resident merge: transition index out of range");
         }

@@ -191,6 +191,7 @@ struct mrp_context {
         return hipEventSynchronize(block_ev);
     }
     DevPool pool;
+    int test_hooks = 0;   /* mrp_context_set_test_hooks (test suite only) */
     int phase_groups = 0; /* concurrent batches of mrp_phase_reads_many (mrp_context_set_phase_groups); 0: chosen by batch size */
     std::vector<mrp_context *> siblings; /* further contexts on the same device (concurrent batches of mrp_phase_reads_many) */
     std::mutex sibling_mu;

@@ -67,6 +67,8 @@ hipError_t mrp_launch_sweep_f64(const MrpBatchDev &d, const int32_t *order_dev, 
  * per merge column, 16-bit transitions */
 #define MRP_LSE_CUR_LDS_MAX_MERGE 8000 /* 20 B of LDS per merge cell up to here, 12 B above (finished values read back from HBM) */
 #define MRP_LSE_MAX_MERGE 13600
+#define MRP_LSE_MAX_TERMS 16384          /* cells per column: 2^14 terms of at most 2^50 units each fit the 64-bit accumulator */
+#define MRP_LSE_MAX_COST (1ll << 27)     /* bound of |log p|: the float reference points of the kernel resolve 8 up to here */
 hipError_t mrp_launch_sweep_lse(const MrpBatchDev &d, const int32_t *order_dev, int64_t n, int max_merge, hipStream_t stream);
 hipError_t mrp_launch_fill_f64(double *p, int64_t n, double v, hipStream_t stream);
 hipError_t mrp_launch_emissions(const DevCol *col_dev, const DevChunk *chunks, const uint64_t *planes,

@@ -37,14 +37,31 @@ struct QueuePlan {
     std::vector<int64_t> batch_off; /* batch b = order[batch_off[b] .. batch_off[b + 1]) */
 };
 
-/* phase.c:257-263: sort by estimated size, largest first; then cut into batches of consecutive chunks */
-QueuePlan plan_queue(int64_t n, const int64_t *cost, int64_t chunks_per_batch) {
+/* phase.c:257-263: sort by estimated size, largest first; then cut into batches of consecutive chunks.
+ * chunks_per_batch >= 1: batches of that many chunks.  0: the library's choice for n_workers pulling threads on n_devices
+ * devices.  A batch is one mrp_phase_reads_many call; a call begins and ends with host work and walks its merge levels one
+ * after the other, the top ones bound by per-column latency whatever the number of chunks, so large batches amortize that
+ * (288 chunks in one call take 140 ms, in four calls on two lanes 225 ms).  A short queue is therefore ONE batch per device
+ * (its upload overlaps the host's setup of the same call); a long one is handed out in batches of MRP_QUEUE_DEFAULT_BATCH
+ * chunks that shrink towards the end ("guided" schedule: remaining / (2 x workers), at least 24), so that the devices finish
+ * within a fraction of a percent of each other (tests/test_work_queue.py: 8 devices, 31 000 chunks). */
+QueuePlan plan_queue(int64_t n, const int64_t *cost, int64_t chunks_per_batch, int n_workers = 1, int n_devices = 1) {
     QueuePlan p;
     p.order.resize((size_t) n);
     std::iota(p.order.begin(), p.order.end(), (int64_t) 0);
     std::stable_sort(p.order.begin(), p.order.end(), [&](int64_t a, int64_t b) { return cost[a] > cost[b]; });
-    if (chunks_per_batch < 1) chunks_per_batch = 1;
-    for (int64_t o = 0; o < n; o += chunks_per_batch) p.batch_off.push_back(o);
+    if (chunks_per_batch >= 1) {
+        for (int64_t o = 0; o < n; o += chunks_per_batch) p.batch_off.push_back(o);
+    } else if (n <= (int64_t) n_devices * (MRP_QUEUE_DEFAULT_BATCH + MRP_QUEUE_DEFAULT_BATCH / 3)) {
+        const int64_t per = std::max<int64_t>(1, (n + n_devices - 1) / n_devices);
+        for (int64_t o = 0; o < n; o += per) p.batch_off.push_back(o);
+    } else {
+        for (int64_t o = 0; o < n;) {
+            p.batch_off.push_back(o);
+            const int64_t left = n - o;
+            o += std::max<int64_t>(24, std::min<int64_t>(MRP_QUEUE_DEFAULT_BATCH, left / (2 * (int64_t) std::max(1, n_workers))));
+        }
+    }
     p.batch_off.push_back(n);
     return p;
 }
@@ -92,7 +109,7 @@ int mrp_queue_dry_run(int32_t n_workers, int64_t n_chunks, const int64_t *cost, 
                       int32_t *worker_of_chunk_out, int64_t *sequence_out) {
     if (n_workers < 1 || n_workers > MRP_MAX_QUEUE_DEVICES || n_chunks < 0 || (n_chunks > 0 && (!cost || !worker_of_chunk_out)))
         return mrp_set_error(MRP_ERR_ARG, "mrp_queue_dry_run: bad arguments");
-    const QueuePlan p = plan_queue(n_chunks, cost, chunks_per_batch);
+    const QueuePlan p = plan_queue(n_chunks, cost, chunks_per_batch, n_workers, n_workers);
     std::atomic<int64_t> seq{0};
     std::vector<int32_t> wob;
     const int rc = run_queue(n_workers, p, [&](int w, int64_t, int64_t first, int64_t count) {
@@ -209,20 +226,7 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
         for (int64_t r = 0; r < c.n_reads; r++) cost[(size_t) i] += c.reads[r].length;
     }
     const int lanes = q->lanes, n_workers = n_devices * lanes;
-    /* A batch is one mrp_phase_reads_many call.  A call begins and ends with host work and walks its merge levels one after the
-     * other, the top ones bound by per-column latency whatever the number of chunks: large batches amortize that (288 chunks in
-     * one call take 140 ms, in four calls on two lanes 225 ms).  So a short queue is ONE batch per device -- its upload overlaps
-     * the host's setup of the same call -- and a long one is cut into batches of about MRP_QUEUE_DEFAULT_BATCH, their number a
-     * multiple of the number of lanes so that the queue does not end with one lane working alone. */
-    if (chunks_per_batch < 1) {
-        if (n_chunks <= (int64_t) n_devices * (MRP_QUEUE_DEFAULT_BATCH + MRP_QUEUE_DEFAULT_BATCH / 3)) chunks_per_batch = (n_chunks + n_devices - 1) / n_devices;
-        else {
-            const int64_t rounds = (n_chunks + (int64_t) n_workers * MRP_QUEUE_DEFAULT_BATCH - 1) / ((int64_t) n_workers * MRP_QUEUE_DEFAULT_BATCH);
-            chunks_per_batch = (n_chunks + rounds * n_workers - 1) / (rounds * n_workers);
-        }
-        if (chunks_per_batch < 1) chunks_per_batch = 1;
-    }
-    const QueuePlan plan = plan_queue(n_chunks, cost.data(), chunks_per_batch);
+    const QueuePlan plan = plan_queue(n_chunks, cost.data(), chunks_per_batch, n_workers, n_devices);
     const int64_t n_batches = (int64_t) plan.batch_off.size() - 1;
     if (stats) stats->batches = n_batches;
 

@@ -1733,7 +1733,7 @@ static void level_finish(int64_t i, void *arg) {
 /* a shadow as the engine is told about it */
 static void r_describe(const world *w, const rhmm *x, uint32_t flags, mrp_xhmm *d) {
     memset(d, 0, sizeof(*d));
-    d->chunk = w->chunk; d->flags = flags;
+    d->chunk = w->chunk; d->flags = flags; d->discarded = &w->failed;
     d->ref_start = x->ref_start; d->ref_end = x->ref_start + x->ref_length;
     d->n_cols = x->n_cols; d->n_a = x->n_a; d->n_b = x->n_b; d->par = x->par;
     d->col_start = x->starts; d->col_read_off = x->roff;
@@ -2192,11 +2192,42 @@ static void *phase_group_main(void *p) {
     return NULL;
 }
 
+/* the chunks of a call that cannot take the resident path, pulled one at a time by up to eight host threads */
+typedef struct {
+    mrp_context *ctx;
+    const mrp_chunk *const *chunks;
+    const mrp_read *const *reads;
+    const int64_t *n_reads;
+    const mrp_params *params;
+    mrp_phase_result **out;
+    int64_t next;
+    int rc;
+    char err[256];
+    int threads;
+    int64_t n;
+} hashing_ctl;
+typedef struct { hashing_ctl *ctl; mrp_context *ctx; } hashing_arg;
+static void *hashing_main(void *p) {
+    hashing_arg *a = p;
+    hashing_ctl *hc = a->ctl;
+    for (;;) {
+        const int64_t c = __atomic_fetch_add(&hc->next, 1, __ATOMIC_RELAXED);
+        if (c >= hc->n || __atomic_load_n(&hc->rc, __ATOMIC_RELAXED) != MRP_OK) return NULL;
+        const int rc = mrp_phase_reads(a->ctx, hc->chunks[c], hc->reads[c], hc->n_reads[c], hc->params, NULL, &hc->out[c]);
+        if (rc != MRP_OK) {
+            int expect = MRP_OK;
+            if (__atomic_compare_exchange_n(&hc->rc, &expect, rc, 0, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) snprintf(hc->err, sizeof(hc->err), "%s", mrp_last_error());
+            return NULL;
+        }
+    }
+}
+
 int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *const *chunks, const mrp_read *const *reads,
                          const int64_t *n_reads, const mrp_params *params, mrp_phase_result **out,
                          mrp_phase_many_stats *stats) {
     if (!ctx || n_chunks < 0 || !params || (n_chunks > 0 && (!chunks || !reads || !n_reads || !out)))
         return mrp_set_error(MRP_ERR_ARG, "mrp_phase_reads_many: bad arguments");
+    if (params->reserved != 0) return mrp_set_error(MRP_ERR_ARG, "mrp_params.reserved must be 0");
     if (stats) memset(stats, 0, sizeof(*stats));
     for (int64_t c = 0; c < n_chunks; c++) out[c] = NULL;
     /* the levels of a batch alternate host work (structure, descriptors) and device work; two interleaved halves of the
@@ -2253,12 +2284,36 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
         free(grp);
     }
     if (rc == MRP_ERR_UNSUPPORTED) {
-        /* parameters or hmm shapes outside the resident path: the hashing path, chunk by chunk */
-        if (stats) memset(stats, 0, sizeof(*stats));
+        /* Parameters or hmm shapes outside the resident path: the hashing path (mrp_phase_reads), one chunk per host thread,
+         * each thread with a context of its own.  Said loudly: this is two orders of magnitude slower than the resident path. */
+        char why[160];
+        snprintf(why, sizeof(why), "%s", mrp_last_error());
+        if (stats) { memset(stats, 0, sizeof(*stats)); snprintf(stats->note, sizeof(stats->note), "%s", why); }
+        static int warned;
+        if (!__atomic_exchange_n(&warned, 1, __ATOMIC_RELAXED) && !getenv("MRP_QUIET"))
+            fprintf(stderr, "margin_rphmm: mrp_phase_reads_many leaves the device-resident path (%s): %lld chunk(s) take the per-chunk hashing path, "
+                            "about 100x slower per chunk\n", why, (long long) n_chunks);
         rc = MRP_OK;
         for (int64_t c = 0; c < n_chunks; c++) { mrp_phase_result_destroy(out[c]); out[c] = NULL; }
-        for (int64_t c = 0; c < n_chunks && rc == MRP_OK; c++)
-            rc = mrp_phase_reads(ctx, chunks[c], reads[c], n_reads[c], params, NULL, &out[c]);
+        int T = mrp_host_threads();
+        if (T > 8) T = 8;
+        if (T > n_chunks) T = (int) n_chunks;
+        if (T < 1) T = 1;
+        hashing_ctl hc = {ctx, chunks, reads, n_reads, params, out, 0, MRP_OK, {0}, T, 0};
+        for (int t = 1; t < T && rc == MRP_OK; t++)
+            if (!mrp_context_sibling(ctx, t - 1)) rc = MRP_ERR_HIP; /* all contexts before the first thread (allocator peers) */
+        if (rc == MRP_OK) {
+            hc.n = n_chunks;
+            pthread_t th[8];
+            int started[8] = {0};
+            hashing_arg ha[8];
+            for (int t = 0; t < T; t++) { ha[t].ctl = &hc; ha[t].ctx = t == 0 ? ctx : mrp_context_sibling(ctx, t - 1); }
+            for (int t = 1; t < T; t++) started[t] = pthread_create(&th[t], NULL, hashing_main, &ha[t]) == 0;
+            hashing_main(&ha[0]);
+            for (int t = 1; t < T; t++) if (started[t]) pthread_join(th[t], NULL);
+            rc = hc.rc;
+            if (rc != MRP_OK) mrp_set_error(rc, "%s", hc.err);
+        }
     }
     if (rc != MRP_OK)
         for (int64_t c = 0; c < n_chunks; c++) { mrp_phase_result_destroy(out[c]); out[c] = NULL; }

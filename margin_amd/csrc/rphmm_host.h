@@ -34,6 +34,7 @@ int mrp_set_error(int code, const char *fmt, ...);
 /* host worker threads for structural code and descriptor building (mrp_set_host_threads, default min(16, cores)) */
 int mrp_host_threads(void);
 int mrp_context_phase_groups(const mrp_context *ctx);
+int mrp_context_test_hooks(const mrp_context *ctx);
 /* urgency of the parallel loops the calling thread posts to the host worker pool from now on (smaller = served first) */
 void mrp_pool_set_priority(int p);
 void mrp_pool_set_tag(int t);
@@ -69,6 +70,7 @@ typedef struct mrp_xhmm {
     const mrp_xpar *par;          /* [n_a + n_b] path A then path B, each in reference order */
     const int32_t *col_start;     /* [n_cols] first site of every column (the last one ends at ref_end) */
     const int32_t *col_read_off;  /* [n_cols + 1] prefix sums of the column depths */
+    const int *discarded;         /* optional: non-zero once the hmm's chunk has been given up (a parent was discarded at an earlier level) */
     /* static bounds (mrp_side_bound per side and column): launch classes and range checks; the exact sizes are computed on
      * the device from the parents' counts */
     int64_t bound_cells, bound_merge;

@@ -28,7 +28,7 @@ def assert_job_equal(flat, res, exact=True, atol=0.0):
             assert (np.isneginf(x) == np.isneginf(y)).all(), a
             assert np.allclose(x[fin], y[fin], rtol=0, atol=atol), (a, np.abs(x[fin] - y[fin]).max())
     for a in ("hmm_forward", "hmm_backward"):
-        x, y = float(flat[a]), float(res[a][0])
+        x, y = float(np.asarray(flat[a]).reshape(-1)[0]), float(np.asarray(res[a]).reshape(-1)[0])
         if exact:
             assert x == y, (a, x, y)
         else:

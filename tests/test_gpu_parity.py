@@ -253,3 +253,77 @@ def test_launches_queued_back_to_back_keep_their_own_events(gpu_ctx, small_ont):
         assert_job_equal(f, j.results(), exact=True)
     batch.close()
     dchunk.close()
+
+
+def _hand_made_job(chunk, cols, partitions, merges, flags):
+    """A flat job from explicit columns [(start, length, [read ids])], per-column partition lists and per-merge-column
+    (mask_from, mask_to, [(from, to)]) tuples; the reads' bytes start where the column does (profileSeq.c:41-47)."""
+    K = len(cols)
+    co, ro, rbo, part = [0], [0], [], []
+    for (start, _length, reads), P in zip(cols, partitions):
+        for r in reads:
+            rd = chunk.reads[r]
+            rbo.append(rd.pool_off + int(chunk.allele_offset[start] - chunk.allele_offset[rd.ref_start]))
+        ro.append(len(rbo))
+        part += list(P)
+        co.append(len(part))
+    mo, mfrom, mto = [0], [], []
+    for (_mf, _mt, pairs) in merges:
+        mfrom += [p[0] for p in pairs]
+        mto += [p[1] for p in pairs]
+        mo.append(len(mfrom))
+    return dict(n_columns=K, flags=flags, col_ref_start=np.array([c[0] for c in cols], dtype=np.int32),
+                col_length=np.array([c[1] for c in cols], dtype=np.int32), col_depth=np.array([len(c[2]) for c in cols], dtype=np.int32),
+                col_cell_off=np.array(co, dtype=np.int64), col_read_off=np.array(ro, dtype=np.int64), read_byte_off=np.array(rbo, dtype=np.int64),
+                partition=np.array(part, dtype=np.uint64), mask_from=np.array([m[0] for m in merges], dtype=np.uint64),
+                mask_to=np.array([m[1] for m in merges], dtype=np.uint64), mcol_cell_off=np.array(mo if K > 1 else [0], dtype=np.int64),
+                merge_from=np.array(mfrom, dtype=np.uint64), merge_to=np.array(mto, dtype=np.uint64))
+
+
+def _run_one_job(gpu_ctx, chunk, flat):
+    from margin_amd.capi import Batch, Job
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    j = Job(dchunk, flat, int(flat["flags"]), False)
+    b = Batch(gpu_ctx)
+    b.add(j)
+    b.upload(); b.launch(); b.download()
+    st = b.stats()
+    r = j.results()
+    b.close()
+    dchunk.close()
+    return r, st
+
+
+def test_sum_mode_column_of_2_to_the_14_cells_takes_the_generic_kernel(gpu_ctx):
+    """The log-sum-exp kernel with the merge column in LDS accumulates in 64-bit fixed point, 2^50 units per term: a column of
+    2^14 equal-valued cells would wrap its accumulator.  Such an hmm goes to the generic fp64 kernel (mrp_api.cpp launch plan)
+    and its sums are the sequential logAddP of hmm.c:15-20 within 1e-9 (checked against the naive evaluation)."""
+    from tests import bruteforce
+    chunk = synth.make_ont_chunk(seed=21, region_bp=2_000, n_sites=4, coverage=40)
+    full = [i for i, r in enumerate(chunk.reads) if r.ref_start == 0 and r.length == 4][:1]
+    assert full, "no read spans the four sites"
+    n = 1 << 14
+    flat = _hand_made_job(chunk, [(0, 2, full), (2, 2, full)], [[i & 1 for i in range(n)], [0, 1]], [(1, 1, [(0, 0), (1, 1)])], flags=0)
+    ref = bruteforce.forward_backward(chunk, flat, 0)
+    r, st = _run_one_job(gpu_ctx, chunk, flat)
+    assert st.n_hmms_generic == 1 and st.n_hmms_lse == 0 and st.n_hmms_int32 == 0
+    assert_job_equal(ref, r, exact=False, atol=1e-9)
+    # every cell of the first column has one of two values: the column total is value + log(2^13) on either side
+    assert np.isfinite(r["col_total"]).all() and abs(float(r["hmm_forward"][0]) - float(ref["hmm_forward"][0])) <= 1e-9
+
+
+def test_sum_mode_large_costs_take_the_generic_kernel(gpu_ctx):
+    """|log p| beyond 2^27 (the float reference points of the LDS kernel stop resolving single units there): a column of
+    64 reads over 8 300 sites has a cost bound of 1.35e8 and is swept by the generic fp64 kernel, equal to the naive evaluation."""
+    from tests import bruteforce
+    rng = np.random.default_rng(5)
+    n_sites, depth = 8300, 64
+    A = np.full(n_sites, 2, dtype=np.uint32)
+    reads_raw = [(f"r{i:02d}", 0, n_sites, 1, 0, rng.integers(0, 256, size=2 * n_sites, dtype=np.uint8)) for i in range(depth)]
+    chunk = synth._finish(A, reads_raw, None, None)
+    parts = [int(x) for x in rng.integers(0, 1 << 63, size=2, dtype=np.uint64)]
+    flat = _hand_made_job(chunk, [(0, n_sites, list(range(depth)))], [parts], [], flags=0)
+    ref = bruteforce.forward_backward(chunk, flat, 0)
+    r, st = _run_one_job(gpu_ctx, chunk, flat)
+    assert st.n_hmms_generic == 1 and st.n_hmms_lse == 0
+    assert_job_equal(ref, r, exact=False, atol=1e-6)  # values of magnitude 1e7-1e8: one ulp is 1e-8

@@ -109,12 +109,29 @@ def test_resident_falls_back_outside_its_range(gpu_ctx, orc):
         capi.get_rp_hmms_resident(gpu_ctx, dchunk, chunk, params)
     assert ei.value.code == capi.MRP_ERR_UNSUPPORTED
     got, st = capi.phase_reads_many(gpu_ctx, [dchunk], [chunk], params)
-    assert st.resident == 0
+    assert st.resident == 0 and b"maxNotSumTransitions" in st.note  # the reason is reported, not only resident = 0
     host = capi.phase_reads(gpu_ctx, dchunk, chunk, params)
     for k in PHASE_KEYS:
         assert (np.asarray(got[0][k]) == np.asarray(host[k])).all(), k
     assert got[0]["reads1"] == host["reads1"] and got[0]["reads2"] == host["reads2"]
     dchunk.close()
+
+
+def test_more_partitions_than_the_resident_kernels_keep_take_the_hashing_path_in_parallel(gpu_ctx, orc):
+    """maxPartitionsInAColumn = 200 is the reference's code default (parser.c:22-23); the resident kernels keep at most 116
+    per column.  The call does not fail: its chunks go through the hashing path, several host threads with a context each,
+    and equal the oracle; the statistics say why."""
+    pd = _params()
+    pd["minPartitionsInAColumn"], pd["maxPartitionsInAColumn"] = 50, 200
+    params = capi.Params.from_reference_names(pd)
+    chunks = [synth.make_ont_chunk(seed=71 + i, region_bp=30_000, n_sites=60, coverage=16 + 2 * i) for i in range(5)]
+    dchunks = [capi.DeviceChunk.from_chunk(gpu_ctx, c) for c in chunks]
+    got, st = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
+    assert st.resident == 0 and b"partitions per column" in st.note
+    for chunk, g in zip(chunks, got):
+        _assert_equals_oracle(orc, chunk, g, pd)
+    for d in dchunks:
+        d.close()
 
 
 def test_bubbles_to_haplotype_tags_end_to_end(gpu_ctx, orc):
@@ -422,21 +439,24 @@ def test_resident_merge_check_failure_sends_only_that_chunk_to_the_hashing_path(
     """MRP_ENGINE_ERR_MERGE -- "a merge cell the kept cells lead to would itself be pruned" (hmm.c:1090-1100) -- cannot be
     produced by an input in max-plus mode (a merge cell's posterior is at least that of every cell leading to it, so
     whenever more than minPartitionsInAColumn cells are kept they and their merge cells all pass the threshold); the
-    kernel checks it all the same.  The check's way out is exercised by fault injection (mrp_params.reserved bit 0: one
+    kernel checks it all the same.  The check's way out is exercised by fault injection (mrp_context_set_test_hooks bit 0: one
     hmm of the second level reports the error): that hmm's chunk, and only it, is redone on the hashing path; results are
     the oracle's."""
     pd = _params()
     params = capi.Params.from_reference_names(pd)
-    params.reserved = 1
+    gpu_ctx.set_test_hooks(1)
     chunks = [synth.make_ont_chunk(seed=91 + i, region_bp=50_000, n_sites=100, coverage=20 + 4 * i) for i in range(4)]
     dchunks = [capi.DeviceChunk.from_chunk(gpu_ctx, c) for c in chunks]
     got, st = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
     assert st.resident == 1 and st.fallback_chunks == 1
     for chunk, g in zip(chunks, got):
         _assert_equals_oracle(orc, chunk, g, pd)
-    params.reserved = 0
+    gpu_ctx.set_test_hooks(0)
     _, st0 = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
     assert st0.resident == 1 and st0.fallback_chunks == 0
+    params.reserved = 1  # a parameter struct with a stray reserved field is refused, not interpreted
+    with pytest.raises(capi.MrpError):
+        capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
     for d in dchunks:
         d.close()
 
@@ -445,7 +465,7 @@ def test_resident_merge_check_failure_sends_only_that_chunk_to_the_hashing_path(
 def test_one_pass_cross_emission_equals_the_two_kernel_path_and_the_oracle(gpu_ctx, orc, case):
     """Merge levels compute a cell's emission from per-parent-cell tables inside the cross product kernel and write no
     partition (emissions.c:125-154 is a sum over the reads of the partition, partitions.c:21-28 concatenates the two
-    parents' reads).  Same chunks through the separate cross product + emission kernels (mrp_params.reserved bit 1): both
+    parents' reads).  Same chunks through the separate cross product + emission kernels (mrp_context_set_test_hooks bit 1): both
     equal the oracle.  The cases cover sites with different allele counts inside one column, columns whose sites do not
     fit one table fill (long reads: hundreds of allele slots per column at the low levels) and a site with more alleles
     than the tables hold for wide columns (that chunk takes the hashing path)."""
@@ -461,8 +481,11 @@ def test_one_pass_cross_emission_equals_the_two_kernel_path_and_the_oracle(gpu_c
     dchunks = [capi.DeviceChunk.from_chunk(gpu_ctx, c) for c in chunks]
     params = capi.Params.from_reference_names(pd)
     got1, st1 = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
-    params.reserved = 2
-    got2, st2 = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
+    gpu_ctx.set_test_hooks(2)
+    try:
+        got2, st2 = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
+    finally:
+        gpu_ctx.set_test_hooks(0)
     assert st1.resident == 1 and st2.resident == 1 and st2.fallback_chunks == 0
     if case != "many_alleles":
         assert st1.fallback_chunks == 0

@@ -33,8 +33,8 @@ def main():
     args = ap.parse_args()
     pd = synth.shipped_phase_params()
     params = capi.Params.from_reference_names(pd)
-    params.reserved = int(os.environ.get("MRP_PARAMS_RESERVED", "0"))  # bit 1: separate cross product / emission kernels (A/B)
     ctx = capi.Context(0)
+    ctx.set_test_hooks(int(os.environ.get("MRP_TEST_HOOKS", "0")))  # bit 1: separate cross product / emission kernels (A/B)
     if os.environ.get("MRP_PHASE_GROUPS"):
         ctx.set_phase_groups(int(os.environ["MRP_PHASE_GROUPS"]))
     if os.environ.get("MRP_HOST_THREADS"):
