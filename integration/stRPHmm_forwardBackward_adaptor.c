@@ -48,8 +48,38 @@ typedef stList *adp_mcells;
 #define ADP_ABORT(...) st_errAbort(__VA_ARGS__)
 #define ADP_MALLOC(n) st_malloc(n)
 #define ADP_DEVICE_FOR_THIS_THREAD() (omp_get_thread_num() % mrp_device_count())
+/* the body this file replaces, kept in impl/hmm.c under this name: hmms below the size threshold stay on it */
+void stRPHmm_forwardBackward_cpu(stRPHmm *hmm);
+#define ADP_CPU_FORWARD_BACKWARD(hmm) stRPHmm_forwardBackward_cpu(hmm)
 #include <omp.h>
 #endif
+
+/* An hmm with fewer cells than this is swept by the CPU body: a device sweep costs a flatten, an upload, a launch and a
+ * download (~0.3 ms whatever the size), the CPU body ~0.1 us per cell.  Most hmms of a chunk are that small (the first
+ * merge levels: a few reads each), most CELLS are in the few large ones.  MRP_ADAPTOR_MIN_CELLS overrides (0: everything on
+ * the device); measured with tools/adaptor_probe.py, INTEGRATION.md. */
+#ifndef MRP_ADAPTOR_MIN_CELLS_DEFAULT
+#define MRP_ADAPTOR_MIN_CELLS_DEFAULT 4096
+#endif
+static int64_t adpMinCells = -1;
+static int64_t adp_min_cells(void) {
+    if (adpMinCells < 0) {
+        const char *e = getenv("MRP_ADAPTOR_MIN_CELLS");
+        adpMinCells = e != NULL ? atoll(e) : MRP_ADAPTOR_MIN_CELLS_DEFAULT;
+        if (adpMinCells < 0) adpMinCells = 0;
+    }
+    return adpMinCells;
+}
+void mrpAdaptor_setMinCells(int64_t cells) { adpMinCells = cells < 0 ? 0 : cells; } /* overrides the environment / the default */
+static int adp_is_small(stRPHmm *hmm, int64_t limit) { /* fewer than `limit` cells? (stops counting at the limit) */
+    int64_t n = 0;
+    for (stRPColumn *c = hmm->firstColumn;; c = ADP_MCOL_NEXT(c->nColumn)) {
+        for (stRPCell *cell = c->head; cell != NULL; cell = cell->nCell)
+            if (++n >= limit) return 0;
+        if (c->nColumn == NULL) break;
+    }
+    return 1;
+}
 
 /* ---- per-thread state ----------------------------------------------------------------------------------------- */
 typedef struct {
@@ -321,9 +351,16 @@ void stRPHmm_forwardBackwardMany(stRPHmm **hmms, int64_t n) {
     if (n <= 0) return;
     adp_flat *flat = ADP_MALLOC(sizeof(*flat) * (size_t) n);
     mrp_hmm_job *jobs = ADP_MALLOC(sizeof(*jobs) * (size_t) n);
-    for (int64_t i = 0; i < n; i++) { adp_flatten(hmms[i], &flat[i]); jobs[i] = flat[i].job; }
-    if (mrp_fb_run(adp_context(), n, jobs) != MRP_OK) ADP_ABORT("margin_rphmm: %s", mrp_last_error());
-    for (int64_t i = 0; i < n; i++) { adp_scatter(&flat[i]); adp_release(&flat[i]); }
+    const int64_t limit = adp_min_cells();
+    int64_t m = 0;
+    for (int64_t i = 0; i < n; i++) {
+        if (limit > 0 && adp_is_small(hmms[i], limit)) { ADP_CPU_FORWARD_BACKWARD(hmms[i]); continue; }
+        adp_flatten(hmms[i], &flat[m]);
+        jobs[m] = flat[m].job;
+        m++;
+    }
+    if (m > 0 && mrp_fb_run(adp_context(), m, jobs) != MRP_OK) ADP_ABORT("margin_rphmm: %s", mrp_last_error());
+    for (int64_t i = 0; i < m; i++) { adp_scatter(&flat[i]); adp_release(&flat[i]); }
     free(jobs);
     free(flat);
 }

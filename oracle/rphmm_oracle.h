@@ -210,6 +210,8 @@ orc_genome_fragment *orc_phase_profile_seqs(orc_profile_seq **seqs, const uint8_
  * code (coordination.c:312, bubbleGraph.c:2749, hmm.c:1332), before prune mutates the hmm. */
 typedef void (*orc_fb_observer)(orc_hmm *hmm, void *user);
 void orc_set_fb_observer(orc_fb_observer fn, void *user);
+/* replaces the driver's stRPHmm_forwardBackward calls (one) / the sweep loop of one mergeTwoTilingPaths call (many); NULL restores */
+void orc_set_fb_override(void (*one)(orc_hmm *), void (*many)(orc_hmm **, int64_t));
 
 /* Wall-clock seconds spent inside orc_hmm_forwardBackward since the last reset, and calls. */
 void orc_fb_timer_reset(void);

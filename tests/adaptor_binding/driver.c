@@ -7,6 +7,7 @@ void stRPHmm_forwardBackwardMany(stRPHmm **hmms, int64_t n);
 void mrpAdaptor_registerProfileSeqs(stReference *ref, stProfileSeq **seqs, int64_t n);
 void mrpAdaptor_unregister(stReference *ref);
 void mrpAdaptor_threadCleanup(void);
+void mrpAdaptor_setMinCells(int64_t cells);
 
 /* every field stRPHmm_forwardBackward has to set, overwritten with NaN */
 void adp_test_poison(orc_hmm *hmm) {
@@ -26,3 +27,4 @@ void adp_test_forward_backward_many(orc_hmm **hmms, int64_t n) { stRPHmm_forward
 void adp_test_register(orc_reference *ref, orc_profile_seq **seqs, int64_t n) { mrpAdaptor_registerProfileSeqs(ref, seqs, n); }
 void adp_test_unregister(orc_reference *ref) { mrpAdaptor_unregister(ref); }
 void adp_test_cleanup(void) { mrpAdaptor_threadCleanup(); }
+void adp_test_set_min_cells(int64_t cells) { mrpAdaptor_setMinCells(cells); }

@@ -29,4 +29,5 @@ typedef orc_merge_column *adp_mcells;
 #define ADP_ABORT(...) do { fprintf(stderr, __VA_ARGS__); fprintf(stderr, "\n"); abort(); } while (0)
 #define ADP_MALLOC(n) malloc(n)
 #define ADP_DEVICE_FOR_THIS_THREAD() 0
+#define ADP_CPU_FORWARD_BACKWARD(hmm) orc_hmm_forwardBackward(hmm) /* the oracle's own body stands in for impl/hmm.c:931-942 */
 #endif

@@ -34,7 +34,9 @@ def build_adaptor(orc):
     L.adp_test_forward_backward_many.argtypes = [P(P(orc.Hmm)), C.c_int64]
     L.adp_test_register.argtypes = [C.c_void_p, P(C.c_void_p), C.c_int64]
     L.adp_test_unregister.argtypes = [C.c_void_p]
-    for f in ("adp_test_poison", "adp_test_forward_backward", "adp_test_forward_backward_many", "adp_test_register", "adp_test_unregister", "adp_test_cleanup"):
+    L.adp_test_set_min_cells.argtypes = [C.c_int64]
+    for f in ("adp_test_poison", "adp_test_forward_backward", "adp_test_forward_backward_many", "adp_test_register", "adp_test_unregister", "adp_test_cleanup",
+              "adp_test_set_min_cells"):
         getattr(L, f).restype = None
     return L
 
@@ -43,7 +45,7 @@ def test_adaptor_compiles_against_the_binding_and_exports_the_seam(orc):
     """CPU: the adaptor builds warning-free against the oracle binding and defines the function it replaces."""
     L = build_adaptor(orc)
     for name in ("stRPHmm_forwardBackward", "stRPHmm_forwardBackwardMany", "mrpAdaptor_registerProfileSeqs", "mrpAdaptor_unregister",
-                 "mrpAdaptor_threadCleanup"):
+                 "mrpAdaptor_threadCleanup", "mrpAdaptor_setMinCells"):
         assert hasattr(L, name)
 
 
@@ -55,8 +57,8 @@ def _same(exp, got):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("registered", [True, False])
-def test_adaptor_reproduces_every_post_condition(orc, registered):
+@pytest.mark.parametrize("registered,min_cells", [(True, 0), (False, 0), (True, 4096)])
+def test_adaptor_reproduces_every_post_condition(orc, registered, min_cells):
     """Inside the oracle's phasing driver, right after each of ITS stRPHmm_forwardBackward calls (coordination.c:312 at every
     merge level, bubbleGraph.c:2749 with the ancestor model): the results are saved, every field the function has to set is
     overwritten with NaN, the adaptor sweeps the live linked-list hmm on the GPU, and the graph must hold the oracle's values
@@ -64,6 +66,8 @@ def test_adaptor_reproduces_every_post_condition(orc, registered):
     carries on (prune, next level) with the adaptor's values: the final haplotypes equal an undisturbed run's."""
     L = orc.lib()
     A = build_adaptor(orc)
+    # min_cells = 0: every hmm on the device; 4096 (the adaptor's default): the small ones stay on the CPU body it replaces
+    A.adp_test_set_min_cells(min_cells)
     chunk = synth.make_ont_chunk(seed=41, region_bp=70_000, n_sites=140, coverage=26, allele_choices=(2, 3), allele_probs=(0.8, 0.2))
     rng = np.random.default_rng(5)
     chunk.sub = rng.integers(0, 200, size=chunk.sub.shape).astype(np.uint16)
@@ -111,6 +115,7 @@ def test_adaptor_batched_variant(orc):
     sweeps of the same hmms, one by one."""
     L = orc.lib()
     A = build_adaptor(orc)
+    A.adp_test_set_min_cells(0)
     chunk = synth.make_ont_chunk(seed=43, region_bp=60_000, n_sites=120, coverage=24)
     pd = dict(synth.shipped_phase_params(), includeAncestorSubProb=0)
     oc = orc.OracleChunk(chunk)
