@@ -967,13 +967,16 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t prune_rsrc(const void *
 #define PRUNE_SP 128  /* slots of the selection buffers (S <= MRP_PRUNE_MAX_S) */
 #define PRUNE_TAB 5   /* per side and buffer: cnt, start, list, nx, pv, 128 entries each */
 
-template <int T, int CPT>
+/* T threads; the bin-streaming waves (all but the first four) form NGRP groups (2: alternating over the columns, a column's f and
+ * b sit in a group's registers for two column times; 1: one group, requested one column ahead) and hold CPT loads of VEC cells
+ * per lane and array. */
+template <int T, int CPT, int NGRP, int VEC>
 __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
                                                       PruneParams p, PruneScratch sc) {
     constexpr int W = T / WAVE;
-    constexpr int NBG = (W - 4) / 2;     /* waves per bin-streaming group */
+    constexpr int NBG = (W - 4) / NGRP;  /* waves per bin-streaming group */
     constexpr int LG = NBG * WAVE;       /* lanes per group */
-    static_assert(W >= 6 && ((W - 4) & 1) == 0, "role layout");
+    static_assert(W >= 6 && ((W - 4) % NGRP) == 0 && (NGRP == 1 || NGRP == 2) && (VEC == 1 || VEC == 4), "role layout");
     extern __shared__ uint32_t lds[];
     const int S = p.S;
     const int nb = p.n_bins;
@@ -994,11 +997,23 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
     uint32_t *tab = pref + 512;                /* [2 buffers][2 sides][PRUNE_TAB][128] */
     uint32_t *htab_key = tab + 4 * PRUNE_TAB * 128; /* [256] merge cell -> first kept cell that uses it (open addressing); wave 2 */
     uint32_t *htab_val = htab_key + 256;       /* [256] */
-    uint8_t *flags = reinterpret_cast<uint8_t *>(htab_val + 256); /* [max_merge] kept flag per merge cell (backward pass) */
-    uint16_t *bins = reinterpret_cast<uint16_t *>(flags + ((p.max_merge + 15) & ~15)); /* [2][cap_c] posterior bin per cell */
+    uint32_t *flagw = htab_val + 256;          /* [max_merge bits] kept flag per merge cell (backward pass) */
+    const int n_flagw = ((p.max_merge + 127) >> 7) << 2; /* words, a multiple of four */
+    uint16_t *bins = reinterpret_cast<uint16_t *>(flagw + n_flagw); /* [2][cap_c] posterior bin per cell */
+    auto flag_get = [&](uint32_t i) -> bool { return (flagw[i >> 5] >> (i & 31u)) & 1u; };
+    auto flag_set = [&](uint32_t i) { atomicOr(&flagw[i >> 5], 1u << (i & 31u)); };
+    auto flag_clr = [&](uint32_t i) { atomicAnd(&flagw[i >> 5], ~(1u << (i & 31u))); };
 
     const int tid = threadIdx.x, lane = tid & (WAVE - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+    /* The four role waves of a workgroup sit on the CU's four SIMDs (wave i on SIMD i mod 4).  Workgroups that share a CU
+     * rotate the roles: otherwise every chain wave -- the one wave of a workgroup that is busy all the time -- would issue
+     * from SIMD 0 and the workgroups would take turns on it.  MRP_PRUNE_NO_ROT (development) switches that off. */
+    const int hw_wave = __builtin_amdgcn_readfirstlane(tid / WAVE);
+#ifdef MRP_PRUNE_NO_ROT
+    const int wave = hw_wave;
+#else
+    const int wave = hw_wave < 4 ? ((hw_wave + (int) (blockIdx.x & 3u)) & 3) : hw_wave;
+#endif
     const uint64_t lt_mask = (1ull << lane) - 1ull;
 
     for (int64_t hi_ = blockIdx.x; hi_ < n_hmms; hi_ += gridDim.x) {
@@ -1009,7 +1024,7 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
         for (int i = tid; i < 2 * nb_r; i += T) hist[i] = 0;
         for (int i = tid; i < 1024; i += T) bmp_c[i] = 0; /* both bitmaps */
         for (int i = tid; i < 512; i += T) heads[i] = 0;
-        for (int i = tid; i < (p.max_merge + 3) / 4; i += T) reinterpret_cast<uint32_t *>(flags)[i] = 0;
+        for (int i = tid; i < n_flagw; i += T) flagw[i] = 0;
         if (tid < 64) sh[tid] = 0u;
         __syncthreads();
 
@@ -1551,45 +1566,77 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
              * size (beyond the column -- and beyond the last column -- the buffer descriptor's range check returns 0 without
              * touching memory): a load under a condition would make every slot a loop-carried merge of old and new value,
              * which costs a second register set. */
-            int32_t r_f[CPT], r_b[CPT];
-            const int bw = wave - 4, grp = bw & 1, gidx = bw >> 1;
-            const int base_c = gidx * WAVE + lane, voff = base_c * 4;
+            int32_t r_f[CPT * VEC], r_b[CPT * VEC];
+            const int bw = wave - 4, grp = NGRP == 2 ? (bw & 1) : 0, gidx = NGRP == 2 ? (bw >> 1) : bw;
+            const int base_c = gidx * WAVE + lane, voff = base_c * 4 * VEC;
             int n_have = 0; /* cells of the column in the registers */
             auto bins_load = [&](int col) {
                 const bool valid = col < K;
                 const SweepCol c = k_load(d.scols + h.col0 + (valid ? col : 0));
                 n_have = valid ? c.n_cells : 0;
-                const int bytes_ = __builtin_amdgcn_readfirstlane(n_have * 4);
+                /* (VEC = 4: the last load of a column reads up to three cells of what follows it -- the hmm's cells are padded
+                 * to a multiple of four, the arrays end with slack -- and bins_store leaves them out) */
+                const int bytes_ = __builtin_amdgcn_readfirstlane(((n_have + VEC - 1) & ~(VEC - 1)) * 4);
                 const auto rf_ = prune_rsrc(d.cell_f32 + c.cell_off, bytes_);
                 const auto rb_ = prune_rsrc(d.cell_b32 + c.cell_off, bytes_);
 #pragma unroll
                 for (int j = 0; j < CPT; j++) { /* one lane offset for all loads; the step from load to load rides in the scalar offset */
-                    r_f[j] = (int32_t) __builtin_amdgcn_raw_buffer_load_b32(rf_, voff, j * LG * 4, 0);
-                    r_b[j] = (int32_t) __builtin_amdgcn_raw_buffer_load_b32(rb_, voff, j * LG * 4, 0);
+                    if (VEC == 1) {
+                        r_f[j] = (int32_t) __builtin_amdgcn_raw_buffer_load_b32(rf_, voff, j * LG * 4, 0);
+                        r_b[j] = (int32_t) __builtin_amdgcn_raw_buffer_load_b32(rb_, voff, j * LG * 4, 0);
+                    } else {
+                        const auto vf = __builtin_amdgcn_raw_buffer_load_b128(rf_, voff, j * LG * 16, 0);
+                        const auto vb = __builtin_amdgcn_raw_buffer_load_b128(rb_, voff, j * LG * 16, 0);
+#pragma unroll
+                        for (int q = 0; q < VEC; q++) { r_f[j * VEC + q] = (int32_t) vf[q]; r_b[j * VEC + q] = (int32_t) vb[q]; }
+                    }
                 }
             };
             auto bins_store = [&](int col) { /* the bins of column col into buffer col & 1 */
                 uint16_t *dst = bins + (col & 1) * cap_c;
-                const int nj = (n_have + LG - 1) / LG;
+                const int nj = (n_have + LG * VEC - 1) / (LG * VEC);
 #pragma unroll
                 for (int j = 0; j < CPT; j++) {
                     if (j < nj) { /* (the lane's cell against a scalar bound, the step in the store's immediate offset: no
                                    * per-slot index registers) */
-                        if (base_c < n_have - j * LG) dst[base_c + j * LG] = (uint16_t) posterior_bin(r_f[j], r_b[j], total, nb, &errbits);
+                        if (VEC == 1) {
+                            if (base_c < n_have - j * LG) dst[base_c + j * LG] = (uint16_t) posterior_bin(r_f[j], r_b[j], total, nb, &errbits);
+                        } else {
+                            const int left = n_have - (j * LG + base_c) * VEC; /* cells of this load inside the column */
+                            if (left > 0) {
+                                uint32_t bq[VEC];
+#pragma unroll
+                                for (int q = 0; q < VEC; q++) bq[q] = q < left ? (uint32_t) posterior_bin(r_f[j * VEC + q], r_b[j * VEC + q], total, nb, &errbits) : 0u;
+                                *reinterpret_cast<uint2 *>(dst + (j * LG + base_c) * VEC) = make_uint2(bq[0] | (bq[1] << 16), bq[VEC > 2 ? 2 : 0] | (bq[VEC > 3 ? 3 : 0] << 16));
+                            }
+                        }
                     }
                 }
             };
-            /* barrier schedule: one after the prologue (step -1), one per column (steps 0 .. K - 1), one before the last merge
-             * list.  Group 0 acts at steps -1, 1, 3, ... (columns 0, 2, 4, ...), group 1 at steps 0, 2, ... */
-            bins_load(grp);
-            if (grp == 1) lds_barrier(); /* step -1 */
-            ROLE_CLK_INIT();
-            for (int st = grp - 1; st < K; st += 2) {
-                bins_store(st + 1);
-                __builtin_amdgcn_sched_barrier(0); /* the new column's loads reuse the registers of the one just stored */
-                bins_load(st + 3);
-                ROLE_BARRIER();                 /* end of step st */
-                if (st + 1 < K) ROLE_BARRIER(); /* step st + 1: the other group's */
+            if (NGRP == 2) {
+                /* barrier schedule: one after the prologue (step -1), one per column (steps 0 .. K - 1), one before the last merge
+                 * list.  Group 0 acts at steps -1, 1, 3, ... (columns 0, 2, 4, ...), group 1 at steps 0, 2, ... */
+                bins_load(grp);
+                if (grp == 1) lds_barrier(); /* step -1 */
+                ROLE_CLK_INIT();
+                for (int st = grp - 1; st < K; st += 2) {
+                    bins_store(st + 1);
+                    __builtin_amdgcn_sched_barrier(0); /* the new column's loads reuse the registers of the one just stored */
+                    bins_load(st + 3);
+                    ROLE_BARRIER();                 /* end of step st */
+                    if (st + 1 < K) ROLE_BARRIER(); /* step st + 1: the other group's */
+                }
+            } else {
+                /* one group: at step st the bins of column st + 1 (requested during step st - 1) are stored and column st + 2
+                 * is requested: a column's f and b have one column time to arrive */
+                bins_load(0);
+                ROLE_CLK_INIT();
+                for (int st = -1; st < K; st++) {
+                    bins_store(st + 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    bins_load(st + 2);
+                    ROLE_BARRIER(); /* end of step st */
+                }
             }
             if (gidx == 0) ROLE_CLK_DONE(4 + grp);
             lds_barrier();
@@ -1632,12 +1679,12 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const int i = lane + u * WAVE;
-                    keep[u] = i < nk && (k + 1 == K || flags[cur.cn[u] & 0xFFFFu] != 0);
+                    keep[u] = i < nk && (k + 1 == K || flag_get(cur.cn[u] & 0xFFFFu));
                 }
                 const uint64_t m0 = __ballot(keep[0]), m1 = __ballot(keep[1]);
                 const int ns = __popcll(m0) + __popcll(m1);
-                if (pmk[0]) flags[pm[0]] = 0;
-                if (pmk[1]) flags[pm[1]] = 0;
+                if (pmk[0]) flag_clr(pm[0]);
+                if (pmk[1]) flag_clr(pm[1]);
                 if (ns != nk) {
                     if (keep[0]) {
                         const int pos = (int) lanemask_lt_count(m0, lane);
@@ -1653,14 +1700,14 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                 }
                 if (k == 0) break;
                 /* merge column k - 1 keeps the merge cells some surviving cell comes from (:1141-1155) */
-                if (keep[0]) flags[cur.cn[0] >> 16] = 1;
-                if (keep[1]) flags[cur.cn[1] >> 16] = 1;
+                if (keep[0]) flag_set(cur.cn[0] >> 16);
+                if (keep[1]) flag_set(cur.cn[1] >> 16);
                 const int nmp = nx1.nm;
                 bool mk[2];
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const int i = lane + u * WAVE;
-                    mk[u] = i < nmp && flags[nx1.mm[u]] != 0;
+                    mk[u] = i < nmp && flag_get(nx1.mm[u]);
                 }
                 const uint64_t q0 = __ballot(mk[0]), q1 = __ballot(mk[1]);
                 const int nms = __popcll(q0) + __popcll(q1);
@@ -1670,17 +1717,18 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                     if (lane == 0) sc.n_keptm[lcol - 1] = nms;
                 }
                 /* leave flagged exactly the surviving merge cells of column k - 1 */
-                if (keep[0]) flags[cur.cn[0] >> 16] = 0;
-                if (keep[1]) flags[cur.cn[1] >> 16] = 0;
-                if (mk[0]) flags[nx1.mm[0]] = 1;
-                if (mk[1]) flags[nx1.mm[1]] = 1;
+                if (keep[0]) flag_clr(cur.cn[0] >> 16);
+                if (keep[1]) flag_clr(cur.cn[1] >> 16);
+                wave_lds_fence();
+                if (mk[0]) flag_set(nx1.mm[0]);
+                if (mk[1]) flag_set(nx1.mm[1]);
                 pm[0] = nx1.mm[0]; pm[1] = nx1.mm[1];
                 pmk[0] = mk[0]; pmk[1] = mk[1];
                 cur = nx1;
                 nx1 = nx2;
             }
-            if (pmk[0]) flags[pm[0]] = 0;
-            if (pmk[1]) flags[pm[1]] = 0;
+            if (pmk[0]) flag_clr(pm[0]);
+            if (pmk[1]) flag_clr(pm[1]);
         }
         if (errbits) { atomicOr(sc.err, errbits); atomicOr(sc.err_hmm + hi_, errbits); }
         __syncthreads();
@@ -1690,8 +1738,11 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
 static size_t prune_lds_bytes(const PruneParams &p) {
     const size_t cap = (size_t) ((p.max_cells + 3) & ~3);
     const size_t dwords = 4 * PRUNE_SP + PRUNE_SP + 4 * PRUNE_SP + 64 + 2 * 1024 + 512 + 512 + 2 * PRUNE_SP + 2 * PRUNE_SP + 512 + 512 + 4 * PRUNE_TAB * 128 + 512;
-    return dwords * 4 + (size_t) ((p.max_merge + 15) & ~15) + 2 * cap * 2 + 16;
+    return dwords * 4 + (size_t) (((p.max_merge + 127) >> 7) << 2) * 4 + 2 * cap * 2 + 16;
 }
+
+/* columns of up to this many cells: one group of four bin-streaming waves, ten 16-byte loads per lane and array */
+#define MRP_PRUNE_MID_CELLS (4 * WAVE * 10 * 4)
 
 hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, const PruneHmm *hmms_dev, int64_t n_hmms, PruneParams p,
                             PruneScratch s, hipStream_t stream) {
@@ -1700,8 +1751,9 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, con
     /* once per device (thread-safe: the concurrent halves of a call launch from two host threads) */
     static PerDeviceOnce once;
     const hipError_t configured = once.run([] {
-        hipError_t e = hipFuncSetAttribute((const void *) mrp_prune_kernel<512, 32>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *) mrp_prune_kernel<1024, 36>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute((const void *) mrp_prune_kernel<512, 32, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *) mrp_prune_kernel<512, 10, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *) mrp_prune_kernel<1024, 36, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return e;
     });
     if (configured != hipSuccess) return configured;
@@ -1709,12 +1761,24 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, con
     if (lds > (size_t) MRP_LDS_BUDGET) return hipErrorInvalidValue;
     const dim3 grid((unsigned) (n_hmms < 65536 ? n_hmms : 65536));
     const PruneIn in{d.scols, ccols_dev, d.cell_f32, d.cell_b32, d.merge_f32, d.merge_b32, d.hmm_fb};
-    /* the bin-streaming groups hold a column's f and b in registers: 2 waves x 32 cells per lane per group at 512 threads,
-     * 6 waves x 36 at 1 024 */
+    /* The bin-streaming waves hold a column's f and b in registers: two groups of 2 waves x 32 cells per lane at 512 threads;
+     * one group of 4 waves x 40 cells per lane (16-byte loads) at 512 threads for columns of up to 10 240 cells -- the
+     * 100 x 100 cells of the shipped parameters: half the waves and 77 KB of LDS let two workgroups share a CU where the
+     * 1 024-thread variant (two groups of 6 waves x 36 cells, up to 13 824 cells) fills it alone. */
+    if (getenv("MRP_PRUNE_OCC")) { /* development: workgroups of each variant a CU holds at this LDS size */
+        int a = 0, b2 = 0, c2 = 0;
+        (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (const void *) mrp_prune_kernel<512, 32, 2, 1>, 512, lds);
+        (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, (const void *) mrp_prune_kernel<512, 10, 1, 4>, 512, lds);
+        (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&c2, (const void *) mrp_prune_kernel<1024, 36, 2, 1>, 1024, lds);
+        fprintf(stderr, "prune: max_cells %d max_merge %d lds %zu B: workgroups per CU  <512,32> %d  <512,10,x4> %d  <1024,36> %d\n", p.max_cells, p.max_merge, lds, a, b2, c2);
+    }
+    const char *force = getenv("MRP_PRUNE_VARIANT"); /* development: "big" sends mid-sized columns to the 1 024-thread variant */
     if (p.max_cells <= 2 * WAVE * 32)
-        hipLaunchKernelGGL((mrp_prune_kernel<512, 32>), grid, dim3(512), lds, stream, in, hmms_dev, n_hmms, p, s);
+        hipLaunchKernelGGL((mrp_prune_kernel<512, 32, 2, 1>), grid, dim3(512), lds, stream, in, hmms_dev, n_hmms, p, s);
+    else if (p.max_cells <= MRP_PRUNE_MID_CELLS && !(force && force[0] == 'b'))
+        hipLaunchKernelGGL((mrp_prune_kernel<512, 10, 1, 4>), grid, dim3(512), lds, stream, in, hmms_dev, n_hmms, p, s);
     else
-        hipLaunchKernelGGL((mrp_prune_kernel<1024, 36>), grid, dim3(1024), lds, stream, in, hmms_dev, n_hmms, p, s);
+        hipLaunchKernelGGL((mrp_prune_kernel<1024, 36, 2, 1>), grid, dim3(1024), lds, stream, in, hmms_dev, n_hmms, p, s);
     return hipGetLastError();
 }
 
