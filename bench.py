@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--chunks", type=int, default=int(os.environ.get("MRP_BENCH_CHUNKS", "288")), help="synthetic 1 Mb chunks per GPU")
+    ap.add_argument("--chunks", type=int, default=int(os.environ.get("MRP_BENCH_CHUNKS", "576")), help="synthetic 1 Mb chunks per GPU")
     ap.add_argument("--sites", type=int, default=2000)
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--threads", type=int, default=int(os.environ.get("MRP_BENCH_THREADS", "0")))
@@ -174,6 +174,7 @@ def main():
 
     # ---- the same chunks from HOST memory through the work queue (PCIe-inclusive) --------------------------------
     if args.queue_runs > 0 and not single_process_multi:
+        ctx.trim()  # the queue's workers have contexts (and allocator caches) of their own
         q = capi.Queue([local_rank])
         descs = capi.chunk_descs(chunks)
         q.phase(chunks, params, chunks_per_batch=args.queue_batch, descs=descs, convert=False)
@@ -192,6 +193,8 @@ def main():
         q.close()
 
     # ---- the shapes of BASELINE.json configs[2] and configs[4] on one GPU (same call, other chunks) ---------------
+    if not single_process_multi:
+        ctx.trim()
     if args.shape_runs > 0 and not single_process_multi:
         def shape_leg(name, what, make, n):
             with ThreadPoolExecutor(max_workers=n_threads) as ex:
@@ -266,16 +269,24 @@ def main():
         alg = float(s.algorithmic_bytes)
         alg_sweep = 16.0 * C + 32.0 * M + 8.0 * K
         achieved = alg_sweep / (sweep_avg * 1e-3) / 1e9
+        # HBM bytes of one launch from the PMC counters: measured by tools/collect_profiles_r03.sh on this workload and stamped
+        # with the hash of the kernel source it was measured on -- a stale file is ignored rather than quoted
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r02", "traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            if int(tj.get("chunks", -1)) == n_rec:  # measured on this workload
-                traffic, traffic_src = float(tj["sweep_kernel_hbm_bytes_per_launch"]), tj.get("source")
+        import hashlib
+        k_sha = hashlib.sha256(open(os.path.join(ROOT, "margin_amd", "csrc", "mrp_kernels.hip"), "rb").read()).hexdigest()
+        for tpath in (os.path.join(ROOT, "profiles", "r03", "traffic.json"), os.path.join(ROOT, "profiles", "r02", "traffic.json")):
+            if traffic is None and os.path.exists(tpath):
+                tj = json.load(open(tpath))
+                if int(tj.get("chunks", -1)) == n_rec and tj.get("kernel_source_sha256") == k_sha:
+                    traffic, traffic_src = float(tj["sweep_kernel_hbm_bytes_per_launch"]), tj.get("source")
         replay_ms = 1e3 * r_el / done
         rec_units = float(sum(c.units for c in chunks[:n_rec]))
         out["roofline"] = dict(bound="hbm", kernel="mrp_sweep_i32_kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
                                frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                               # the same launch priced on the bytes that really crossed the HBM interface (the 32 B per merge
+                               # cell of the algorithmic credit live in LDS): what the kernel sustains
+                               frac_of_measured_traffic=(traffic / (sweep_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                               frac_note="frac = ALGORITHMIC bytes (SURVEY.md 8d) / kernel time / peak; the kernel moves fewer bytes than that credit",
                                algorithmic_bytes_per_launch=alg_sweep, kernel_ms=sweep_avg,
                                what=f"all {sweeps} forward/backward sweeps of {n_rec} chunks (every merge level + final) recorded by the hashing path and "
                                     f"replayed as ONE dependency-free batch: the kernels' throughput, not a phasing rate",

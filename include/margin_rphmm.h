@@ -59,14 +59,17 @@ int mrp_device_count(void);
 int mrp_context_create(int device, mrp_context **out);
 void mrp_context_destroy(mrp_context *ctx);
 int mrp_context_synchronize(mrp_context *ctx);
+/* A context keeps the device memory of its last calls cached (allocating and freeing gigabytes per call costs more than the
+ * call); this gives the cache back to the driver, e.g. before another context of the same device starts a large job. */
+int mrp_context_trim(mrp_context *ctx);
 /* Optional, once, BEFORE the process's first HIP call (its own or this library's): asks the ROCm runtime for 16 hardware
  * queues (GPU_MAX_HW_QUEUES, unless the environment already sets it).  The runtime multiplexes HIP streams onto 4 hardware
  * queues by default and kernels of streams that share a queue serialize; the concurrent batches of mrp_phase_reads_many
  * launch on four streams each (96 chunks: 68 ms instead of 82 ms on an MI355X).  Without the call everything works, slower. */
 int mrp_runtime_init(void);
 /* mrp_phase_reads_many splits its chunks into this many interleaved batches that run concurrently on the context and its
- * sibling contexts (one batch's host work beside the others' kernels); 1..8, or 0 (default): one batch per 24 chunks, at
- * most 4. */
+ * sibling contexts (one batch's host work beside the others' kernels); 1..8, or 0 (default): one batch per 24 chunks up to
+ * 4, from 320 chunks on one per 64 chunks up to 8. */
 int mrp_context_set_phase_groups(mrp_context *ctx, int groups);
 /* Test suite only (a private switch, not a parameter: a caller's uninitialised struct field cannot turn it on).  Bit 0, fault
  * injection: the resident path reports MRP_ENGINE_ERR_MERGE for one hmm of its second level, which must send exactly that

@@ -23,7 +23,7 @@ FLAG_INCLUDE_ANCESTOR_SUB_PROB = 2
 #: every symbol include/margin_rphmm.h declares (checked by the CPU test-suite)
 EXPORTED_SYMBOLS = [
     "mrp_last_error", "mrp_version", "mrp_runtime_init", "mrp_device_count", "mrp_context_create", "mrp_context_destroy",
-    "mrp_context_synchronize", "mrp_hmm_split", "mrp_hmm_split_where_phasing_is_uncertain", "mrp_context_set_phase_groups", "mrp_context_set_test_hooks", "mrp_set_host_threads", "mrp_chunk_create", "mrp_chunk_destroy", "mrp_fb_run", "mrp_batch_create",
+    "mrp_context_synchronize", "mrp_context_trim", "mrp_hmm_split", "mrp_hmm_split_where_phasing_is_uncertain", "mrp_context_set_phase_groups", "mrp_context_set_test_hooks", "mrp_set_host_threads", "mrp_chunk_create", "mrp_chunk_destroy", "mrp_fb_run", "mrp_batch_create",
     "mrp_batch_add", "mrp_batch_upload", "mrp_batch_launch", "mrp_batch_download", "mrp_batch_destroy",
     "mrp_batch_stats", "mrp_count_bit_vectors", "mrp_emissions", "mrp_get_rp_hmms", "mrp_hmm_destroy", "mrp_free",
     "mrp_hmm_view", "mrp_hmm_forward_backward", "mrp_hmm_prune", "mrp_hmm_forward_trace_back", "mrp_phase_reads",
@@ -214,6 +214,7 @@ def load():
     L.mrp_context_destroy.argtypes = [vp]
     L.mrp_context_destroy.restype = None
     L.mrp_context_synchronize.argtypes = [vp]
+    L.mrp_context_trim.argtypes = [vp]
     L.mrp_context_set_phase_groups.argtypes = [vp, C.c_int]
     L.mrp_context_set_test_hooks.argtypes = [vp, C.c_int]
     L.mrp_set_host_threads.argtypes = [C.c_int]
@@ -296,6 +297,9 @@ class Context:
 
     def synchronize(self):
         _check(load().mrp_context_synchronize(self.h))
+
+    def trim(self):
+        _check(load().mrp_context_trim(self.h))
 
     def set_phase_groups(self, groups: int):
         _check(load().mrp_context_set_phase_groups(self.h, groups))

@@ -148,6 +148,18 @@ void mrp_context_destroy(mrp_context *ctx) {
     delete ctx;
 }
 
+/* the device memory the context (and the contexts it owns) keeps cached for its next call goes back to the driver */
+int mrp_context_trim(mrp_context *ctx) {
+    if (!ctx) return fail(MRP_ERR_ARG, "context is NULL");
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    std::lock_guard<std::mutex> lock(ctx->sibling_mu);
+    for (mrp_context *s_ : ctx->siblings) { s_->pool.reclaim(); s_->pool.trim(); }
+    ctx->pool.reclaim();
+    ctx->pool.trim();
+    return MRP_OK;
+}
+
 int mrp_context_synchronize(mrp_context *ctx) {
     if (!ctx) return fail(MRP_ERR_ARG, "context is NULL");
     HIP_TRY(hipSetDevice(ctx->device));

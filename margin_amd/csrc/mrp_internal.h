@@ -63,7 +63,8 @@ struct DevPool {
     std::multimap<size_t, void *> free_blocks;
     std::vector<std::pair<size_t, void *>> pending;
     size_t cached_bytes = 0;                 /* bytes in free_blocks */
-    size_t cache_limit = (size_t) 64 << 30;  /* beyond this the largest cached blocks go back to the driver */
+    size_t cache_limit = (size_t) 24 << 30;  /* beyond this the largest cached blocks go back to the driver (a call runs up to
+                                              * eight concurrent batches, each with a pool of its own: 8 x 24 GB of 288) */
     /* the pools of the other contexts of the same device (siblings of mrp_phase_reads_many's concurrent halves, their
      * parent): when the driver is out of memory their idle blocks are given back too */
     DevPool *peers[16] = {nullptr};

@@ -42,24 +42,29 @@ struct QueuePlan {
  * devices.  A batch is one mrp_phase_reads_many call; a call begins and ends with host work and walks its merge levels one
  * after the other, the top ones bound by per-column latency whatever the number of chunks, so large batches amortize that
  * (288 chunks in one call take 140 ms, in four calls on two lanes 225 ms).  A short queue is therefore ONE batch per device
- * (its upload overlaps the host's setup of the same call); a long one is handed out in batches of MRP_QUEUE_DEFAULT_BATCH
- * chunks that shrink towards the end ("guided" schedule: remaining / (2 x workers), at least 24), so that the devices finish
- * within a fraction of a percent of each other (tests/test_work_queue.py: 8 devices, 31 000 chunks). */
+ * (its upload overlaps the host's setup of the same call), a somewhat longer one is one batch per lane; a long one is handed
+ * out in batches of MRP_QUEUE_DEFAULT_BATCH chunks that shrink towards the end ("guided" schedule: remaining / workers, at
+ * least 48), so that the devices finish within two percent of each other (tests/test_work_queue.py: 8 devices, 31 000
+ * chunks) without the tail of the queue dissolving into small, latency-bound calls. */
 QueuePlan plan_queue(int64_t n, const int64_t *cost, int64_t chunks_per_batch, int n_workers = 1, int n_devices = 1) {
     QueuePlan p;
     p.order.resize((size_t) n);
     std::iota(p.order.begin(), p.order.end(), (int64_t) 0);
     std::stable_sort(p.order.begin(), p.order.end(), [&](int64_t a, int64_t b) { return cost[a] > cost[b]; });
+    const int64_t big = MRP_QUEUE_DEFAULT_BATCH, short_queue = big + big / 3;
+    const int lanes = std::max(1, n_workers / std::max(1, n_devices));
     if (chunks_per_batch >= 1) {
         for (int64_t o = 0; o < n; o += chunks_per_batch) p.batch_off.push_back(o);
-    } else if (n <= (int64_t) n_devices * (MRP_QUEUE_DEFAULT_BATCH + MRP_QUEUE_DEFAULT_BATCH / 3)) {
-        const int64_t per = std::max<int64_t>(1, (n + n_devices - 1) / n_devices);
+    } else if (n <= (int64_t) n_devices * short_queue * lanes) {
+        /* at most one batch per lane: one per device while that stays below ~384 chunks, else one per lane */
+        const int64_t parts = n <= (int64_t) n_devices * short_queue ? n_devices : (int64_t) n_devices * lanes;
+        const int64_t per = std::max<int64_t>(1, (n + parts - 1) / parts);
         for (int64_t o = 0; o < n; o += per) p.batch_off.push_back(o);
     } else {
-        for (int64_t o = 0; o < n;) {
+        for (int64_t o = 0; o < n;) { /* full batches while every worker can still get one, then shrinking, at least 48 chunks */
             p.batch_off.push_back(o);
             const int64_t left = n - o;
-            o += std::max<int64_t>(24, std::min<int64_t>(MRP_QUEUE_DEFAULT_BATCH, left / (2 * (int64_t) std::max(1, n_workers))));
+            o += std::max<int64_t>(48, std::min<int64_t>(big, left / (int64_t) std::max(1, n_workers)));
         }
     }
     p.batch_off.push_back(n);

@@ -2233,7 +2233,10 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
     /* the levels of a batch alternate host work (structure, descriptors) and device work; two interleaved halves of the
      * chunks, each with its own context and host thread, keep both busy */
     int G = mrp_context_phase_groups(ctx); /* mrp_context_set_phase_groups; 0 (default): by batch size */
-    if (G <= 0) G = (int) (n_chunks / 24 > 4 ? 4 : n_chunks / 24); /* measured on MI355X: 4 groups from 96 chunks on, 2 at 48 */
+    /* measured on MI355X (tools/pipeline_probe.py): 2 groups at 48 chunks, 4 from 96 to 288 (6 or 8 are slower there: a group
+     * needs some 64 chunks to keep its share of the device busy), 8 from 512 on (384 chunks: 146-161 ms with 8 groups against
+     * 167-169 with 4; 576: 204-219 against 229-245) */
+    if (G <= 0) G = n_chunks < 320 ? (int) (n_chunks / 24 > 4 ? 4 : n_chunks / 24) : (int) (n_chunks / 64);
     if (G < 1) G = 1;
     if (G > 8) G = 8;
     if (n_chunks < 4 * G) G = 1;
