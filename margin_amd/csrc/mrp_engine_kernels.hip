@@ -901,6 +901,49 @@ static __device__ __forceinline__ void wave_bitonic_sort128(uint32_t &k0, uint32
     bitonic_merge<64>(k0, k1, lane);
     bitonic_merge<128>(k0, k1, lane);
 }
+/* the same for 64 NR keys, NR per lane (index lane + 64 u in register u): ascending */
+template <int NR, int K, int J>
+static __device__ __forceinline__ void bitonic_step_n(uint32_t (&k)[NR], int lane) {
+    if (J >= 64) { /* the partner sits in another register of the same lane; K > J >= 64: the direction depends on u alone */
+        constexpr int dj = J / 64;
+#pragma unroll
+        for (int u = 0; u < NR; u++)
+            if ((u & dj) == 0) {
+                const bool asc = ((u * 64) & K) == 0;
+                const uint32_t a = k[u], b = k[u | dj], lo = a < b ? a : b, hi = a < b ? b : a;
+                k[u] = asc ? lo : hi;
+                k[u | dj] = asc ? hi : lo;
+            }
+    } else {
+#pragma unroll
+        for (int u = 0; u < NR; u++) {
+            const uint32_t pv = lane_xor<J>(k[u], lane);
+            const bool lower = (lane & J) == 0, asc = ((lane + 64 * u) & K) == 0;
+            const uint32_t mn = k[u] < pv ? k[u] : pv, mx = k[u] < pv ? pv : k[u];
+            k[u] = (lower == asc) ? mn : mx;
+        }
+    }
+}
+template <int NR, int K>
+static __device__ __forceinline__ void bitonic_merge_n(uint32_t (&k)[NR], int lane) {
+    if (K >= 512) bitonic_step_n<NR, K, 256>(k, lane);
+    if (K >= 256) bitonic_step_n<NR, K, 128>(k, lane);
+    if (K >= 128) bitonic_step_n<NR, K, 64>(k, lane);
+    if (K >= 64) bitonic_step_n<NR, K, 32>(k, lane);
+    if (K >= 32) bitonic_step_n<NR, K, 16>(k, lane);
+    if (K >= 16) bitonic_step_n<NR, K, 8>(k, lane);
+    if (K >= 8) bitonic_step_n<NR, K, 4>(k, lane);
+    if (K >= 4) bitonic_step_n<NR, K, 2>(k, lane);
+    bitonic_step_n<NR, K, 1>(k, lane);
+}
+template <int NR>
+static __device__ __forceinline__ void wave_bitonic_sort_n(uint32_t (&k)[NR], int lane) {
+    bitonic_merge_n<NR, 2>(k, lane); bitonic_merge_n<NR, 4>(k, lane); bitonic_merge_n<NR, 8>(k, lane); bitonic_merge_n<NR, 16>(k, lane);
+    bitonic_merge_n<NR, 32>(k, lane); bitonic_merge_n<NR, 64>(k, lane);
+    if (NR >= 2) bitonic_merge_n<NR, 128>(k, lane);
+    if (NR >= 4) bitonic_merge_n<NR, 256>(k, lane);
+    if (NR >= 8) bitonic_merge_n<NR, 512>(k, lane);
+}
 /* orders this wave's LDS traffic for the compiler (the LDS itself executes one wave's instructions in issue order) */
 
 /*
@@ -955,12 +998,14 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t prune_rsrc(const void *
 #endif
 
 #ifdef PRUNE_EXP_CLOCK2 /* sections of the chain wave instead: kept merge cells, candidates, histogram + cutoff, selection, ties, next merge cells */
-#define SEC_INIT() uint64_t sec_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; uint64_t sec_t = __builtin_amdgcn_s_memtime()
+#define SEC_INIT() uint64_t sec_[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; uint64_t sec_t = __builtin_amdgcn_s_memtime()
+#define SEC_COUNT(i) do { sec_[i] += 1; } while (0) /* columns by path: 8 keep-all, 9 sorted, 10 histogram (one chunk), 11 histogram (several chunks) */
 #define SEC(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); sec_[i] += t_ - sec_t; sec_t = t_; } while (0)
-#define SEC_DONE() do { if (hi_ == 0 && lane == 0) for (int i_ = 0; i_ < 8; i_++) atomicAdd((unsigned long long *) (sc.err + 4) + i_, (unsigned long long) sec_[i_]); } while (0)
+#define SEC_DONE() do { if (hi_ == 0 && lane == 0) for (int i_ = 0; i_ < 12; i_++) atomicAdd((unsigned long long *) (sc.err + 4) + i_, (unsigned long long) sec_[i_]); } while (0)
 #else
 #define SEC_INIT() do { } while (0)
 #define SEC(i) do { } while (0)
+#define SEC_COUNT(i) do { } while (0)
 #define SEC_DONE() do { } while (0)
 #endif
 
@@ -1157,8 +1202,6 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                 kml[0] = 0u;   /* column 0: every cell is "linked" (one virtual merge cell in front of it) */
                 sh[40] = 1u;
             }
-            CrossCol cc = k_load(d.ccols + h.col0);
-            CrossCol cc_next = K > 1 ? k_load(d.ccols + h.col0 + 1) : cc;
             lds_barrier();
             ROLE_CLK_INIT();
             SEC_INIT();
@@ -1166,9 +1209,10 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                 SEC(7);
                 /* the descriptor of the column after next: requested first, so that its latency hides behind this column's work
                  * (a scalar load issued just before the barrier would be waited for there: the barrier drains lgkmcnt) */
-                CrossCol cc_ahead = cc_next;
-                if (k + 2 < K) cc_ahead = k_load(d.ccols + h.col0 + k + 2);
                 const int b = k & 1;
+                /* what the chain needs of the column's CrossCol comes through LDS from the table wave (sh[48 + 2 b ..]): a scalar
+                 * load here would sit in the same counter as the LDS traffic, and every LDS wait of the column would wait for it */
+                const uint32_t cd0 = sh[48 + 4 * b], cd1 = sh[49 + 4 * b];
                 uint32_t *skey = sel + b * 2 * PRUNE_SP, *snp = skey + PRUNE_SP;
                 const uint32_t *tA = tab + b * 2 * PRUNE_TAB * 128, *tB = tA + PRUNE_TAB * 128;
                 const uint32_t *cntA = tA, *startA = tA + 128, *listA = tA + 256, *nxA = tA + 384;
@@ -1176,10 +1220,11 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                 const uint16_t *bin_k = bins + b * cap_c;
                 uint32_t *hk = hist + b * nb_r;
                 uint32_t *kmn = kml + (b ^ 1) * PRUNE_SP; /* the kept merge cells leading into column k + 1 */
-                const bool inv = (cc.flags & MRP_XF_INVERTED) != 0;
-                const uint32_t C2 = cc.C2 > 128u ? 128u : cc.C2, Mb = cc.Mb;
-                const bool a_cp = inv && cc.a_part && cc.d1 > 0, b_cp = inv && cc.b_part && cc.d2 > 0;
-                const bool out_ap = (cc.flags & MRP_XF_OUT_A_PAIRED) != 0, out_bp = (cc.flags & MRP_XF_OUT_B_PAIRED) != 0;
+                const uint32_t cflags = cd1 & 0xFFu;
+                const bool inv = (cflags & MRP_XF_INVERTED) != 0;
+                const uint32_t C2 = (cd0 & 0xFFFFu) > 128u ? 128u : (cd0 & 0xFFFFu), Mb = cd0 >> 16;
+                const bool a_cp = inv && (cd1 & 0x100u), b_cp = inv && (cd1 & 0x200u);
+                const bool out_ap = (cflags & MRP_XF_OUT_A_PAIRED) != 0, out_bp = (cflags & MRP_XF_OUT_B_PAIRED) != 0;
                 const bool has_next = k + 1 < K;
                 const int nkm = (int) sh[40 + b];
                 /* this lane's kept merge cells (two at most): the parents' cells each links, as list ranges.  An entry of the
@@ -1321,6 +1366,7 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                 const int n_chunks = (L + 511) >> 9;
                 int n = 0;
                 if (keep_all) {
+                    SEC_COUNT(8);
                     int at = 0;
                     for (int c = 0; c < n_chunks; c++) {
                         const int ns = load_chunk(c << 9);
@@ -1336,8 +1382,58 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                     }
                     n = at;
                     SEC(1);
+                } else if (L <= 4 * WAVE) {
+                    /* Up to four slots of candidates: selection by SORTING.  The keys bin << 14 | cell are distinct and their ascending
+                     * order is the stable descending-posterior order of the reference (hmm.c:1043, :1071: smaller bin = larger
+                     * posterior, ties in list order = cell index): the kept cells are the first n of the sorted candidates.  One
+                     * bitonic sort in registers over as many slots as the column needs replaces histogram, cutoff search,
+                     * selection pass and tie ranking (measured: 29 000 cycles per such column against 10 000 for a column that
+                     * keeps all its candidates).  What rides along with a candidate (its parent cells, the merge cell it comes
+                     * from) is re-derived from the cell index for the kept ones. */
+                    SEC_COUNT(9);
+                    const int ns = load_chunk(0);
+                    int g = L;
+                    if (!thr_all) {
+                        g = 0;
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (j < ns) g += __popcll(__ballot(key[j] != 0xFFFFFFFFu && (int) (key[j] >> 14) <= p.thr_bin));
+                    }
+                    n = kept_count(L, g, p.min_p, p.max_p);
+                    if (ns <= 2) { uint32_t kk[2] = {key[0], key[1]}; wave_bitonic_sort_n<2>(kk, lane); key[0] = kk[0]; key[1] = kk[1]; }
+                    else { uint32_t kk[4] = {key[0], key[1], key[2], key[3]}; wave_bitonic_sort_n<4>(kk, lane); key[0] = kk[0]; key[1] = kk[1]; key[2] = kk[2]; key[3] = kk[3]; }
+                    const uint32_t Pb = cd1 >> 16;
+                    const bool in_ap = (cflags & MRP_XF_IN_A_PAIRED) != 0, in_bp = (cflags & MRP_XF_IN_B_PAIRED) != 0;
+                    const uint32_t *pvA = tA + 512, *pvB = tB + 512;
+                    const float rc2 = __builtin_amdgcn_rcpf((float) (C2 ? C2 : 1u)), rc22 = __builtin_amdgcn_rcpf((float) (C2 ? 2u * C2 : 1u));
+#pragma unroll
+                    for (int j = 0; j < 2; j++) { /* n <= S <= 128: the kept cells are in the first two registers */
+                        if (j * WAVE < n) {
+                            const bool take = j * WAVE + lane < n;
+                            const uint32_t e = take ? key[j] & 0x3FFFu : 0u;
+                            uint32_t c1, c2; /* cross_cell(e), the divisions through float reciprocals (exact: e < 2^14, one correction step) */
+                            if (!inv) {
+                                uint32_t q = (uint32_t) ((float) e * rc2);
+                                if (q * C2 > e) q--;
+                                if ((q + 1u) * C2 <= e) q++;
+                                c1 = q; c2 = e - q * C2;
+                            } else if (!a_cp) { c1 = 0u; c2 = e; }
+                            else {
+                                uint32_t r = (uint32_t) ((float) e * rc22);
+                                if (r * 2u * C2 > e) r--;
+                                if ((r + 1u) * 2u * C2 <= e) r++;
+                                const uint32_t t = e - r * 2u * C2, hh = t >> 1;
+                                if (t & 1u) { c1 = 2u * r + 1u; c2 = b_cp ? (hh ^ 1u) : hh; } else { c1 = 2u * r; c2 = hh; }
+                            }
+                            c1 &= 127u; c2 &= 127u;
+                            const uint32_t prv = k > 0 ? pair_index(pvA[c1], pvB[c2], Pb, inv, in_ap, in_bp) : 0u;
+                            emit(take, j * WAVE + lane, key[j], c1 | (c2 << 8) | (prv << 16));
+                        }
+                    }
+                    SEC(4);
                 } else {
                     /* pass 1: histogram of the posterior bins */
+                    SEC_COUNT(n_chunks > 1 ? 11 : 10);
                     int ns = 0;
                     for (int c = 0; c < n_chunks; c++) {
                         ns = load_chunk(c << 9);
@@ -1452,8 +1548,6 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                     }
                 }
                 SEC(6);
-                cc = cc_next;
-                cc_next = cc_ahead;
                 ROLE_BARRIER();
             }
             ROLE_CLK_DONE(0);
@@ -1536,6 +1630,11 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
             auto tab_build = [&]() { /* tables of column tcol into buffer tcol & 1, from the registers loaded last time */
                 if (tcol < K) {
                     uint32_t *tb = tab + (tcol & 1) * 2 * PRUNE_TAB * 128;
+                    if (lane == 0) { /* the chain's view of the column (read after the barrier that ends this step) */
+                        sh[48 + 4 * (tcol & 1)] = (uint32_t) tcc.C2 | ((uint32_t) tcc.Mb << 16);
+                        sh[49 + 4 * (tcol & 1)] = (uint32_t) tcc.flags | ((tcc.a_part && tcc.d1 > 0) ? 0x100u : 0u) | ((tcc.b_part && tcc.d2 > 0) ? 0x200u : 0u) |
+                                                  ((uint32_t) tcc.Pb << 16);
+                    }
                     uint32_t C1 = tcc.C1, C2 = tcc.C2;
                     if (C1 > 128u || C2 > 128u) { errbits |= MRP_ENGINE_ERR_RANGE; C1 = C1 > 128u ? 128u : C1; C2 = C2 > 128u ? 128u : C2; }
                     tab_build_side(tb, r_na, C1, tcc.Pa, tcc.in_a, tcc.out_a);
