@@ -1016,12 +1016,14 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t prune_rsrc(const void *
  * b sit in a group's registers for two column times; 1: one group, requested one column ahead) and hold CPT loads of VEC cells
  * per lane and array. */
 template <int T, int CPT, int NGRP, int VEC>
-__global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
+__global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
                                                       PruneParams p, PruneScratch sc) {
     constexpr int W = T / WAVE;
-    constexpr int NBG = (W - 4) / NGRP;  /* waves per bin-streaming group */
-    constexpr int LG = NBG * WAVE;       /* lanes per group */
-    static_assert(W >= 6 && ((W - 4) % NGRP) == 0 && (NGRP == 1 || NGRP == 2) && (VEC == 1 || VEC == 4), "role layout");
+    constexpr int NBG = (W - 4) / NGRP;  /* waves per bin-streaming group; none (T = 256): columns of at most 64 CPT cells, whose
+                                          * bins the table wave writes beside its tables -- four waves per workgroup, four
+                                          * workgroups per CU where the register file allows two of eight waves */
+    constexpr int LG = NBG > 0 ? NBG * WAVE : WAVE; /* lanes per group */
+    static_assert((W == 4 || W >= 6) && ((W - 4) % NGRP) == 0 && (NGRP == 1 || NGRP == 2) && (VEC == 1 || VEC == 4), "role layout");
     extern __shared__ uint32_t lds[];
     const int S = p.S;
     const int nb = p.n_bins;
@@ -1581,11 +1583,23 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
         } else if (wave == 3) {
             /* wave 3: the parents' transitions of the column after next */
             uint32_t r_na[2] = {0u, 0u}, r_nb[2] = {0u, 0u};
+            int32_t t_f[W == 4 ? CPT : 1], t_b[W == 4 ? CPT : 1]; /* T = 256: f and b of the column whose tables are built next */
+            int t_n = 0;
             CrossCol tcc = {};
             int tcol = 0;
             auto tab_load = [&]() {
                 if (tcol < K) {
                     tcc = k_load(d.ccols + h.col0 + tcol);
+                    if (W == 4) {
+                        const SweepCol c = k_load(d.scols + h.col0 + tcol);
+                        t_n = c.n_cells;
+#pragma unroll
+                        for (int j = 0; j < (W == 4 ? CPT : 1); j++) {
+                            const int cell = lane + j * WAVE;
+                            t_f[j] = cell < t_n ? d.cell_f32[c.cell_off + cell] : MRP_NEG_I32;
+                            t_b[j] = cell < t_n ? d.cell_b32[c.cell_off + cell] : MRP_NEG_I32;
+                        }
+                    }
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
                         const uint32_t c = (uint32_t) (lane + u * WAVE);
@@ -1634,6 +1648,15 @@ __global__ void __launch_bounds__(T, T == 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                         sh[48 + 4 * (tcol & 1)] = (uint32_t) tcc.C2 | ((uint32_t) tcc.Mb << 16);
                         sh[49 + 4 * (tcol & 1)] = (uint32_t) tcc.flags | ((tcc.a_part && tcc.d1 > 0) ? 0x100u : 0u) | ((tcc.b_part && tcc.d2 > 0) ? 0x200u : 0u) |
                                                   ((uint32_t) tcc.Pb << 16);
+                    }
+                    if (W == 4) { /* the column's posterior bins */
+                        uint16_t *dst = bins + (tcol & 1) * cap_c;
+                        if (t_n > CPT * WAVE) { errbits |= MRP_ENGINE_ERR_RANGE; t_n = CPT * WAVE; }
+#pragma unroll
+                        for (int j = 0; j < (W == 4 ? CPT : 1); j++) {
+                            const int cell = lane + j * WAVE;
+                            if (cell < t_n) dst[cell] = (uint16_t) posterior_bin(t_f[j], t_b[j], total, nb, &errbits);
+                        }
                     }
                     uint32_t C1 = tcc.C1, C2 = tcc.C2;
                     if (C1 > 128u || C2 > 128u) { errbits |= MRP_ENGINE_ERR_RANGE; C1 = C1 > 128u ? 128u : C1; C2 = C2 > 128u ? 128u : C2; }
@@ -1851,6 +1874,7 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, con
     static PerDeviceOnce once;
     const hipError_t configured = once.run([] {
         hipError_t e = hipFuncSetAttribute((const void *) mrp_prune_kernel<512, 32, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e == hipSuccess) e = hipFuncSetAttribute((const void *) mrp_prune_kernel<256, 4, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *) mrp_prune_kernel<512, 10, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e == hipSuccess) e = hipFuncSetAttribute((const void *) mrp_prune_kernel<1024, 36, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         return e;
@@ -1866,13 +1890,19 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, con
      * 1 024-thread variant (two groups of 6 waves x 36 cells, up to 13 824 cells) fills it alone. */
     if (getenv("MRP_PRUNE_OCC")) { /* development: workgroups of each variant a CU holds at this LDS size */
         int a = 0, b2 = 0, c2 = 0;
+        int a0 = 0;
+        (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&a0, (const void *) mrp_prune_kernel<256, 4, 1, 1>, 256, lds);
+        fprintf(stderr, "prune: <256,4> %d workgroups per CU; ", a0);
         (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (const void *) mrp_prune_kernel<512, 32, 2, 1>, 512, lds);
         (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, (const void *) mrp_prune_kernel<512, 10, 1, 4>, 512, lds);
         (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&c2, (const void *) mrp_prune_kernel<1024, 36, 2, 1>, 1024, lds);
         fprintf(stderr, "prune: max_cells %d max_merge %d lds %zu B: workgroups per CU  <512,32> %d  <512,10,x4> %d  <1024,36> %d\n", p.max_cells, p.max_merge, lds, a, b2, c2);
     }
     const char *force = getenv("MRP_PRUNE_VARIANT"); /* development: "big" sends mid-sized columns to the 1 024-thread variant */
-    if (p.max_cells <= 2 * WAVE * 32)
+    /* columns of at most 256 cells (the first merge levels: a few reads per hmm): four waves, the table wave writes the bins */
+    if (p.max_cells <= 4 * WAVE && !(force && force[0] == 's'))
+        hipLaunchKernelGGL((mrp_prune_kernel<256, 4, 1, 1>), grid, dim3(256), lds, stream, in, hmms_dev, n_hmms, p, s);
+    else if (p.max_cells <= 2 * WAVE * 32)
         hipLaunchKernelGGL((mrp_prune_kernel<512, 32, 2, 1>), grid, dim3(512), lds, stream, in, hmms_dev, n_hmms, p, s);
     else if (p.max_cells <= MRP_PRUNE_MID_CELLS && !(force && force[0] == 'b'))
         hipLaunchKernelGGL((mrp_prune_kernel<512, 10, 1, 4>), grid, dim3(512), lds, stream, in, hmms_dev, n_hmms, p, s);
