@@ -1729,7 +1729,7 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                                 uint32_t bq[VEC];
 #pragma unroll
                                 for (int q = 0; q < VEC; q++) bq[q] = q < left ? (uint32_t) posterior_bin(r_f[j * VEC + q], r_b[j * VEC + q], total, nb, &errbits) : 0u;
-                                *reinterpret_cast<uint2 *>(dst + (j * LG + base_c) * VEC) = make_uint2(bq[0] | (bq[1] << 16), bq[VEC > 2 ? 2 : 0] | (bq[VEC > 3 ? 3 : 0] << 16));
+                                *reinterpret_cast<uint2 *>(dst + (j * LG + base_c) * VEC) = make_uint2(bq[0] | (bq[VEC > 1 ? 1 : 0] << 16), bq[VEC > 2 ? 2 : 0] | (bq[VEC > 3 ? 3 : 0] << 16));
                             }
                         }
                     }
