@@ -612,7 +612,9 @@ int mrp_batch_add_impl(mrp_batch *b, const mrp_hmm_job *job, bool resident, int6
  * among equals. */
 std::atomic<long long> g_pool_task_cpu_ns{0};
 std::atomic<long long> g_pool_tag_cpu_ns[16];
+static thread_local long long t_pool_task_cpu_ns = 0; /* pool tasks executed by the calling thread itself */
 extern "C" long long mrp_pool_task_cpu_ns(void) { return g_pool_task_cpu_ns.load(); }
+extern "C" long long mrp_pool_task_cpu_ns_this_thread(void) { return t_pool_task_cpu_ns; }
 extern "C" long long mrp_pool_tag_cpu_ns(int tag) { return g_pool_tag_cpu_ns[tag & 15].load(); }
 namespace {
 thread_local int t_pool_priority = 0;
@@ -643,7 +645,7 @@ struct mrp_host_pool {
             int tag;
             Acc(int t) : tag(t) { clock_gettime(CLOCK_THREAD_CPUTIME_ID, &a); }
             ~Acc() { timespec b; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &b); const long long d = (b.tv_sec - a.tv_sec) * 1000000000ll + (b.tv_nsec - a.tv_nsec);
-                     g_pool_task_cpu_ns.fetch_add(d); g_pool_tag_cpu_ns[tag & 15].fetch_add(d); }
+                     g_pool_task_cpu_ns.fetch_add(d); g_pool_tag_cpu_ns[tag & 15].fetch_add(d); t_pool_task_cpu_ns += d; }
         } acc(j->tag);
         for (;;) {
             const int64_t lo = j->next.fetch_add(j->grain);

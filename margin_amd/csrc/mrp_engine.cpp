@@ -215,6 +215,10 @@ int mrp_engine_create(mrp_context *ctx, const mrp_params *params, mrp_engine **o
 void mrp_engine_destroy(mrp_engine *e) {
     if (!e) return;
     mrp_context *ctx = e->ctx;
+    if (getenv("MRP_TIMING")) {
+        fprintf(stderr, "  context waits so far: %.1f ms wall, %.1f ms of thread CPU inside them\n", ctx->wait_wall_ms, ctx->wait_cpu_ms);
+        ctx->wait_wall_ms = ctx->wait_cpu_ms = 0;
+    }
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
     (void) hipStreamSynchronize(ctx->pre);

@@ -2174,17 +2174,19 @@ typedef struct {
     char err[256];
 } phase_group;
 long long mrp_pool_task_cpu_ns(void);
+long long mrp_pool_task_cpu_ns_this_thread(void);
 static double thread_cpu_ms(void) { struct timespec t; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t); return 1e3 * t.tv_sec + 1e-6 * t.tv_nsec; }
 static void *phase_group_main(void *p) {
     phase_group *g = p;
     const double cpu0 = thread_cpu_ms();
-    const long long pool0 = mrp_pool_task_cpu_ns();
+    const long long pool0 = mrp_pool_task_cpu_ns(), mine0 = mrp_pool_task_cpu_ns_this_thread();
     mrp_pool_adopt(g->pool);
     mrp_pool_set_priority(g->index); /* batch 0's host loops first: the batches reach their device-heavy levels one after the other */
     g->rc = phase_many_resident(g->ctx, g->n, g->chunks, g->reads, g->n_reads, g->params, g->out, &g->stats);
     mrp_pool_set_priority(0);
     if (getenv("MRP_TIMING")) {
-        fprintf(stderr, "  batch %d: cpu of its own thread %.1f ms; pool tasks (all batches, while it ran) %.1f ms; cumulative by loop:", g->index, thread_cpu_ms() - cpu0, (mrp_pool_task_cpu_ns() - pool0) * 1e-6);
+        fprintf(stderr, "  batch %d: cpu of its own thread %.1f ms (%.1f of it pool tasks it ran itself); pool tasks (all batches, while it ran) %.1f ms; cumulative by loop:", g->index,
+                thread_cpu_ms() - cpu0, (mrp_pool_task_cpu_ns_this_thread() - mine0) * 1e-6, (mrp_pool_task_cpu_ns() - pool0) * 1e-6);
         for (int t = 0; t < 12; t++) fprintf(stderr, " %d:%.0f", t, mrp_pool_tag_cpu_ns(t) * 1e-6);
         fprintf(stderr, "\n");
     }
