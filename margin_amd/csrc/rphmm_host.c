@@ -1598,8 +1598,14 @@ typedef VEC(xbuild) xbuild_vec;
 /* mergeTwoTilingPaths coordination.c:263-339, structure only: the overlap components that need a cross
  * product are appended to xs (and, unpruned, to res); the others pass through */
 static int64_t g_ns[6]; /* MRP_TIMING: components, tiling paths, cross shadows, destroy */
-static double tcpu_ms(void) { struct timespec t; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t); return 1e3 * (double) t.tv_sec + 1e-6 * (double) t.tv_nsec; }
-#define T_ADD(slot, t0) __atomic_fetch_add(&g_ns[slot], (int64_t) ((tcpu_ms() - (t0)) * 1e6), __ATOMIC_RELAXED)
+/* (only under MRP_TIMING: the thread CPU clock is a system call, and r_prepare_merge would make six of them per overlap
+ * component -- 700 000 per call, 0.2 s of CPU) */
+static int g_prepare_timing;
+static double tcpu_ms(void) {
+    if (!g_prepare_timing) return 0.0;
+    struct timespec t; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t); return 1e3 * (double) t.tv_sec + 1e-6 * (double) t.tv_nsec;
+}
+#define T_ADD(slot, t0) do { if (g_prepare_timing) __atomic_fetch_add(&g_ns[slot], (int64_t) ((tcpu_ms() - (t0)) * 1e6), __ATOMIC_RELAXED); } while (0)
 static int r_prepare_merge(const world *w, int32_t stride, r_hmm_vec *tp1, r_hmm_vec *tp2, r_hmm_vec *res, xbuild_vec *xs, r_hmm_vec *garbage) {
     double tq = tcpu_ms();
     ar_on();
@@ -1820,7 +1826,7 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
         /* (on this thread: the blocks go back to the shadow pool through one thread's front instead of sixteen fighting for
          * the pool's locks -- 30 ms of CPU per call instead of 180) */
         for (int64_t i = 0; i < n_items; i++) level_drop_garbage(i, items);
-        T_ADD(3, t2);
+        (void) t2;
         g_t_prepare += t1 - t0; g_t_level += now_ms() - t1;
         if (getenv("MRP_TIMING"))
             fprintf(stderr, "    host level %d: prepare %.2f ms, gather %.2f, stage %.2f, sort %.2f | launch (waits for the level before) %.2f | settle+garbage %.2f\n",
@@ -2059,6 +2065,7 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
     many_state *st = xcalloc((size_t) n_chunks + 1, sizeof(*st));
     rnode_vec tree = {0};
     const int timing = getenv("MRP_TIMING") != NULL;
+    g_prepare_timing = getenv("MRP_TIMING_PREPARE") != NULL;
     double tt[6];
     tt[0] = now_ms(); g_t_prepare = g_t_level = 0;
     for (int q = 0; q < 6; q++) __atomic_store_n(&g_ns[q], 0, __ATOMIC_RELAXED); /* (diagnostics shared by the concurrent halves) */
