@@ -23,12 +23,17 @@ MRP_PHASE_GROUPS=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format cs
 python3 $R/tools/trace_levels.py $O/t_lv > $O/pipeline_levels_96chunks_1batch.txt
 MRP_PHASE_GROUPS=4 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/t_g4 -o t -- python3 $R/tools/pipeline_probe.py --chunks 288 --repeat 3 --check-host 0 > $O/probe_288_g4.log 2>&1 || exit 1
 python3 $R/tools/trace_busy.py $O/t_g4 4 > $O/pipeline_busy_288chunks_4batches.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/t_g8 -o t -- python3 $R/tools/pipeline_probe.py --chunks 576 --repeat 3 --check-host 0 > $O/probe_576_g8.log 2>&1 || exit 1
+python3 $R/tools/trace_busy.py $O/t_g8 8 > $O/pipeline_busy_576chunks_8batches.txt
 # 5. host threads: the same 288-chunk call with 16 and with 4 threads in the library's pool (wall, process CPU time)
 for t in 16 4; do
   ( cd $R && MRP_HOST_THREADS=$t timeout -k 10 300 python3 tools/pipeline_probe.py --chunks 288 --repeat 6 --check-host 0 > $O/probe_288_t$t.log 2>&1 ) || exit 1
 done
-grep -H "^run" $O/probe_96_g1.log $O/probe_288_g4.log $O/probe_288_t16.log $O/probe_288_t4.log > $O/probe_runs.txt
+for t in 16 8 4; do
+  ( cd $R && MRP_HOST_THREADS=$t timeout -k 10 300 python3 tools/pipeline_probe.py --chunks 576 --repeat 5 --check-host 0 > $O/probe_576_t$t.log 2>&1 ) || exit 1
+done
+( cd $O && grep -H "^run" probe_96_g1.log probe_288_g4.log probe_576_g8.log probe_288_t16.log probe_288_t4.log probe_576_t16.log probe_576_t8.log probe_576_t4.log > probe_runs.txt )
 # 6. what linking the adaptor alone gives (the seam per hmm / per merge call, beside the oracle and the whole-chunk path)
 ( cd $R && timeout -k 10 600 python3 tools/adaptor_probe.py --chunks 8 --threads 8 > $O/adaptor_probe.txt 2>&1 ) || exit 1
-rm -rf $O/t_stats $O/t_FETCH_SIZE $O/t_WRITE_SIZE $O/t_sq $O/t_lv $O/t_g4
+rm -rf $O/t_stats $O/t_FETCH_SIZE $O/t_WRITE_SIZE $O/t_sq $O/t_lv $O/t_g4 $O/t_g8
 ls -la $O
