@@ -179,17 +179,20 @@ def main():
         descs = capi.chunk_descs(chunks)
         q.phase(chunks, params, chunks_per_batch=args.queue_batch, descs=descs, convert=False)
         barrier()
-        t0 = time.perf_counter()
+        q_ms = []
         for _ in range(args.queue_runs):
+            t0 = time.perf_counter()
             _, qst = q.phase(chunks, params, chunks_per_batch=args.queue_batch, descs=descs, convert=False)
-        barrier()
-        q_el = time.perf_counter() - t0
+            barrier()
+            q_ms.append(1e3 * (time.perf_counter() - t0))
+        # the median run (every run is listed): a run that meets a cold allocator after another tenant's memory pressure takes seconds
+        q_el = sorted(q_ms)[len(q_ms) // 2] * 1e-3
         q_el, q_units = sharding.reduce_elapsed_and_units(dist, q_el, units, device=reduce_dev)
         out["queue"] = dict(what="mrp_queue_phase_chunks: the same chunks from HOST memory (PCIe-inclusive): sorted by estimated cost, pulled in "
                                  "batches by one worker per device, the next batch's site tables and profile bytes uploaded on a second stream "
                                  "while the current batch is phased",
-                            value=q_units * args.queue_runs / q_el, unit="het-site-reads/s", ms_per_run=1e3 * q_el / args.queue_runs,
-                            batches=int(qst.batches), runs=args.queue_runs, vs_resident=(q_units * args.queue_runs / q_el) / value)
+                            value=q_units / q_el, unit="het-site-reads/s", ms_per_run=1e3 * q_el, runs_ms=[round(x, 1) for x in q_ms],
+                            batches=int(qst.batches), runs=args.queue_runs, vs_resident=(q_units / q_el) / value)
         q.close()
 
     # ---- the shapes of BASELINE.json configs[2] and configs[4] on one GPU (same call, other chunks) ---------------

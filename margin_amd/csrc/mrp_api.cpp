@@ -58,6 +58,10 @@ void mrp_chunk_host_view(const mrp_chunk *chunk, mrp_chunk_host *out) {
 }
 mrp_context *mrp_chunk_context(const mrp_chunk *chunk) { return chunk->ctx; }
 int mrp_context_device(const mrp_context *ctx) { return ctx->device; }
+void mrp_context_pool_bytes(mrp_context *ctx, int64_t *cached, int64_t *device_held) {
+    { std::lock_guard<std::mutex> lock(ctx->pool.mu); *cached = (int64_t) ctx->pool.cached_bytes; }
+    *device_held = ctx->pool.device >= 0 ? (int64_t) DevPoolRegistry::get().held[ctx->pool.device].load() : 0;
+}
 mrp_context *mrp_context_sibling(mrp_context *ctx, int i) {
     std::lock_guard<std::mutex> lock(ctx->sibling_mu);
     while ((int) ctx->siblings.size() <= i) {
@@ -65,13 +69,6 @@ mrp_context *mrp_context_sibling(mrp_context *ctx, int i) {
         if (mrp_context_create(ctx->device, &s) != MRP_OK) return nullptr;
         s->phase_groups = 1;
         s->test_hooks = ctx->test_hooks;
-        /* every pool of the family knows the others (out-of-memory retry) */
-        std::vector<mrp_context *> family(ctx->siblings);
-        family.push_back(ctx);
-        for (mrp_context *o : family) {
-            if (o->pool.n_peers < 16) o->pool.peers[o->pool.n_peers++] = &s->pool;
-            if (s->pool.n_peers < 16) s->pool.peers[s->pool.n_peers++] = &o->pool;
-        }
         ctx->siblings.push_back(s);
     }
     return ctx->siblings[(size_t) i];
@@ -111,6 +108,7 @@ int mrp_context_create(int device, mrp_context **out) {
     mrp_context *ctx = new (std::nothrow) mrp_context();
     if (!ctx) return fail(MRP_ERR_NOMEM, "out of host memory");
     ctx->device = device;
+    ctx->pool.attach(device); /* (the registry of the device's pools: budget, out-of-memory retry) */
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->pre, hipStreamNonBlocking);
@@ -309,6 +307,12 @@ int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *co
         });
         if (off[(size_t) n] > 0) e = hipMemcpyAsync(db, hb, off[(size_t) n], hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(blk->ready, ctx->stream);
+        if (e == hipSuccess && getenv("MRP_TIMING_UPLOAD")) { /* diagnosis only: waits for the copy */
+            const auto t0 = std::chrono::steady_clock::now();
+            e = hipEventSynchronize(blk->ready);
+            fprintf(stderr, "  chunk block: %lld chunks, %.1f MB, copy waited %.2f ms\n", (long long) n, (double) off[(size_t) n] / 1e6,
+                    std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        }
         if (e == hipSuccess)
             for (int64_t i = 0; i < n; i++) { out[i]->ready = blk->ready; out[i]->owns_ready = false; out[i]->ready_pending.store(true); }
     }

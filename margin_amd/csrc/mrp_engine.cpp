@@ -334,7 +334,10 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
             idx = (int) b->chunks.size(); b->chunks.push_back(ch);
             /* a chunk still being uploaded (work queue): the level's structure kernel and, through L->uploaded, its other
              * kernels are ordered behind the end of the upload */
-            if (ch->ready_pending.load()) ENG_TRY(hipStreamWaitEvent(cs, ch->ready, 0));
+            if (ch->ready_pending.load()) {
+                if (hipEventQuery(ch->ready) == hipSuccess) ch->ready_pending.store(false); /* over: never asked again */
+                else ENG_TRY(hipStreamWaitEvent(cs, ch->ready, 0));
+            }
         }
         chunk_index[(size_t) i] = idx;
         const bool anc = (h.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;

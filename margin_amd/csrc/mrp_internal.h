@@ -60,6 +60,32 @@ template <class T> using HostVec = std::vector<T, DefaultInitAllocator<T>>;
  * milliseconds and hipFree synchronizes the device, so blocks are kept and handed out again by size
  * class (1/8-octave rounding).  A released block becomes reusable only at the next reclaim(), which the
  * owners call right after they synchronized the context's stream: nothing in flight can still touch it. */
+struct DevPool;
+/* Every pool of the process, by device: what the pools of a device hold together (live and cached) is kept below the
+ * device's memory less a head room (the runtime allocates scratch and queue memory of its own and ABORTS when it cannot),
+ * and a pool the driver refuses a block gives back what idles in all of them, whoever owns them (the halves of one call,
+ * a work queue's lanes, a caller's other contexts). */
+struct DevPoolRegistry {
+    static constexpr int MAX_DEVICES = 64;
+    std::mutex mu;
+    std::vector<DevPool *> pools;
+    std::atomic<size_t> held[MAX_DEVICES];   /* bytes the pools of a device got from hipMalloc and have not given back */
+    std::atomic<size_t> budget[MAX_DEVICES]; /* 0: not asked yet */
+    DevPoolRegistry() { for (int d = 0; d < MAX_DEVICES; d++) { held[d].store(0); budget[d].store(0); } }
+    static DevPoolRegistry &get() { static DevPoolRegistry r; return r; }
+    size_t budget_of(int device) {
+        size_t b = budget[device].load(std::memory_order_relaxed);
+        if (b == 0) {
+            size_t free_b = 0, total = 0;
+            b = hipMemGetInfo(&free_b, &total) == hipSuccess && total > 0 ? total - total / 8 : ~(size_t) 0; /* (the calling thread's device) */
+            if (const char *e = getenv("MRP_POOL_BUDGET_MB")) { const long long v = atoll(e); if (v > 0) b = (size_t) v << 20; }
+            budget[device].store(b, std::memory_order_relaxed);
+        }
+        return b;
+    }
+    inline void trim_device(int device, DevPool *but);
+};
+
 struct DevPool {
     std::mutex mu;
     std::multimap<size_t, void *> free_blocks;
@@ -67,11 +93,29 @@ struct DevPool {
     size_t cached_bytes = 0;                 /* bytes in free_blocks */
     size_t cache_limit = (size_t) 24 << 30;  /* beyond this the largest cached blocks go back to the driver (a call runs up to
                                               * eight concurrent batches, each with a pool of its own: 8 x 24 GB of 288) */
-    /* the pools of the other contexts of the same device (siblings of mrp_phase_reads_many's concurrent halves, their
-     * parent): when the driver is out of memory their idle blocks are given back too */
-    DevPool *peers[16] = {nullptr};
-    int n_peers = 0;
-    std::mutex *peers_mu = nullptr;
+    int device = -1;                         /* attach(): the device whose registry entry this pool is */
+    void attach(int dev) {
+        device = dev >= 0 && dev < DevPoolRegistry::MAX_DEVICES ? dev : -1;
+        if (device < 0) return;
+        DevPoolRegistry &r = DevPoolRegistry::get();
+        std::lock_guard<std::mutex> lock(r.mu);
+        r.pools.push_back(this);
+    }
+    void detach() {
+        if (device < 0) return;
+        DevPoolRegistry &r = DevPoolRegistry::get();
+        std::lock_guard<std::mutex> lock(r.mu);
+        for (size_t i = 0; i < r.pools.size(); i++)
+            if (r.pools[i] == this) { r.pools.erase(r.pools.begin() + (long) i); break; }
+        device = -1;
+    }
+    void held_add(size_t b) { if (device >= 0) DevPoolRegistry::get().held[device].fetch_add(b, std::memory_order_relaxed); }
+    void held_sub(size_t b) { if (device >= 0) DevPoolRegistry::get().held[device].fetch_sub(b, std::memory_order_relaxed); }
+    bool over_budget() const {
+        if (device < 0) return false;
+        DevPoolRegistry &r = DevPoolRegistry::get();
+        return r.held[device].load(std::memory_order_relaxed) > r.budget_of(device);
+    }
     static size_t size_class(size_t bytes) {
         if (bytes < 256) bytes = 256;
         const int lg = 63 - __builtin_clzll((unsigned long long) bytes);
@@ -83,13 +127,21 @@ struct DevPool {
         *cls_out = cls;
         {
             std::lock_guard<std::mutex> lock(mu);
-            auto it = free_blocks.find(cls);
-            if (it != free_blocks.end()) {
+            /* best fit: the smallest idle block of this class or up to half as large again (the batches of a work queue differ
+             * by some per cent from call to call: exact classes alone would miss, and every miss is a hipMalloc of a gigabyte) */
+            auto it = free_blocks.lower_bound(cls);
+            if (it != free_blocks.end() && it->first <= cls + cls / 2) {
                 *p = it->second;
+                *cls_out = it->first;
+                cached_bytes -= it->first;
                 free_blocks.erase(it);
-                cached_bytes -= cls;
                 return hipSuccess;
             }
+        }
+        if (device >= 0 && DevPoolRegistry::get().held[device].load(std::memory_order_relaxed) + cls > DevPoolRegistry::get().budget_of(device)) {
+            trim(); /* the device's budget: first what idles here, then what idles in the other pools */
+            if (DevPoolRegistry::get().held[device].load(std::memory_order_relaxed) + cls > DevPoolRegistry::get().budget_of(device))
+                DevPoolRegistry::get().trim_device(device, this);
         }
         hipError_t e = hipMalloc(p, cls);
         if (e != hipSuccess) { /* give the cache back and try once more */
@@ -97,12 +149,12 @@ struct DevPool {
             trim();
             e = hipMalloc(p, cls);
         }
-        if (e != hipSuccess && n_peers > 0) { /* ... and what idles in the other contexts of this device */
+        if (e != hipSuccess && device >= 0) { /* ... and what idles in the other contexts of this device */
             (void) hipGetLastError();
-            for (int i = 0; i < n_peers; i++)
-                if (peers[i]) peers[i]->trim();
+            DevPoolRegistry::get().trim_device(device, this);
             e = hipMalloc(p, cls);
         }
+        if (e == hipSuccess) held_add(cls);
         return e;
     }
     void release(void *p, size_t cls) {
@@ -116,24 +168,32 @@ struct DevPool {
             cached_bytes += b.first;
         }
         pending.clear();
-        while (cached_bytes > cache_limit && !free_blocks.empty()) {
+        while ((cached_bytes > cache_limit || over_budget()) && !free_blocks.empty()) {
             auto it = std::prev(free_blocks.end());
             (void) hipFree(it->second);
+            held_sub(it->first);
             cached_bytes -= it->first;
             free_blocks.erase(it);
         }
     }
     void trim() { /* frees the reusable blocks */
         std::lock_guard<std::mutex> lock(mu);
-        for (auto &b : free_blocks) (void) hipFree(b.second);
+        for (auto &b : free_blocks) { (void) hipFree(b.second); held_sub(b.first); }
         free_blocks.clear();
         cached_bytes = 0;
     }
     void destroy() { /* context teardown: everything, after a device synchronize */
         reclaim();
         trim();
+        detach();
     }
 };
+
+inline void DevPoolRegistry::trim_device(int device, DevPool *but) {
+    std::lock_guard<std::mutex> lock(mu);
+    for (DevPool *q : pools)
+        if (q != but && q->device == device) q->trim();
+}
 
 template <typename T>
 struct DevBuf {

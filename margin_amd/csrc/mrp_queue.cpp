@@ -51,15 +51,25 @@ QueuePlan plan_queue(int64_t n, const int64_t *cost, int64_t chunks_per_batch, i
     p.order.resize((size_t) n);
     std::iota(p.order.begin(), p.order.end(), (int64_t) 0);
     std::stable_sort(p.order.begin(), p.order.end(), [&](int64_t a, int64_t b) { return cost[a] > cost[b]; });
-    const int64_t big = MRP_QUEUE_DEFAULT_BATCH, short_queue = big + big / 3;
+    /* one call takes up to ~640 chunks of the 1 Mb kind in its eight concurrent groups (768 still fit the 288 GB of an MI355X,
+     * 1 152 do not): below that ONE batch per device is the fastest (576 chunks: 186 ms in one call, 218 ms as two calls on two lanes) */
+    const int64_t big = MRP_QUEUE_DEFAULT_BATCH, short_queue = 640;
     const int lanes = std::max(1, n_workers / std::max(1, n_devices));
     if (chunks_per_batch >= 1) {
         for (int64_t o = 0; o < n; o += chunks_per_batch) p.batch_off.push_back(o);
     } else if (n <= (int64_t) n_devices * short_queue * lanes) {
-        /* at most one batch per lane: one per device while that stays below ~384 chunks, else one per lane */
-        const int64_t parts = n <= (int64_t) n_devices * short_queue ? n_devices : (int64_t) n_devices * lanes;
-        const int64_t per = std::max<int64_t>(1, (n + parts - 1) / parts);
-        for (int64_t o = 0; o < n; o += per) p.batch_off.push_back(o);
+        /* at most one batch per lane: one per device while that stays below ~640 chunks, else one per lane */
+        const int64_t parts = std::min<int64_t>(n, n <= (int64_t) n_devices * short_queue ? n_devices : (int64_t) n_devices * lanes);
+        /* these batches all start at once: deal the chunks out in stripes (batch b takes the b-th, (b + parts)-th, ... of the
+         * cost order), so that every batch gets its share of the expensive ones -- consecutive runs of a largest-first order
+         * would make the first batch the slowest by a third */
+        std::vector<int64_t> striped;
+        striped.reserve((size_t) n);
+        for (int64_t b = 0; b < parts; b++) {
+            p.batch_off.push_back((int64_t) striped.size());
+            for (int64_t i = b; i < n; i += parts) striped.push_back(p.order[(size_t) i]);
+        }
+        p.order.swap(striped);
     } else {
         for (int64_t o = 0; o < n;) { /* full batches while every worker can still get one, then shrinking, at least 48 chunks */
             p.batch_off.push_back(o);

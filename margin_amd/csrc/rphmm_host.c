@@ -2140,6 +2140,11 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
         fprintf(stderr, "mrp_phase_reads_many: setup %.1f ms, merge levels %.1f ms (host prepare %.1f, engine %.1f), download %.1f, "
                         "final sweep %.1f, trace back + genome fragments %.1f\n", tt[1] - tt[0], tt[2] - tt[1], g_t_prepare, g_t_level,
                 tt[3] - tt[2], tt[4] - tt[3], tt[5] - tt[4]);
+    if (timing) {
+        int64_t cached = 0, held = 0;
+        mrp_context_pool_bytes(ctx, &cached, &held);
+        fprintf(stderr, "  device memory: %.1f GB idle in this context's pool, %.1f GB held by all pools of the device\n", (double) cached * 1e-9, (double) held * 1e-9);
+    }
     if (timing)
         fprintf(stderr, "  prepare (summed over threads): components %.1f ms, tiling paths %.1f, cross shadows %.1f, garbage %.1f\n",
                 g_ns[0] * 1e-6, g_ns[1] * 1e-6, g_ns[2] * 1e-6, g_ns[3] * 1e-6);
