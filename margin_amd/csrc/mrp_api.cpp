@@ -112,7 +112,14 @@ int mrp_context_create(int device, mrp_context **out) {
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
     if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->pre, hipStreamNonBlocking);
-    for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking);
+    {
+        const char *ax = getenv("MRP_AUX_STREAMS");
+        ctx->aux_owned = !(ax && ax[0] == '0');
+        for (int i = 0; i < 2 && e == hipSuccess; i++) {
+            if (ctx->aux_owned) e = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking);
+            else ctx->aux[i] = ctx->stream;
+        }
+    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->join[i], hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -140,7 +147,7 @@ void mrp_context_destroy(mrp_context *ctx) {
     for (auto &e : ctx->join)
         if (e) (void) hipEventDestroy(e);
     for (auto &st : ctx->aux)
-        if (st) (void) hipStreamDestroy(st);
+        if (st && ctx->aux_owned) (void) hipStreamDestroy(st);
     if (ctx->pre) (void) hipStreamDestroy(ctx->pre);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;

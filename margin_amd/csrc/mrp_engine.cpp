@@ -557,7 +557,7 @@ static int level_finish(mrp_engine *e) {
     if (rc == MRP_OK && getenv("MRP_TIMING")) {
         fprintf(stderr, "  level: %lld hmms %lld cols %lld cells: staged in %.1f ms, launch (layout + totals + queue) %.1f ms\n", (long long) Lp->n,
                 (long long) Lp->total_cols, (long long) Lp->totals[0], Lp->t_staged - Lp->t_begin, Lp->t_launch_ms);
-#if defined(PRUNE_EXP_CLOCK) || defined(PRUNE_EXP_CLOCK2)
+#if defined(PRUNE_EXP_CLOCK) || defined(PRUNE_EXP_CLOCK2) || defined(XE_CLOCK)
         fprintf(stderr, "  prune clocks (first hmm; shader cycles):");
         for (int i = 0; i < 12; i++) fprintf(stderr, " %llu", Lp->clk[i]);
         fprintf(stderr, "\n");
@@ -705,7 +705,7 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
     }
     ENG_TRY(hipMemcpyAsync(L->err, L->d_err.p, 16, hipMemcpyDeviceToHost, s));
     ENG_TRY(hipMemcpyAsync(L->err_hmm, L->d_err_hmm.p, sizeof(int32_t) * (size_t) n, hipMemcpyDeviceToHost, s));
-#if defined(PRUNE_EXP_CLOCK) || defined(PRUNE_EXP_CLOCK2)
+#if defined(PRUNE_EXP_CLOCK) || defined(PRUNE_EXP_CLOCK2) || defined(XE_CLOCK)
     ENG_TRY(hipMemcpyAsync(L->clk, L->d_err.p + 4, 96, hipMemcpyDeviceToHost, s));
 #endif
     L->t_launch_ms = eng_now() - t0;

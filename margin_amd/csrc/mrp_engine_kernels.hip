@@ -203,7 +203,9 @@ hipError_t mrp_launch_cross(const CrossCol *cols_dev, int64_t n_cols, uint64_t *
  * With inverted partitions cells 2q, 2q+1 are complements and share their cost (hap1 <-> hap2): a lane computes it once.
  * HBM traffic: 8 B written per cell (cost + transitions), nothing read per cell.
  */
-#define XE_WAVES 4
+#ifndef XE_WAVES
+#define XE_WAVES 1
+#endif
 #ifndef XE_CAP
 #define XE_CAP 832 /* table dwords per wave: 200 parent cells (two pruned columns of 100) x 4 allele slots, 128 x 6; with 25 KB of LDS
                     * per workgroup six workgroups = 24 waves share a CU (1 024 dwords: five; -9 % on the kernel) */
@@ -255,11 +257,14 @@ static __device__ __forceinline__ uint32_t xe_cost(const uint32_t *pa, const uin
  * NW4 = 16-read groups the side's reads span; the partition is shifted up to the merged column's read positions, then down
  * by the first group (rowbuf points at that group's words). */
 template <int NW4, bool SIDE_B>
-static __device__ __forceinline__ void xe_fill_side(uint32_t *rows, uint32_t ST, const uint64_t *__restrict__ part, uint32_t C, uint32_t up,
+static __device__ __forceinline__ void xe_fill_side(uint32_t *rows, uint32_t ST, uint64_t P0, uint64_t P1, uint32_t C, uint32_t up,
                                                     uint32_t down, uint32_t nsl, const uint32_t *rowbuf, const uint32_t *totbuf, int lane) {
-    for (uint32_t cc = lane; cc < ((C + WAVE - 1) & ~(uint32_t) (WAVE - 1)); cc += WAVE) {
+    /* the partitions of parent cells lane and lane + 64 are in the lane's registers (P0, P1: requested with everything else
+     * the column needs, right after its descriptor) */
+    for (uint32_t u = 0; u * WAVE < C; u++) {
+        const uint32_t cc = (uint32_t) lane + u * WAVE;
         const bool act = cc < C;
-        uint64_t P = (act && part) ? part[cc] : 0ull;
+        uint64_t P = act ? (u ? P1 : P0) : 0ull;
         P = up < 64u ? (P << up) >> down : 0ull;
         uint32_t sel[4 * NW4];
 #pragma unroll
@@ -296,18 +301,60 @@ static __device__ __forceinline__ uint32_t xe_term_b(uint32_t kind, bool none, u
     if (!inv || !a_paired) return j | (j << 16);
     return (2u * j) | ((2u * (b_paired ? (j ^ 1u) : j)) << 16);
 }
-static __device__ __forceinline__ void xe_stage_transitions(const CrossCol &c, bool inv, uint2 *tra, uint2 *trb, int lane) {
+/* np0, np1: the transitions of parent cells lane and lane + 64 of each side (registers) */
+static __device__ __forceinline__ void xe_stage_transitions(const CrossCol &c, bool inv, uint2 *tra, uint2 *trb, int lane, const uint32_t *npa,
+                                                            const uint32_t *npb) {
     const bool oap = (c.flags & MRP_XF_OUT_A_PAIRED) != 0, obp = (c.flags & MRP_XF_OUT_B_PAIRED) != 0;
     const bool iap = (c.flags & MRP_XF_IN_A_PAIRED) != 0, ibp = (c.flags & MRP_XF_IN_B_PAIRED) != 0;
     const bool no_out = c.out_a == MRP_CONN_NONE, no_in = c.in_a == MRP_CONN_NONE;
-    for (uint32_t i = lane; i < min((uint32_t) c.C1, 128u); i += WAVE) {
-        const uint32_t n1 = c.a_part ? c.a_np[i] : 0u;
-        tra[i] = make_uint2(xe_term_a(c.out_a, no_out, n1 & 0xFFFFu, i, c.Mb, inv, oap), xe_term_a(c.in_a, no_in, n1 >> 16, i, c.Pb, inv, iap));
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const uint32_t i = (uint32_t) lane + (uint32_t) u * WAVE;
+        if (i < min((uint32_t) c.C1, 128u))
+            tra[i] = make_uint2(xe_term_a(c.out_a, no_out, npa[u] & 0xFFFFu, i, c.Mb, inv, oap), xe_term_a(c.in_a, no_in, npa[u] >> 16, i, c.Pb, inv, iap));
+        if (i < min((uint32_t) c.C2, 128u))
+            trb[i] = make_uint2(xe_term_b(c.out_b, no_out, npb[u] & 0xFFFFu, i, inv, oap, obp), xe_term_b(c.in_b, no_in, npb[u] >> 16, i, inv, iap, ibp));
     }
-    for (uint32_t i = lane; i < min((uint32_t) c.C2, 128u); i += WAVE) {
-        const uint32_t n2 = c.b_part ? c.b_np[i] : 0u;
-        trb[i] = make_uint2(xe_term_b(c.out_b, no_out, n2 & 0xFFFFu, i, inv, oap, obp), xe_term_b(c.in_b, no_in, n2 >> 16, i, inv, iap, ibp));
+}
+/* verify_side over a side of at most 128 parent cells held in registers (entry e = lane + 64 u; its complement e ^ 1 sits in
+ * the neighbouring lane) */
+static __device__ __forceinline__ int xe_verify_side(bool have, const uint64_t *P, const uint32_t *np, uint32_t C, uint32_t depth, uint32_t M_out,
+                                                     uint32_t M_in, uint32_t out_kind, uint32_t in_kind, bool inv, bool out_paired, bool in_paired,
+                                                     int lane) {
+    if (!have) return 0;
+    int bad = 0;
+    const bool cells_paired = inv && depth > 0;
+    if (cells_paired && (C & 1u)) return MRP_ENGINE_ERR_STRUCTURE;
+    const uint64_t acc = accept_mask(depth);
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const uint32_t e = (uint32_t) lane + (uint32_t) u * WAVE;
+        const uint32_t v = np[u], nx = v & 0xFFFFu, pv = v >> 16;
+        const uint32_t v_other = (uint32_t) __shfl_xor((int) v, 1, WAVE);
+        const uint64_t p_other = ((uint64_t) (uint32_t) __shfl_xor((int) (uint32_t) (P[u] >> 32), 1, WAVE) << 32) |
+                                 (uint32_t) __shfl_xor((int) (uint32_t) P[u], 1, WAVE);
+        if (e >= C) continue;
+        uint32_t vo = v;
+        if (cells_paired) {
+            if (p_other != (~P[u] & acc)) bad |= MRP_ENGINE_ERR_STRUCTURE;
+            vo = v_other;
+        }
+        if (out_kind == MRP_CONN_REAL) {
+            if (nx >= M_out) bad |= MRP_ENGINE_ERR_RANGE;
+            if (inv) {
+                if (out_paired) { if ((M_out & 1u) || (vo & 0xFFFFu) != (nx ^ 1u)) bad |= MRP_ENGINE_ERR_STRUCTURE; }
+                else if (M_out != 1u) bad |= MRP_ENGINE_ERR_STRUCTURE;
+            }
+        }
+        if (in_kind == MRP_CONN_REAL) {
+            if (pv >= M_in) bad |= MRP_ENGINE_ERR_RANGE;
+            if (inv) {
+                if (in_paired) { if ((M_in & 1u) || (vo >> 16) != (pv ^ 1u)) bad |= MRP_ENGINE_ERR_STRUCTURE; }
+                else if (M_in != 1u) bad |= MRP_ENGINE_ERR_STRUCTURE;
+            }
+        }
     }
+    return bad;
 }
 static __device__ __forceinline__ uint32_t xe_np(uint2 a, uint2 b) { /* next | prev << 16 */
     const uint32_t nxt = (a.x & 0x7FFFFFFFu) + ((int32_t) a.x < 0 ? b.x >> 16 : b.x & 0xFFFFu);
@@ -315,10 +362,18 @@ static __device__ __forceinline__ uint32_t xe_np(uint2 a, uint2 b) { /* next | p
     return nxt | (prv << 16);
 }
 
+#ifdef XE_CLOCK /* development: where a wave of mrp_cross_emit_kernel spends its time (summed over the waves of a launch, clock ticks) */
+#define XE_T(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); xe_sec[i] += t_ - xe_t; xe_t = t_; } while (0)
+#else
+#define XE_T(i) do { } while (0)
+#endif
 struct __attribute__((packed, aligned(4))) xe_u32x4 { uint32_t x, y, z, w; };
 struct __attribute__((packed, aligned(4))) xe_u32x2 { uint32_t x, y; };
 
-__global__ void __launch_bounds__(XE_WAVES * WAVE) mrp_cross_emit_kernel(const CrossCol *__restrict__ ccols, const DevCol *__restrict__ cols,
+#ifndef XE_MIN_WAVES
+#define XE_MIN_WAVES 1
+#endif
+__global__ void __launch_bounds__(XE_WAVES * WAVE, XE_MIN_WAVES) mrp_cross_emit_kernel(const CrossCol *__restrict__ ccols, const DevCol *__restrict__ cols,
                                                                          const DevChunk *__restrict__ chunks, int64_t n_cols,
                                                                          const uint32_t *__restrict__ slot_bytes,
                                                                          const uint32_t *__restrict__ slot_total,
@@ -333,9 +388,17 @@ __global__ void __launch_bounds__(XE_WAVES * WAVE) mrp_cross_emit_kernel(const C
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / WAVE));
     uint32_t *tab = tab_all[wave], *rowbuf = row_all[wave], *totbuf = tot_all[wave];
     uint2 *tra = tr_all[wave], *trb = tr_all[wave] + 128;
+#ifdef XE_CLOCK
+    uint64_t xe_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xe_t = __builtin_amdgcn_s_memtime();
+#endif
     for (int64_t col = (int64_t) blockIdx.x * XE_WAVES + wave; col < n_cols; col += (int64_t) gridDim.x * XE_WAVES) {
         const CrossCol c = k_load(ccols + col);
         const DevCol dc = k_load(cols + col);
+#ifdef XE_CLOCK
+        if (c.x_cell_off == -0x123456789LL || dc.slot_off == -0x123456789LL) continue; /* (uses the descriptors: the wait for them is section 0) */
+        XE_T(0);
+        xe_sec[7] += 1;
+#endif
         const bool inv = (c.flags & MRP_XF_INVERTED) != 0;
         const uint32_t C1 = c.C1, C2 = c.C2, C = C1 * C2;
         const bool a_cells_paired = inv && c.a_part && c.d1 > 0, b_cells_paired = inv && c.b_part && c.d2 > 0;
@@ -345,16 +408,43 @@ __global__ void __launch_bounds__(XE_WAVES * WAVE) mrp_cross_emit_kernel(const C
         const uint32_t A_uni = (dc.flags >> 8) & 0xFFu; /* allele count shared by the column's sites, 0 if they differ (layout kernel) */
         const int w4_all = (dc.depth + 15) >> 4;
         const int w4_a = ((int) c.d1 + 15) >> 4, w4_b = (int) c.d1 >> 4;
-        /* everything the column needs from HBM is requested here, independent of each other: the parents' transitions
-         * (staged for the cells' lookups), the first fill's packed bytes, and the pair order check's reads */
-        xe_stage_transitions(c, inv, tra, trb, lane);
-        int bad = 0;
-        {
-            bad = verify_side(c.a_part, c.a_np, C1, c.d1, c.Ma, c.Pa, c.out_a, c.in_a, inv,
-                              (c.flags & MRP_XF_OUT_A_PAIRED) != 0, (c.flags & MRP_XF_IN_A_PAIRED) != 0, lane, WAVE);
-            bad |= verify_side(c.b_part, c.b_np, C2, c.d2, c.Mb, c.Pb, c.out_b, c.in_b, inv,
-                               (c.flags & MRP_XF_OUT_B_PAIRED) != 0, (c.flags & MRP_XF_IN_B_PAIRED) != 0, lane, WAVE);
+        /* Everything the column needs from HBM is requested HERE, in one round trip behind the two descriptors: the parents'
+         * transitions and partitions (parent cells lane and lane + 64 of either side stay in the lane's registers: the pair
+         * order check, the transition terms and the table rows all start from them) and, when the column's sites share their
+         * allele count (so that the first table fill's slots are known from the descriptor alone), that fill's packed bytes
+         * and byte sums.  Round 2 asked for them one after the other (transitions, order check, packed bytes, partitions):
+         * four dependent trips to memory per column, half of the kernel's time. */
+        const bool have_a = c.a_part != nullptr, have_b = c.b_part != nullptr;
+        uint32_t npa[2], npb[2];
+        uint64_t Pa[2], Pb[2];
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const uint32_t i = (uint32_t) lane + (uint32_t) u * WAVE;
+            const bool ia = have_a && i < C1, ib = have_b && i < C2;
+            npa[u] = ia ? c.a_np[i] : 0u;
+            Pa[u] = ia ? c.a_part[i] : 0ull;
+            npb[u] = ib ? c.b_np[i] : 0u;
+            Pb[u] = ib ? c.b_part[i] : 0ull;
         }
+        constexpr int XE_PRE = XE_ROWS * 16 / WAVE;
+        const uint32_t pre_cnt = A_uni ? min((uint32_t) dc.n_sites, slot_room / A_uni) : 0u;
+        const uint32_t pre_nsl = pre_cnt * A_uni; /* 0: the first fill asks for its slots itself */
+        uint32_t pre_rows[XE_PRE], pre_tot = 0u;
+#pragma unroll
+        for (int k = 0; k < XE_PRE; k++) {
+            const uint32_t i = (uint32_t) lane + (uint32_t) k * WAVE;
+            pre_rows[k] = i < pre_nsl * 16u ? slot_bytes[dc.slot_off * 16 + i] : 0u;
+        }
+        if ((uint32_t) lane < pre_nsl) pre_tot = slot_total[dc.slot_off + lane];
+#ifdef XE_CLOCK
+        if (__builtin_amdgcn_readfirstlane((int) (npa[0] ^ npb[0] ^ pre_rows[0] ^ (uint32_t) Pa[0] ^ (uint32_t) Pb[0])) == 0x7EADBEEF) continue; /* wait for the loads: section 1 */
+        XE_T(1);
+#endif
+        xe_stage_transitions(c, inv, tra, trb, lane, npa, npb);
+        int bad = xe_verify_side(have_a, Pa, npa, C1, c.d1, c.Ma, c.Pa, c.out_a, c.in_a, inv,
+                                 (c.flags & MRP_XF_OUT_A_PAIRED) != 0, (c.flags & MRP_XF_IN_A_PAIRED) != 0, lane);
+        bad |= xe_verify_side(have_b, Pb, npb, C2, c.d2, c.Mb, c.Pb, c.out_b, c.in_b, inv,
+                              (c.flags & MRP_XF_OUT_B_PAIRED) != 0, (c.flags & MRP_XF_IN_B_PAIRED) != 0, lane);
         if ((!c.a_part && C1 != 1u) || (!c.b_part && C2 != 1u) || C1 > 128u || C2 > 128u || (int) c.d1 + (int) c.d2 != dc.depth) bad |= MRP_ENGINE_ERR_RANGE;
         if (bad) { atomicOr(err, bad); atomicOr(err_hmm + col_hmm[col], bad); }
         if (__any(bad != 0)) { /* the level is discarded by the host; keep the arrays defined meanwhile */
@@ -363,7 +453,10 @@ __global__ void __launch_bounds__(XE_WAVES * WAVE) mrp_cross_emit_kernel(const C
         }
         const uint32_t *aoff = A_uni ? nullptr : chunks[dc.chunk].allele_offset + dc.site_start;
         uint32_t site0 = 0, sl0 = 0;
-        while (site0 < (uint32_t) dc.n_sites) {
+        XE_T(2); /* transition terms, order check */
+        /* one table fill and the cells' costs over its sites; the first is called with the registers above, the others (columns
+         * of many sites or alleles: the low levels) ask again, so that nothing of the front end stays live over the cells */
+        auto fill_and_cost = [&](const bool first_chunk, uint64_t Qa0, uint64_t Qa1, uint64_t Qb0, uint64_t Qb1) {
             /* as many whole sites as fit */
             uint32_t cnt, nsl;
             uint64_t ends = 0; /* bit (slot): the slot is the last allele of its site */
@@ -385,7 +478,6 @@ __global__ void __launch_bounds__(XE_WAVES * WAVE) mrp_cross_emit_kernel(const C
                        (uint32_t) __builtin_amdgcn_readfirstlane((int) ends); /* wave-uniform: the site loop branches on scalars */
             }
             const int64_t slot_g = dc.slot_off + sl0;
-            const bool first_chunk = site0 == 0;
             if (cnt == 0) {
                 /* A site with more alleles than the tables hold for this many parent cells (rare): its cells are costed
                  * one by one from their merged partitions, straight from the packed bytes in HBM. */
@@ -408,45 +500,68 @@ __global__ void __launch_bounds__(XE_WAVES * WAVE) mrp_cross_emit_kernel(const C
                 }
                 site0 += 1u;
                 sl0 += A;
-                continue;
+                return;
             }
             const uint32_t ST = (nsl + 3u) & ~3u; /* row stride: 16-byte rows */
             uint32_t *tb = tab + C1 * ST;
             {
-                /* the packed bytes and byte sums of the slots: one coalesced read, then LDS */
-                for (uint32_t i = lane; i < nsl * 16u; i += WAVE) rowbuf[i] = slot_bytes[slot_g * 16 + i];
-                if ((uint32_t) lane < nsl) totbuf[lane] = slot_total[slot_g + lane];
+                /* the packed bytes and byte sums of the slots: one coalesced read (the first fill's is in flight since the top of
+                 * the column), then LDS */
+                if (first_chunk && pre_nsl) {
+#pragma unroll
+                    for (int k = 0; k < XE_PRE; k++) {
+                        const uint32_t i = (uint32_t) lane + (uint32_t) k * WAVE;
+                        if (i < nsl * 16u) rowbuf[i] = pre_rows[k];
+                    }
+                    if ((uint32_t) lane < nsl) totbuf[lane] = pre_tot;
+                } else {
+                    for (uint32_t i = lane; i < nsl * 16u; i += WAVE) rowbuf[i] = slot_bytes[slot_g * 16 + i];
+                    if ((uint32_t) lane < nsl) totbuf[lane] = slot_total[slot_g + lane];
+                }
                 wave_lds_fence();
                 if (Cs >= 24u) { /* many parent cells: a lane per parent cell */
                     const uint32_t *rowb = rowbuf + 4 * w4_b;
                     switch (w4_a) {
-                    case 0: case 1: xe_fill_side<1, false>(tab, ST, c.a_part, C1, 0u, 0u, nsl, rowbuf, totbuf, lane); break;
-                    case 2: xe_fill_side<2, false>(tab, ST, c.a_part, C1, 0u, 0u, nsl, rowbuf, totbuf, lane); break;
-                    case 3: xe_fill_side<3, false>(tab, ST, c.a_part, C1, 0u, 0u, nsl, rowbuf, totbuf, lane); break;
-                    default: xe_fill_side<4, false>(tab, ST, c.a_part, C1, 0u, 0u, nsl, rowbuf, totbuf, lane); break;
+                    case 0: case 1: xe_fill_side<1, false>(tab, ST, Qa0, Qa1, C1, 0u, 0u, nsl, rowbuf, totbuf, lane); break;
+                    case 2: xe_fill_side<2, false>(tab, ST, Qa0, Qa1, C1, 0u, 0u, nsl, rowbuf, totbuf, lane); break;
+                    case 3: xe_fill_side<3, false>(tab, ST, Qa0, Qa1, C1, 0u, 0u, nsl, rowbuf, totbuf, lane); break;
+                    default: xe_fill_side<4, false>(tab, ST, Qa0, Qa1, C1, 0u, 0u, nsl, rowbuf, totbuf, lane); break;
                     }
                     switch (min(w4_all, 4) - min(w4_b, 3)) { /* d1 = 64: side B has no reads, any group of zero bits will do */
-                    case 0: case 1: xe_fill_side<1, true>(tb, ST, c.b_part, C2, c.d1, 16u * min(w4_b, 3), nsl, rowbuf + 4 * min(w4_b, 3), totbuf, lane); break;
-                    case 2: xe_fill_side<2, true>(tb, ST, c.b_part, C2, c.d1, 16u * w4_b, nsl, rowb, totbuf, lane); break;
-                    case 3: xe_fill_side<3, true>(tb, ST, c.b_part, C2, c.d1, 16u * w4_b, nsl, rowb, totbuf, lane); break;
-                    default: xe_fill_side<4, true>(tb, ST, c.b_part, C2, c.d1, 16u * w4_b, nsl, rowb, totbuf, lane); break;
+                    case 0: case 1: xe_fill_side<1, true>(tb, ST, Qb0, Qb1, C2, c.d1, 16u * min(w4_b, 3), nsl, rowbuf + 4 * min(w4_b, 3), totbuf, lane); break;
+                    case 2: xe_fill_side<2, true>(tb, ST, Qb0, Qb1, C2, c.d1, 16u * w4_b, nsl, rowb, totbuf, lane); break;
+                    case 3: xe_fill_side<3, true>(tb, ST, Qb0, Qb1, C2, c.d1, 16u * w4_b, nsl, rowb, totbuf, lane); break;
+                    default: xe_fill_side<4, true>(tb, ST, Qb0, Qb1, C2, c.d1, 16u * w4_b, nsl, rowb, totbuf, lane); break;
                     }
-                } else { /* few parent cells (the low levels: long columns of few cells): lanes along (slot, parent cell) */
-                    for (uint32_t idx = lane; idx < C1 * nsl; idx += WAVE) {
-                        const uint32_t slot = idx / C1, cc = idx - slot * C1;
-                        const uint64_t P = c.a_part ? c.a_part[cc] : 0ull;
-                        const uint32_t t = slot_dot(rowbuf + slot * 16, P, 0, w4_a);
-                        tab[cc * ST + slot] = t | ((totbuf[slot] - t) << 16);
+                } else { /* few parent cells (the low levels: long columns of few cells): lanes along (slot, parent cell); the
+                          * partition of parent cell cc comes from lane cc's register */
+                    for (uint32_t i0 = 0; i0 < C1 * nsl; i0 += WAVE) {
+                        const uint32_t idx = i0 + (uint32_t) lane;
+                        const bool act = idx < C1 * nsl;
+                        const uint32_t slot = act ? idx / C1 : 0u, cc = act ? idx - slot * C1 : 0u;
+                        const uint64_t P = ((uint64_t) (uint32_t) __shfl((int) (uint32_t) (Qa0 >> 32), (int) cc, WAVE) << 32) |
+                                           (uint32_t) __shfl((int) (uint32_t) Qa0, (int) cc, WAVE);
+                        if (act) {
+                            const uint32_t t = slot_dot(rowbuf + slot * 16, P, 0, w4_a);
+                            tab[cc * ST + slot] = t | ((totbuf[slot] - t) << 16);
+                        }
                     }
-                    for (uint32_t idx = lane; idx < C2 * nsl; idx += WAVE) {
-                        const uint32_t slot = idx / C2, cc = idx - slot * C2;
-                        const uint64_t P = (c.b_part && c.d1 < 64) ? c.b_part[cc] << c.d1 : 0ull;
-                        const uint32_t t = slot_dot(rowbuf + slot * 16, P, w4_b, w4_all);
-                        tb[cc * ST + slot] = t - (t << 16);
+                    for (uint32_t i0 = 0; i0 < C2 * nsl; i0 += WAVE) {
+                        const uint32_t idx = i0 + (uint32_t) lane;
+                        const bool act = idx < C2 * nsl;
+                        const uint32_t slot = act ? idx / C2 : 0u, cc = act ? idx - slot * C2 : 0u;
+                        const uint64_t Pr = ((uint64_t) (uint32_t) __shfl((int) (uint32_t) (Qb0 >> 32), (int) cc, WAVE) << 32) |
+                                            (uint32_t) __shfl((int) (uint32_t) Qb0, (int) cc, WAVE);
+                        if (act) {
+                            const uint64_t P = c.d1 < 64 ? Pr << c.d1 : 0ull;
+                            const uint32_t t = slot_dot(rowbuf + slot * 16, P, w4_b, w4_all);
+                            tb[cc * ST + slot] = t - (t << 16);
+                        }
                     }
                 }
             }
             wave_lds_fence();
+            XE_T(3); /* table fill */
             if (a_cells_paired) {
                 /* The cells of the column are a grid: row r = pair (2r, 2r + 1) of side A cells, position h = side B cell;
                  * cells e = 2 (r C2 + h) and e + 1 are complements and share their cost.  A lane keeps ONE h: its side B
@@ -513,10 +628,27 @@ __global__ void __launch_bounds__(XE_WAVES * WAVE) mrp_cross_emit_kernel(const C
                 }
             }
             wave_lds_fence(); /* the tables are rewritten by the next chunk of sites / the next column */
+            XE_T(4); /* cells */
             site0 += cnt;
             sl0 += nsl;
+        };
+        if ((uint32_t) dc.n_sites > 0u) fill_and_cost(true, Pa[0], Pa[1], Pb[0], Pb[1]);
+        while (site0 < (uint32_t) dc.n_sites) {
+            uint64_t Qa[2], Qb[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const uint32_t i = (uint32_t) lane + (uint32_t) u * WAVE;
+                Qa[u] = (have_a && i < C1) ? c.a_part[i] : 0ull;
+                Qb[u] = (have_b && i < C2) ? c.b_part[i] : 0ull;
+            }
+            fill_and_cost(false, Qa[0], Qa[1], Qb[0], Qb[1]);
         }
     }
+#ifdef XE_CLOCK
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    XE_T(5); /* the stores in flight at the end */
+    if (lane == 0 && (blockIdx.x & 63u) == 0u) for (int i = 0; i < 8; i++) atomicAdd((unsigned long long *) (err + 4) + i, (unsigned long long) xe_sec[i]); /* a sample of the waves */
+#endif
 }
 
 hipError_t mrp_launch_cross_emit(const CrossCol *cols_dev, const MrpBatchDev &d, int32_t *err, const int32_t *col_hmm_dev, int32_t *err_hmm,

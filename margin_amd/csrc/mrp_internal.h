@@ -236,6 +236,7 @@ struct mrp_context {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t aux[2] = {nullptr, nullptr}; /* size classes of the recursion kernel run side by side */
+    bool aux_owned = true;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipStream_t pre = nullptr; /* copy stream: uploads of a staged level of the resident engine, beside the kernels of the level before */
     hipEvent_t last_emission = nullptr; /* end of the emission kernel of the most recent launch on this context (owned by its batch) */
