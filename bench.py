@@ -174,7 +174,11 @@ def main():
 
     # ---- the same chunks from HOST memory through the work queue (PCIe-inclusive) --------------------------------
     if args.queue_runs > 0 and not single_process_multi:
-        ctx.trim()  # the queue's workers have contexts (and allocator caches) of their own
+        # the queue's workers have contexts, streams and allocator caches of their own: the resident leg's go first (a caller of
+        # the queue holds no second family of contexts whose streams would share the device's hardware queues with the queue's)
+        for d_ in dchunks:
+            d_.close()
+        ctx.close()
         q = capi.Queue([local_rank])
         descs = capi.chunk_descs(chunks)
         q.phase(chunks, params, chunks_per_batch=args.queue_batch, descs=descs, convert=False)
@@ -194,6 +198,9 @@ def main():
                             value=q_units / q_el, unit="het-site-reads/s", ms_per_run=1e3 * q_el, runs_ms=[round(x, 1) for x in q_ms],
                             batches=int(qst.batches), runs=args.queue_runs, vs_resident=(q_units / q_el) / value)
         q.close()
+        ctx = capi.Context(local_rank)
+        ctx.set_phase_groups(args.phase_groups)
+        dchunks = []
 
     # ---- the shapes of BASELINE.json configs[2] and configs[4] on one GPU (same call, other chunks) ---------------
     if not single_process_multi:

@@ -58,6 +58,7 @@ void mrp_chunk_host_view(const mrp_chunk *chunk, mrp_chunk_host *out) {
 }
 mrp_context *mrp_chunk_context(const mrp_chunk *chunk) { return chunk->ctx; }
 int mrp_context_device(const mrp_context *ctx) { return ctx->device; }
+void mrp_context_set_grouped(mrp_context *ctx, int grouped) { ctx->grouped = grouped != 0; }
 void mrp_context_pool_bytes(mrp_context *ctx, int64_t *cached, int64_t *device_held) {
     { std::lock_guard<std::mutex> lock(ctx->pool.mu); *cached = (int64_t) ctx->pool.cached_bytes; }
     *device_held = ctx->pool.device >= 0 ? (int64_t) DevPoolRegistry::get().held[ctx->pool.device].load() : 0;
@@ -68,6 +69,7 @@ mrp_context *mrp_context_sibling(mrp_context *ctx, int i) {
         mrp_context *s = nullptr;
         if (mrp_context_create(ctx->device, &s) != MRP_OK) return nullptr;
         s->phase_groups = 1;
+        s->grouped = true;
         s->test_hooks = ctx->test_hooks;
         ctx->siblings.push_back(s);
     }
@@ -111,15 +113,6 @@ int mrp_context_create(int device, mrp_context **out) {
     ctx->pool.attach(device); /* (the registry of the device's pools: budget, out-of-memory retry) */
     hipError_t e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
     for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&ctx->ev[i]);
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&ctx->pre, hipStreamNonBlocking);
-    {
-        const char *ax = getenv("MRP_AUX_STREAMS");
-        ctx->aux_owned = !(ax && ax[0] == '0');
-        for (int i = 0; i < 2 && e == hipSuccess; i++) {
-            if (ctx->aux_owned) e = hipStreamCreateWithFlags(&ctx->aux[i], hipStreamNonBlocking);
-            else ctx->aux[i] = ctx->stream;
-        }
-    }
     if (e == hipSuccess) e = hipEventCreateWithFlags(&ctx->fork, hipEventDisableTiming);
     for (int i = 0; i < 2 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&ctx->join[i], hipEventDisableTiming);
     if (e != hipSuccess) {
@@ -147,7 +140,7 @@ void mrp_context_destroy(mrp_context *ctx) {
     for (auto &e : ctx->join)
         if (e) (void) hipEventDestroy(e);
     for (auto &st : ctx->aux)
-        if (st && ctx->aux_owned) (void) hipStreamDestroy(st);
+        if (st) (void) hipStreamDestroy(st);
     if (ctx->pre) (void) hipStreamDestroy(ctx->pre);
     if (ctx->stream) (void) hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -993,20 +986,27 @@ int mrp_batch_launch(mrp_batch *b) {
         HIP_TRY(mrp_launch_fill_f64(b->d_hmm_fb.p, 2 * d.n_hmms, neg, s));
     }
     /* size classes side by side: wide on the main stream, mid and narrow on the auxiliary streams */
-    HIP_TRY(hipEventRecord(ctx->fork, s));
-    HIP_TRY(hipStreamWaitEvent(ctx->aux[0], ctx->fork, 0));
-    HIP_TRY(hipStreamWaitEvent(ctx->aux[1], ctx->fork, 0));
+    hipStream_t a0 = s, a1 = s;
+    if (s == ctx->stream) HIP_TRY(ctx->side_streams(&a0, &a1));
+    const bool side = a0 != s;
+    if (side) {
+        HIP_TRY(hipEventRecord(ctx->fork, s));
+        HIP_TRY(hipStreamWaitEvent(a0, ctx->fork, 0));
+        HIP_TRY(hipStreamWaitEvent(a1, ctx->fork, 0));
+    }
     const int t_wide = 512, t_mid = 512, t_narrow = 64; /* workgroup sizes of the recursion kernel's classes (measured) */
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_wide.p, (int64_t) b->order_wide.size(), t_wide, b->max_merge_wide, s));
-    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_mid.p, (int64_t) b->order_mid.size(), t_mid, b->max_merge_mid, ctx->aux[0]));
-    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), t_narrow, b->max_merge_narrow, ctx->aux[1]));
+    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_mid.p, (int64_t) b->order_mid.size(), t_mid, b->max_merge_mid, a0));
+    HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), t_narrow, b->max_merge_narrow, a1));
     HIP_TRY(mrp_launch_sweep_f64(d, b->d_order_f64.p, (int64_t) b->order_gen.size(), 256, s));
     HIP_TRY(mrp_launch_sweep_lse(d, b->d_order_lse.p, (int64_t) b->order_lse.size(), b->max_merge_lse, s));
     HIP_TRY(mrp_launch_sweep_lse(d, b->d_order_lse_big.p, (int64_t) b->order_lse_big.size(), std::max(b->max_merge_lse_big, MRP_LSE_CUR_LDS_MAX_MERGE + 2), s));
-    HIP_TRY(hipEventRecord(ctx->join[0], ctx->aux[0]));
-    HIP_TRY(hipEventRecord(ctx->join[1], ctx->aux[1]));
-    HIP_TRY(hipStreamWaitEvent(s, ctx->join[0], 0));
-    HIP_TRY(hipStreamWaitEvent(s, ctx->join[1], 0));
+    if (side) {
+        HIP_TRY(hipEventRecord(ctx->join[0], a0));
+        HIP_TRY(hipEventRecord(ctx->join[1], a1));
+        HIP_TRY(hipStreamWaitEvent(s, ctx->join[0], 0));
+        HIP_TRY(hipStreamWaitEvent(s, ctx->join[1], 0));
+    }
     HIP_TRY(hipEventRecord(ev[2], s));
     b->n_launches++;
     b->launched = true;

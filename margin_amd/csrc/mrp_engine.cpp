@@ -130,7 +130,7 @@ static void level_retire(mrp_engine *e, mrp_engine_level_state *L) {
     mrp_context *ctx = e->ctx;
     (void) hipSetDevice(ctx->device);
     (void) ctx->wait_stream(ctx->stream); /* before the buffers go back to the pool */
-    (void) ctx->wait_stream(ctx->pre);
+    if (ctx->pre) (void) ctx->wait_stream(ctx->pre);
     if (L->b) {
         L->b->recycle();
         e->spare.push_back(L->b);
@@ -221,7 +221,7 @@ void mrp_engine_destroy(mrp_engine *e) {
     }
     (void) hipSetDevice(ctx->device);
     (void) hipStreamSynchronize(ctx->stream);
-    (void) hipStreamSynchronize(ctx->pre);
+    if (ctx->pre) (void) hipStreamSynchronize(ctx->pre);
     if (e->staged) { level_retire(e, e->staged); e->staged = nullptr; }
     if (e->running) { level_retire(e, e->running); e->running = nullptr; }
     {   /* kept for the next engine of this context */
@@ -281,7 +281,8 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     if (n == 0) return MRP_OK;
     mrp_context *ctx = e->ctx;
     ENG_TRY(hipSetDevice(ctx->device));
-    hipStream_t cs = ctx->pre; /* copy stream: nothing here depends on the kernels in flight */
+    hipStream_t cs = nullptr; /* copy stream: nothing here depends on the kernels in flight */
+    ENG_TRY(ctx->copy_stream(&cs));
     const int S = e->pp.S;
     if (e->n_segs >= mrp_engine::MAX_SEGS) return mrp_set_error(MRP_ERR_UNSUPPORTED, "more than %d levels", mrp_engine::MAX_SEGS);
     std::unique_ptr<mrp_engine_level_state> L;

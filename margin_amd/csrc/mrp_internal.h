@@ -235,10 +235,28 @@ struct DevBuf {
 struct mrp_context {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t aux[2] = {nullptr, nullptr}; /* size classes of the recursion kernel run side by side */
-    bool aux_owned = true;
+    /* Streams beyond the main one are made when first asked for: the device's hardware queues (GPU_MAX_HW_QUEUES, 16 after
+     * mrp_runtime_init) are dealt to streams in creation order, and every stream more than that shares a queue with another --
+     * whose kernels it then waits for.  A context that is one of several concurrent batches (`grouped`: the siblings of
+     * mrp_phase_reads_many, a work queue's contexts) runs its size classes on its main stream (2 streams a batch, 16 for the
+     * eight batches of a call); a context on its own runs them side by side on two more. */
+    hipStream_t aux[2] = {nullptr, nullptr};
+    bool grouped = false;
+    hipError_t side_streams(hipStream_t *a0, hipStream_t *a1) {
+        static const bool off = [] { const char *e = getenv("MRP_AUX_STREAMS"); return e && e[0] == '0'; }();
+        if (grouped || off) { *a0 = *a1 = stream; return hipSuccess; }
+        for (int i = 0; i < 2; i++)
+            if (!aux[i]) { const hipError_t e = hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking); if (e != hipSuccess) return e; }
+        *a0 = aux[0]; *a1 = aux[1];
+        return hipSuccess;
+    }
+    hipError_t copy_stream(hipStream_t *cs) { /* uploads of a staged level of the resident engine, beside the kernels of the level before */
+        if (!pre) { const hipError_t e = hipStreamCreateWithFlags(&pre, hipStreamNonBlocking); if (e != hipSuccess) return e; }
+        *cs = pre;
+        return hipSuccess;
+    }
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipStream_t pre = nullptr; /* copy stream: uploads of a staged level of the resident engine, beside the kernels of the level before */
+    hipStream_t pre = nullptr; /* copy_stream() */
     hipEvent_t last_emission = nullptr; /* end of the emission kernel of the most recent launch on this context (owned by its batch) */
     hipEvent_t fork = nullptr, join[2] = {nullptr, nullptr};
     /* Waiting for a stream without burning a core: hipStreamSynchronize polls (a batch thread of mrp_phase_reads_many spent

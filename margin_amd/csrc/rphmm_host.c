@@ -2275,7 +2275,7 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
             for (int64_t i = 0; i < q->n; i++) { q->chunks[i] = chunks[g + i * G]; q->reads[i] = reads[g + i * G]; q->n_reads[i] = n_reads[g + i * G]; }
             if (!q->ctx) { q->rc = MRP_ERR_HIP; snprintf(q->err, sizeof(q->err), "%s", mrp_last_error()); }
         }
-        /* (threads only after every sibling context exists: creating one rewires the allocator peers of the others) */
+        mrp_context_set_grouped(ctx, 1); /* (the siblings always are) */
         for (int g = 1; g < G; g++)
             if (grp[g].ctx && pthread_create(&th[g], NULL, phase_group_main, &grp[g]) == 0) started[g] = 1;
         if (grp[0].ctx) phase_group_main(&grp[0]);
@@ -2283,6 +2283,7 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
             if (started[g]) pthread_join(th[g], NULL);
             else if (grp[g].ctx) phase_group_main(&grp[g]); /* thread creation failed: run it here */
         }
+        mrp_context_set_grouped(ctx, 0);
         for (int g = 0; g < G; g++) {
             phase_group *q = &grp[g];
             if (q->rc != MRP_OK && (rc == MRP_OK || rc == MRP_ERR_UNSUPPORTED)) rc = mrp_set_error(q->rc, "%s", q->err);
