@@ -41,18 +41,18 @@ struct QueuePlan {
  * chunks_per_batch >= 1: batches of that many chunks.  0: the library's choice for n_workers pulling threads on n_devices
  * devices.  A batch is one mrp_phase_reads_many call; a call begins and ends with host work and walks its merge levels one
  * after the other, the top ones bound by per-column latency whatever the number of chunks, so large batches amortize that
- * (288 chunks in one call take 140 ms, in four calls on two lanes 225 ms).  A short queue is therefore ONE batch per device
- * (its upload overlaps the host's setup of the same call), a somewhat longer one is one batch per lane; a long one is handed
- * out in batches of MRP_QUEUE_DEFAULT_BATCH chunks that shrink towards the end ("guided" schedule: remaining / workers, at
- * least 48), so that the devices finish within two percent of each other (tests/test_work_queue.py: 8 devices, 31 000
- * chunks) without the tail of the queue dissolving into small, latency-bound calls. */
+ * (576 chunks in one call take 170-182 ms, in two calls on two lanes 218 ms).  A short queue is therefore ONE batch per device
+ * (its upload overlaps the host's setup of the same call); a long one is handed out in batches of MRP_QUEUE_DEFAULT_BATCH chunks
+ * that shrink towards the end ("guided" schedule: remaining / workers, at least 96), so that the devices finish within two
+ * percent of each other (tests/test_work_queue.py: 8 devices, 31 000 chunks) without the tail of the queue dissolving into
+ * small, latency-bound calls. */
 QueuePlan plan_queue(int64_t n, const int64_t *cost, int64_t chunks_per_batch, int n_workers = 1, int n_devices = 1) {
     QueuePlan p;
     p.order.resize((size_t) n);
     std::iota(p.order.begin(), p.order.end(), (int64_t) 0);
     std::stable_sort(p.order.begin(), p.order.end(), [&](int64_t a, int64_t b) { return cost[a] > cost[b]; });
-    /* one call takes up to ~640 chunks of the 1 Mb kind in its eight concurrent groups (768 still fit the 288 GB of an MI355X,
-     * 1 152 do not): below that ONE batch per device is the fastest (576 chunks: 186 ms in one call, 218 ms as two calls on two lanes) */
+    /* one call is at its best rate with some 576 chunks of the 1 Mb kind in its eight concurrent batches (640: 198 ms, 768:
+     * 243 ms): up to 640 chunks per device ONE batch per device is the fastest */
     const int64_t big = MRP_QUEUE_DEFAULT_BATCH, short_queue = 640;
     const int lanes = std::max(1, n_workers / std::max(1, n_devices));
     if (chunks_per_batch >= 1) {
@@ -71,10 +71,10 @@ QueuePlan plan_queue(int64_t n, const int64_t *cost, int64_t chunks_per_batch, i
         }
         p.order.swap(striped);
     } else {
-        for (int64_t o = 0; o < n;) { /* full batches while every worker can still get one, then shrinking, at least 48 chunks */
+        for (int64_t o = 0; o < n;) { /* full batches while every worker can still get one, then shrinking, at least 96 chunks */
             p.batch_off.push_back(o);
             const int64_t left = n - o;
-            o += std::max<int64_t>(48, std::min<int64_t>(big, left / (int64_t) std::max(1, n_workers)));
+            o += std::max<int64_t>(96, std::min<int64_t>(big, left / (int64_t) std::max(1, n_workers)));
         }
     }
     p.batch_off.push_back(n);
@@ -150,10 +150,12 @@ struct mrp_queue {
     std::vector<mrp_host_pool *> pools;        /* [device] */
     std::vector<mrp_chunk_block *> blocks;     /* [(device * lanes + lane) * 2 + parity] storage of a lane's current / next batch */
     int threads_per_device = 0;
-    /* Two batches of a device are in flight at a time (two "lanes", each a host thread with its own contexts): a call of
-     * mrp_phase_reads_many begins and ends with host work and latency-bound levels that leave the device half empty;
-     * the other lane's call fills it.  MRP_QUEUE_LANES=1..4 overrides. */
-    int lanes = 2;
+    /* Batches of a device in flight at a time ("lanes", each a host thread with its own contexts).  One: a call of
+     * mrp_phase_reads_many already runs eight concurrent batches on 16 streams, one per hardware queue of the device; a second
+     * lane's streams would share those queues, and the kernels of a stream wait for those of the stream it shares a queue
+     * with (measured: two lanes of 288 chunks 218 ms, one call of 576 chunks 182 ms).  The next batch's upload runs beside
+     * the current call either way.  MRP_QUEUE_LANES=1..4 overrides. */
+    int lanes = 1;
 };
 
 int mrp_queue_create(const int32_t *devices, int32_t n_devices, mrp_queue **out) {

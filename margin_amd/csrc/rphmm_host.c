@@ -2247,10 +2247,10 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
     /* the levels of a batch alternate host work (structure, descriptors) and device work; two interleaved halves of the
      * chunks, each with its own context and host thread, keep both busy */
     int G = mrp_context_phase_groups(ctx); /* mrp_context_set_phase_groups; 0 (default): by batch size */
-    /* measured on MI355X (tools/pipeline_probe.py): 2 groups at 48 chunks, 4 from 96 to 288 (6 or 8 are slower there: a group
-     * needs some 64 chunks to keep its share of the device busy), 8 from 512 on (384 chunks: 146-161 ms with 8 groups against
-     * 167-169 with 4; 576: 204-219 against 229-245) */
-    if (G <= 0) G = n_chunks < 320 ? (int) (n_chunks / 24 > 4 ? 4 : n_chunks / 24) : (int) (n_chunks / 64);
+    /* measured on MI355X (bench.py --chunks N --phase-groups G, two streams a batch): 48 chunks 45.3 ms with 2 batches, 42.5
+     * with 4; 96: 52.3 with 4, 54.8 with 8; 144: 66.4 / 68.0; 192: 80.2 / 78.6; 288: 104.5 / 96.9; 432: 139.9 with 6, 130.5
+     * with 8; 576 with 8: 169.5 (2.04e8 units/s, the best rate; 768: 243 ms).  More than 8 would share hardware queues. */
+    if (G <= 0) G = n_chunks < 192 ? (int) (n_chunks / 12 > 4 ? 4 : n_chunks / 12) : 8;
     if (G < 1) G = 1;
     if (G > 8) G = 8;
     if (n_chunks < 4 * G) G = 1;
