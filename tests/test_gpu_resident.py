@@ -1,5 +1,7 @@
 """GPU parity of the device-resident merge (cross product -> sweep -> prune without leaving HBM,
 SURVEY.md 8 f-1) against the oracle and against the hashing host path."""
+import os
+
 import numpy as np
 import pytest
 
@@ -494,3 +496,48 @@ def test_one_pass_cross_emission_equals_the_two_kernel_path_and_the_oracle(gpu_c
         _assert_equals_oracle(orc, chunk, b, pd)
     for d in dchunks:
         d.close()
+
+
+def test_device_memory_budget_gives_cached_blocks_back_without_changing_results(gpu_ctx, orc):
+    """The device pools of a process share one budget per device (mrp_internal.h DevPoolRegistry; MRP_POOL_BUDGET_MB, read once
+    per process, hence a child process): with a budget (64 MB) below what even the live arrays of the call need, every
+    reclaim gives blocks back to the driver and the next level allocates afresh -- results must not move, across repeated calls
+    with different chunk subsets (best-fit reuse of blocks of other sizes) and through the work queue."""
+    import json, subprocess, sys
+    code = r'''
+import json, sys
+import numpy as np
+from margin_amd import capi, synth
+pd = synth.shipped_phase_params()
+params = capi.Params.from_reference_names(pd)
+chunks = [synth.make_ont_chunk(seed=700 + s, region_bp=100_000, n_sites=int(90 + 7 * s), coverage=20.0 + s) for s in range(24)]
+def key(r):
+    return [[int(x) for x in np.asarray(r[k]).tolist()] for k in ("hap1", "hap2", "genotype", "support1", "support2")] + [r["reads1"], r["reads2"]]
+ctx = capi.Context(0)
+ctx.set_phase_groups(4)
+dch = [capi.DeviceChunk.from_chunk(ctx, c) for c in chunks]
+out = []
+for lo, hi in ((0, 24), (3, 19), (0, 24)):
+    res, st = capi.phase_reads_many(ctx, dch[lo:hi], chunks[lo:hi], params)
+    assert st.resident == 1
+    out.append([key(r) for r in res])
+assert out[0] == out[2] and out[0][3:19] == out[1]
+q = capi.Queue([0])
+qres, _ = q.phase(chunks, params, chunks_per_batch=0)
+q.close()
+assert [key(r) for r in qres] == out[0]
+print(json.dumps(out[0][:4]))
+'''
+    env = dict(os.environ, MRP_POOL_BUDGET_MB="64", MRP_QUIET="1")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    small_budget = json.loads(r.stdout.strip().splitlines()[-1])
+    pd = _params()
+    for s in range(4):
+        c = synth.make_ont_chunk(seed=700 + s, region_bp=100_000, n_sites=int(90 + 7 * s), coverage=20.0 + s)
+        oc = orc.OracleChunk(c)
+        ref = oc.phase(pd)
+        oc.close()
+        assert small_budget[s] == [[int(x) for x in np.asarray(ref[k]).tolist()] for k in ("hap1", "hap2", "genotype", "support1", "support2")] + [ref["reads1"], ref["reads2"]]

@@ -18,11 +18,11 @@ done
 python3 $R/tools/r02_summary.py traffic $O/t_FETCH_SIZE $O/t_WRITE_SIZE 96 $O/traffic.json profiles/r03 $R/margin_amd/csrc/mrp_kernels.hip > /dev/null
 timeout -k 10 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU --output-format csv -d $O/t_sq -o t -- $BENCH --steps 1 --warmup 0 --roofline-steps 4 > $O/bench_sq.json 2> $O/bench_sq.err || exit 1
 python3 $R/tools/r02_summary.py pmc $O/t_sq > $O/pmc_sq.txt
-# 4. the levels of the resident pipeline: one batch (per-dispatch listing), four concurrent batches (device occupancy)
+# 4. the levels of the resident pipeline: one batch (per-dispatch listing), eight concurrent batches (device occupancy)
 MRP_PHASE_GROUPS=1 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/t_lv -o t -- python3 $R/tools/pipeline_probe.py --chunks 96 --repeat 3 --check-host 0 > $O/probe_96_g1.log 2>&1 || exit 1
 python3 $R/tools/trace_levels.py $O/t_lv > $O/pipeline_levels_96chunks_1batch.txt
-MRP_PHASE_GROUPS=4 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/t_g4 -o t -- python3 $R/tools/pipeline_probe.py --chunks 288 --repeat 3 --check-host 0 > $O/probe_288_g4.log 2>&1 || exit 1
-python3 $R/tools/trace_busy.py $O/t_g4 4 > $O/pipeline_busy_288chunks_4batches.txt
+timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/t_g4 -o t -- python3 $R/tools/pipeline_probe.py --chunks 288 --repeat 3 --check-host 0 > $O/probe_288_g8.log 2>&1 || exit 1
+python3 $R/tools/trace_busy.py $O/t_g4 8 > $O/pipeline_busy_288chunks_8batches.txt
 timeout -k 10 300 rocprofv3 --kernel-trace --output-format csv -d $O/t_g8 -o t -- python3 $R/tools/pipeline_probe.py --chunks 576 --repeat 3 --check-host 0 > $O/probe_576_g8.log 2>&1 || exit 1
 python3 $R/tools/trace_busy.py $O/t_g8 8 > $O/pipeline_busy_576chunks_8batches.txt
 # 5. host threads: the same 288-chunk call with 16 and with 4 threads in the library's pool (wall, process CPU time)
@@ -32,7 +32,10 @@ done
 for t in 16 8 4; do
   ( cd $R && MRP_HOST_THREADS=$t timeout -k 10 300 python3 tools/pipeline_probe.py --chunks 576 --repeat 5 --check-host 0 > $O/probe_576_t$t.log 2>&1 ) || exit 1
 done
-( cd $O && grep -H "^run" probe_96_g1.log probe_288_g4.log probe_576_g8.log probe_288_t16.log probe_288_t4.log probe_576_t16.log probe_576_t8.log probe_576_t4.log > probe_runs.txt )
+( cd $O && grep -H "^run" probe_96_g1.log probe_288_g8.log probe_576_g8.log probe_288_t16.log probe_288_t4.log probe_576_t16.log probe_576_t8.log probe_576_t4.log > probe_runs.txt )
+# 5b. the work queue from host memory: one batch (576 chunks) beside the resident call, and a queue of three batches
+( cd $R && timeout -k 10 600 python3 tools/queue_probe.py --runs 4 2>&1 | grep " ms" > $O/queue_probe.txt ) || exit 1
+( cd $R && timeout -k 10 600 python3 tools/queue_long.py 2>&1 | grep "queue:\|resident:" > $O/queue_long.txt ) || exit 1
 # 6. what linking the adaptor alone gives (the seam per hmm / per merge call, beside the oracle and the whole-chunk path)
 ( cd $R && timeout -k 10 600 python3 tools/adaptor_probe.py --chunks 8 --threads 8 > $O/adaptor_probe.txt 2>&1 ) || exit 1
 rm -rf $O/t_stats $O/t_FETCH_SIZE $O/t_WRITE_SIZE $O/t_sq $O/t_lv $O/t_g4 $O/t_g8
