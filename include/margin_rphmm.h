@@ -320,7 +320,7 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
  * off).  Chunks are independent until stitching: no collective, no traffic between devices.  A device may be listed more
  * than once (two workers sharing it). */
 #define MRP_MAX_QUEUE_DEVICES 16
-#define MRP_QUEUE_DEFAULT_BATCH 576 /* chunks per batch when the caller passes 0 (one batch per device when the queue is short, smaller ones at its end) */
+#define MRP_QUEUE_DEFAULT_BATCH 192 /* chunks per batch when the caller passes 0 and the queue is longer than 640 chunks per device (a shorter one is one batch per device; smaller batches at the end) */
 typedef struct mrp_chunk_desc {     /* one genome chunk in host memory: what mrp_chunk_create and mrp_phase_reads take */
     int64_t n_sites;
     const uint32_t *allele_number;

@@ -58,7 +58,7 @@ void mrp_chunk_host_view(const mrp_chunk *chunk, mrp_chunk_host *out) {
 }
 mrp_context *mrp_chunk_context(const mrp_chunk *chunk) { return chunk->ctx; }
 int mrp_context_device(const mrp_context *ctx) { return ctx->device; }
-void mrp_context_set_grouped(mrp_context *ctx, int grouped) { ctx->grouped = grouped != 0; }
+int mrp_context_set_grouped(mrp_context *ctx, int grouped) { const int was = ctx->grouped ? 1 : 0; ctx->grouped = grouped != 0; return was; }
 void mrp_context_pool_bytes(mrp_context *ctx, int64_t *cached, int64_t *device_held) {
     { std::lock_guard<std::mutex> lock(ctx->pool.mu); *cached = (int64_t) ctx->pool.cached_bytes; }
     *device_held = ctx->pool.device >= 0 ? (int64_t) DevPoolRegistry::get().held[ctx->pool.device].load() : 0;
@@ -756,7 +756,7 @@ int mrp_set_host_threads(int n) {
     return MRP_OK;
 }
 int mrp_context_set_phase_groups(mrp_context *ctx, int groups) {
-    if (!ctx || groups < 0 || groups > 8) return fail(MRP_ERR_ARG, "mrp_context_set_phase_groups: bad arguments");
+    if (!ctx || groups < 0 || groups > 16) return fail(MRP_ERR_ARG, "mrp_context_set_phase_groups: bad arguments");
     ctx->phase_groups = groups;
     return MRP_OK;
 }
@@ -994,7 +994,8 @@ int mrp_batch_launch(mrp_batch *b) {
         HIP_TRY(hipStreamWaitEvent(a0, ctx->fork, 0));
         HIP_TRY(hipStreamWaitEvent(a1, ctx->fork, 0));
     }
-    const int t_wide = 512, t_mid = 512, t_narrow = 64; /* workgroup sizes of the recursion kernel's classes (measured) */
+    static const int t_mid_env = getenv("MRP_SWEEP_T_MID") ? atoi(getenv("MRP_SWEEP_T_MID")) : 0, t_wide_env = getenv("MRP_SWEEP_T_WIDE") ? atoi(getenv("MRP_SWEEP_T_WIDE")) : 0; /* (development) */
+    const int t_wide = t_wide_env ? t_wide_env : 512, t_mid = t_mid_env ? t_mid_env : 512, t_narrow = 64; /* workgroup sizes of the recursion kernel's classes (measured) */
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_wide.p, (int64_t) b->order_wide.size(), t_wide, b->max_merge_wide, s));
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_mid.p, (int64_t) b->order_mid.size(), t_mid, b->max_merge_mid, a0));
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), t_narrow, b->max_merge_narrow, a1));

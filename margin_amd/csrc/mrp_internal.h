@@ -91,8 +91,11 @@ struct DevPool {
     std::multimap<size_t, void *> free_blocks;
     std::vector<std::pair<size_t, void *>> pending;
     size_t cached_bytes = 0;                 /* bytes in free_blocks */
-    size_t cache_limit = (size_t) 24 << 30;  /* beyond this the largest cached blocks go back to the driver (a call runs up to
-                                              * eight concurrent batches, each with a pool of its own: 8 x 24 GB of 288) */
+    size_t cache_limit = (size_t) 64 << 30;  /* beyond this the largest cached blocks go back to the driver; what really bounds the
+                                              * caches is the device's budget (registry): a batch of a call keeps some 170 MB
+                                              * per 1 Mb chunk of its widest level for reuse (576 chunks in eight batches: 107 GB
+                                              * held, 96 of them idle between calls); a limit of 24 GB per pool made every call
+                                              * with more than ~100 chunks per batch give back and re-allocate (4x slower) */
     int device = -1;                         /* attach(): the device whose registry entry this pool is */
     void attach(int dev) {
         device = dev >= 0 && dev < DevPoolRegistry::MAX_DEVICES ? dev : -1;
@@ -251,6 +254,8 @@ struct mrp_context {
         return hipSuccess;
     }
     hipError_t copy_stream(hipStream_t *cs) { /* uploads of a staged level of the resident engine, beside the kernels of the level before */
+        static const bool off = [] { const char *e = getenv("MRP_COPY_STREAM"); return e && e[0] == '0'; }(); /* (development) */
+        if (off) { *cs = stream; return hipSuccess; }
         if (!pre) { const hipError_t e = hipStreamCreateWithFlags(&pre, hipStreamNonBlocking); if (e != hipSuccess) return e; }
         *cs = pre;
         return hipSuccess;

@@ -40,26 +40,25 @@ struct QueuePlan {
 /* phase.c:257-263: sort by estimated size, largest first; then cut into batches of consecutive chunks.
  * chunks_per_batch >= 1: batches of that many chunks.  0: the library's choice for n_workers pulling threads on n_devices
  * devices.  A batch is one mrp_phase_reads_many call; a call begins and ends with host work and walks its merge levels one
- * after the other, the top ones bound by per-column latency whatever the number of chunks, so large batches amortize that
- * (576 chunks in one call take 170-182 ms, in two calls on two lanes 218 ms).  A short queue is therefore ONE batch per device
- * (its upload overlaps the host's setup of the same call); a long one is handed out in batches of MRP_QUEUE_DEFAULT_BATCH chunks
- * that shrink towards the end ("guided" schedule: remaining / workers, at least 96), so that the devices finish within two
- * percent of each other (tests/test_work_queue.py: 8 devices, 31 000 chunks) without the tail of the queue dissolving into
- * small, latency-bound calls. */
+ * after the other, the top ones bound by per-column latency whatever the number of chunks.  A short queue (up to 640 chunks
+ * per device) is ONE batch per device: the call runs it as eight concurrent batches of its own (576 chunks: 170-182 ms).  A
+ * longer one is handed out in batches of MRP_QUEUE_DEFAULT_BATCH chunks to the lanes of the devices (four per device, each
+ * call two concurrent batches: the same eight in flight, but at different levels -- while one lane is in its host-bound
+ * head or its latency-bound top levels the others stream; measured on 2 304 chunks: 153-160 ms per 576 against 174-177 for
+ * one lane of 576-chunk calls), shrinking towards the end (several devices: "guided" schedule, remaining / workers, at least 96) so that the
+ * devices finish within two percent of each other (tests/test_work_queue.py: 8 devices, 31 000 chunks) without the tail of
+ * the queue dissolving into small, latency-bound calls. */
 QueuePlan plan_queue(int64_t n, const int64_t *cost, int64_t chunks_per_batch, int n_workers = 1, int n_devices = 1) {
     QueuePlan p;
     p.order.resize((size_t) n);
     std::iota(p.order.begin(), p.order.end(), (int64_t) 0);
     std::stable_sort(p.order.begin(), p.order.end(), [&](int64_t a, int64_t b) { return cost[a] > cost[b]; });
-    /* one call is at its best rate with some 576 chunks of the 1 Mb kind in its eight concurrent batches (640: 198 ms, 768:
-     * 243 ms): up to 640 chunks per device ONE batch per device is the fastest */
+    /* up to 640 chunks per device ONE call per device is the fastest */
     const int64_t big = MRP_QUEUE_DEFAULT_BATCH, short_queue = 640;
-    const int lanes = std::max(1, n_workers / std::max(1, n_devices));
     if (chunks_per_batch >= 1) {
         for (int64_t o = 0; o < n; o += chunks_per_batch) p.batch_off.push_back(o);
-    } else if (n <= (int64_t) n_devices * short_queue * lanes) {
-        /* at most one batch per lane: one per device while that stays below ~640 chunks, else one per lane */
-        const int64_t parts = std::min<int64_t>(n, n <= (int64_t) n_devices * short_queue ? n_devices : (int64_t) n_devices * lanes);
+    } else if (n <= (int64_t) n_devices * short_queue) {
+        const int64_t parts = std::min<int64_t>(n, n_devices);
         /* these batches all start at once: deal the chunks out in stripes (batch b takes the b-th, (b + parts)-th, ... of the
          * cost order), so that every batch gets its share of the expensive ones -- consecutive runs of a largest-first order
          * would make the first batch the slowest by a third */
@@ -74,7 +73,8 @@ QueuePlan plan_queue(int64_t n, const int64_t *cost, int64_t chunks_per_batch, i
         for (int64_t o = 0; o < n;) { /* full batches while every worker can still get one, then shrinking, at least 96 chunks */
             p.batch_off.push_back(o);
             const int64_t left = n - o;
-            o += std::max<int64_t>(96, std::min<int64_t>(big, left / (int64_t) std::max(1, n_workers)));
+            /* (one device: nothing to even out between its lanes, which share it -- full batches to the end) */
+            o += n_devices > 1 ? std::max<int64_t>(96, std::min<int64_t>(big, left / (int64_t) std::max(1, n_workers))) : std::min<int64_t>(big, left);
         }
     }
     p.batch_off.push_back(n);
@@ -122,7 +122,7 @@ int mrp_queue_plan(int64_t n_chunks, const int64_t *cost, int64_t chunks_per_bat
 
 int mrp_queue_dry_run(int32_t n_workers, int64_t n_chunks, const int64_t *cost, int64_t chunks_per_batch, double usec_per_cost,
                       int32_t *worker_of_chunk_out, int64_t *sequence_out) {
-    if (n_workers < 1 || n_workers > MRP_MAX_QUEUE_DEVICES || n_chunks < 0 || (n_chunks > 0 && (!cost || !worker_of_chunk_out)))
+    if (n_workers < 1 || n_workers > 4 * MRP_MAX_QUEUE_DEVICES || n_chunks < 0 || (n_chunks > 0 && (!cost || !worker_of_chunk_out))) /* (workers = devices x lanes) */
         return mrp_set_error(MRP_ERR_ARG, "mrp_queue_dry_run: bad arguments");
     const QueuePlan p = plan_queue(n_chunks, cost, chunks_per_batch, n_workers, n_workers);
     std::atomic<int64_t> seq{0};
@@ -150,12 +150,9 @@ struct mrp_queue {
     std::vector<mrp_host_pool *> pools;        /* [device] */
     std::vector<mrp_chunk_block *> blocks;     /* [(device * lanes + lane) * 2 + parity] storage of a lane's current / next batch */
     int threads_per_device = 0;
-    /* Batches of a device in flight at a time ("lanes", each a host thread with its own contexts).  One: a call of
-     * mrp_phase_reads_many already runs eight concurrent batches on 16 streams, one per hardware queue of the device; a second
-     * lane's streams would share those queues, and the kernels of a stream wait for those of the stream it shares a queue
-     * with (measured: two lanes of 288 chunks 218 ms, one call of 576 chunks 182 ms).  The next batch's upload runs beside
-     * the current call either way.  MRP_QUEUE_LANES=1..4 overrides. */
-    int lanes = 1;
+    /* Calls of a device in flight at a time ("lanes", each a host thread with its own contexts); see plan_queue.  A short
+     * queue uses one of them.  MRP_QUEUE_LANES=1..4 overrides. */
+    int lanes = 4;
 };
 
 int mrp_queue_create(const int32_t *devices, int32_t n_devices, mrp_queue **out) {
@@ -253,6 +250,11 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
     std::mutex pool_mu;
     std::atomic<int64_t> next{0};
     std::atomic<int> status{MRP_OK};
+    /* a device holds what its calls in flight need (some 170 MB per 1 Mb chunk, DevPool): four lanes for batches of up to 288
+     * chunks, two up to 576, one beyond */
+    int64_t max_batch = 0;
+    for (int64_t b = 0; b < n_batches; b++) max_batch = std::max(max_batch, plan.batch_off[(size_t) b + 1] - plan.batch_off[(size_t) b]);
+    const int active_lanes = n_batches <= (int64_t) n_devices ? 1 : (max_batch <= 288 ? lanes : (max_batch <= 576 ? std::min(lanes, 2) : 1));
     const char *aff_env = getenv("MRP_QUEUE_AFFINITY");
     const bool bind = n_devices > 1 && !(aff_env && aff_env[0] == '0');
 
@@ -293,6 +295,9 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
             cpu_set_t set;
             if (device_cpuset(devices[d], &set)) (void) pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
         }
+        if (w % lanes >= active_lanes) return; /* (large caller-chosen batches: fewer calls of a device in flight) */
+        const int64_t first_batch = next.fetch_add(1);
+        if (first_batch >= n_batches) return; /* nothing for this lane: no contexts, no streams */
         int r = MRP_OK;
         if (!q->ctx[(size_t) w]) r = mrp_context_create(devices[d], &q->ctx[(size_t) w]);
         if (r == MRP_OK && !q->stage_ctx[(size_t) w]) r = mrp_context_create(devices[d], &q->stage_ctx[(size_t) w]);
@@ -304,14 +309,14 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
             }
         }
         if (r != MRP_OK) { fail(r, mrp_last_error()); return; }
+        if (lanes > 1) (void) mrp_context_set_grouped(q->ctx[(size_t) w], 1); /* the lanes of a device are concurrent batches of it */
         mrp_pool_adopt(q->pools[(size_t) d]);
         Staged cur;
         int parity = 0;
-        {
-            const int64_t b = next.fetch_add(1);
-            if (b >= n_batches) { mrp_pool_adopt(nullptr); return; }
-            stage(w, b, parity, &cur);
-        }
+        /* the lanes of a device share it: a call of a long queue runs 8 / lanes concurrent batches, the one call of a short
+         * queue as many as its size asks for */
+        (void) mrp_context_set_phase_groups(q->ctx[(size_t) w], n_batches > (int64_t) n_devices ? std::max(1, 8 / active_lanes) : 0);
+        stage(w, first_batch, parity, &cur);
         while (cur.batch >= 0) {
             if (cur.rc != MRP_OK) { fail(cur.rc, cur.err); drop(&cur); break; }
             if (status.load() != MRP_OK) { drop(&cur); break; }

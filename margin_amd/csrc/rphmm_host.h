@@ -29,7 +29,7 @@ void mrp_chunk_host_view(const mrp_chunk *chunk, mrp_chunk_host *out);
 mrp_context *mrp_chunk_context(const mrp_chunk *chunk);
 int mrp_context_device(const mrp_context *ctx);
 /* the context is one of several concurrent batches of its device: no side streams (mrp_internal.h) */
-void mrp_context_set_grouped(mrp_context *ctx, int grouped);
+int mrp_context_set_grouped(mrp_context *ctx, int grouped); /* returns the previous setting */
 /* device memory of the context's pool: bytes cached for reuse, and what all pools of its device hold together (live + cached) */
 void mrp_context_pool_bytes(mrp_context *ctx, int64_t *cached, int64_t *device_held);
 /* a further context (stream, allocator cache) on the same device, owned by ctx and destroyed with it; i = 0, 1, ... */

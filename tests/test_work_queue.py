@@ -43,8 +43,8 @@ def test_queue_dry_run_is_complete_ordered_and_dynamic(n_workers, per_batch):
 
 
 def test_whole_genome_queue_on_eight_devices_is_balanced():
-    """BASELINE.json configs[3]: ~31 000 chunks of ~100 kb over the 8 devices of a node, one pulling thread
-    each.  With the library's own batch sizes (chunks_per_batch = 0: 576 chunks per batch, shrinking towards the end
+    """BASELINE.json configs[3]: ~31 000 chunks of ~100 kb over the 8 devices of a node, four lanes each = 32
+    pulling threads.  With the library's own batch sizes (chunks_per_batch = 0: 192 chunks per batch, shrinking towards the end
     of the queue) every chunk is taken once and no device carries more than 2 % above the mean of the estimated cost
     (het-sites x reads) -- the stand-in workers sleep in proportion to it, so the hand-out is the dynamic one of a real run."""
     rng = np.random.default_rng(31_000)
@@ -52,7 +52,7 @@ def test_whole_genome_queue_on_eight_devices_is_balanced():
     sites = np.clip(rng.normal(130, 25, size=n), 20, 400)          # het sites per chunk
     depth = np.clip(rng.normal(30, 6, size=n), 5, 64)              # coverage varies along the genome
     cost = (sites * depth * 2.0).astype(np.int64)                  # reads x het sites each spans (~2 x depth x sites / ...): units
-    lanes, devices = 1, 8
+    lanes, devices = 4, 8
     usec = 2.0e5 * devices * lanes / float(cost.sum())             # about 0.2 s of stand-in work per pulling thread
     worker, seq = capi.queue_dry_run(devices * lanes, cost, 0, usec_per_cost=usec)
     assert sorted(seq.tolist()) == list(range(n))
@@ -63,7 +63,7 @@ def test_whole_genome_queue_on_eight_devices_is_balanced():
     # the batches follow the queue's order, full-sized first
     order, batch = capi.queue_plan(cost, 0)
     sizes = np.bincount(batch)
-    assert sizes.max() <= 576 and sizes[0] == 576 and sizes.min() >= 96 and (np.diff(sizes[:-1]) <= 0).all()
+    assert sizes.max() <= 192 and sizes[0] == 192 and sizes[:-1].min() >= 96 and (np.diff(sizes[:-1]) <= 0).all()
 
 
 def test_queue_rejects_bad_arguments():
@@ -71,7 +71,7 @@ def test_queue_rejects_bad_arguments():
     cost = np.ones(4, dtype=np.int64)
     w = np.zeros(4, dtype=np.int32)
     assert L.mrp_queue_dry_run(0, 4, cost.ctypes.data, 1, 0.0, w.ctypes.data, None) == capi.MRP_ERR_ARG
-    assert L.mrp_queue_dry_run(capi.MAX_QUEUE_DEVICES + 1, 4, cost.ctypes.data, 1, 0.0, w.ctypes.data, None) == capi.MRP_ERR_ARG
+    assert L.mrp_queue_dry_run(4 * capi.MAX_QUEUE_DEVICES + 1, 4, cost.ctypes.data, 1, 0.0, w.ctypes.data, None) == capi.MRP_ERR_ARG
     # without a device the real queue fails loudly: no CPU fallback
     if L.mrp_device_count() == 0:
         import ctypes as C
