@@ -59,6 +59,11 @@ void mrp_chunk_host_view(const mrp_chunk *chunk, mrp_chunk_host *out) {
 mrp_context *mrp_chunk_context(const mrp_chunk *chunk) { return chunk->ctx; }
 int mrp_context_device(const mrp_context *ctx) { return ctx->device; }
 int mrp_context_set_grouped(mrp_context *ctx, int grouped) { const int was = ctx->grouped ? 1 : 0; ctx->grouped = grouped != 0; return was; }
+int64_t mrp_context_device_budget(mrp_context *ctx) { /* bytes the pools of the context's device may hold together */
+    if (ctx->pool.device < 0 || hipSetDevice(ctx->device) != hipSuccess) return 0;
+    const size_t b = DevPoolRegistry::get().budget_of(ctx->pool.device);
+    return b > (size_t) 1 << 62 ? 0 : (int64_t) b;
+}
 void mrp_context_pool_bytes(mrp_context *ctx, int64_t *cached, int64_t *device_held) {
     { std::lock_guard<std::mutex> lock(ctx->pool.mu); *cached = (int64_t) ctx->pool.cached_bytes; }
     *device_held = ctx->pool.device >= 0 ? (int64_t) DevPoolRegistry::get().held[ctx->pool.device].load() : 0;

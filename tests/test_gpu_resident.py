@@ -498,11 +498,13 @@ def test_one_pass_cross_emission_equals_the_two_kernel_path_and_the_oracle(gpu_c
         d.close()
 
 
-def test_device_memory_budget_gives_cached_blocks_back_without_changing_results(gpu_ctx, orc):
+@pytest.mark.parametrize("knob", [{"MRP_POOL_BUDGET_MB": "64"}, {"MRP_CALL_UNITS": "40000"}], ids=["pool_budget_64MB", "call_sliced_at_40000_units"])
+def test_device_memory_budget_gives_cached_blocks_back_without_changing_results(gpu_ctx, orc, knob):
     """The device pools of a process share one budget per device (mrp_internal.h DevPoolRegistry; MRP_POOL_BUDGET_MB, read once
     per process, hence a child process): with a budget (64 MB) below what even the live arrays of the call need, every
     reclaim gives blocks back to the driver and the next level allocates afresh -- results must not move, across repeated calls
-    with different chunk subsets (best-fit reuse of blocks of other sizes) and through the work queue."""
+    with different chunk subsets (best-fit reuse of blocks of other sizes) and through the work queue.  Second knob: a call whose
+    (read, site) units exceed what the device's budget holds runs as consecutive slices (MRP_CALL_UNITS: here ~8 slices)."""
     import json, subprocess, sys
     code = r'''
 import json, sys
@@ -528,7 +530,7 @@ q.close()
 assert [key(r) for r in qres] == out[0]
 print(json.dumps(out[0][:4]))
 '''
-    env = dict(os.environ, MRP_POOL_BUDGET_MB="64", MRP_QUIET="1")
+    env = dict(os.environ, MRP_QUIET="1", **knob)
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=env, cwd=root)
