@@ -111,6 +111,13 @@ def test_two_workers_on_one_device_phase_every_chunk(orc):
         assert st2.batches == 2
         for a, b in zip(got, again):
             assert (np.asarray(a["hap1"]) == np.asarray(b["hap1"])).all() and a["reads1"] == b["reads1"]
+        # more batches than pulling threads (two devices x four lanes): every lane stages its next batch beside the current call
+        twice = chunks + chunks
+        many, st3 = q.phase(twice, params, chunks_per_batch=1)
+        assert st3.batches == len(twice) and sum(st3.chunks_per_device[:2]) == len(twice)
+        for a, b in zip(got + got, many):
+            assert (np.asarray(a["hap1"]) == np.asarray(b["hap1"])).all() and (np.asarray(a["hap2"]) == np.asarray(b["hap2"])).all()
+            assert a["reads1"] == b["reads1"] and a["reads2"] == b["reads2"]
     finally:
         q.close()
     # the one-shot form, one worker

@@ -32,10 +32,11 @@ done
 for t in 16 8 4; do
   ( cd $R && MRP_HOST_THREADS=$t timeout -k 10 300 python3 tools/pipeline_probe.py --chunks 576 --repeat 5 --check-host 0 > $O/probe_576_t$t.log 2>&1 ) || exit 1
 done
-( cd $O && grep -H "^run" probe_96_g1.log probe_288_g8.log probe_576_g8.log probe_288_t16.log probe_288_t4.log probe_576_t16.log probe_576_t8.log probe_576_t4.log > probe_runs.txt )
-# 5b. the work queue from host memory: one batch (576 chunks) beside the resident call, and a queue of three batches
+( cd $R && timeout -k 10 300 python3 tools/pipeline_probe.py --chunks 1152 --repeat 4 --check-host 0 > $O/probe_1152_t16.log 2>&1 ) || exit 1
+( cd $O && grep -H "^run" probe_96_g1.log probe_288_g8.log probe_576_g8.log probe_288_t16.log probe_288_t4.log probe_576_t16.log probe_576_t8.log probe_576_t4.log probe_1152_t16.log > probe_runs.txt )
+# 5b. the work queue from host memory: one batch (576 chunks) beside the resident call, and a queue of twelve batches (2 304 chunks)
 ( cd $R && timeout -k 10 600 python3 tools/queue_probe.py --runs 4 2>&1 | grep " ms" > $O/queue_probe.txt ) || exit 1
-( cd $R && timeout -k 10 600 python3 tools/queue_long.py 2>&1 | grep "queue:\|resident:" > $O/queue_long.txt ) || exit 1
+( cd $R && timeout -k 10 600 python3 tools/queue_long.py --chunks 2304 2>&1 | grep "queue:\|resident:" > $O/queue_long.txt ) || exit 1
 # 6. what linking the adaptor alone gives (the seam per hmm / per merge call, beside the oracle and the whole-chunk path)
 ( cd $R && timeout -k 10 600 python3 tools/adaptor_probe.py --chunks 8 --threads 8 > $O/adaptor_probe.txt 2>&1 ) || exit 1
 rm -rf $O/t_stats $O/t_FETCH_SIZE $O/t_WRITE_SIZE $O/t_sq $O/t_lv $O/t_g4 $O/t_g8
