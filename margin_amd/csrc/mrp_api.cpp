@@ -999,8 +999,8 @@ int mrp_batch_launch(mrp_batch *b) {
         HIP_TRY(hipStreamWaitEvent(a0, ctx->fork, 0));
         HIP_TRY(hipStreamWaitEvent(a1, ctx->fork, 0));
     }
-    static const int t_mid_env = getenv("MRP_SWEEP_T_MID") ? atoi(getenv("MRP_SWEEP_T_MID")) : 0, t_wide_env = getenv("MRP_SWEEP_T_WIDE") ? atoi(getenv("MRP_SWEEP_T_WIDE")) : 0; /* (development) */
-    const int t_wide = t_wide_env ? t_wide_env : 512, t_mid = t_mid_env ? t_mid_env : 512, t_narrow = 64; /* workgroup sizes of the recursion kernel's classes (measured) */
+    const int t_wide = 512, t_mid = 512, t_narrow = 64; /* workgroup sizes of the recursion kernel's classes (measured; in the
+                                                         * concurrent batches of a call 64 to 512 threads for the mid class make no difference) */
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_wide.p, (int64_t) b->order_wide.size(), t_wide, b->max_merge_wide, s));
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_mid.p, (int64_t) b->order_mid.size(), t_mid, b->max_merge_mid, a0));
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), t_narrow, b->max_merge_narrow, a1));

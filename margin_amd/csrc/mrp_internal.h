@@ -246,16 +246,13 @@ struct mrp_context {
     hipStream_t aux[2] = {nullptr, nullptr};
     bool grouped = false;
     hipError_t side_streams(hipStream_t *a0, hipStream_t *a1) {
-        static const bool off = [] { const char *e = getenv("MRP_AUX_STREAMS"); return e && e[0] == '0'; }();
-        if (grouped || off) { *a0 = *a1 = stream; return hipSuccess; }
+        if (grouped) { *a0 = *a1 = stream; return hipSuccess; }
         for (int i = 0; i < 2; i++)
             if (!aux[i]) { const hipError_t e = hipStreamCreateWithFlags(&aux[i], hipStreamNonBlocking); if (e != hipSuccess) return e; }
         *a0 = aux[0]; *a1 = aux[1];
         return hipSuccess;
     }
     hipError_t copy_stream(hipStream_t *cs) { /* uploads of a staged level of the resident engine, beside the kernels of the level before */
-        static const bool off = [] { const char *e = getenv("MRP_COPY_STREAM"); return e && e[0] == '0'; }(); /* (development) */
-        if (off) { *cs = stream; return hipSuccess; }
         if (!pre) { const hipError_t e = hipStreamCreateWithFlags(&pre, hipStreamNonBlocking); if (e != hipSuccess) return e; }
         *cs = pre;
         return hipSuccess;

@@ -2194,32 +2194,7 @@ static void *phase_group_main(void *p) {
     const long long pool0 = mrp_pool_task_cpu_ns(), mine0 = mrp_pool_task_cpu_ns_this_thread();
     mrp_pool_adopt(g->pool);
     mrp_pool_set_priority(g->index); /* batch 0's host loops first: the batches reach their device-heavy levels one after the other */
-    {
-        /* (development) MRP_ROUNDS=k: the batch takes its chunks in k rounds one after the other, the first of a size that
-         * differs from batch to batch, so that the batches of a call drift apart instead of reaching every level together */
-        const char *re = getenv("MRP_ROUNDS");
-        const int rounds = re ? atoi(re) : 1;
-        if (rounds <= 1 || g->n < 8 * rounds) {
-            g->rc = phase_many_resident(g->ctx, g->n, g->chunks, g->reads, g->n_reads, g->params, g->out, &g->stats);
-        } else {
-            int64_t first = g->n * (g->index % 8 + 1) / (8 * rounds) + g->n / (2 * rounds); /* between 1/2 and 3/2 of a round */
-            if (first < 4) first = 4;
-            int64_t done = 0;
-            g->rc = MRP_OK;
-            for (int r = 0; done < g->n && g->rc == MRP_OK; r++) {
-                int64_t take = r == 0 ? first : (g->n - done + (rounds - r) - 1) / (rounds - r > 0 ? rounds - r : 1);
-                if (take > g->n - done || r >= rounds - 1) take = g->n - done;
-                mrp_phase_many_stats st;
-                memset(&st, 0, sizeof(st));
-                g->rc = phase_many_resident(g->ctx, take, g->chunks + done, g->reads + done, g->n_reads + done, g->params, g->out + done, &st);
-                g->stats.resident = st.resident; g->stats.fallback_chunks += st.fallback_chunks;
-                if (st.levels > g->stats.levels) g->stats.levels = st.levels;
-                g->stats.hmms += st.hmms; g->stats.columns += st.columns; g->stats.cells += st.cells; g->stats.merge_cells += st.merge_cells;
-                g->stats.device_ms += st.device_ms; g->stats.cross_ms += st.cross_ms; g->stats.sweep_ms += st.sweep_ms; g->stats.prune_ms += st.prune_ms;
-                done += take;
-            }
-        }
-    }
+    g->rc = phase_many_resident(g->ctx, g->n, g->chunks, g->reads, g->n_reads, g->params, g->out, &g->stats);
     mrp_pool_set_priority(0);
     if (getenv("MRP_TIMING")) {
         fprintf(stderr, "  batch %d: cpu of its own thread %.1f ms (%.1f of it pool tasks it ran itself); pool tasks (all batches, while it ran) %.1f ms; cumulative by loop:", g->index,
@@ -2316,7 +2291,6 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
     /* measured on MI355X (bench.py --chunks N --phase-groups G, two streams a batch): 48 chunks 45.3 ms with 2 batches, 42.5
      * with 4; 96: 52.3 with 4, 54.8 with 8; 144: 66.4 / 68.0; 192: 80.2 / 78.6; 288: 104.5 / 96.9; 432: 139.9 with 6, 130.5
      * with 8; 576 with 8: 169.5 (2.04e8 units/s, the best rate; 768: 243 ms).  More than 8 would share hardware queues. */
-    if (G <= 0) { const char *e = getenv("MRP_GROUPS"); if (e && atoi(e) > 0) G = atoi(e); } /* (development) */
     if (G <= 0) G = n_chunks < 192 ? (int) (n_chunks / 12 > 4 ? 4 : n_chunks / 12) : 8;
     if (G < 1) G = 1;
     if (G > 16) G = 16;
