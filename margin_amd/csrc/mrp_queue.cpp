@@ -41,7 +41,7 @@ struct QueuePlan {
  * chunks_per_batch >= 1: batches of that many chunks.  0: the library's choice for n_workers pulling threads on n_devices
  * devices.  A batch is one mrp_phase_reads_many call; a call begins and ends with host work and walks its merge levels one
  * after the other, the top ones bound by per-column latency whatever the number of chunks.  A short queue (up to 640 chunks
- * per device) is ONE batch per device: the call runs it as eight concurrent batches of its own (576 chunks: 170-182 ms).  A
+ * of the 1 Mb kind per device; sizes are counted in units, below) is ONE batch per device: the call runs it as eight concurrent batches of its own (576 chunks: 170-182 ms).  A
  * longer one is handed out in batches of MRP_QUEUE_DEFAULT_BATCH chunks to the lanes of the devices (four per device, each
  * call two concurrent batches: the same eight in flight, but at different levels -- while one lane is in its host-bound
  * head or its latency-bound top levels the others stream; measured on 2 304 chunks: 153-160 ms per 576 against 174-177 for
@@ -53,11 +53,18 @@ QueuePlan plan_queue(int64_t n, const int64_t *cost, int64_t chunks_per_batch, i
     p.order.resize((size_t) n);
     std::iota(p.order.begin(), p.order.end(), (int64_t) 0);
     std::stable_sort(p.order.begin(), p.order.end(), [&](int64_t a, int64_t b) { return cost[a] > cost[b]; });
-    /* up to 640 chunks per device ONE call per device is the fastest */
-    const int64_t big = MRP_QUEUE_DEFAULT_BATCH, short_queue = 640;
+    /* Sizes are counted in UNITS (a chunk's cost: its reads x the het sites they span), with the 1 Mb, 30x chunk of
+     * BASELINE.json configs[1] (60 000 units) as the yardstick the policy was measured on: what a call costs the device and
+     * what it keeps there grow with its units, not with its chunks -- 192 chunks of 130 sites would be a call of 9 ms. */
+    const int64_t unit_chunk = MRP_QUEUE_UNITS_PER_CHUNK;
+    const int64_t big = MRP_QUEUE_DEFAULT_BATCH * unit_chunk, short_queue = 640 * unit_chunk;
+    auto units = [&](int64_t pos) { return std::max<int64_t>(1, cost[p.order[(size_t) pos]]); };
+    int64_t total = 0;
+    for (int64_t i = 0; i < n; i++) total += units(i);
     if (chunks_per_batch >= 1) {
         for (int64_t o = 0; o < n; o += chunks_per_batch) p.batch_off.push_back(o);
-    } else if (n <= (int64_t) n_devices * short_queue) {
+    } else if (total <= (int64_t) n_devices * short_queue) {
+        /* up to 640 yardstick chunks per device ONE call per device is the fastest */
         const int64_t parts = std::min<int64_t>(n, n_devices);
         /* these batches all start at once: deal the chunks out in stripes (batch b takes the b-th, (b + parts)-th, ... of the
          * cost order), so that every batch gets its share of the expensive ones -- consecutive runs of a largest-first order
@@ -70,11 +77,16 @@ QueuePlan plan_queue(int64_t n, const int64_t *cost, int64_t chunks_per_batch, i
         }
         p.order.swap(striped);
     } else {
-        for (int64_t o = 0; o < n;) { /* full batches while every worker can still get one, then shrinking, at least 96 chunks */
+        int64_t left = total;
+        for (int64_t o = 0; o < n;) { /* full batches while every worker can still get one, then shrinking, at least half a batch */
             p.batch_off.push_back(o);
-            const int64_t left = n - o;
             /* (one device: nothing to even out between its lanes, which share it -- full batches to the end) */
-            o += n_devices > 1 ? std::max<int64_t>(96, std::min<int64_t>(big, left / (int64_t) std::max(1, n_workers))) : std::min<int64_t>(big, left);
+            const int64_t target = n_devices > 1 ? std::max<int64_t>(big / 2, std::min<int64_t>(big, left / (int64_t) std::max(1, n_workers))) : big;
+            int64_t got = 0;
+            do { got += units(o); o++; } while (o < n && got + units(o) / 2 < target);
+            if (left - got < target / 2) /* (what would be left is no batch of its own) */
+                while (o < n) { got += units(o); o++; }
+            left -= got;
         }
     }
     p.batch_off.push_back(n);
@@ -250,11 +262,16 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
     std::mutex pool_mu;
     std::atomic<int64_t> next{0};
     std::atomic<int> status{MRP_OK};
-    /* a device holds what its calls in flight need (some 170 MB per 1 Mb chunk, DevPool): four lanes for batches of up to 288
-     * chunks, two up to 576, one beyond */
+    /* a device holds what its calls in flight need (some 170 MB per 1 Mb chunk = 60 000 units, DevPool): four lanes for batches of
+     * up to 288 such chunks, two up to 576, one beyond */
     int64_t max_batch = 0;
-    for (int64_t b = 0; b < n_batches; b++) max_batch = std::max(max_batch, plan.batch_off[(size_t) b + 1] - plan.batch_off[(size_t) b]);
-    const int active_lanes = n_batches <= (int64_t) n_devices ? 1 : (max_batch <= 288 ? lanes : (max_batch <= 576 ? std::min(lanes, 2) : 1));
+    for (int64_t b = 0; b < n_batches; b++) {
+        int64_t u = 0;
+        for (int64_t i = plan.batch_off[(size_t) b]; i < plan.batch_off[(size_t) b + 1]; i++) u += cost[(size_t) plan.order[(size_t) i]];
+        max_batch = std::max(max_batch, u);
+    }
+    const int64_t yard = MRP_QUEUE_UNITS_PER_CHUNK;
+    const int active_lanes = n_batches <= (int64_t) n_devices ? 1 : (max_batch <= 288 * yard ? lanes : (max_batch <= 576 * yard ? std::min(lanes, 2) : 1));
     const char *aff_env = getenv("MRP_QUEUE_AFFINITY");
     const bool bind = n_devices > 1 && !(aff_env && aff_env[0] == '0');
 

@@ -44,8 +44,7 @@ def test_queue_dry_run_is_complete_ordered_and_dynamic(n_workers, per_batch):
 
 def test_whole_genome_queue_on_eight_devices_is_balanced():
     """BASELINE.json configs[3]: ~31 000 chunks of ~100 kb over the 8 devices of a node, four lanes each = 32
-    pulling threads.  With the library's own batch sizes (chunks_per_batch = 0: 192 chunks per batch, shrinking towards the end
-    of the queue) every chunk is taken once and no device carries more than 2 % above the mean of the estimated cost
+    pulling threads.  With the library's own batch sizes (chunks_per_batch = 0; cut by units, here one striped batch per pulling thread) every chunk is taken once and no device carries more than 2 % above the mean of the estimated cost
     (het-sites x reads) -- the stand-in workers sleep in proportion to it, so the hand-out is the dynamic one of a real run."""
     rng = np.random.default_rng(31_000)
     n = 31_000
@@ -60,10 +59,14 @@ def test_whole_genome_queue_on_eight_devices_is_balanced():
     assert (per_device > 0).all()
     imbalance = per_device.max() / per_device.mean() - 1.0
     assert imbalance <= 0.02, (imbalance, per_device.tolist())
-    # the batches follow the queue's order, full-sized first
+    # one device: the batches follow the queue's order and are cut by UNITS (192 chunks of 60 000 units = 1.152e7 per batch: ~1 480 of
+    # these small chunks), not by chunk count
     order, batch = capi.queue_plan(cost, 0)
-    sizes = np.bincount(batch)
-    assert sizes.max() <= 192 and sizes[0] == 192 and sizes[:-1].min() >= 96 and (np.diff(sizes[:-1]) <= 0).all()
+    per_batch = np.bincount(batch, weights=cost.astype(np.float64))
+    assert (np.diff(batch[order]) >= 0).all() and (np.diff(cost[order]) <= 0).all()
+    assert len(per_batch) == int(round(cost.sum() / 1.152e7))
+    assert (np.abs(per_batch[:-1] / 1.152e7 - 1.0) < 0.01).all() and 0.5 * 1.152e7 <= per_batch[-1] <= 1.5 * 1.152e7
+    assert np.bincount(batch).min() > 800  # (the first batches hold the most expensive chunks: fewer of them)
 
 
 def test_queue_rejects_bad_arguments():
