@@ -1227,8 +1227,10 @@ static void genome_fragment(const world *w, mrp_phase_result *g, const mrp_hmm *
         g->n_reads1 = a; g->n_reads2 = b;
         for (int64_t k = 0; k < K; k++) { /* :211-226 */
             const int32_t *cr = h->col_reads.a + h->read_off.a[k];
-            for (int32_t i = 0; i < h->col_depth.a[k]; i++) if (m12[cr[i]]) p[k] ^= (uint64_t) 1 << i;
-            for (int32_t i = 0; i < h->col_depth.a[k]; i++) if (m21[cr[i]]) p[k] ^= (uint64_t) 1 << i;
+            uint64_t flip = 0; /* (a read moved both ways -- it sat in both lists -- is flipped twice: not at all) */
+            for (int32_t i = 0; i < h->col_depth.a[k]; i++) flip |= (uint64_t) (m12[cr[i]] ^ m21[cr[i]]) << i;
+            if (!flip) continue; /* fillInPredictedGenome is a function of the column and its partition: unchanged */
+            p[k] ^= flip;
             fill_in_predicted_genome(w, g, h, k, p[k], scratch);
         }
     }
