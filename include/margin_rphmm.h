@@ -64,12 +64,13 @@ int mrp_context_synchronize(mrp_context *ctx);
 int mrp_context_trim(mrp_context *ctx);
 /* Optional, once, BEFORE the process's first HIP call (its own or this library's): asks the ROCm runtime for 16 hardware
  * queues (GPU_MAX_HW_QUEUES, unless the environment already sets it).  The runtime multiplexes HIP streams onto 4 hardware
- * queues by default and kernels of streams that share a queue serialize; the concurrent batches of mrp_phase_reads_many
- * launch on four streams each (96 chunks: 68 ms instead of 82 ms on an MI355X).  Without the call everything works, slower. */
+ * queues by default and kernels of streams that share a queue serialize; the eight concurrent batches of a
+ * mrp_phase_reads_many call launch on two streams each, 16 in all (576 chunks: 189 ms with 16 queues, 225 with 8).  Without the
+ * call everything works, slower. */
 int mrp_runtime_init(void);
 /* mrp_phase_reads_many splits its chunks into this many interleaved batches that run concurrently on the context and its
- * sibling contexts (one batch's host work beside the others' kernels); 1..8, or 0 (default): one batch per 24 chunks up to
- * 4, from 320 chunks on one per 64 chunks up to 8. */
+ * sibling contexts (one batch's host work beside the others' kernels); 1..16, or 0 (default): one batch per 12 chunks up to
+ * 4, eight from 192 chunks on.  (A call whose units exceed what the device's memory budget holds runs as consecutive slices.) */
 int mrp_context_set_phase_groups(mrp_context *ctx, int groups);
 /* Test suite only (a private switch, not a parameter: a caller's uninitialised struct field cannot turn it on).  Bit 0, fault
  * injection: the resident path reports MRP_ENGINE_ERR_MERGE for one hmm of its second level, which must send exactly that
