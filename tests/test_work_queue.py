@@ -129,3 +129,22 @@ def test_two_workers_on_one_device_phase_every_chunk(orc):
     with pytest.raises(capi.MrpError) as ei:
         capi.phase_chunks_on_devices([7], chunks[:1], params)
     assert ei.value.code == capi.MRP_ERR_ARG
+
+
+def test_library_batches_are_cut_by_units_for_mixed_chunk_sizes():
+    """chunks_per_batch = 0 on one device: 900 chunks of the 1 Mb kind (~60 000 units) mixed with 6 000 of the 100 kb kind (~4 000
+    units) and a few without reads.  More than 640 yardstick chunks of work, so the queue is cut into batches of about
+    192 x 60 000 units each, in cost order: the first batches hold ~190 large chunks, the last ones thousands of small ones; every
+    chunk is in exactly one batch."""
+    rng = np.random.default_rng(5)
+    cost = np.concatenate([rng.integers(50_000, 70_000, size=900), rng.integers(2_000, 6_000, size=6_000), np.zeros(7, dtype=np.int64)]).astype(np.int64)
+    rng.shuffle(cost)
+    order, batch = capi.queue_plan(cost, 0)
+    assert sorted(order.tolist()) == list(range(len(cost)))
+    assert (np.diff(cost[order]) <= 0).all() and (np.diff(batch[order]) >= 0).all() and batch[order][0] == 0
+    per_batch = np.bincount(batch, weights=cost.astype(np.float64))
+    target = 192 * 60_000
+    assert len(per_batch) == int(round(cost.sum() / target))
+    assert (np.abs(per_batch[:-1] / target - 1.0) < 0.01).all() and 0.5 * target <= per_batch[-1] <= 1.5 * target
+    sizes = np.bincount(batch)
+    assert 160 <= sizes[0] <= 230 and sizes[-1] > 1000
