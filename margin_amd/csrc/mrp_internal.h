@@ -76,8 +76,8 @@ struct DevPoolRegistry {
     size_t budget_of(int device) {
         size_t b = budget[device].load(std::memory_order_relaxed);
         if (b == 0) {
-            size_t free_b = 0, total = 0;
-            b = hipMemGetInfo(&free_b, &total) == hipSuccess && total > 0 ? total - total / 8 : ~(size_t) 0; /* (the calling thread's device) */
+            size_t total = 0; /* (by ordinal: the calling thread's current device may be another one) */
+            b = hipDeviceTotalMem(&total, device) == hipSuccess && total > 0 ? total - total / 8 : ~(size_t) 0;
             if (const char *e = getenv("MRP_POOL_BUDGET_MB")) { const long long v = atoll(e); if (v > 0) b = (size_t) v << 20; }
             budget[device].store(b, std::memory_order_relaxed);
         }
