@@ -597,15 +597,23 @@ def phase_reads(ctx: Context, dchunk: DeviceChunk, chunk, params: Params, record
     return out
 
 
-def phase_reads_many(ctx: Context, dchunks: Sequence[DeviceChunk], chunks: Sequence, params: Params, convert: bool = True):
-    """mrp_phase_reads_many -> (list of result dicts, PhaseManyStats).  convert=False skips the Python copies of the
-    results (timing runs)."""
-    L = load()
+def phase_many_args(dchunks: Sequence[DeviceChunk], chunks: Sequence):
+    """the argument arrays of mrp_phase_reads_many for these chunks, built once (a timing loop hands them back through
+    `prepared` instead of rebuilding three ctypes arrays per call)"""
     n = len(chunks)
     keep = [read_records(c) for c in chunks]
     ch = (C.c_void_p * max(n, 1))(*[d.h for d in dchunks])
     rd = (C.POINTER(ReadRec) * max(n, 1))(*[C.cast(k[0], C.POINTER(ReadRec)) for k in keep])
     nr = (C.c_int64 * max(n, 1))(*[len(c.reads) for c in chunks])
+    return ch, rd, nr, keep
+
+
+def phase_reads_many(ctx: Context, dchunks: Sequence[DeviceChunk], chunks: Sequence, params: Params, convert: bool = True, prepared=None):
+    """mrp_phase_reads_many -> (list of result dicts, PhaseManyStats).  convert=False skips the Python copies of the
+    results (timing runs); prepared = phase_many_args(dchunks, chunks)."""
+    L = load()
+    n = len(chunks)
+    ch, rd, nr, _keep = prepared if prepared is not None else phase_many_args(dchunks, chunks)
     res = (C.POINTER(PhaseResult) * max(n, 1))()
     st = PhaseManyStats()
     _check(L.mrp_phase_reads_many(ctx.h, n, ch, rd, nr, C.byref(params), res, C.byref(st)))
