@@ -78,10 +78,15 @@ QueuePlan plan_queue(int64_t n, const int64_t *cost, int64_t chunks_per_batch, i
         p.order.swap(striped);
     } else {
         int64_t left = total;
-        for (int64_t o = 0; o < n;) { /* full batches while every worker can still get one, then shrinking, at least half a batch */
+        /* one device: its lanes share it, so there is nothing to even out between them towards the end -- but they should all be
+         * busy to the end: as many equal batches as fill whole rounds of the lanes (1 152 chunks on four lanes: 8 batches of 144
+         * rather than 6 of 192, of which the last two would run on half the lanes) */
+        const int64_t lanes_of_device = std::max(1, n_workers / std::max(1, n_devices));
+        const int64_t rounds = (total + lanes_of_device * big - 1) / (lanes_of_device * big);
+        const int64_t even = (total + rounds * lanes_of_device - 1) / (rounds * lanes_of_device);
+        for (int64_t o = 0; o < n;) { /* several devices: full batches while every worker can still get one, then shrinking, at least half a batch */
             p.batch_off.push_back(o);
-            /* (one device: nothing to even out between its lanes, which share it -- full batches to the end) */
-            const int64_t target = n_devices > 1 ? std::max<int64_t>(big / 2, std::min<int64_t>(big, left / (int64_t) std::max(1, n_workers))) : big;
+            const int64_t target = n_devices > 1 ? std::max<int64_t>(big / 2, std::min<int64_t>(big, left / (int64_t) std::max(1, n_workers))) : even;
             int64_t got = 0;
             do { got += units(o); o++; } while (o < n && got + units(o) / 2 < target);
             if (left - got < target / 2) /* (what would be left is no batch of its own) */

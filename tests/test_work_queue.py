@@ -64,8 +64,9 @@ def test_whole_genome_queue_on_eight_devices_is_balanced():
     order, batch = capi.queue_plan(cost, 0)
     per_batch = np.bincount(batch, weights=cost.astype(np.float64))
     assert (np.diff(batch[order]) >= 0).all() and (np.diff(cost[order]) <= 0).all()
-    assert len(per_batch) == int(round(cost.sum() / 1.152e7))
-    assert (np.abs(per_batch[:-1] / 1.152e7 - 1.0) < 0.01).all() and 0.5 * 1.152e7 <= per_batch[-1] <= 1.5 * 1.152e7
+    n_batches = int(np.ceil(cost.sum() / 1.152e7))
+    assert len(per_batch) == n_batches
+    assert (np.abs(per_batch[:-1] / (cost.sum() / n_batches) - 1.0) < 0.01).all() and 0.5 * 1.152e7 <= per_batch[-1] <= 1.5 * 1.152e7
     assert np.bincount(batch).min() > 800  # (the first batches hold the most expensive chunks: fewer of them)
 
 
@@ -143,8 +144,9 @@ def test_library_batches_are_cut_by_units_for_mixed_chunk_sizes():
     assert sorted(order.tolist()) == list(range(len(cost)))
     assert (np.diff(cost[order]) <= 0).all() and (np.diff(batch[order]) >= 0).all() and batch[order][0] == 0
     per_batch = np.bincount(batch, weights=cost.astype(np.float64))
-    target = 192 * 60_000
-    assert len(per_batch) == int(round(cost.sum() / target))
+    n_batches = int(np.ceil(cost.sum() / (192 * 60_000)))   # whole rounds of the (here: one) lane, equal batches of at most 192 x 60 000 units
+    target = cost.sum() / n_batches
+    assert len(per_batch) == n_batches
     assert (np.abs(per_batch[:-1] / target - 1.0) < 0.01).all() and 0.5 * target <= per_batch[-1] <= 1.5 * target
     sizes = np.bincount(batch)
     assert 160 <= sizes[0] <= 230 and sizes[-1] > 1000
