@@ -75,7 +75,9 @@ int mrp_context_set_phase_groups(mrp_context *ctx, int groups);
 /* Test suite only (a private switch, not a parameter: a caller's uninitialised struct field cannot turn it on).  Bit 0, fault
  * injection: the resident path reports MRP_ENGINE_ERR_MERGE for one hmm of its second level, which must send exactly that
  * chunk to the hashing path.  Bit 1: the resident merge levels run the separate cross product and emission kernels -- the
- * path the final level and the ancestor model take -- instead of the one-pass kernel, for A/B parity and timing. */
+ * path the final level and the ancestor model take -- instead of the one-pass kernel, for A/B parity and timing.  Bit 2 (one shot:
+ * cleared when it fires): the next device allocation of at least 1 MB on the context's device is refused as out of memory, which
+ * a resident call must survive by redoing itself in two halves. */
 int mrp_context_set_test_hooks(mrp_context *ctx, int hooks);
 /* size of the host worker pool (structure of the merge levels, descriptors, classification of alignment pairs): the
  * process-wide pool of contexts used directly, and EACH worker's own pool of a work queue (mrp_queue_*: one pool per device).
@@ -313,8 +315,9 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
 /* ---- the chunks of a node's worth of work over its GPUs ---------------------------------------------
  * Replaces the chunk loop of phase.c:276-473 together with its ordering (phase.c:257-263, chunks by estimated depth,
  * largest first) and its schedule ("#pragma omp parallel for schedule(dynamic,1)", :276-279), with devices in the role
- * of the threads: two host threads ("lanes") per entry of devices[] pull the next batch of chunks_per_batch (0: about 288) consecutive
- * chunks of that order, phases it (mrp_phase_reads_many) and stores the results at the chunks' own positions of out[];
+ * of the threads: up to four host threads ("lanes", MRP_QUEUE_LANES) per entry of devices[] pull the next batch of chunks_per_batch
+ * (0: the library's choice, cut by units -- one batch per device for a short queue, MRP_QUEUE_DEFAULT_BATCH = 192 yardstick chunks
+ * otherwise) consecutive chunks of that order, phase it (mrp_phase_reads_many) and stores the results at the chunks' own positions of out[];
  * while a batch is phased the worker's NEXT batch is uploaded on a second stream (site tables + profile bytes, one wait per
  * batch).  Every worker has its own host thread pool (mrp_set_host_threads per device) and, when the queue drives more than
  * one device, runs on the CPUs next to its device (/sys/bus/pci/devices/.../local_cpulist; MRP_QUEUE_AFFINITY=0 turns that
@@ -352,10 +355,12 @@ int mrp_phase_chunks_on_devices(const int32_t *devices, int32_t n_devices, int64
 /* the order of the queue alone (host only): order_out[n_chunks] = chunk indices, largest cost first, ties in input
  * order; batch_of_chunk_out (optional) = the batch each chunk travels in */
 int mrp_queue_plan(int64_t n_chunks, const int64_t *cost, int64_t chunks_per_batch, int64_t *order_out, int64_t *batch_of_chunk_out);
-/* the queue itself with stand-in workers that sleep usec_per_cost microseconds per unit of cost instead of phasing (host
- * only; what the CPU test-suite drives): worker_of_chunk_out[i] = the worker that took chunk i, sequence_out[i]
- * (optional) = the global position at which it was taken */
-int mrp_queue_dry_run(int32_t n_workers, int64_t n_chunks, const int64_t *cost, int64_t chunks_per_batch, double usec_per_cost,
+/* the queue itself with stand-in workers (host only; what the CPU test-suite drives): the plan and the hand-out
+ * mrp_queue_phase_chunks uses for n_devices devices with `lanes` pulling threads each (the real queue: 4, MRP_QUEUE_LANES) --
+ * same batches, same lanes in use, a lane takes its next batch when it starts on the current one -- but a call is replaced
+ * by a sleep of usec_per_cost microseconds per unit of cost.  worker_of_chunk_out[i] = device * lanes + lane that took chunk
+ * i, sequence_out[i] (optional) = the global position at which it was taken */
+int mrp_queue_dry_run(int32_t n_devices, int32_t lanes, int64_t n_chunks, const int64_t *cost, int64_t chunks_per_batch, double usec_per_cost,
                       int32_t *worker_of_chunk_out, int64_t *sequence_out);
 
 /* ---- the frame around the path: host code, no device needed ----------------------- */

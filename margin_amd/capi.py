@@ -278,7 +278,7 @@ def load():
     L.mrp_queue_destroy.restype = None
     L.mrp_queue_phase_chunks.argtypes = [vp, i64, P(ChunkDesc), P(Params), i64, P(P(PhaseResult)), P(QueueStats)]
     L.mrp_queue_plan.argtypes = [i64, vp, i64, vp, vp]
-    L.mrp_queue_dry_run.argtypes = [i32, i64, vp, i64, C.c_double, vp, vp]
+    L.mrp_queue_dry_run.argtypes = [i32, i32, i64, vp, i64, C.c_double, vp, vp]
     _lib = L
     return L
 
@@ -700,11 +700,12 @@ def queue_plan(cost, chunks_per_batch: int):
     return order, batch
 
 
-def queue_dry_run(n_workers: int, cost, chunks_per_batch: int, usec_per_cost: float = 0.0):
+def queue_dry_run(n_devices: int, lanes: int, cost, chunks_per_batch: int, usec_per_cost: float = 0.0):
+    """worker (= device * lanes + lane) and global take position of every chunk"""
     cost = np.ascontiguousarray(cost, dtype=np.int64)
     worker = np.full(len(cost), -1, dtype=np.int32)
     seq = np.full(len(cost), -1, dtype=np.int64)
-    _check(load().mrp_queue_dry_run(n_workers, len(cost), cost.ctypes.data, chunks_per_batch, usec_per_cost, worker.ctypes.data, seq.ctypes.data))
+    _check(load().mrp_queue_dry_run(n_devices, lanes, len(cost), cost.ctypes.data, chunks_per_batch, usec_per_cost, worker.ctypes.data, seq.ctypes.data))
     return worker, seq
 
 

@@ -64,6 +64,9 @@ int64_t mrp_context_device_budget(mrp_context *ctx) { /* bytes the pools of the 
     const size_t b = DevPoolRegistry::get().budget_of(ctx->pool.device);
     return b > (size_t) 1 << 62 ? 0 : (int64_t) b;
 }
+uint64_t mrp_context_oom_events(mrp_context *ctx) { /* device allocations refused for good on the context's device so far */
+    return ctx->pool.device >= 0 ? DevPoolRegistry::get().oom_events[ctx->pool.device].load() : 0;
+}
 void mrp_context_pool_bytes(mrp_context *ctx, int64_t *cached, int64_t *device_held) {
     { std::lock_guard<std::mutex> lock(ctx->pool.mu); *cached = (int64_t) ctx->pool.cached_bytes; }
     *device_held = ctx->pool.device >= 0 ? (int64_t) DevPoolRegistry::get().held[ctx->pool.device].load() : 0;
@@ -767,7 +770,9 @@ int mrp_context_set_phase_groups(mrp_context *ctx, int groups) {
 }
 int mrp_context_phase_groups(const mrp_context *ctx) { return ctx->phase_groups; }
 int mrp_context_set_test_hooks(mrp_context *ctx, int hooks) {
-    if (!ctx || hooks < 0 || hooks > 3) return fail(MRP_ERR_ARG, "mrp_context_set_test_hooks: bad arguments");
+    if (!ctx || hooks < 0 || hooks > 7) return fail(MRP_ERR_ARG, "mrp_context_set_test_hooks: bad arguments");
+    if ((hooks & 4) && ctx->pool.device >= 0) DevPoolRegistry::get().inject_oom[ctx->pool.device].store(1);
+    hooks &= 3;
     ctx->test_hooks = hooks;
     for (mrp_context *s_ : ctx->siblings) s_->test_hooks = hooks;
     return MRP_OK;

@@ -71,17 +71,38 @@ struct DevPoolRegistry {
     std::vector<DevPool *> pools;
     std::atomic<size_t> held[MAX_DEVICES];   /* bytes the pools of a device got from hipMalloc and have not given back */
     std::atomic<size_t> budget[MAX_DEVICES]; /* 0: not asked yet */
-    DevPoolRegistry() { for (int d = 0; d < MAX_DEVICES; d++) { held[d].store(0); budget[d].store(0); } }
+    DevPoolRegistry() { for (int d = 0; d < MAX_DEVICES; d++) { held[d].store(0); budget[d].store(0); oom_events[d].store(0); inject_oom[d].store(0); } }
     static DevPoolRegistry &get() { static DevPoolRegistry r; return r; }
+    std::atomic<int> inject_oom[MAX_DEVICES];      /* test hook (mrp_context_set_test_hooks bit 2): refuse the next large allocation */
+    std::atomic<uint64_t> oom_events[MAX_DEVICES]; /* allocations the driver refused for good (after every cache was given back) */
+    /* What the pools of a device may hold together: the memory that is FREE when the first pool of the process asks (another
+     * process, or allocations of the caller's own, are not ours to count on) less a head room of a sixteenth of the device,
+     * and never more than the device less an eighth.  MRP_POOL_BUDGET_MB overrides. */
     size_t budget_of(int device) {
         size_t b = budget[device].load(std::memory_order_relaxed);
         if (b == 0) {
-            size_t total = 0; /* (by ordinal: the calling thread's current device may be another one) */
+            size_t total = 0, free_now = 0, tot2 = 0; /* (by ordinal: the calling thread's current device may be another one) */
             b = hipDeviceTotalMem(&total, device) == hipSuccess && total > 0 ? total - total / 8 : ~(size_t) 0;
+            int cur = -1;
+            if (total > 0 && hipGetDevice(&cur) == hipSuccess && hipSetDevice(device) == hipSuccess) {
+                if (hipMemGetInfo(&free_now, &tot2) == hipSuccess && free_now > 0) {
+                    const size_t ours = held[device].load(std::memory_order_relaxed), room = total / 16;
+                    const size_t avail = free_now + ours > room ? free_now + ours - room : free_now + ours;
+                    if (avail < b) b = avail;
+                }
+                (void) hipSetDevice(cur);
+            }
+            (void) hipGetLastError();
             if (const char *e = getenv("MRP_POOL_BUDGET_MB")) { const long long v = atoll(e); if (v > 0) b = (size_t) v << 20; }
             budget[device].store(b, std::memory_order_relaxed);
         }
         return b;
+    }
+    /* after the driver refused an allocation although nothing idles in any pool: what we hold now is what there is */
+    void shrink_budget(int device) {
+        const size_t ours = held[device].load(std::memory_order_relaxed);
+        size_t b = budget[device].load(std::memory_order_relaxed);
+        if (ours > ((size_t) 1 << 30) && (b == 0 || ours < b)) budget[device].store(ours, std::memory_order_relaxed);
     }
     inline void trim_device(int device, DevPool *but);
 };
@@ -146,6 +167,11 @@ struct DevPool {
             if (DevPoolRegistry::get().held[device].load(std::memory_order_relaxed) + cls > DevPoolRegistry::get().budget_of(device))
                 DevPoolRegistry::get().trim_device(device, this);
         }
+        if (device >= 0 && cls >= ((size_t) 1 << 20) && DevPoolRegistry::get().inject_oom[device].load(std::memory_order_relaxed) > 0 &&
+            DevPoolRegistry::get().inject_oom[device].exchange(0) > 0) { /* fault injection of the test suite */
+            DevPoolRegistry::get().oom_events[device].fetch_add(1, std::memory_order_relaxed);
+            return hipErrorOutOfMemory;
+        }
         hipError_t e = hipMalloc(p, cls);
         if (e != hipSuccess) { /* give the cache back and try once more */
             (void) hipGetLastError();
@@ -158,6 +184,10 @@ struct DevPool {
             e = hipMalloc(p, cls);
         }
         if (e == hipSuccess) held_add(cls);
+        else if (e == hipErrorOutOfMemory && device >= 0) { /* callers that can re-slice their work look at this count */
+            DevPoolRegistry::get().oom_events[device].fetch_add(1, std::memory_order_relaxed);
+            DevPoolRegistry::get().shrink_budget(device);
+        }
         return e;
     }
     void release(void *p, size_t cls) {

@@ -16,6 +16,8 @@
 #include <chrono>
 #include <cstdio>
 #include <cstring>
+#include <functional>
+#include <system_error>
 #include <mutex>
 #include <numeric>
 #include <string>
@@ -84,9 +86,11 @@ QueuePlan plan_queue(int64_t n, const int64_t *cost, int64_t chunks_per_batch, i
         const int64_t lanes_of_device = std::max(1, n_workers / std::max(1, n_devices));
         const int64_t rounds = (total + lanes_of_device * big - 1) / (lanes_of_device * big);
         const int64_t even = (total + rounds * lanes_of_device - 1) / (rounds * lanes_of_device);
-        for (int64_t o = 0; o < n;) { /* several devices: full batches while every worker can still get one, then shrinking, at least half a batch */
+        for (int64_t o = 0; o < n;) { /* several devices: full batches while every lane can still get two, then shrinking, at least a quarter batch */
             p.batch_off.push_back(o);
-            const int64_t target = n_devices > 1 ? std::max<int64_t>(big / 2, std::min<int64_t>(big, left / (int64_t) std::max(1, n_workers))) : even;
+            /* (a lane holds two batches, the one it phases and the one it took ahead: what is left is shared out as if there were
+             * twice the lanes; the floor of a quarter batch keeps the tail from dissolving into latency-bound calls) */
+            const int64_t target = n_devices > 1 ? std::max<int64_t>(big / 4, std::min<int64_t>(big, left / (2 * (int64_t) std::max(1, n_workers)))) : even;
             int64_t got = 0;
             do { got += units(o); o++; } while (o < n && got + units(o) / 2 < target);
             if (left - got < target / 2) /* (what would be left is no batch of its own) */
@@ -98,27 +102,84 @@ QueuePlan plan_queue(int64_t n, const int64_t *cost, int64_t chunks_per_batch, i
     return p;
 }
 
-/* One worker per device: pulls batch indices from the shared counter until the queue is empty (schedule(dynamic,1)).
- * fn(worker, first position in plan.order, count) returns a status; the first failure stops the queue. */
-template <class Fn>
-int run_queue(int n_workers, const QueuePlan &plan, Fn fn, std::vector<int32_t> *worker_of_batch) {
+/* How many calls of a device run at a time: a device holds what its calls in flight need (some 170 MB per 1 Mb chunk = 60 000 units,
+ * DevPool): four lanes for batches of up to 288 such chunks, two up to 576, one beyond; a queue of no more batches than
+ * devices needs one lane each. */
+int active_lanes_of(const QueuePlan &plan, const int64_t *cost, int n_devices, int lanes) {
     const int64_t n_batches = (int64_t) plan.batch_off.size() - 1;
-    std::atomic<int64_t> next{0};
+    int64_t max_batch = 0;
+    for (int64_t b = 0; b < n_batches; b++) {
+        int64_t u = 0;
+        for (int64_t i = plan.batch_off[(size_t) b]; i < plan.batch_off[(size_t) b + 1]; i++) u += cost[(size_t) plan.order[(size_t) i]];
+        max_batch = std::max(max_batch, u);
+    }
+    const int64_t yard = MRP_QUEUE_UNITS_PER_CHUNK;
+    return n_batches <= (int64_t) n_devices ? 1 : (max_batch <= 288 * yard ? lanes : (max_batch <= 576 * yard ? std::min(lanes, 2) : 1));
+}
+
+/* The hand-out of the queue, shared by the real workers and the dry run: lane w = device w / lanes; a lane that is active takes
+ * its first batch (fixed, below), then -- schedule(dynamic,1), one batch ahead -- takes its NEXT batch when it starts on the current one
+ * (`prefetch(w, next batch)` runs beside `phase(w, current batch)`: the real worker uploads there) and goes on until the shared
+ * counter runs out.  A lane without a first batch does nothing (no contexts, no streams).  begin(w) / end(w) bracket a lane that
+ * got work; any non-zero status stops the queue.  Every lane is a host thread; lane 0 runs on the caller's thread unless
+ * `own_thread_for_lane0`. */
+struct LaneHooks {
+    std::function<int(int)> begin;                     /* lane */
+    std::function<int(int, int64_t)> prefetch;         /* lane, batch: may run on another thread than phase */
+    std::function<int(int, int64_t)> phase;            /* lane, batch */
+    std::function<void(int, int64_t)> discard;         /* lane, batch: a prefetched batch that will not be phased */
+    std::function<void(int)> end;
+};
+int run_lanes(int n_devices, int lanes, int active_lanes, int64_t n_batches, const LaneHooks &hk, bool own_thread_for_lane0,
+              const std::function<void(int)> &on_thread_start) {
+    const int n_workers = n_devices * lanes;
+    /* The FIRST batch of a lane is fixed: batch (lane of device) * n_devices + device, so the largest batches start on different
+     * devices and no lane that starts early can take (and, one ahead, reserve) the work of a device whose thread is not up yet --
+     * with as many batches as devices every device gets exactly one.  From there on the hand-out is dynamic. */
+    std::atomic<int64_t> next{std::min<int64_t>(n_batches, (int64_t) n_devices * active_lanes)};
     std::atomic<int> status{MRP_OK};
-    if (worker_of_batch) worker_of_batch->assign((size_t) n_batches, -1);
+    auto fail = [&](int rc) { int expect = MRP_OK; status.compare_exchange_strong(expect, rc); };
     auto work = [&](int w) {
-        for (;;) {
-            if (status.load() != MRP_OK) return;
-            const int64_t b = next.fetch_add(1);
-            if (b >= n_batches) return;
-            if (worker_of_batch) (*worker_of_batch)[(size_t) b] = w;
-            const int rc = fn(w, b, plan.batch_off[(size_t) b], plan.batch_off[(size_t) b + 1] - plan.batch_off[(size_t) b]);
-            if (rc != MRP_OK) { int expect = MRP_OK; status.compare_exchange_strong(expect, rc); return; }
+        if (on_thread_start) on_thread_start(w);
+        if (w % lanes >= active_lanes) return; /* (large caller-chosen batches: fewer calls of a device in flight) */
+        const int64_t first = (int64_t) (w % lanes) * n_devices + w / lanes;
+        if (first >= n_batches) return;
+        int rc = hk.begin ? hk.begin(w) : MRP_OK;
+        if (rc != MRP_OK) { fail(rc); return; }
+        rc = hk.prefetch ? hk.prefetch(w, first) : MRP_OK;
+        int64_t cur = first;
+        while (cur >= 0) {
+            if (rc != MRP_OK) { fail(rc); if (hk.discard) hk.discard(w, cur); break; }
+            if (status.load() != MRP_OK) { if (hk.discard) hk.discard(w, cur); break; }
+            const int64_t nb = next.fetch_add(1);
+            int prc = MRP_OK;
+            std::thread stager;
+            bool inline_stage = false;
+            if (nb < n_batches && hk.prefetch) {
+                try { stager = std::thread([&, nb] { prc = hk.prefetch(w, nb); }); }
+                catch (const std::system_error &) { inline_stage = true; } /* no thread to be had: stage after the call instead */
+            }
+            rc = hk.phase(w, cur);
+            if (stager.joinable()) stager.join();
+            if (inline_stage) prc = hk.prefetch(w, nb);
+            if (rc != MRP_OK) { fail(rc); if (nb < n_batches && hk.discard) hk.discard(w, nb); break; }
+            cur = nb < n_batches ? nb : -1;
+            rc = prc;
         }
+        if (hk.end) hk.end(w);
     };
     std::vector<std::thread> th;
-    for (int w = 1; w < n_workers; w++) th.emplace_back(work, w);
-    work(0);
+    std::vector<int> inline_lanes; /* lanes whose thread could not be created run on the caller's thread, after lane 0 */
+    for (int w = 1; w < n_workers; w++) {
+        try { th.emplace_back(work, w); }
+        catch (const std::system_error &) { inline_lanes.push_back(w); }
+    }
+    if (own_thread_for_lane0) {
+        bool started = false;
+        try { std::thread t0(work, 0); started = true; t0.join(); }
+        catch (const std::system_error &) { if (!started) work(0); }
+    } else work(0);
+    for (int w : inline_lanes) work(w);
     for (auto &t : th) t.join();
     return status.load();
 }
@@ -137,16 +198,19 @@ int mrp_queue_plan(int64_t n_chunks, const int64_t *cost, int64_t chunks_per_bat
     return MRP_OK;
 }
 
-int mrp_queue_dry_run(int32_t n_workers, int64_t n_chunks, const int64_t *cost, int64_t chunks_per_batch, double usec_per_cost,
+int mrp_queue_dry_run(int32_t n_devices, int32_t lanes, int64_t n_chunks, const int64_t *cost, int64_t chunks_per_batch, double usec_per_cost,
                       int32_t *worker_of_chunk_out, int64_t *sequence_out) {
-    if (n_workers < 1 || n_workers > 4 * MRP_MAX_QUEUE_DEVICES || n_chunks < 0 || (n_chunks > 0 && (!cost || !worker_of_chunk_out))) /* (workers = devices x lanes) */
+    if (n_devices < 1 || n_devices > MRP_MAX_QUEUE_DEVICES || lanes < 1 || lanes > 4 || n_chunks < 0 || (n_chunks > 0 && (!cost || !worker_of_chunk_out)))
         return mrp_set_error(MRP_ERR_ARG, "mrp_queue_dry_run: bad arguments");
-    const QueuePlan p = plan_queue(n_chunks, cost, chunks_per_batch, n_workers, n_workers);
+    /* the plan and the hand-out of mrp_queue_phase_chunks for the same devices and lanes (worker = device * lanes + lane); the
+     * stand-in for a call sleeps in proportion to the batch's cost, the stand-in for the upload of the next batch does nothing */
+    const QueuePlan p = plan_queue(n_chunks, cost, chunks_per_batch, n_devices * lanes, n_devices);
+    const int64_t n_batches = (int64_t) p.batch_off.size() - 1;
     std::atomic<int64_t> seq{0};
-    std::vector<int32_t> wob;
-    const int rc = run_queue(n_workers, p, [&](int w, int64_t, int64_t first, int64_t count) {
+    LaneHooks hk;
+    hk.phase = [&](int w, int64_t b) {
         int64_t c = 0;
-        for (int64_t i = first; i < first + count; i++) {
+        for (int64_t i = p.batch_off[(size_t) b]; i < p.batch_off[(size_t) b + 1]; i++) {
             const int64_t chunk = p.order[(size_t) i];
             worker_of_chunk_out[chunk] = w;
             if (sequence_out) sequence_out[chunk] = seq.fetch_add(1);
@@ -154,8 +218,8 @@ int mrp_queue_dry_run(int32_t n_workers, int64_t n_chunks, const int64_t *cost, 
         }
         if (usec_per_cost > 0) std::this_thread::sleep_for(std::chrono::microseconds((int64_t) (usec_per_cost * (double) c)));
         return (int) MRP_OK;
-    }, &wob);
-    return rc;
+    };
+    return run_lanes(n_devices, lanes, active_lanes_of(p, cost, n_devices, lanes), n_batches, hk, false, nullptr);
 }
 
 struct mrp_queue {
@@ -265,61 +329,33 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
     struct PerDev { int64_t chunks = 0, units = 0, fallback = 0; double busy_ms = 0, stage_wait_ms = 0; };
     std::vector<PerDev> per((size_t) n_workers);
     std::mutex pool_mu;
-    std::atomic<int64_t> next{0};
-    std::atomic<int> status{MRP_OK};
-    /* a device holds what its calls in flight need (some 170 MB per 1 Mb chunk = 60 000 units, DevPool): four lanes for batches of
-     * up to 288 such chunks, two up to 576, one beyond */
-    int64_t max_batch = 0;
-    for (int64_t b = 0; b < n_batches; b++) {
-        int64_t u = 0;
-        for (int64_t i = plan.batch_off[(size_t) b]; i < plan.batch_off[(size_t) b + 1]; i++) u += cost[(size_t) plan.order[(size_t) i]];
-        max_batch = std::max(max_batch, u);
-    }
-    const int64_t yard = MRP_QUEUE_UNITS_PER_CHUNK;
-    const int active_lanes = n_batches <= (int64_t) n_devices ? 1 : (max_batch <= 288 * yard ? lanes : (max_batch <= 576 * yard ? std::min(lanes, 2) : 1));
+    const int active_lanes = active_lanes_of(plan, cost.data(), n_devices, lanes);
     const char *aff_env = getenv("MRP_QUEUE_AFFINITY");
     const bool bind = n_devices > 1 && !(aff_env && aff_env[0] == '0');
 
-    /* the chunks of one batch on the device (uploads queued on the staging context's stream and waited for once) */
+    /* the chunks of one batch on the device (uploads queued on the staging context's stream; the chunks carry the event that
+     * ends the upload, the first device work that reads one waits for it) */
     struct Staged {
         int64_t batch = -1, first = 0, count = 0;
         std::vector<mrp_chunk *> dch;
-        int rc = MRP_OK;
-        std::string err;
     };
+    struct Lane { Staged st[2]; int n_staged = 0; void *caller_pool = nullptr; };
+    std::vector<Lane> lane_state((size_t) n_workers);
     const bool timing = getenv("MRP_TIMING") != nullptr;
     const auto t_call = std::chrono::steady_clock::now();
     auto since = [&]() { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_call).count(); };
-    auto stage = [&](int w, int64_t b, int parity, Staged *st) {
-        const auto ts0 = std::chrono::steady_clock::now();
-        st->batch = b; st->first = plan.batch_off[(size_t) b]; st->count = plan.batch_off[(size_t) b + 1] - st->first;
-        st->dch.assign((size_t) st->count, nullptr);
-        mrp_context *sc = q->stage_ctx[(size_t) w];
-        sc->pool.reclaim(); /* the block of the batch before last was emptied after its call returned */
-        mrp_chunk_block *&blk = q->blocks[(size_t) w * 2 + (size_t) parity];
-        if (!blk) blk = new (std::nothrow) mrp_chunk_block();
-        std::vector<const mrp_chunk_desc *> dl((size_t) st->count);
-        for (int64_t i = 0; i < st->count; i++) dl[(size_t) i] = &chunks[plan.order[(size_t) (st->first + i)]];
-        st->rc = blk ? mrp_chunk_block_create(sc, st->count, dl.data(), st->dch.data(), blk) : mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
-        /* (not waited for: the chunks carry the event that ends the upload, the first device work that reads one waits) */
-        if (st->rc != MRP_OK) st->err = mrp_last_error();
-        if (timing) fprintf(stderr, "  [%7.1f] queue lane %d: batch %lld (%lld chunks) staged in %.1f ms\n", since(), w, (long long) b, (long long) st->count,
-                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count());
-    };
     auto drop = [&](Staged *st) {
         for (auto *c : st->dch) if (c) mrp_chunk_destroy(c);
         st->dch.clear();
+        st->batch = -1;
     };
-    auto work = [&](int w) {
-        auto fail = [&](int rc, const std::string &msg) { errs[(size_t) w] = msg; int expect = MRP_OK; status.compare_exchange_strong(expect, rc); };
+    auto staged_of = [&](int w, int64_t b) -> Staged * {
+        Lane &L = lane_state[(size_t) w];
+        return L.st[0].batch == b ? &L.st[0] : (L.st[1].batch == b ? &L.st[1] : nullptr);
+    };
+    LaneHooks hk;
+    hk.begin = [&](int w) {
         const int d = w / lanes; /* the device this lane works for */
-        if (bind) { /* before the first thread of this worker is created: they inherit it */
-            cpu_set_t set;
-            if (device_cpuset(devices[d], &set)) (void) pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
-        }
-        if (w % lanes >= active_lanes) return; /* (large caller-chosen batches: fewer calls of a device in flight) */
-        const int64_t first_batch = next.fetch_add(1);
-        if (first_batch >= n_batches) return; /* nothing for this lane: no contexts, no streams */
         int r = MRP_OK;
         if (!q->ctx[(size_t) w]) r = mrp_context_create(devices[d], &q->ctx[(size_t) w]);
         if (r == MRP_OK && !q->stage_ctx[(size_t) w]) r = mrp_context_create(devices[d], &q->stage_ctx[(size_t) w]);
@@ -330,62 +366,72 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
                 if (!q->pools[(size_t) d]) r = mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
             }
         }
-        if (r != MRP_OK) { fail(r, mrp_last_error()); return; }
+        if (r != MRP_OK) { errs[(size_t) w] = mrp_last_error(); return r; }
         if (lanes > 1) (void) mrp_context_set_grouped(q->ctx[(size_t) w], 1); /* the lanes of a device are concurrent batches of it */
+        lane_state[(size_t) w].caller_pool = mrp_pool_current(); /* (lane 0 may run on the caller's thread: its pool comes back at the end) */
         mrp_pool_adopt(q->pools[(size_t) d]);
-        Staged cur;
-        int parity = 0;
         /* the lanes of a device share it: a call of a long queue runs 8 / lanes concurrent batches, the one call of a short
          * queue as many as its size asks for */
         (void) mrp_context_set_phase_groups(q->ctx[(size_t) w], n_batches > (int64_t) n_devices ? std::max(1, 8 / active_lanes) : 0);
-        stage(w, first_batch, parity, &cur);
-        while (cur.batch >= 0) {
-            if (cur.rc != MRP_OK) { fail(cur.rc, cur.err); drop(&cur); break; }
-            if (status.load() != MRP_OK) { drop(&cur); break; }
-            auto t0 = std::chrono::steady_clock::now();
-            /* the next batch of this worker is uploaded while the current one is phased (schedule(dynamic,1), one batch ahead) */
-            Staged nxt;
-            std::thread stager;
-            const int64_t nb = next.fetch_add(1);
-            parity ^= 1;
-            if (nb < n_batches) stager = std::thread([&, nb, parity] { mrp_pool_adopt(q->pools[(size_t) d]); stage(w, nb, parity, &nxt); });
-            const int64_t count = cur.count;
-            std::vector<const mrp_chunk *> cch((size_t) count);
-            std::vector<const mrp_read *> rd((size_t) count);
-            std::vector<int64_t> nr((size_t) count);
-            std::vector<mrp_phase_result *> res((size_t) count, nullptr);
-            for (int64_t i = 0; i < count; i++) {
-                const mrp_chunk_desc &c = chunks[plan.order[(size_t) (cur.first + i)]];
-                cch[(size_t) i] = cur.dch[(size_t) i]; rd[(size_t) i] = c.reads; nr[(size_t) i] = c.n_reads;
-            }
-            mrp_phase_many_stats ps{};
-            r = mrp_phase_reads_many(q->ctx[(size_t) w], count, cch.data(), rd.data(), nr.data(), params, res.data(), &ps);
-            std::string msg = r == MRP_OK ? std::string() : std::string(mrp_last_error());
-            for (int64_t i = 0; i < count; i++) {
-                const int64_t chunk = plan.order[(size_t) (cur.first + i)];
-                if (r == MRP_OK) { out[chunk] = res[(size_t) i]; per[(size_t) w].units += cost[(size_t) chunk]; }
-            }
-            if (r == MRP_OK) { per[(size_t) w].chunks += count; per[(size_t) w].fallback += ps.resident ? ps.fallback_chunks : count; }
-            auto t1 = std::chrono::steady_clock::now();
-            if (timing) fprintf(stderr, "  [%7.1f] queue lane %d: batch %lld phased in %.1f ms\n", since(), w, (long long) cur.batch, std::chrono::duration<double, std::milli>(t1 - t0).count());
-            if (stager.joinable()) stager.join();
-            per[(size_t) w].stage_wait_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
-            drop(&cur);
-            if (timing) fprintf(stderr, "  [%7.1f] queue lane %d: chunks dropped\n", since(), w);
-            per[(size_t) w].busy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-            if (r != MRP_OK) { fail(r, msg); drop(&nxt); break; }
-            cur = std::move(nxt);
-        }
-        mrp_pool_adopt(nullptr);
+        return (int) MRP_OK;
     };
-    {
-        std::vector<std::thread> th;
-        for (int w = 1; w < n_workers; w++) th.emplace_back(work, w);
-        if (bind) { std::thread t0(work, 0); t0.join(); } /* (the caller's own affinity is left alone) */
-        else work(0);
-        for (auto &t : th) t.join();
-    }
-    const int rc = status.load();
+    hk.prefetch = [&](int w, int64_t b) { /* (the first batch on the lane's thread, the later ones on a thread beside the call) */
+        const auto ts0 = std::chrono::steady_clock::now();
+        const int d = w / lanes;
+        mrp_pool_adopt(q->pools[(size_t) d]);
+        Lane &L = lane_state[(size_t) w];
+        const int parity = L.n_staged++ & 1;
+        Staged *st = &L.st[parity];
+        st->batch = b; st->first = plan.batch_off[(size_t) b]; st->count = plan.batch_off[(size_t) b + 1] - st->first;
+        st->dch.assign((size_t) st->count, nullptr);
+        mrp_context *sc = q->stage_ctx[(size_t) w];
+        sc->pool.reclaim(); /* the block of the batch before last was emptied after its call returned */
+        mrp_chunk_block *&blk = q->blocks[(size_t) w * 2 + (size_t) parity];
+        if (!blk) blk = new (std::nothrow) mrp_chunk_block();
+        std::vector<const mrp_chunk_desc *> dl((size_t) st->count);
+        for (int64_t i = 0; i < st->count; i++) dl[(size_t) i] = &chunks[plan.order[(size_t) (st->first + i)]];
+        const int rc = blk ? mrp_chunk_block_create(sc, st->count, dl.data(), st->dch.data(), blk) : mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
+        if (rc != MRP_OK) errs[(size_t) w] = mrp_last_error();
+        if (timing) fprintf(stderr, "  [%7.1f] queue lane %d: batch %lld (%lld chunks) staged in %.1f ms\n", since(), w, (long long) b, (long long) st->count,
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count());
+        return rc;
+    };
+    hk.discard = [&](int w, int64_t b) { if (Staged *st = staged_of(w, b)) drop(st); };
+    hk.phase = [&](int w, int64_t b) {
+        Staged *cur = staged_of(w, b);
+        if (!cur) { errs[(size_t) w] = "work queue: batch was not staged"; return (int) MRP_ERR_ARG; }
+        auto t0 = std::chrono::steady_clock::now();
+        const int64_t count = cur->count;
+        std::vector<const mrp_chunk *> cch((size_t) count);
+        std::vector<const mrp_read *> rd((size_t) count);
+        std::vector<int64_t> nr((size_t) count);
+        std::vector<mrp_phase_result *> res((size_t) count, nullptr);
+        for (int64_t i = 0; i < count; i++) {
+            const mrp_chunk_desc &c = chunks[plan.order[(size_t) (cur->first + i)]];
+            cch[(size_t) i] = cur->dch[(size_t) i]; rd[(size_t) i] = c.reads; nr[(size_t) i] = c.n_reads;
+        }
+        mrp_phase_many_stats ps{};
+        const int r = mrp_phase_reads_many(q->ctx[(size_t) w], count, cch.data(), rd.data(), nr.data(), params, res.data(), &ps);
+        if (r != MRP_OK) errs[(size_t) w] = mrp_last_error();
+        for (int64_t i = 0; i < count; i++) {
+            const int64_t chunk = plan.order[(size_t) (cur->first + i)];
+            if (r == MRP_OK) { out[chunk] = res[(size_t) i]; per[(size_t) w].units += cost[(size_t) chunk]; }
+        }
+        if (r == MRP_OK) { per[(size_t) w].chunks += count; per[(size_t) w].fallback += ps.resident ? ps.fallback_chunks : count; }
+        if (timing) fprintf(stderr, "  [%7.1f] queue lane %d: batch %lld phased in %.1f ms\n", since(), w, (long long) b,
+                            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+        drop(cur);
+        per[(size_t) w].busy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        return r;
+    };
+    hk.end = [&](int w) { mrp_pool_adopt(lane_state[(size_t) w].caller_pool); };
+    /* before the first thread of a worker is created (they inherit it): the CPUs next to its device */
+    std::function<void(int)> on_start;
+    if (bind) on_start = [&](int w) {
+        cpu_set_t set;
+        if (device_cpuset(devices[w / lanes], &set)) (void) pthread_setaffinity_np(pthread_self(), sizeof(set), &set);
+    };
+    int rc = run_lanes(n_devices, lanes, active_lanes, n_batches, hk, /* the caller's own affinity is left alone */ bind, on_start);
     if (timing) fprintf(stderr, "  [%7.1f] queue: workers joined\n", since());
     if (stats)
         for (int w = 0; w < n_workers; w++) {

@@ -2238,6 +2238,64 @@ static void *hashing_main(void *p) {
     }
 }
 
+static int phase_many_once(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *const *chunks, const mrp_read *const *reads,
+                           const int64_t *n_reads, const mrp_params *params, mrp_phase_result **out, mrp_phase_many_stats *stats);
+
+static void stats_add(mrp_phase_many_stats *stats, const mrp_phase_many_stats *st, int first) {
+    if (first) { *stats = *st; return; }
+    stats->resident = stats->resident && st->resident; stats->fallback_chunks += st->fallback_chunks;
+    if (st->levels > stats->levels) stats->levels = st->levels;
+    stats->hmms += st->hmms; stats->columns += st->columns; stats->cells += st->cells; stats->merge_cells += st->merge_cells;
+    stats->device_ms += st->device_ms; stats->cross_ms += st->cross_ms; stats->sweep_ms += st->sweep_ms; stats->prune_ms += st->prune_ms;
+    if (st->note[0] && !stats->note[0]) memcpy(stats->note, st->note, sizeof(stats->note));
+}
+
+/* A call of at most `cap` (read, site) units at a time: what a call keeps on the device grows with its units (measured 214 GB
+ * for 1 152 chunks of 60 000 units, ~3.1 KB per unit: the cells of the widest merge level of every concurrent batch), so a call
+ * beyond the device's budget runs as consecutive slices that fit.  The estimate is only that: when the driver still refuses
+ * an allocation (memory held by another process, a pool grown by best-fit reuse) the slice is redone as two halves after
+ * every cache of the context has been given back -- down to single chunks -- instead of failing the call. */
+static int phase_many_capped(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *const *chunks, const mrp_read *const *reads,
+                             const int64_t *n_reads, const mrp_params *params, mrp_phase_result **out, mrp_phase_many_stats *stats,
+                             int64_t cap, int depth) {
+    int64_t total = 0;
+    for (int64_t c = 0; c < n_chunks; c++)
+        for (int64_t r = 0; r < n_reads[c]; r++) total += reads[c][r].length;
+    if (total <= cap || n_chunks <= 1) {
+        const uint64_t oom0 = mrp_context_oom_events(ctx);
+        int rc = phase_many_once(ctx, n_chunks, chunks, reads, n_reads, params, out, stats);
+        if (rc == MRP_ERR_HIP && n_chunks > 1 && depth < 8 && mrp_context_oom_events(ctx) != oom0) {
+            static int warned;
+            if (!__atomic_exchange_n(&warned, 1, __ATOMIC_RELAXED) && !getenv("MRP_QUIET"))
+                fprintf(stderr, "margin_rphmm: the device refused memory for a call of %lld chunks (%lld units): redone in two halves\n",
+                        (long long) n_chunks, (long long) total);
+            for (int64_t c = 0; c < n_chunks; c++) { mrp_phase_result_destroy(out[c]); out[c] = NULL; }
+            mrp_context_trim(ctx);
+            return phase_many_capped(ctx, n_chunks, chunks, reads, n_reads, params, out, stats, total / 2 + 1, depth + 1);
+        }
+        return rc;
+    }
+    int rc = MRP_OK;
+    int64_t c0 = 0;
+    if (stats) memset(stats, 0, sizeof(*stats));
+    while (c0 < n_chunks && rc == MRP_OK) {
+        int64_t c1 = c0, u = 0;
+        while (c1 < n_chunks) {
+            int64_t uc = 0;
+            for (int64_t r = 0; r < n_reads[c1]; r++) uc += reads[c1][r].length;
+            if (c1 > c0 && u + uc > cap) break;
+            u += uc; c1++;
+        }
+        mrp_phase_many_stats st;
+        rc = phase_many_capped(ctx, c1 - c0, chunks + c0, reads + c0, n_reads + c0, params, out + c0, &st, cap, depth);
+        if (stats && rc == MRP_OK) stats_add(stats, &st, c0 == 0);
+        c0 = c1;
+    }
+    if (rc != MRP_OK)
+        for (int64_t c = 0; c < n_chunks; c++) { mrp_phase_result_destroy(out[c]); out[c] = NULL; }
+    return rc;
+}
+
 int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *const *chunks, const mrp_read *const *reads,
                          const int64_t *n_reads, const mrp_params *params, mrp_phase_result **out,
                          mrp_phase_many_stats *stats) {
@@ -2246,47 +2304,19 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
     if (params->reserved != 0) return mrp_set_error(MRP_ERR_ARG, "mrp_params.reserved must be 0");
     if (stats) memset(stats, 0, sizeof(*stats));
     for (int64_t c = 0; c < n_chunks; c++) out[c] = NULL;
-    {
-        /* What a call keeps on the device grows with its (read, site) units: measured 214 GB for 1 152 chunks of 60 000 units
-         * (~3.1 KB per unit: the cells of the widest merge level of every concurrent batch).  A call that would not fit the
-         * device's budget runs as consecutive slices that do; MRP_CALL_UNITS overrides the slice size (tests). */
-        const int64_t budget = mrp_context_device_budget(ctx);
-        int64_t cap = budget > 0 ? budget / 3400 : (int64_t) 7e7;
-        const char *ce = getenv("MRP_CALL_UNITS");
-        if (ce && atoll(ce) > 0) cap = atoll(ce);
-        int64_t total = 0;
-        for (int64_t c = 0; c < n_chunks; c++)
-            for (int64_t r = 0; r < n_reads[c]; r++) total += reads[c][r].length;
-        if (total > cap && n_chunks > 1) {
-            int rc = MRP_OK;
-            int64_t c0 = 0;
-            while (c0 < n_chunks && rc == MRP_OK) {
-                int64_t c1 = c0, u = 0;
-                while (c1 < n_chunks) {
-                    int64_t uc = 0;
-                    for (int64_t r = 0; r < n_reads[c1]; r++) uc += reads[c1][r].length;
-                    if (c1 > c0 && u + uc > cap) break;
-                    u += uc; c1++;
-                }
-                mrp_phase_many_stats st;
-                rc = mrp_phase_reads_many(ctx, c1 - c0, chunks + c0, reads + c0, n_reads + c0, params, out + c0, &st);
-                if (stats && rc == MRP_OK) {
-                    if (c0 == 0) *stats = st;
-                    else {
-                        stats->resident = stats->resident && st.resident; stats->fallback_chunks += st.fallback_chunks;
-                        if (st.levels > stats->levels) stats->levels = st.levels;
-                        stats->hmms += st.hmms; stats->columns += st.columns; stats->cells += st.cells; stats->merge_cells += st.merge_cells;
-                        stats->device_ms += st.device_ms; stats->cross_ms += st.cross_ms; stats->sweep_ms += st.sweep_ms; stats->prune_ms += st.prune_ms;
-                        if (st.note[0] && !stats->note[0]) memcpy(stats->note, st.note, sizeof(stats->note));
-                    }
-                }
-                c0 = c1;
-            }
-            if (rc != MRP_OK)
-                for (int64_t c = 0; c < n_chunks; c++) { mrp_phase_result_destroy(out[c]); out[c] = NULL; }
-            return rc;
-        }
-    }
+    /* the slice size from the device's budget (free memory when the process's first pool asked, mrp_internal.h); MRP_CALL_UNITS
+     * overrides it (tests) */
+    const int64_t budget = mrp_context_device_budget(ctx);
+    int64_t cap = budget > 0 ? budget / 3400 : (int64_t) 7e7;
+    const char *ce = getenv("MRP_CALL_UNITS");
+    if (ce && atoll(ce) > 0) cap = atoll(ce);
+    return phase_many_capped(ctx, n_chunks, chunks, reads, n_reads, params, out, stats, cap, 0);
+}
+
+static int phase_many_once(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *const *chunks, const mrp_read *const *reads,
+                           const int64_t *n_reads, const mrp_params *params, mrp_phase_result **out, mrp_phase_many_stats *stats) {
+    if (stats) memset(stats, 0, sizeof(*stats));
+    for (int64_t c = 0; c < n_chunks; c++) out[c] = NULL;
     /* the levels of a batch alternate host work (structure, descriptors) and device work; two interleaved halves of the
      * chunks, each with its own context and host thread, keep both busy */
     int G = mrp_context_phase_groups(ctx); /* mrp_context_set_phase_groups; 0 (default): by batch size */

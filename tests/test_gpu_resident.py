@@ -543,3 +543,32 @@ print(json.dumps(out[0][:4]))
         ref = oc.phase(pd)
         oc.close()
         assert small_budget[s] == [[int(x) for x in np.asarray(ref[k]).tolist()] for k in ("hap1", "hap2", "genotype", "support1", "support2")] + [ref["reads1"], ref["reads2"]]
+
+
+def test_a_refused_device_allocation_redoes_the_call_in_two_halves(orc):
+    """the pools' budget is an estimate (free memory at first use, ~3.4 KB per unit); when the driver refuses
+    an allocation all the same, mrp_phase_reads_many gives its caches back and redoes the call as two slices instead of failing.
+    The refusal is injected (mrp_context_set_test_hooks bit 2: the next allocation of at least 1 MB is refused once); the
+    results are those of the undisturbed call and of the oracle."""
+    pd = _params()
+    params = capi.Params.from_reference_names(pd)
+    chunks = [synth.make_ont_chunk(seed=900 + s, region_bp=150_000, n_sites=int(110 + 9 * s), coverage=22.0 + s) for s in range(6)]
+    with capi.Context(0) as ctx:
+        ctx.set_phase_groups(1)
+        dch = [capi.DeviceChunk.from_chunk(ctx, c) for c in chunks]
+        ref, st0 = capi.phase_reads_many(ctx, dch, chunks, params)
+        assert st0.resident == 1
+        ctx.set_test_hooks(4)
+        got, st = capi.phase_reads_many(ctx, dch, chunks, params)
+        assert st.resident == 1 and st.hmms == st0.hmms and st.cells == st0.cells  # (two slices: the same hmms, summed)
+        for a, b in zip(ref, got):
+            for k in PHASE_KEYS:
+                assert (np.asarray(a[k]) == np.asarray(b[k])).all(), k
+            assert a["reads1"] == b["reads1"] and a["reads2"] == b["reads2"]
+        oc = orc.OracleChunk(chunks[2])
+        o = oc.phase(pd)
+        oc.close()
+        for k in ("hap1", "hap2", "genotype", "support1", "support2"):
+            assert (np.asarray(got[2][k]) == np.asarray(o[k])).all(), k
+        for d in dch:
+            d.close()

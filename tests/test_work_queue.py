@@ -18,13 +18,16 @@ def test_queue_order_largest_first_ties_in_input_order():
     assert len(empty) == 0
 
 
-@pytest.mark.parametrize("n_workers,per_batch", [(1, 1), (2, 1), (3, 2), (8, 1), (16, 4)])
-def test_queue_dry_run_is_complete_ordered_and_dynamic(n_workers, per_batch):
+@pytest.mark.parametrize("n_devices,lanes,per_batch", [(1, 1, 1), (2, 1, 1), (3, 1, 2), (2, 4, 1), (4, 4, 4)])
+def test_queue_dry_run_is_complete_ordered_and_dynamic(n_devices, lanes, per_batch):
     """Every chunk is taken exactly once; a worker takes its batches in the queue's order (largest first); the schedule is
-    dynamic: with one very expensive batch, the worker that holds it takes no other while the rest drain the queue."""
+    dynamic: with one very expensive batch, the worker that holds it takes at most the batch it had already reserved
+    (a lane takes its next batch when it starts on the current one, as the real worker does to upload it meanwhile) while the
+    rest drain the queue."""
+    n_workers = n_devices * lanes
     rng = np.random.default_rng(n_workers * 10 + per_batch)
     cost = rng.integers(1, 50, size=97).astype(np.int64)
-    worker, seq = capi.queue_dry_run(n_workers, cost, per_batch, usec_per_cost=2.0)
+    worker, seq = capi.queue_dry_run(n_devices, lanes, cost, per_batch, usec_per_cost=2.0)
     assert (worker >= 0).all() and (worker < n_workers).all()
     assert sorted(seq.tolist()) == list(range(len(cost)))
     order, batch = capi.queue_plan(cost, per_batch)
@@ -37,9 +40,9 @@ def test_queue_dry_run_is_complete_ordered_and_dynamic(n_workers, per_batch):
     if n_workers >= 2:
         big = cost.copy()
         big[13] = 40_000  # 80 ms at 2 us per unit: the others are through long before
-        worker, _ = capi.queue_dry_run(n_workers, big, 1, usec_per_cost=2.0)
+        worker, _ = capi.queue_dry_run(n_devices, lanes, big, 1, usec_per_cost=2.0)
         holder = worker[13]
-        assert (worker == holder).sum() <= 2  # the expensive chunk heads the queue; its worker gets at most the wake-up race's second
+        assert (worker == holder).sum() <= 2  # the expensive chunk heads the queue; its worker holds only the one batch it took ahead
 
 
 def test_whole_genome_queue_on_eight_devices_is_balanced():
@@ -53,12 +56,14 @@ def test_whole_genome_queue_on_eight_devices_is_balanced():
     cost = (sites * depth * 2.0).astype(np.int64)                  # reads x het sites each spans (~2 x depth x sites / ...): units
     lanes, devices = 4, 8
     usec = 2.0e5 * devices * lanes / float(cost.sum())             # about 0.2 s of stand-in work per pulling thread
-    worker, seq = capi.queue_dry_run(devices * lanes, cost, 0, usec_per_cost=usec)
+    worker, seq = capi.queue_dry_run(devices, lanes, cost, 0, usec_per_cost=usec)
     assert sorted(seq.tolist()) == list(range(n))
     per_device = np.bincount(worker // lanes, weights=cost.astype(np.float64), minlength=devices)
     assert (per_device > 0).all()
     imbalance = per_device.max() / per_device.mean() - 1.0
     assert imbalance <= 0.02, (imbalance, per_device.tolist())
+    # this queue (2.4e8 units) is below 640 yardstick chunks per device: ONE striped batch per device, one lane each
+    assert len(set(worker.tolist())) == devices and (worker % lanes == 0).all()
     # one device: the batches follow the queue's order and are cut by UNITS (192 chunks of 60 000 units = 1.152e7 per batch: ~1 480 of
     # these small chunks), not by chunk count
     order, batch = capi.queue_plan(cost, 0)
@@ -70,12 +75,47 @@ def test_whole_genome_queue_on_eight_devices_is_balanced():
     assert np.bincount(batch).min() > 800  # (the first batches hold the most expensive chunks: fewer of them)
 
 
+def test_long_queue_on_eight_devices_takes_the_guided_schedule_and_stays_balanced():
+    """More than 640 yardstick chunks (60 000 units) per device: the multi-device branch of the plan -- batches of at most 192
+    yardstick chunks, shrinking towards the end (what is left / twice the lanes, at least a quarter batch: a lane holds the batch
+    it phases and the one it took ahead) -- handed out dynamically to 8 devices x 4 lanes.  The stand-in calls sleep in
+    proportion to their units; every lane of every device takes work and the devices end within 4 % of the mean cost."""
+    rng = np.random.default_rng(8)
+    n = 90_000
+    sites = np.clip(rng.normal(130, 25, size=n), 20, 400)
+    depth = np.clip(rng.normal(30, 6, size=n), 5, 64)
+    cost = (sites * depth * 2.0).astype(np.int64)
+    lanes, devices = 4, 8
+    assert cost.sum() > devices * 640 * 60_000
+    usec = 4.0e5 * devices * lanes / float(cost.sum())  # about 0.4 s of stand-in work per lane
+    worker, seq = capi.queue_dry_run(devices, lanes, cost, 0, usec_per_cost=usec)
+    assert sorted(seq.tolist()) == list(range(n)) and (worker >= 0).all()
+    assert len(set(worker.tolist())) == devices * lanes
+    per_device = np.bincount(worker // lanes, weights=cost.astype(np.float64), minlength=devices)
+    imbalance = per_device.max() / per_device.mean() - 1.0
+    assert imbalance <= 0.04, (imbalance, per_device.tolist())
+    # the first batches are fixed: batch b of the plan (the most expensive chunks) starts on device b % 8, lane b // 8
+    order = np.argsort(-cost, kind="stable")
+    assert [int(worker[order[0]]), int(worker[order[-1]] >= 0)] == [0, 1]
+    first_of_worker = {int(w): int(np.flatnonzero(worker[order] == w)[0]) for w in set(worker.tolist())}
+    starts = sorted(first_of_worker.items(), key=lambda kv: kv[1])
+    assert [w for w, _ in starts[:devices]] == [d * lanes for d in range(devices)]
+    # no batch above 192 yardstick chunks; the tail is made of quarter batches, not dust: a worker's share of a run of the cost order
+    full = 192 * 60_000
+    wo = worker[order]
+    cuts = np.flatnonzero(np.diff(wo) != 0) + 1
+    sizes = np.array([c.sum() for c in np.split(cost[order].astype(np.float64), cuts)])
+    assert sizes.max() <= 2.04 * full   # (two consecutive batches of one lane show as one run)
+    assert np.sort(sizes)[1] >= 0.2 * full and np.median(sizes[-32:]) <= 0.3 * full
+
+
 def test_queue_rejects_bad_arguments():
     L = capi.load()
     cost = np.ones(4, dtype=np.int64)
     w = np.zeros(4, dtype=np.int32)
-    assert L.mrp_queue_dry_run(0, 4, cost.ctypes.data, 1, 0.0, w.ctypes.data, None) == capi.MRP_ERR_ARG
-    assert L.mrp_queue_dry_run(4 * capi.MAX_QUEUE_DEVICES + 1, 4, cost.ctypes.data, 1, 0.0, w.ctypes.data, None) == capi.MRP_ERR_ARG
+    assert L.mrp_queue_dry_run(0, 1, 4, cost.ctypes.data, 1, 0.0, w.ctypes.data, None) == capi.MRP_ERR_ARG
+    assert L.mrp_queue_dry_run(capi.MAX_QUEUE_DEVICES + 1, 1, 4, cost.ctypes.data, 1, 0.0, w.ctypes.data, None) == capi.MRP_ERR_ARG
+    assert L.mrp_queue_dry_run(1, 5, 4, cost.ctypes.data, 1, 0.0, w.ctypes.data, None) == capi.MRP_ERR_ARG
     # without a device the real queue fails loudly: no CPU fallback
     if L.mrp_device_count() == 0:
         import ctypes as C
