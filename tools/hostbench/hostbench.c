@@ -14,6 +14,8 @@ mrp_context *mrp_chunk_context(const mrp_chunk *chunk) { (void) chunk; return (m
 int mrp_context_device(const mrp_context *ctx) { (void) ctx; return 0; }
 int mrp_context_set_grouped(mrp_context *ctx, int grouped) { (void) ctx; (void) grouped; return 0; }
 int64_t mrp_context_device_budget(mrp_context *ctx) { (void) ctx; return 0; }
+uint64_t mrp_context_oom_events(mrp_context *ctx) { (void) ctx; return 0; }
+int mrp_context_trim(mrp_context *ctx) { (void) ctx; return 0; }
 void mrp_context_pool_bytes(mrp_context *ctx, int64_t *cached, int64_t *device_held) { (void) ctx; *cached = 0; *device_held = 0; }
 mrp_context *mrp_context_sibling(mrp_context *ctx, int i) { (void) i; return ctx; }
 int mrp_set_error(int code, const char *fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap); return code; }
