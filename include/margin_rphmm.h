@@ -77,7 +77,8 @@ int mrp_context_set_phase_groups(mrp_context *ctx, int groups);
  * chunk to the hashing path.  Bit 1: the resident merge levels run the separate cross product and emission kernels -- the
  * path the final level and the ancestor model take -- instead of the one-pass kernel, for A/B parity and timing.  Bit 2 (one shot:
  * cleared when it fires): the next device allocation of at least 1 MB on the context's device is refused as out of memory, which
- * a resident call must survive by redoing itself in two halves. */
+ * a resident call must survive by redoing itself in two halves.  Bit 3: the prune kernel's general chain (one entry per cell) instead
+ * of the chain on complement pairs that includeInvertedPartitions with even column limits selects, for A/B parity. */
 int mrp_context_set_test_hooks(mrp_context *ctx, int hooks);
 /* size of the host worker pool (structure of the merge levels, descriptors, classification of alignment pairs): the
  * process-wide pool of contexts used directly, and EACH worker's own pool of a work queue (mrp_queue_*: one pool per device).

@@ -770,9 +770,9 @@ int mrp_context_set_phase_groups(mrp_context *ctx, int groups) {
 }
 int mrp_context_phase_groups(const mrp_context *ctx) { return ctx->phase_groups; }
 int mrp_context_set_test_hooks(mrp_context *ctx, int hooks) {
-    if (!ctx || hooks < 0 || hooks > 7) return fail(MRP_ERR_ARG, "mrp_context_set_test_hooks: bad arguments");
+    if (!ctx || hooks < 0 || hooks > 15) return fail(MRP_ERR_ARG, "mrp_context_set_test_hooks: bad arguments");
     if ((hooks & 4) && ctx->pool.device >= 0) DevPoolRegistry::get().inject_oom[ctx->pool.device].store(1);
-    hooks &= 3;
+    hooks &= ~4;
     ctx->test_hooks = hooks;
     for (mrp_context *s_ : ctx->siblings) s_->test_hooks = hooks;
     return MRP_OK;

@@ -167,6 +167,10 @@ int mrp_engine_create(mrp_context *ctx, const mrp_params *params, mrp_engine **o
     pp.min_p = (int32_t) params->min_partitions_in_a_column;
     pp.max_p = (int32_t) std::min<int64_t>(params->max_partitions_in_a_column, 1 << 20);
     if (pp.max_p < 0) pp.max_p = 0;
+    /* the prune chain on complement pairs (mrp_prune_kernel<..., PAIRS>): every cell has its twin and the limits never cut
+     * a pair.  MRP_PRUNE_PAIRS=0 (development) and test hook bit 3 keep the general chain for A/B parity. */
+    pp.pairs = params->include_inverted_partitions && (pp.min_p & 1) == 0 && (pp.max_p & 1) == 0 ? 1 : 0;
+    if (const char *pe = getenv("MRP_PRUNE_PAIRS")) { if (pe[0] == '0') pp.pairs = 0; }
     /* posterior = min(1, exp(s)), s = f + b - total an integer <= 0 (column.c:177-193).  Ranking by the
      * integer is ranking by the double as long as consecutive integers give distinct doubles; from the
      * underflow point of exp down every posterior is 0.0 and they all tie: that is the last bin. */
@@ -472,6 +476,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         pp.max_cells = std::max(pp.max_cells, x[i].bound_max_cells);
         pp.max_merge = std::max(pp.max_merge, x[i].bound_max_merge);
     }
+    if (ctx->test_hooks & 8) pp.pairs = 0; /* test hook: the general prune chain, for A/B parity with the chain on complement pairs */
     pp.pad = (ctx->test_hooks & 1) && e->stats.levels + (e->running ? 1 : 0) == 1 ? 1 : 0; /* test hook, see mrp_context_set_test_hooks */
 
     tm[tmi++] = eng_now();

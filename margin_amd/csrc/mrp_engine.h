@@ -158,7 +158,9 @@ struct PruneParams {
     int32_t n_bins;         /* posterior keys: bin = min(total - f - b, n_bins - 1); exp(-(n_bins - 1)) == 0 */
     int32_t thr_bin;        /* bins <= thr_bin have posterior >= minPosteriorProbabilityForPartition */
     int32_t max_cells, max_merge; /* largest column / merge column of the level (LDS sizing) */
-    int32_t pad;
+    int32_t pad;            /* fault injection of the tests (mrp_context_set_test_hooks bit 0) */
+    int32_t pairs;          /* includeInvertedPartitions with even min_p / max_p: the prune chain runs on complement pairs */
+    int32_t pad2;
 };
 
 struct PruneScratch {

@@ -1148,7 +1148,7 @@ static __device__ __forceinline__ __amdgpu_buffer_rsrc_t prune_rsrc(const void *
 /* T threads; the bin-streaming waves (all but the first four) form NGRP groups (2: alternating over the columns, a column's f and
  * b sit in a group's registers for two column times; 1: one group, requested one column ahead) and hold CPT loads of VEC cells
  * per lane and array. */
-template <int T, int CPT, int NGRP, int VEC>
+template <int T, int CPT, int NGRP, int VEC, bool PAIRS>
 __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
                                                       PruneParams p, PruneScratch sc) {
     constexpr int W = T / WAVE;
@@ -1213,6 +1213,45 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
          * Stage 1 (wave 1, column kk from selection buffer kk & 1): stable sort of the kept cells, kept lists to HBM, the
          * posterior bins of the merge cells they lead to; leaves next | prev and that bin per sorted kept cell in LDS. */
         auto lists_stage1 = [&](int kk, int64_t mcell_off) {
+            if constexpr (PAIRS) {
+                /* Complement pairs (see the chain wave): the selection holds UNITS, at most 64; a unit's two cells tie and are
+                 * neighbours in list order, so the sorted units, each expanded to (cell 2u, cell 2u + 1), are the sorted cells */
+                const int b = kk & 1;
+                const uint32_t *skey = sel + b * 2 * PRUNE_SP, *snp_in = skey + PRUNE_SP;
+                uint32_t *snp = s1 + b * 2 * PRUNE_SP, *sbin = snp + PRUNE_SP;
+                const int n = (int) sh[32 + b];
+                const uint32_t fl = sh[44 + b]; /* bit 0: the column's cells come in pairs, 1: the merge cells after it, 2: those before it */
+                const uint32_t o_pm = (fl >> 1) & 1u, i_pm = (fl >> 2) & 1u;
+                const int64_t lcol = h.col0 + kk;
+                const bool has_merge = kk + 1 < K;
+                uint32_t key[1];
+                int32_t pre_mf = 0, pre_mb = 0;
+                key[0] = lane < n ? (skey[lane] << 7) | (uint32_t) lane : 0xFFFFFFFFu; /* bin (10) | unit (14) | slot (7) */
+                if (has_merge && lane < n) {
+                    const uint32_t m = snp_in[lane] & 0xFFFFu;
+                    pre_mf = d.merge_f32[mcell_off + m];
+                    pre_mb = d.merge_b32[mcell_off + m];
+                }
+                wave_bitonic_sort_n<1>(key, lane);
+                if (has_merge) {
+                    if (lane < n) um[lane] = (uint32_t) posterior_bin(pre_mf, pre_mb, total, nb, &errbits);
+                    wave_lds_fence();
+                }
+                if (lane < n) {
+                    const uint32_t src = key[0] & 0x7Fu, u = (key[0] >> 7) & 0x3FFFu, np_ = snp_in[src];
+                    if (fl & 1u) {
+                        *reinterpret_cast<uint32_t *>(sc.kept + lcol * S + 2 * lane) = (2u * u) | ((2u * u + 1u) << 16);
+                        *reinterpret_cast<uint2 *>(sc.kept_np + lcol * S + 2 * lane) = make_uint2(np_, np_ ^ o_pm ^ (i_pm << 16));
+                    } else { /* a column of one cell */
+                        sc.kept[lcol * S + lane] = (uint16_t) u;
+                        sc.kept_np[lcol * S + lane] = np_;
+                    }
+                    snp[lane] = np_;
+                    if (has_merge) sbin[lane] = um[src];
+                }
+                if (lane == 0) { sc.n_kept[lcol] = (fl & 1u) ? 2 * n : n; sh[36 + b] = (uint32_t) n; sh[46 + b] = fl; }
+                return;
+            }
             const int b = kk & 1;
             const uint32_t *skey = sel + b * 2 * PRUNE_SP, *snp_in = skey + PRUNE_SP;
             uint32_t *snp = s1 + b * 2 * PRUNE_SP, *sbin = snp + PRUNE_SP;
@@ -1260,6 +1299,59 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
         /* Stage 2 (wave 2, one column later): distinct next merge cells in order of first use, stable sort by posterior,
          * kept merge list to HBM. */
         auto lists_stage2 = [&](int kk) {
+            if constexpr (PAIRS) {
+                const int b = kk & 1;
+                const uint32_t *snp = s1 + b * 2 * PRUNE_SP, *sbin = snp + PRUNE_SP;
+                const int n = (int) sh[36 + b];
+                const uint32_t o_pm = (sh[46 + b] >> 1) & 1u;
+                const int64_t lcol = h.col0 + kk;
+                int mn_out = 0;
+                if (kk + 1 < K) {
+                    /* distinct next merge UNITS in order of first use; the two merge cells of a unit enter the list in the order the
+                     * unit's first user reaches them: its even cell first (bit q of that cell's merge cell index), then its twin */
+                    for (int i = lane; i < 256; i += WAVE) { htab_key[i] = 0xFFFFFFFFu; htab_val[i] = 0xFFFFFFFFu; }
+                    wave_lds_fence();
+                    uint32_t my_mu = 0u, my_q = 0u;
+                    int slot = 0;
+                    if (lane < n) {
+                        const uint32_t mfull = snp[lane] & 0xFFFFu;
+                        my_mu = mfull >> o_pm; my_q = mfull & o_pm;
+                        int q = (int) ((my_mu * 2654435761u) >> 24);
+                        for (;;) {
+                            const uint32_t prev = atomicCAS(&htab_key[q], 0xFFFFFFFFu, my_mu);
+                            if (prev == 0xFFFFFFFFu || prev == my_mu) break;
+                            q = (q + 1) & 255;
+                        }
+                        slot = q;
+                        atomicMin(&htab_val[q], (uint32_t) lane);
+                    }
+                    wave_lds_fence();
+                    const bool first = lane < n && htab_val[slot] == (uint32_t) lane;
+                    const uint64_t f0 = __ballot(first);
+                    const int mnl = __popcll(f0);
+                    uint32_t mkey[1] = {0xFFFFFFFFu};
+                    bool pass_thr = false;
+                    if (first) {
+                        const int pos = (int) lanemask_lt_count(f0, lane);
+                        const int bin = (int) sbin[lane];
+                        pass_thr = bin <= p.thr_bin;
+                        mkey[0] = ((uint32_t) bin << 20) | ((uint32_t) pos << 14) | (my_mu << 1) | my_q;
+                    }
+                    const int gm = __popcll(__ballot(pass_thr));
+                    const int wm = o_pm ? 2 : 1;
+                    const int mn = kept_count(mnl * wm, gm * wm, p.min_p, p.max_p);
+                    if (mn != mnl * wm || (p.pad && hi_ == 0 && kk == 0)) errbits |= MRP_ENGINE_ERR_MERGE;
+                    wave_bitonic_sort_n<1>(mkey, lane);
+                    if (lane < mnl) {
+                        const uint32_t mu = (mkey[0] >> 1) & 0x1FFFu, q = mkey[0] & 1u;
+                        if (o_pm) *reinterpret_cast<uint32_t *>(sc.keptm + lcol * S + 2 * lane) = (2u * mu + q) | ((2u * mu + (q ^ 1u)) << 16);
+                        else sc.keptm[lcol * S + lane] = (uint16_t) mu;
+                    }
+                    mn_out = mnl * wm;
+                }
+                if (lane == 0) sc.n_keptm[lcol] = mn_out;
+                return;
+            }
             const int b = kk & 1;
             const uint32_t *snp = s1 + b * 2 * PRUNE_SP, *sbin = snp + PRUNE_SP;
             const int n = (int) sh[36 + b];
@@ -1340,6 +1432,323 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
             lds_barrier();
             ROLE_CLK_INIT();
             SEC_INIT();
+            if constexpr (PAIRS) {
+            /* ---- the chain on complement PAIRS (includeInvertedPartitions, even column limits) ----
+             * Every cell of a cross product column has its complement next to it (cells 2u, 2u + 1 = "unit" u; the order rule of
+             * cross_cell / pair_index), with the same cost, f, b and posterior, and the twin's merge cells are the twins of its
+             * merge cells.  A kept merge cell is kept with its twin, linked cells are linked with their twins, ties between twins
+             * fall in list order (2u before 2u + 1), and the limits are even, so the forward pass never separates a pair: the
+             * chain carries UNITS -- half the kept merge cells (one per lane), half the candidates, half the selection -- and waves
+             * 1 and 2 write both cells of every kept unit.  A unit is named by ANY of its two members where that is cheaper:
+             *   unit(x, y)   = (x >> 1) * Y + ((y ^ (x & xm)) >> sb)      x, y: indices on side A / B, Y: side B's count
+             *   parity(x, y) = (x & pa) | (y & sb)                         which member of its unit the pair (x, y) is
+             * with xm = both sides paired, sb = only side B paired, pa = side A paired (all wave-uniform).  A column or merge
+             * column with neither side paired has one self-complementary entry: a unit of one cell.  The cells linked to ONE
+             * member of a kept merge unit are one member of every linked unit, so the enumeration is that of the general
+             * kernel over half the entries; only behind a merge column of one cell both members turn up, and the odd ones are
+             * dropped. */
+            for (int k = 0; k < K; k++) {
+                SEC(7);
+                const int b = k & 1;
+                const uint32_t cd0 = sh[48 + 4 * b], cd1 = sh[49 + 4 * b];
+                uint32_t *skey = sel + b * 2 * PRUNE_SP, *snp = skey + PRUNE_SP;
+                const uint32_t *tA = tab + b * 2 * PRUNE_TAB * 128, *tB = tA + PRUNE_TAB * 128;
+                const uint32_t *cntA = tA, *startA = tA + 128, *listA = tA + 256, *nxA = tA + 384;
+                const uint32_t *cntB = tB, *startB = tB + 128, *listB = tB + 256, *nxB = tB + 384;
+                const uint16_t *bin_k = bins + b * cap_c;
+                uint32_t *hk = hist + b * nb_r;
+                uint32_t *kmn = kml + (b ^ 1) * PRUNE_SP; /* the kept merge units leading into column k + 1 */
+                const uint32_t cflags = cd1 & 0xFFu;
+                const uint32_t C2 = (cd0 & 0xFFFFu) > 128u ? 128u : (cd0 & 0xFFFFu), Mb = cd0 >> 16, Pb = cd1 >> 16;
+                const bool a_cp = (cd1 & 0x100u) != 0, b_cp = (cd1 & 0x200u) != 0;
+                const bool out_ap = (cflags & MRP_XF_OUT_A_PAIRED) != 0, out_bp = (cflags & MRP_XF_OUT_B_PAIRED) != 0;
+                const bool in_ap = (cflags & MRP_XF_IN_A_PAIRED) != 0, in_bp = (cflags & MRP_XF_IN_B_PAIRED) != 0;
+                const bool has_next = k + 1 < K;
+                const uint32_t c_xm = (a_cp && b_cp) ? 1u : 0u, c_sb = (!a_cp && b_cp) ? 1u : 0u, c_pa = a_cp ? 1u : 0u;
+                const uint32_t o_xm = (out_ap && out_bp) ? 1u : 0u, o_sb = (!out_ap && out_bp) ? 1u : 0u, o_pa = out_ap ? 1u : 0u;
+                const uint32_t o_pm = (out_ap || out_bp) ? 1u : 0u, i_pm = (in_ap || in_bp) ? 1u : 0u;
+                const uint32_t i_pa = in_ap ? 1u : 0u, i_sb = (!in_ap && in_bp) ? 1u : 0u;
+                const int w_c = (a_cp || b_cp) ? 2 : 1;  /* cells per unit of this column */
+                const bool filt = i_pm == 0u && w_c == 2;  /* behind a merge column of one cell: both members are enumerated */
+                const int nkm = (int) sh[40 + b];
+                /* this lane's kept merge unit: the parents' cells one of its members links, as list ranges.  An entry of the
+                 * list is unit | i << 14 | j << 21: the unit and the indices of that member on either side */
+                const bool has = lane < nkm;
+                const uint32_t ent = has ? kml[b * PRUNE_SP + lane] : 0u;
+                const uint32_t e_mu = ent & 0x3FFFu, e_i = (ent >> 14) & 127u, e_j = (ent >> 21) & 127u;
+                const uint32_t e_sa = startA[e_i], e_sb = startB[e_j];
+                const int e_na = has ? (int) cntA[e_i] : 0, e_nb = has ? (int) cntB[e_j] : 0;
+                const int tot = e_na * e_nb;
+                const int incl = wave_incl_scan(tot, lane);
+                const int L = __builtin_amdgcn_readlane(incl, WAVE - 1); /* pairs of parent cells enumerated */
+                const uint32_t off = (uint32_t) (incl - tot);
+                const uint32_t e_par = (e_i & i_pa) | (e_j & i_sb);     /* which member of its unit the entry names */
+                if (has) *reinterpret_cast<uint2 *>(minfo + 2 * lane) = make_uint2(e_mu | ((uint32_t) e_nb << 14) | (e_par << 22), off | (e_sa << 14) | (e_sb << 21));
+                const int Lu = filt ? L >> 1 : L;  /* linked units */
+                const int Lc = Lu * w_c;           /* linked cells */
+                SEC(0);
+                const bool thr_all = p.thr_bin >= nb - 1;
+                const bool keep_all = Lc <= p.min_p || (thr_all && Lc <= p.max_p); /* the loop of :1073-1079 drops nothing */
+                auto kept_units = [&](int g_units) -> int { return kept_count(Lc, g_units * w_c, p.min_p, p.max_p) / w_c; };
+                uint32_t key[8], aux[8]; /* bin << 14 | unit (0xFFFFFFFF: none);  c1 | c2 << 8 | prev merge cell of the unit's even cell << 16 */
+                auto load_chunk = [&](int q0) -> int {
+                    const int left = L - q0;
+                    const int ns = left >= 512 ? 8 : (left + 63) >> 6;
+                    {   /* marks: index + 1 of the kept merge unit whose range starts (or continues) here */
+                        const int lo = (int) off, hi = lo + tot;
+                        if (tot > 0 && hi > q0 && lo < q0 + 512) heads[lo > q0 ? lo - q0 : 0] = (uint32_t) lane + 1u;
+                    }
+                    wave_lds_fence();
+                    uint32_t own[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        own[j] = 0u;
+                        if (j < ns) { own[j] = heads[j * WAVE + lane]; heads[j * WAVE + lane] = 0u; } /* left clean for the next use */
+                    }
+                    uint32_t carry = 0u; /* the latest mark of the slots before */
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        if (j < ns) { /* inclusive prefix maximum over the lanes (marks grow with the position: max = latest) */
+                            uint32_t v = own[j], t;
+                            t = dpp_mov<0x111>(v); if ((lane & 15) >= 1) v = t > v ? t : v;
+                            t = dpp_mov<0x112>(v); if ((lane & 15) >= 2) v = t > v ? t : v;
+                            t = dpp_mov<0x114>(v); if ((lane & 15) >= 4) v = t > v ? t : v;
+                            t = dpp_mov<0x118>(v); if ((lane & 15) >= 8) v = t > v ? t : v;
+                            t = dpp_mov<0x142, 0xa>(v); if ((lane & 31) >= 16) v = t > v ? t : v;
+                            t = dpp_mov<0x143, 0xc>(v); if (lane >= 32) v = t > v ? t : v;
+                            v = v > carry ? v : carry;
+                            own[j] = v;
+                            carry = (uint32_t) __builtin_amdgcn_readlane((int) v, WAVE - 1);
+                        }
+                    }
+                    uint32_t w0[8], w1[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        key[j] = 0xFFFFFFFFu;
+                        if (j < ns) {
+                            const bool act = j * WAVE + lane < left && own[j] > 0u;
+                            const uint2 r = act ? *reinterpret_cast<const uint2 *>(minfo + 2 * (own[j] - 1u)) : make_uint2(0u, 0u);
+                            w0[j] = r.x; w1[j] = r.y;
+                            if (act) key[j] = 0u;
+                        }
+                    }
+                    uint32_t c1_[8], c2_[8];
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        if (j < ns) {
+                            const uint32_t nbq = (w0[j] >> 14) & 0xFFu, off_ = w1[j] & 0x3FFFu, sa = (w1[j] >> 14) & 0x7Fu, sb = (w1[j] >> 21) & 0x7Fu;
+                            const uint32_t t = (uint32_t) (q0 + j * WAVE + lane) - off_;
+                            /* t = x * nb + y, nb <= 128: exact through a float reciprocal (t < 2^14) */
+                            uint32_t x = (uint32_t) ((float) t * __builtin_amdgcn_rcpf((float) (nbq ? nbq : 1u)));
+                            if (x * nbq > t) x--;
+                            if ((x + 1u) * nbq <= t) x++;
+                            const uint32_t y = t - x * nbq;
+                            c1_[j] = listA[(sa + x) & 127u];
+                            c2_[j] = listB[(sb + y) & 127u];
+                        }
+                    }
+#pragma unroll
+                    for (int j = 0; j < 8; j++) {
+                        if (j < ns) {
+                            const uint32_t c1 = c1_[j], c2 = c2_[j];
+                            const uint32_t par_c = (c1 & c_pa) | (c2 & c_sb);
+                            const uint32_t u = key[j] == 0u ? (c1 >> 1) * C2 + ((c2 ^ (c1 & c_xm)) >> c_sb) : 0u;
+                            const uint32_t mu_in = w0[j] & 0x3FFFu, par_in = (w0[j] >> 22) & 1u;
+                            /* the merge cell the unit's EVEN cell comes from */
+                            aux[j] = c1 | (c2 << 8) | (((mu_in << 1) + ((par_in ^ par_c) & i_pm)) << 16);
+                            const uint32_t bin_ = bin_k[u << 1];
+                            if (key[j] == 0u) key[j] = (filt && par_c != 0u) ? 0xFFFFFFFFu : ((bin_ << 14) | u);
+                        }
+                    }
+                    return ns;
+                };
+                /* a selected candidate: its slot of the selection, and -- the first time its next merge unit is seen -- that unit as
+                 * a kept merge unit of the next column.  Called in wave-uniform control flow, `take` per lane. */
+                int cm = 0;
+                auto emit = [&](bool take, int pos, uint32_t key_, uint32_t aux_) {
+                    const uint32_t c1 = aux_ & 0x7Fu, c2 = (aux_ >> 8) & 0x7Fu;
+                    const uint32_t ii = nxA[c1], jj = nxB[c2];
+                    const uint32_t par_c = (c1 & c_pa) | (c2 & c_sb);
+                    const uint32_t mu2 = has_next ? (ii >> 1) * Mb + ((jj ^ (ii & o_xm)) >> o_sb) : 0u;
+                    const uint32_t par_m = (ii & o_pa) | (jj & o_sb);
+                    const uint32_t nxt_even = (mu2 << 1) + ((par_m ^ par_c) & o_pm); /* the merge cell the unit's EVEN cell leads to */
+                    if (take) { skey[pos] = key_; snp[pos] = nxt_even | (aux_ & 0xFFFF0000u); }
+                    if (has_next) {
+                        bool first = false;
+                        if (take) {
+                            const uint32_t bit = 1u << (mu2 & 31u);
+                            first = (atomicOr(&bmp_m[(mu2 >> 5) & 511u], bit) & bit) == 0u;
+                        }
+                        const uint64_t fm = __ballot(first);
+                        if (first) kmn[cm + __popcll(fm & lt_mask)] = mu2 | (ii << 14) | (jj << 21);
+                        cm += __popcll(fm);
+                    }
+                };
+                const int n_chunks = (L + 511) >> 9;
+                int n = 0;
+                if (keep_all) {
+                    SEC_COUNT(8);
+                    int at = 0;
+                    for (int c = 0; c < n_chunks; c++) {
+                        const int ns = load_chunk(c << 9);
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            if (j < ns) {
+                                const bool act = key[j] != 0xFFFFFFFFu;
+                                const uint64_t am = __ballot(act);
+                                emit(act, at + __popcll(am & lt_mask), key[j], aux[j]);
+                                at += __popcll(am);
+                            }
+                        }
+                    }
+                    n = at;
+                    SEC(1);
+                } else if (L <= 4 * WAVE) {
+                    /* up to four slots of candidate units: selection by SORTING (see the general chain below) */
+                    SEC_COUNT(9);
+                    const int ns = load_chunk(0);
+                    int g = Lu;
+                    if (!thr_all) {
+                        g = 0;
+#pragma unroll
+                        for (int j = 0; j < 4; j++)
+                            if (j < ns) g += __popcll(__ballot(key[j] != 0xFFFFFFFFu && (int) (key[j] >> 14) <= p.thr_bin));
+                    }
+                    n = kept_units(g);
+                    if (ns <= 2) { uint32_t kk[2] = {key[0], key[1]}; wave_bitonic_sort_n<2>(kk, lane); key[0] = kk[0]; }
+                    else { uint32_t kk[4] = {key[0], key[1], key[2], key[3]}; wave_bitonic_sort_n<4>(kk, lane); key[0] = kk[0]; }
+                    const bool in_ap_ = in_ap, in_bp_ = in_bp;
+                    const uint32_t *pvA = tA + 512, *pvB = tB + 512;
+                    const float rc2 = __builtin_amdgcn_rcpf((float) (C2 ? C2 : 1u));
+                    {   /* n <= 64 units: the kept ones are in the first register.  The even cell of unit u and where it comes from: */
+                        const bool take = lane < n;
+                        const uint32_t u = take ? key[0] & 0x3FFFu : 0u;
+                        uint32_t c1, c2;
+                        if (a_cp) {
+                            uint32_t q = (uint32_t) ((float) u * rc2);
+                            if (q * C2 > u) q--;
+                            if ((q + 1u) * C2 <= u) q++;
+                            c1 = 2u * q; c2 = u - q * C2;
+                        } else if (b_cp) { c1 = 0u; c2 = 2u * u; }
+                        else { c1 = 0u; c2 = 0u; }
+                        c1 &= 127u; c2 &= 127u;
+                        const uint32_t prv = k > 0 ? pair_index(pvA[c1], pvB[c2], Pb, true, in_ap_, in_bp_) : 0u;
+                        emit(take, lane, key[0], c1 | (c2 << 8) | (prv << 16));
+                    }
+                    SEC(4);
+                } else {
+                    /* pass 1: histogram of the posterior bins */
+                    SEC_COUNT(n_chunks > 1 ? 11 : 10);
+                    int ns = 0;
+                    for (int c = 0; c < n_chunks; c++) {
+                        ns = load_chunk(c << 9);
+#pragma unroll
+                        for (int j = 0; j < 8; j++)
+                            if (j < ns && key[j] != 0xFFFFFFFFu) {
+                                const int bin_ = (int) (key[j] >> 14);
+                                atomicAdd(&hk[(bin_ & 15) * WAVE + (bin_ >> 4)], 1u);
+                            }
+                    }
+                    wave_lds_fence();
+                    SEC(2);
+                    int v[16];
+                    int tot_l = 0, pass = 0;
+                    const int thr_rel = p.thr_bin - lane * 16; /* bins q <= thr_rel of this lane pass the threshold */
+#pragma unroll
+                    for (int q = 0; q < 16; q++) {
+                        v[q] = (int) hk[q * WAVE + lane];
+                        tot_l += v[q];
+                        if (q <= thr_rel) pass += v[q];
+                    }
+                    const int incl_h = wave_incl_scan(tot_l, lane);
+                    const int g = thr_all ? Lu : __builtin_amdgcn_readlane(wave_incl_scan(pass, lane), WAVE - 1);
+                    n = kept_units(g);
+                    const int ex = incl_h - tot_l;
+                    int myq = -1, myQ = 0, myV = 0;
+                    const bool owner_lane = n > 0 && ex < n && n <= incl_h;
+                    if (owner_lane) {
+                        int cum = ex;
+#pragma unroll
+                        for (int q = 0; q < 16; q++) {
+                            if (myq < 0 && cum + v[q] >= n) { myq = q; myQ = n - cum; myV = v[q]; }
+                            cum += v[q];
+                        }
+                    }
+                    const int myB = lane * 16 + myq;
+                    const uint64_t om = __ballot(owner_lane);
+                    const int srcu = __builtin_amdgcn_readfirstlane(om ? __ffsll((unsigned long long) om) - 1 : 0);
+                    const int B = om ? __builtin_amdgcn_readlane(myB, srcu) : -1;
+                    const int quota = om ? __builtin_amdgcn_readlane(myQ, srcu) : 0;
+                    const int in_B = om ? __builtin_amdgcn_readlane(myV, srcu) : 0;
+                    const int nG = n - quota;
+                    const bool whole_bin = in_B == quota; /* the cutoff bin is kept entirely: no ranking needed */
+                    SEC(3);
+                    /* pass 2: the units above the cutoff bin; those in it are kept directly or marked by unit index */
+                    int gc = 0, ec = 0;
+                    for (int c = 0; c < n_chunks; c++) {
+                        if (n_chunks > 1) ns = load_chunk(c << 9); /* a single chunk is still in the registers */
+#pragma unroll
+                        for (int j = 0; j < 8; j++) {
+                            if (j >= ns) continue;
+                            const int bin_ = key[j] != 0xFFFFFFFFu ? (int) (key[j] >> 14) : nb;
+                            const bool is_g = bin_ < B, is_e = bin_ == B;
+                            const uint64_t mg = __ballot(is_g), me = __ballot(is_e);
+                            const bool take = is_g || (is_e && whole_bin);
+                            emit(take, is_g ? gc + __popcll(mg & lt_mask) : nG + ec + __popcll(me & lt_mask), key[j], aux[j]);
+                            if (is_e && !whole_bin) {
+                                const uint32_t e = key[j] & 0x3FFFu;
+                                atomicOr(&bmp_c[e >> 5], 1u << (e & 31u));
+                            }
+                            gc += __popcll(mg);
+                            ec += __popcll(me);
+                        }
+                    }
+                    SEC(4);
+                    if (!whole_bin && quota > 0) {
+                        /* the first `quota` units of the cutoff bin in list order (= by unit index) */
+                        wave_lds_fence();
+                        {
+                            uint32_t w[8];
+                            int cnt_l = 0;
+#pragma unroll
+                            for (int q = 0; q < 8; q++) { w[q] = bmp_c[lane * 8 + q]; cnt_l += __popc(w[q]); }
+                            int run = wave_incl_scan(cnt_l, lane) - cnt_l;
+#pragma unroll
+                            for (int q = 0; q < 8; q++) { pref[lane * 8 + q] = (uint32_t) run; run += __popc(w[q]); }
+                        }
+                        wave_lds_fence();
+                        for (int c = 0; c < n_chunks; c++) {
+                            if (n_chunks > 1) ns = load_chunk(c << 9);
+#pragma unroll
+                            for (int j = 0; j < 8; j++) {
+                                if (j >= ns) continue;
+                                const bool is_e = key[j] != 0xFFFFFFFFu && (int) (key[j] >> 14) == B;
+                                const uint32_t e = key[j] & 0x3FFFu, wd = is_e ? e >> 5 : 0u;
+                                const int rank = (int) pref[wd] + __popc(bmp_c[wd] & ((1u << (e & 31u)) - 1u));
+                                emit(is_e && rank < quota, nG + rank, key[j], aux[j]);
+                            }
+                        }
+                        wave_lds_fence();
+                        for (int c = 0; c < n_chunks; c++) { /* the marks go */
+                            if (n_chunks > 1) ns = load_chunk(c << 9);
+#pragma unroll
+                            for (int j = 0; j < 8; j++)
+                                if (j < ns && key[j] != 0xFFFFFFFFu && (int) (key[j] >> 14) == B) bmp_c[(key[j] & 0x3FFFu) >> 5] = 0u;
+                        }
+                    }
+                }
+                wave_lds_fence();
+                SEC(5);
+                if (lane == 0) {
+                    sh[32 + b] = (uint32_t) n; sh[40 + (b ^ 1)] = (uint32_t) cm;
+                    sh[44 + b] = (w_c == 2 ? 1u : 0u) | (o_pm << 1) | (i_pm << 2); /* for the list stages */
+                }
+                /* the marks of the next merge units go */
+                if (has_next && lane < cm) bmp_m[((kmn[lane] & 0x3FFFu) >> 5) & 511u] = 0u;
+                SEC(6);
+                ROLE_BARRIER();
+            }
+            } else {
             for (int k = 0; k < K; k++) {
                 SEC(7);
                 /* the descriptor of the column after next: requested first, so that its latency hides behind this column's work
@@ -1685,6 +2094,7 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                 SEC(6);
                 ROLE_BARRIER();
             }
+            } /* PAIRS or not */
             ROLE_CLK_DONE(0);
             SEC_DONE();
             lds_barrier();
@@ -2006,10 +2416,12 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, con
     /* once per device (thread-safe: the concurrent halves of a call launch from two host threads) */
     static PerDeviceOnce once;
     const hipError_t configured = once.run([] {
-        hipError_t e = hipFuncSetAttribute((const void *) mrp_prune_kernel<512, 32, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *) mrp_prune_kernel<256, 4, 1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *) mrp_prune_kernel<512, 10, 1, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e == hipSuccess) e = hipFuncSetAttribute((const void *) mrp_prune_kernel<1024, 36, 2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipSuccess;
+        auto big_lds = [&](const void *f) { if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); };
+        big_lds((const void *) mrp_prune_kernel<512, 32, 2, 1, false>); big_lds((const void *) mrp_prune_kernel<512, 32, 2, 1, true>);
+        big_lds((const void *) mrp_prune_kernel<256, 4, 1, 1, false>); big_lds((const void *) mrp_prune_kernel<256, 4, 1, 1, true>);
+        big_lds((const void *) mrp_prune_kernel<512, 10, 1, 4, false>); big_lds((const void *) mrp_prune_kernel<512, 10, 1, 4, true>);
+        big_lds((const void *) mrp_prune_kernel<1024, 36, 2, 1, false>); big_lds((const void *) mrp_prune_kernel<1024, 36, 2, 1, true>);
         return e;
     });
     if (configured != hipSuccess) return configured;
@@ -2020,27 +2432,21 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, con
     /* The bin-streaming waves hold a column's f and b in registers: two groups of 2 waves x 32 cells per lane at 512 threads;
      * one group of 4 waves x 40 cells per lane (16-byte loads) at 512 threads for columns of up to 10 240 cells -- the
      * 100 x 100 cells of the shipped parameters: half the waves and 77 KB of LDS let two workgroups share a CU where the
-     * 1 024-thread variant (two groups of 6 waves x 36 cells, up to 13 824 cells) fills it alone. */
-    if (getenv("MRP_PRUNE_OCC")) { /* development: workgroups of each variant a CU holds at this LDS size */
-        int a = 0, b2 = 0, c2 = 0;
-        int a0 = 0;
-        (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&a0, (const void *) mrp_prune_kernel<256, 4, 1, 1>, 256, lds);
-        fprintf(stderr, "prune: <256,4> %d workgroups per CU; ", a0);
-        (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&a, (const void *) mrp_prune_kernel<512, 32, 2, 1>, 512, lds);
-        (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&b2, (const void *) mrp_prune_kernel<512, 10, 1, 4>, 512, lds);
-        (void) hipOccupancyMaxActiveBlocksPerMultiprocessor(&c2, (const void *) mrp_prune_kernel<1024, 36, 2, 1>, 1024, lds);
-        fprintf(stderr, "prune: max_cells %d max_merge %d lds %zu B: workgroups per CU  <512,32> %d  <512,10,x4> %d  <1024,36> %d\n", p.max_cells, p.max_merge, lds, a, b2, c2);
-    }
+     * 1 024-thread variant (two groups of 6 waves x 36 cells, up to 13 824 cells) fills it alone.
+     * p.pairs (includeInvertedPartitions and even column limits): the chain runs on complement pairs. */
     const char *force = getenv("MRP_PRUNE_VARIANT"); /* development: "big" sends mid-sized columns to the 1 024-thread variant */
+    const bool pairs = p.pairs != 0;
+#define PRUNE_LAUNCH(T_, CPT_, NGRP_, VEC_)                                                                                               \
+    do {                                                                                                                                  \
+        if (pairs) hipLaunchKernelGGL((mrp_prune_kernel<T_, CPT_, NGRP_, VEC_, true>), grid, dim3(T_), lds, stream, in, hmms_dev, n_hmms, p, s);  \
+        else hipLaunchKernelGGL((mrp_prune_kernel<T_, CPT_, NGRP_, VEC_, false>), grid, dim3(T_), lds, stream, in, hmms_dev, n_hmms, p, s);       \
+    } while (0)
     /* columns of at most 256 cells (the first merge levels: a few reads per hmm): four waves, the table wave writes the bins */
-    if (p.max_cells <= 4 * WAVE && !(force && force[0] == 's'))
-        hipLaunchKernelGGL((mrp_prune_kernel<256, 4, 1, 1>), grid, dim3(256), lds, stream, in, hmms_dev, n_hmms, p, s);
-    else if (p.max_cells <= 2 * WAVE * 32)
-        hipLaunchKernelGGL((mrp_prune_kernel<512, 32, 2, 1>), grid, dim3(512), lds, stream, in, hmms_dev, n_hmms, p, s);
-    else if (p.max_cells <= MRP_PRUNE_MID_CELLS && !(force && force[0] == 'b'))
-        hipLaunchKernelGGL((mrp_prune_kernel<512, 10, 1, 4>), grid, dim3(512), lds, stream, in, hmms_dev, n_hmms, p, s);
-    else
-        hipLaunchKernelGGL((mrp_prune_kernel<1024, 36, 2, 1>), grid, dim3(1024), lds, stream, in, hmms_dev, n_hmms, p, s);
+    if (p.max_cells <= 4 * WAVE && !(force && force[0] == 's')) PRUNE_LAUNCH(256, 4, 1, 1);
+    else if (p.max_cells <= 2 * WAVE * 32) PRUNE_LAUNCH(512, 32, 2, 1);
+    else if (p.max_cells <= MRP_PRUNE_MID_CELLS && !(force && force[0] == 'b')) PRUNE_LAUNCH(512, 10, 1, 4);
+    else PRUNE_LAUNCH(1024, 36, 2, 1);
+#undef PRUNE_LAUNCH
     return hipGetLastError();
 }
 
