@@ -991,6 +991,20 @@ static __device__ __forceinline__ int wave_incl_scan(int v, int lane) {
     t = (int) dpp_mov<0x143, 0xc>((uint32_t) v) + v; if (lane >= 32) v = t;        /* row_bcast:31 */
     return v;
 }
+/* the same with the shifted-in lanes read as zero by the DPP unit itself (bound_ctrl, row masks): an add per step */
+static __device__ __forceinline__ int wave_incl_scan_bc(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  /* row_shr:1 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); /* row_bcast:15 into rows 1 and 3 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); /* row_bcast:31 into rows 2 and 3 */
+    return v;
+}
+/* number of set bits of m below this lane */
+static __device__ __forceinline__ int mbcnt64(uint64_t m) {
+    return (int) __builtin_amdgcn_mbcnt_hi((uint32_t) (m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t) m, 0u));
+}
 template <int J>
 static __device__ __forceinline__ uint32_t lane_xor(uint32_t x, int lane) {
     if (J == 1) return dpp_mov<0xB1>(x); /* quad_perm [1,0,3,2] */
@@ -1217,7 +1231,7 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                 /* Complement pairs (see the chain wave): the selection holds UNITS, at most 64; a unit's two cells tie and are
                  * neighbours in list order, so the sorted units, each expanded to (cell 2u, cell 2u + 1), are the sorted cells */
                 const int b = kk & 1;
-                const uint32_t *skey = sel + b * 2 * PRUNE_SP, *snp_in = skey + PRUNE_SP;
+                const uint2 *selb = reinterpret_cast<const uint2 *>(sel) + b * 64; /* (bin << 14 | unit, next | prev << 16) */
                 uint32_t *snp = s1 + b * 2 * PRUNE_SP, *sbin = snp + PRUNE_SP;
                 const int n = (int) sh[32 + b];
                 const uint32_t fl = sh[44 + b]; /* bit 0: the column's cells come in pairs, 1: the merge cells after it, 2: those before it */
@@ -1226,9 +1240,10 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                 const bool has_merge = kk + 1 < K;
                 uint32_t key[1];
                 int32_t pre_mf = 0, pre_mb = 0;
-                key[0] = lane < n ? (skey[lane] << 7) | (uint32_t) lane : 0xFFFFFFFFu; /* bin (10) | unit (14) | slot (7) */
+                const uint2 mine = selb[lane];
+                key[0] = lane < n ? (mine.x << 7) | (uint32_t) lane : 0xFFFFFFFFu; /* bin (10) | unit (14) | slot (7) */
                 if (has_merge && lane < n) {
-                    const uint32_t m = snp_in[lane] & 0xFFFFu;
+                    const uint32_t m = mine.y & 0xFFFFu;
                     pre_mf = d.merge_f32[mcell_off + m];
                     pre_mb = d.merge_b32[mcell_off + m];
                 }
@@ -1238,7 +1253,7 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                     wave_lds_fence();
                 }
                 if (lane < n) {
-                    const uint32_t src = key[0] & 0x7Fu, u = (key[0] >> 7) & 0x3FFFu, np_ = snp_in[src];
+                    const uint32_t src = key[0] & 0x7Fu, u = (key[0] >> 7) & 0x3FFFu, np_ = selb[src].y;
                     if (fl & 1u) {
                         *reinterpret_cast<uint32_t *>(sc.kept + lcol * S + 2 * lane) = (2u * u) | ((2u * u + 1u) << 16);
                         *reinterpret_cast<uint2 *>(sc.kept_np + lcol * S + 2 * lane) = make_uint2(np_, np_ ^ o_pm ^ (i_pm << 16));
@@ -1447,14 +1462,23 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
              * member of a kept merge unit are one member of every linked unit, so the enumeration is that of the general
              * kernel over half the entries; only behind a merge column of one cell both members turn up, and the odd ones are
              * dropped. */
+            /* One slot of 64 candidates at a time, start to finish (owner, parent cells, unit, posterior bin, next merge unit):
+             * the slots of a column are independent, but a column links 65 units on average -- one or two slots -- and code that
+             * keeps eight slots in flight at once spends more instructions moving its register tuples through the "has this slot
+             * work" branches than on the work.  Records of the kept merge units (16 bytes, with the reciprocal for the division
+             * by the side-B count), the selection (key and transitions as one 8-byte entry) and the marks sit in LDS. */
+            uint4 *rec = reinterpret_cast<uint4 *>(minfo);       /* [64] per kept merge unit of the column */
             for (int k = 0; k < K; k++) {
                 SEC(7);
                 const int b = k & 1;
-                const uint32_t cd0 = sh[48 + 4 * b], cd1 = sh[49 + 4 * b];
-                uint32_t *skey = sel + b * 2 * PRUNE_SP, *snp = skey + PRUNE_SP;
+                const uint2 cd = *reinterpret_cast<const uint2 *>(sh + 48 + 4 * b);
+                const int nkm = (int) sh[40 + b];
+                const uint32_t ent_ = kml[b * PRUNE_SP + lane];
+                const uint32_t cd0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) cd.x), cd1 = (uint32_t) __builtin_amdgcn_readfirstlane((int) cd.y);
+                uint2 *selb = reinterpret_cast<uint2 *>(sel) + b * 64; /* selection of column k: (bin << 14 | unit, next | prev << 16 of the unit's even cell) */
                 const uint32_t *tA = tab + b * 2 * PRUNE_TAB * 128, *tB = tA + PRUNE_TAB * 128;
-                const uint32_t *cntA = tA, *startA = tA + 128, *listA = tA + 256, *nxA = tA + 384;
-                const uint32_t *cntB = tB, *startB = tB + 128, *listB = tB + 256, *nxB = tB + 384;
+                const uint32_t *csA = tA + 128, *listA = tA + 256, *nxA = tA + 384;
+                const uint32_t *csB = tB + 128, *listB = tB + 256, *nxB = tB + 384;
                 const uint16_t *bin_k = bins + b * cap_c;
                 uint32_t *hk = hist + b * nb_r;
                 uint32_t *kmn = kml + (b ^ 1) * PRUNE_SP; /* the kept merge units leading into column k + 1 */
@@ -1470,109 +1494,68 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                 const uint32_t i_pa = in_ap ? 1u : 0u, i_sb = (!in_ap && in_bp) ? 1u : 0u;
                 const int w_c = (a_cp || b_cp) ? 2 : 1;  /* cells per unit of this column */
                 const bool filt = i_pm == 0u && w_c == 2;  /* behind a merge column of one cell: both members are enumerated */
-                const int nkm = (int) sh[40 + b];
                 /* this lane's kept merge unit: the parents' cells one of its members links, as list ranges.  An entry of the
                  * list is unit | i << 14 | j << 21: the unit and the indices of that member on either side */
                 const bool has = lane < nkm;
-                const uint32_t ent = has ? kml[b * PRUNE_SP + lane] : 0u;
-                const uint32_t e_mu = ent & 0x3FFFu, e_i = (ent >> 14) & 127u, e_j = (ent >> 21) & 127u;
-                const uint32_t e_sa = startA[e_i], e_sb = startB[e_j];
-                const int e_na = has ? (int) cntA[e_i] : 0, e_nb = has ? (int) cntB[e_j] : 0;
-                const int tot = e_na * e_nb;
-                const int incl = wave_incl_scan(tot, lane);
+                const uint32_t ent = has ? ent_ : 0u;
+                const uint32_t e_i = (ent >> 14) & 127u, e_j = (ent >> 21) & 127u;
+                const uint32_t e_csa = csA[e_i], e_csb = csB[e_j]; /* first entry | size << 8 of the group in the inverted lists */
+                const uint32_t e_nb = has ? e_csb >> 8 : 0u;
+                const int tot = has ? (int) ((e_csa >> 8) * e_nb) : 0;
+                if (has && tot == 0) errbits |= MRP_ENGINE_ERR_RANGE; /* (a kept merge cell links at least one cell: the owners below count on it) */
+                const int incl = wave_incl_scan_bc(tot);
                 const int L = __builtin_amdgcn_readlane(incl, WAVE - 1); /* pairs of parent cells enumerated */
-                const uint32_t off = (uint32_t) (incl - tot);
-                const uint32_t e_par = (e_i & i_pa) | (e_j & i_sb);     /* which member of its unit the entry names */
-                if (has) *reinterpret_cast<uint2 *>(minfo + 2 * lane) = make_uint2(e_mu | ((uint32_t) e_nb << 14) | (e_par << 22), off | (e_sa << 14) | (e_sb << 21));
+                const int off = incl - tot;
+                {
+                    const uint32_t e_par = (e_i & i_pa) | (e_j & i_sb);     /* which member of its unit the entry names */
+                    const float rn = __builtin_amdgcn_rcpf((float) (e_nb ? e_nb : 1u));
+                    if (has) rec[lane] = make_uint4((ent & 0x3FFFu) | (e_nb << 14) | (e_par << 22), (uint32_t) off | ((e_csa & 0xFFu) << 14) | ((e_csb & 0xFFu) << 21),
+                                                    __float_as_uint(rn), 0u);
+                }
                 const int Lu = filt ? L >> 1 : L;  /* linked units */
                 const int Lc = Lu * w_c;           /* linked cells */
                 SEC(0);
                 const bool thr_all = p.thr_bin >= nb - 1;
                 const bool keep_all = Lc <= p.min_p || (thr_all && Lc <= p.max_p); /* the loop of :1073-1079 drops nothing */
                 auto kept_units = [&](int g_units) -> int { return kept_count(Lc, g_units * w_c, p.min_p, p.max_p) / w_c; };
-                uint32_t key[8], aux[8]; /* bin << 14 | unit (0xFFFFFFFF: none);  c1 | c2 << 8 | prev merge cell of the unit's even cell << 16 */
-                auto load_chunk = [&](int q0) -> int {
-                    const int left = L - q0;
-                    const int ns = left >= 512 ? 8 : (left + 63) >> 6;
-                    {   /* marks: index + 1 of the kept merge unit whose range starts (or continues) here */
-                        const int lo = (int) off, hi = lo + tot;
-                        if (tot > 0 && hi > q0 && lo < q0 + 512) heads[lo > q0 ? lo - q0 : 0] = (uint32_t) lane + 1u;
-                    }
+                /* candidates q0 .. q0 + 63: key = bin << 14 | unit (0xFFFFFFFF: none), the parent cells the enumeration met, and the
+                 * merge cell the unit's EVEN cell comes from */
+                auto slot = [&](int q0, uint32_t &c1, uint32_t &c2, uint32_t &prv_even) -> uint32_t {
+                    /* marks: index + 1 of the kept merge unit whose range starts (or, at position 0, continues) here.  The
+                     * ranges follow each other without gaps, so the owner of a position is the first owner plus the marks
+                     * up to it: no prefix maximum */
+                    if (tot > 0 && off + tot > q0 && off < q0 + WAVE) heads[off > q0 ? off - q0 : 0] = (uint32_t) lane + 1u;
                     wave_lds_fence();
-                    uint32_t own[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        own[j] = 0u;
-                        if (j < ns) { own[j] = heads[j * WAVE + lane]; heads[j * WAVE + lane] = 0u; } /* left clean for the next use */
-                    }
-                    uint32_t carry = 0u; /* the latest mark of the slots before */
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        if (j < ns) { /* inclusive prefix maximum over the lanes (marks grow with the position: max = latest) */
-                            uint32_t v = own[j], t;
-                            t = dpp_mov<0x111>(v); if ((lane & 15) >= 1) v = t > v ? t : v;
-                            t = dpp_mov<0x112>(v); if ((lane & 15) >= 2) v = t > v ? t : v;
-                            t = dpp_mov<0x114>(v); if ((lane & 15) >= 4) v = t > v ? t : v;
-                            t = dpp_mov<0x118>(v); if ((lane & 15) >= 8) v = t > v ? t : v;
-                            t = dpp_mov<0x142, 0xa>(v); if ((lane & 31) >= 16) v = t > v ? t : v;
-                            t = dpp_mov<0x143, 0xc>(v); if (lane >= 32) v = t > v ? t : v;
-                            v = v > carry ? v : carry;
-                            own[j] = v;
-                            carry = (uint32_t) __builtin_amdgcn_readlane((int) v, WAVE - 1);
-                        }
-                    }
-                    uint32_t w0[8], w1[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        key[j] = 0xFFFFFFFFu;
-                        if (j < ns) {
-                            const bool act = j * WAVE + lane < left && own[j] > 0u;
-                            const uint2 r = act ? *reinterpret_cast<const uint2 *>(minfo + 2 * (own[j] - 1u)) : make_uint2(0u, 0u);
-                            w0[j] = r.x; w1[j] = r.y;
-                            if (act) key[j] = 0u;
-                        }
-                    }
-                    uint32_t c1_[8], c2_[8];
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        if (j < ns) {
-                            const uint32_t nbq = (w0[j] >> 14) & 0xFFu, off_ = w1[j] & 0x3FFFu, sa = (w1[j] >> 14) & 0x7Fu, sb = (w1[j] >> 21) & 0x7Fu;
-                            const uint32_t t = (uint32_t) (q0 + j * WAVE + lane) - off_;
-                            /* t = x * nb + y, nb <= 128: exact through a float reciprocal (t < 2^14) */
-                            uint32_t x = (uint32_t) ((float) t * __builtin_amdgcn_rcpf((float) (nbq ? nbq : 1u)));
-                            if (x * nbq > t) x--;
-                            if ((x + 1u) * nbq <= t) x++;
-                            const uint32_t y = t - x * nbq;
-                            c1_[j] = listA[(sa + x) & 127u];
-                            c2_[j] = listB[(sb + y) & 127u];
-                        }
-                    }
-#pragma unroll
-                    for (int j = 0; j < 8; j++) {
-                        if (j < ns) {
-                            const uint32_t c1 = c1_[j], c2 = c2_[j];
-                            const uint32_t par_c = (c1 & c_pa) | (c2 & c_sb);
-                            const uint32_t u = key[j] == 0u ? (c1 >> 1) * C2 + ((c2 ^ (c1 & c_xm)) >> c_sb) : 0u;
-                            const uint32_t mu_in = w0[j] & 0x3FFFu, par_in = (w0[j] >> 22) & 1u;
-                            /* the merge cell the unit's EVEN cell comes from */
-                            aux[j] = c1 | (c2 << 8) | (((mu_in << 1) + ((par_in ^ par_c) & i_pm)) << 16);
-                            const uint32_t bin_ = bin_k[u << 1];
-                            if (key[j] == 0u) key[j] = (filt && par_c != 0u) ? 0xFFFFFFFFu : ((bin_ << 14) | u);
-                        }
-                    }
-                    return ns;
+                    const uint32_t own = heads[lane];
+                    heads[lane] = 0u; /* left clean for the next use */
+                    const uint64_t marks = __ballot(own != 0u);
+                    const int first_owner = __builtin_amdgcn_readfirstlane((int) own) - 1;
+                    const int owner = first_owner + mbcnt64(marks) + (own != 0u ? 1 : 0) - 1;
+                    const bool in = q0 + lane < L;
+                    const uint4 r = rec[in ? owner & 63 : 0];
+                    const uint32_t nbq = (r.x >> 14) & 0xFFu, sa = (r.y >> 14) & 0x7Fu, sb = (r.y >> 21) & 0x7Fu;
+                    const uint32_t t = (uint32_t) (q0 + lane) - (r.y & 0x3FFFu);
+                    /* t = x * nb + y: (t + 0.5) / nb is at least 0.5 / nb away from an integer and the float product is off by less */
+                    const uint32_t x = (uint32_t) (((float) t + 0.5f) * __uint_as_float(r.z));
+                    const uint32_t y = t - x * nbq;
+                    c1 = listA[(sa + x) & 127u];
+                    c2 = listB[(sb + y) & 127u];
+                    const uint32_t par_c = (c1 & c_pa) | (c2 & c_sb);
+                    const uint32_t u = in ? (c1 >> 1) * C2 + ((c2 ^ (c1 & c_xm)) >> c_sb) : 0u;
+                    prv_even = ((r.x & 0x3FFFu) << 1) + ((((r.x >> 22) & 1u) ^ par_c) & i_pm);
+                    const uint32_t bin_ = bin_k[u << 1];
+                    return (!in || (filt && par_c != 0u)) ? 0xFFFFFFFFu : ((bin_ << 14) | u);
                 };
                 /* a selected candidate: its slot of the selection, and -- the first time its next merge unit is seen -- that unit as
                  * a kept merge unit of the next column.  Called in wave-uniform control flow, `take` per lane. */
                 int cm = 0;
-                auto emit = [&](bool take, int pos, uint32_t key_, uint32_t aux_) {
-                    const uint32_t c1 = aux_ & 0x7Fu, c2 = (aux_ >> 8) & 0x7Fu;
-                    const uint32_t ii = nxA[c1], jj = nxB[c2];
+                auto emit = [&](bool take, int pos, uint32_t key_, uint32_t c1, uint32_t c2, uint32_t prv_even) {
+                    const uint32_t ii = nxA[c1 & 127u], jj = nxB[c2 & 127u];
                     const uint32_t par_c = (c1 & c_pa) | (c2 & c_sb);
                     const uint32_t mu2 = has_next ? (ii >> 1) * Mb + ((jj ^ (ii & o_xm)) >> o_sb) : 0u;
                     const uint32_t par_m = (ii & o_pa) | (jj & o_sb);
                     const uint32_t nxt_even = (mu2 << 1) + ((par_m ^ par_c) & o_pm); /* the merge cell the unit's EVEN cell leads to */
-                    if (take) { skey[pos] = key_; snp[pos] = nxt_even | (aux_ & 0xFFFF0000u); }
+                    if (take) selb[pos & 63] = make_uint2(key_, nxt_even | (prv_even << 16));
                     if (has_next) {
                         bool first = false;
                         if (take) {
@@ -1580,77 +1563,74 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                             first = (atomicOr(&bmp_m[(mu2 >> 5) & 511u], bit) & bit) == 0u;
                         }
                         const uint64_t fm = __ballot(first);
-                        if (first) kmn[cm + __popcll(fm & lt_mask)] = mu2 | (ii << 14) | (jj << 21);
+                        if (first) kmn[(cm + mbcnt64(fm)) & 127] = mu2 | (ii << 14) | (jj << 21);
                         cm += __popcll(fm);
                     }
                 };
-                const int n_chunks = (L + 511) >> 9;
                 int n = 0;
                 if (keep_all) {
                     SEC_COUNT(8);
-                    int at = 0;
-                    for (int c = 0; c < n_chunks; c++) {
-                        const int ns = load_chunk(c << 9);
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            if (j < ns) {
-                                const bool act = key[j] != 0xFFFFFFFFu;
-                                const uint64_t am = __ballot(act);
-                                emit(act, at + __popcll(am & lt_mask), key[j], aux[j]);
-                                at += __popcll(am);
-                            }
-                        }
+#pragma unroll 1
+                    for (int q0 = 0; q0 < L; q0 += WAVE) {
+                        uint32_t c1, c2, pe;
+                        const uint32_t key_ = slot(q0, c1, c2, pe);
+                        const uint64_t am = __ballot(key_ != 0xFFFFFFFFu);
+                        emit(key_ != 0xFFFFFFFFu, n + mbcnt64(am), key_, c1, c2, pe);
+                        n += __popcll(am);
                     }
-                    n = at;
                     SEC(1);
                 } else if (L <= 4 * WAVE) {
-                    /* up to four slots of candidate units: selection by SORTING (see the general chain below) */
+                    /* up to four slots of candidate units: selection by SORTING (see the general chain below); what rides along
+                     * with a unit is derived again from its index for the kept ones */
                     SEC_COUNT(9);
-                    const int ns = load_chunk(0);
+                    uint32_t kk[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+                    {
+                        uint32_t c1, c2, pe;
+                        kk[0] = slot(0, c1, c2, pe);
+                        if (L > WAVE) kk[1] = slot(WAVE, c1, c2, pe);
+                        if (L > 2 * WAVE) kk[2] = slot(2 * WAVE, c1, c2, pe);
+                        if (L > 3 * WAVE) kk[3] = slot(3 * WAVE, c1, c2, pe);
+                    }
                     int g = Lu;
                     if (!thr_all) {
                         g = 0;
 #pragma unroll
-                        for (int j = 0; j < 4; j++)
-                            if (j < ns) g += __popcll(__ballot(key[j] != 0xFFFFFFFFu && (int) (key[j] >> 14) <= p.thr_bin));
+                        for (int j = 0; j < 4; j++) g += __popcll(__ballot(kk[j] != 0xFFFFFFFFu && (int) (kk[j] >> 14) <= p.thr_bin));
                     }
                     n = kept_units(g);
-                    if (ns <= 2) { uint32_t kk[2] = {key[0], key[1]}; wave_bitonic_sort_n<2>(kk, lane); key[0] = kk[0]; }
-                    else { uint32_t kk[4] = {key[0], key[1], key[2], key[3]}; wave_bitonic_sort_n<4>(kk, lane); key[0] = kk[0]; }
-                    const bool in_ap_ = in_ap, in_bp_ = in_bp;
+                    if (L <= 2 * WAVE) { uint32_t k2[2] = {kk[0], kk[1]}; wave_bitonic_sort_n<2>(k2, lane); kk[0] = k2[0]; }
+                    else wave_bitonic_sort_n<4>(kk, lane);
                     const uint32_t *pvA = tA + 512, *pvB = tB + 512;
-                    const float rc2 = __builtin_amdgcn_rcpf((float) (C2 ? C2 : 1u));
                     {   /* n <= 64 units: the kept ones are in the first register.  The even cell of unit u and where it comes from: */
                         const bool take = lane < n;
-                        const uint32_t u = take ? key[0] & 0x3FFFu : 0u;
+                        const uint32_t u = take ? kk[0] & 0x3FFFu : 0u;
                         uint32_t c1, c2;
                         if (a_cp) {
-                            uint32_t q = (uint32_t) ((float) u * rc2);
-                            if (q * C2 > u) q--;
-                            if ((q + 1u) * C2 <= u) q++;
+                            const uint32_t q = (uint32_t) (((float) u + 0.5f) * __builtin_amdgcn_rcpf((float) (C2 ? C2 : 1u)));
                             c1 = 2u * q; c2 = u - q * C2;
                         } else if (b_cp) { c1 = 0u; c2 = 2u * u; }
                         else { c1 = 0u; c2 = 0u; }
                         c1 &= 127u; c2 &= 127u;
-                        const uint32_t prv = k > 0 ? pair_index(pvA[c1], pvB[c2], Pb, true, in_ap_, in_bp_) : 0u;
-                        emit(take, lane, key[0], c1 | (c2 << 8) | (prv << 16));
+                        const uint32_t prv = k > 0 ? pair_index(pvA[c1], pvB[c2], Pb, true, in_ap, in_bp) : 0u;
+                        emit(take, lane, kk[0], c1, c2, prv);
                     }
                     SEC(4);
                 } else {
                     /* pass 1: histogram of the posterior bins */
-                    SEC_COUNT(n_chunks > 1 ? 11 : 10);
-                    int ns = 0;
-                    for (int c = 0; c < n_chunks; c++) {
-                        ns = load_chunk(c << 9);
-#pragma unroll
-                        for (int j = 0; j < 8; j++)
-                            if (j < ns && key[j] != 0xFFFFFFFFu) {
-                                const int bin_ = (int) (key[j] >> 14);
-                                atomicAdd(&hk[(bin_ & 15) * WAVE + (bin_ >> 4)], 1u);
-                            }
+                    if (lane == 0) sh[56 + b] = 1u; /* the table wave wipes this histogram before its next use */
+                    SEC_COUNT(L > 512 ? 11 : 10);
+#pragma unroll 1
+                    for (int q0 = 0; q0 < L; q0 += WAVE) {
+                        uint32_t c1, c2, pe;
+                        const uint32_t key_ = slot(q0, c1, c2, pe);
+                        if (key_ != 0xFFFFFFFFu) {
+                            const int bin_ = (int) (key_ >> 14);
+                            atomicAdd(&hk[(bin_ & 15) * WAVE + (bin_ >> 4)], 1u);
+                        }
                     }
                     wave_lds_fence();
                     SEC(2);
+                    /* cutoff bin and quota: lane l owns the 16 consecutive bins [16 l, 16 l + 16) */
                     int v[16];
                     int tot_l = 0, pass = 0;
                     const int thr_rel = p.thr_bin - lane * 16; /* bins q <= thr_rel of this lane pass the threshold */
@@ -1685,27 +1665,26 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                     SEC(3);
                     /* pass 2: the units above the cutoff bin; those in it are kept directly or marked by unit index */
                     int gc = 0, ec = 0;
-                    for (int c = 0; c < n_chunks; c++) {
-                        if (n_chunks > 1) ns = load_chunk(c << 9); /* a single chunk is still in the registers */
-#pragma unroll
-                        for (int j = 0; j < 8; j++) {
-                            if (j >= ns) continue;
-                            const int bin_ = key[j] != 0xFFFFFFFFu ? (int) (key[j] >> 14) : nb;
-                            const bool is_g = bin_ < B, is_e = bin_ == B;
-                            const uint64_t mg = __ballot(is_g), me = __ballot(is_e);
-                            const bool take = is_g || (is_e && whole_bin);
-                            emit(take, is_g ? gc + __popcll(mg & lt_mask) : nG + ec + __popcll(me & lt_mask), key[j], aux[j]);
-                            if (is_e && !whole_bin) {
-                                const uint32_t e = key[j] & 0x3FFFu;
-                                atomicOr(&bmp_c[e >> 5], 1u << (e & 31u));
-                            }
-                            gc += __popcll(mg);
-                            ec += __popcll(me);
+#pragma unroll 1
+                    for (int q0 = 0; q0 < L; q0 += WAVE) {
+                        uint32_t c1, c2, pe;
+                        const uint32_t key_ = slot(q0, c1, c2, pe);
+                        const int bin_ = key_ != 0xFFFFFFFFu ? (int) (key_ >> 14) : nb;
+                        const bool is_g = bin_ < B, is_e = bin_ == B;
+                        const uint64_t mg = __ballot(is_g), me = __ballot(is_e);
+                        const bool take = is_g || (is_e && whole_bin);
+                        emit(take, is_g ? gc + mbcnt64(mg) : nG + ec + mbcnt64(me), key_, c1, c2, pe);
+                        if (is_e && !whole_bin) {
+                            const uint32_t e = key_ & 0x3FFFu;
+                            atomicOr(&bmp_c[e >> 5], 1u << (e & 31u));
                         }
+                        gc += __popcll(mg);
+                        ec += __popcll(me);
                     }
                     SEC(4);
                     if (!whole_bin && quota > 0) {
-                        /* the first `quota` units of the cutoff bin in list order (= by unit index) */
+                        /* the first `quota` units of the cutoff bin in list order (= by unit index): a unit's rank is the number
+                         * of marks below it */
                         wave_lds_fence();
                         {
                             uint32_t w[8];
@@ -1717,23 +1696,21 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                             for (int q = 0; q < 8; q++) { pref[lane * 8 + q] = (uint32_t) run; run += __popc(w[q]); }
                         }
                         wave_lds_fence();
-                        for (int c = 0; c < n_chunks; c++) {
-                            if (n_chunks > 1) ns = load_chunk(c << 9);
-#pragma unroll
-                            for (int j = 0; j < 8; j++) {
-                                if (j >= ns) continue;
-                                const bool is_e = key[j] != 0xFFFFFFFFu && (int) (key[j] >> 14) == B;
-                                const uint32_t e = key[j] & 0x3FFFu, wd = is_e ? e >> 5 : 0u;
-                                const int rank = (int) pref[wd] + __popc(bmp_c[wd] & ((1u << (e & 31u)) - 1u));
-                                emit(is_e && rank < quota, nG + rank, key[j], aux[j]);
-                            }
+#pragma unroll 1
+                        for (int q0 = 0; q0 < L; q0 += WAVE) {
+                            uint32_t c1, c2, pe;
+                            const uint32_t key_ = slot(q0, c1, c2, pe);
+                            const bool is_e = key_ != 0xFFFFFFFFu && (int) (key_ >> 14) == B;
+                            const uint32_t e = key_ & 0x3FFFu, wd = is_e ? e >> 5 : 0u;
+                            const int rank = (int) pref[wd] + __popc(bmp_c[wd] & ((1u << (e & 31u)) - 1u));
+                            emit(is_e && rank < quota, nG + rank, key_, c1, c2, pe);
                         }
                         wave_lds_fence();
-                        for (int c = 0; c < n_chunks; c++) { /* the marks go */
-                            if (n_chunks > 1) ns = load_chunk(c << 9);
-#pragma unroll
-                            for (int j = 0; j < 8; j++)
-                                if (j < ns && key[j] != 0xFFFFFFFFu && (int) (key[j] >> 14) == B) bmp_c[(key[j] & 0x3FFFu) >> 5] = 0u;
+#pragma unroll 1
+                        for (int q0 = 0; q0 < L; q0 += WAVE) { /* the marks go */
+                            uint32_t c1, c2, pe;
+                            const uint32_t key_ = slot(q0, c1, c2, pe);
+                            if (key_ != 0xFFFFFFFFu && (int) (key_ >> 14) == B) bmp_c[(key_ & 0x3FFFu) >> 5] = 0u;
                         }
                     }
                 }
@@ -2124,30 +2101,55 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
             lds_barrier();
             lists_stage2(K - 1);
         } else if (wave == 3) {
-            /* wave 3: the parents' transitions of the column after next */
+            /* wave 3: the parents' transitions of the column after next.  Three columns are in the pipe: the tables of column
+             * t are built from the registers while the transitions of column t + 1 and the descriptor of column t + 2 are in
+             * flight.  The descriptors come by VECTOR loads (lane l = dword l of the CrossCol, lanes 16.. = the SweepCol) and
+             * are taken apart with v_readlane a step later: a scalar load shares lgkmcnt with the LDS traffic of the table
+             * build, and a wave that first has to wait for its descriptor before it can ask for the transitions it points to
+             * pays two memory latencies per column -- with the chain on complement pairs this wave had become the slowest role. */
             uint32_t r_na[2] = {0u, 0u}, r_nb[2] = {0u, 0u};
             int32_t t_f[W == 4 ? CPT : 1], t_b[W == 4 ? CPT : 1]; /* T = 256: f and b of the column whose tables are built next */
             int t_n = 0;
             CrossCol tcc = {};
             int tcol = 0;
-            auto tab_load = [&]() {
+            auto desc_load = [&](int col) -> uint32_t {
+                uint32_t v = 0u;
+                if (col < K) {
+                    if (lane < 16) v = reinterpret_cast<const uint32_t *>(d.ccols + h.col0 + col)[lane];
+                    else if (W == 4 && lane < 24) v = reinterpret_cast<const uint32_t *>(d.scols + h.col0 + col)[lane - 16];
+                }
+                return v;
+            };
+            auto fld = [&](uint32_t v, int l) -> uint32_t { return (uint32_t) __builtin_amdgcn_readlane((int) v, l); };
+            /* the transitions (and, T = 256, f and b) of the column the descriptor vector dv describes: requests only */
+            auto tab_load = [&](uint32_t dv) {
+                CrossCol c = {};
+                c.a_part = reinterpret_cast<const uint64_t *>(((uint64_t) fld(dv, 1) << 32) | fld(dv, 0));
+                c.b_part = reinterpret_cast<const uint64_t *>(((uint64_t) fld(dv, 3) << 32) | fld(dv, 2));
+                c.a_np = reinterpret_cast<const uint32_t *>(((uint64_t) fld(dv, 5) << 32) | fld(dv, 4));
+                c.b_np = reinterpret_cast<const uint32_t *>(((uint64_t) fld(dv, 7) << 32) | fld(dv, 6));
+                const uint32_t w10 = fld(dv, 10), w11 = fld(dv, 11), w12 = fld(dv, 12), w13 = fld(dv, 13), w14 = fld(dv, 14);
+                c.C1 = (uint16_t) w10; c.C2 = (uint16_t) (w10 >> 16); c.Ma = (uint16_t) w11; c.Mb = (uint16_t) (w11 >> 16);
+                c.Pa = (uint16_t) w12; c.Pb = (uint16_t) (w12 >> 16);
+                c.d1 = (uint8_t) w13; c.d2 = (uint8_t) (w13 >> 8); c.out_a = (uint8_t) (w13 >> 16); c.out_b = (uint8_t) (w13 >> 24);
+                c.in_a = (uint8_t) w14; c.in_b = (uint8_t) (w14 >> 8); c.flags = (uint8_t) (w14 >> 16);
+                tcc = c;
                 if (tcol < K) {
-                    tcc = k_load(d.ccols + h.col0 + tcol);
                     if (W == 4) {
-                        const SweepCol c = k_load(d.scols + h.col0 + tcol);
-                        t_n = c.n_cells;
+                        const int64_t cell_off = (int64_t) (((uint64_t) fld(dv, 17) << 32) | fld(dv, 16));
+                        t_n = (int) fld(dv, 20);
 #pragma unroll
                         for (int j = 0; j < (W == 4 ? CPT : 1); j++) {
                             const int cell = lane + j * WAVE;
-                            t_f[j] = cell < t_n ? d.cell_f32[c.cell_off + cell] : MRP_NEG_I32;
-                            t_b[j] = cell < t_n ? d.cell_b32[c.cell_off + cell] : MRP_NEG_I32;
+                            t_f[j] = cell < t_n ? d.cell_f32[cell_off + cell] : MRP_NEG_I32;
+                            t_b[j] = cell < t_n ? d.cell_b32[cell_off + cell] : MRP_NEG_I32;
                         }
                     }
 #pragma unroll
                     for (int u = 0; u < 2; u++) {
-                        const uint32_t c = (uint32_t) (lane + u * WAVE);
-                        r_na[u] = (tcc.a_np && c < tcc.C1) ? tcc.a_np[c] : 0u;
-                        r_nb[u] = (tcc.b_np && c < tcc.C2) ? tcc.b_np[c] : 0u;
+                        const uint32_t cidx = (uint32_t) (lane + u * WAVE);
+                        r_na[u] = (tcc.a_np && cidx < tcc.C1) ? tcc.a_np[cidx] : 0u;
+                        r_nb[u] = (tcc.b_np && cidx < tcc.C2) ? tcc.b_np[cidx] : 0u;
                     }
                 }
             };
@@ -2175,13 +2177,14 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                 const int i0 = wave_incl_scan(c0, lane);
                 const int t0 = __shfl(i0, WAVE - 1, WAVE);
                 const int i1 = wave_incl_scan(c1, lane);
-                start[lane] = (uint32_t) (i0 - c0);
-                start[lane + WAVE] = (uint32_t) (t0 + i1 - c1);
+                /* (the chain on pairs reads a group's first entry and size as one word) */
+                start[lane] = (uint32_t) (i0 - c0) | (PAIRS ? (uint32_t) c0 << 8 : 0u);
+                start[lane + WAVE] = (uint32_t) (t0 + i1 - c1) | (PAIRS ? (uint32_t) c1 << 8 : 0u);
                 wave_lds_fence();
 #pragma unroll
                 for (int u = 0; u < 2; u++) {
                     const uint32_t c = (uint32_t) (lane + u * WAVE);
-                    if (c < C) list[start[grp_[u]] + rank[u]] = c;
+                    if (c < C) list[(start[grp_[u]] & 0xFFu) + rank[u]] = c;
                 }
             };
             auto tab_build = [&]() { /* tables of column tcol into buffer tcol & 1, from the registers loaded last time */
@@ -2208,18 +2211,25 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                 }
             };
 
-            /* the parents' transitions: tables of column 0, request for column 1 */
-            tcol = 0; tab_load(); tab_build();
-            tcol = 1; tab_load();
+            /* the parents' transitions: tables of column 0, requests for column 1, descriptor of column 2 */
+            uint32_t dv_next;
+            tcol = 0; tab_load(desc_load(0)); tab_build();
+            tcol = 1; tab_load(desc_load(1));
+            dv_next = desc_load(2);
             lds_barrier();
             ROLE_CLK_INIT();
             for (int k = 0; k < K; k++) {
-                /* tables of column k + 1 (loaded while column k - 1 was worked on), then the request for k + 2 */
+                /* tables of column k + 1 (requested while column k - 1 was worked on), then the requests for k + 2 (its
+                 * descriptor was requested a step ago) and the descriptor of k + 3 */
                 tab_build();
                 tcol++;
-                tab_load();
+                tab_load(dv_next);
+                dv_next = desc_load(k + 3);
                 uint32_t *hn = hist + ((k + 1) & 1) * nb_r;
-                for (int i = lane; i < nb_r; i += WAVE) hn[i] = 0u;
+                if (!PAIRS || sh[56 + ((k + 1) & 1)] != 0u) { /* (the chain on pairs says when it has used a histogram: one column in a hundred) */
+                    for (int i = lane; i < nb_r; i += WAVE) hn[i] = 0u;
+                    if (PAIRS && lane == 0) sh[56 + ((k + 1) & 1)] = 0u;
+                }
                 ROLE_BARRIER();
             }
             ROLE_CLK_DONE(3);
@@ -2278,12 +2288,12 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                     }
                 }
             };
+            ROLE_CLK_INIT();
             if (NGRP == 2) {
                 /* barrier schedule: one after the prologue (step -1), one per column (steps 0 .. K - 1), one before the last merge
                  * list.  Group 0 acts at steps -1, 1, 3, ... (columns 0, 2, 4, ...), group 1 at steps 0, 2, ... */
                 bins_load(grp);
                 if (grp == 1) lds_barrier(); /* step -1 */
-                ROLE_CLK_INIT();
                 for (int st = grp - 1; st < K; st += 2) {
                     bins_store(st + 1);
                     __builtin_amdgcn_sched_barrier(0); /* the new column's loads reuse the registers of the one just stored */
@@ -2295,7 +2305,6 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                 /* one group: at step st the bins of column st + 1 (requested during step st - 1) are stored and column st + 2
                  * is requested: a column's f and b have one column time to arrive */
                 bins_load(0);
-                ROLE_CLK_INIT();
                 for (int st = -1; st < K; st++) {
                     bins_store(st + 1);
                     __builtin_amdgcn_sched_barrier(0);
