@@ -1175,7 +1175,8 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
     const int S = p.S;
     const int nb = p.n_bins;
     const int nb_r = 1024; /* 16 bins per lane of the cutoff search: bin b lives at (b & 15) * 64 + (b >> 4) */
-    const int cap_c = (p.max_cells + 3) & ~3;
+    /* posterior bins in LDS, two columns: one per cell; PAIRS: one per unit (cells 2u, 2u + 1 tie) */
+    const int cap_c = PAIRS ? ((p.max_cells + 1) / 2 + 3) & ~3 : (p.max_cells + 3) & ~3;
     /* LDS layout (dwords) */
     uint32_t *sel = lds;                       /* [2][2][SP] selection of column k in buffer k & 1: key = bin << 14 | cell, np = next | prev << 16 */
     uint32_t *um = sel + 4 * PRUNE_SP;         /* [SP] posterior bin of the merge cell each selected cell leads to (selection order); wave 1 */
@@ -1543,7 +1544,7 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                     const uint32_t par_c = (c1 & c_pa) | (c2 & c_sb);
                     const uint32_t u = in ? (c1 >> 1) * C2 + ((c2 ^ (c1 & c_xm)) >> c_sb) : 0u;
                     prv_even = ((r.x & 0x3FFFu) << 1) + ((((r.x >> 22) & 1u) ^ par_c) & i_pm);
-                    const uint32_t bin_ = bin_k[u << 1];
+                    const uint32_t bin_ = bin_k[u];
                     return (!in || (filt && par_c != 0u)) ? 0xFFFFFFFFu : ((bin_ << 14) | u);
                 };
                 /* a selected candidate: its slot of the selection, and -- the first time its next merge unit is seen -- that unit as
@@ -2201,7 +2202,8 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
 #pragma unroll
                         for (int j = 0; j < (W == 4 ? CPT : 1); j++) {
                             const int cell = lane + j * WAVE;
-                            if (cell < t_n) dst[cell] = (uint16_t) posterior_bin(t_f[j], t_b[j], total, nb, &errbits);
+                            if (PAIRS) { if (cell < t_n && (cell & 1) == 0) dst[cell >> 1] = (uint16_t) posterior_bin(t_f[j], t_b[j], total, nb, &errbits); }
+                            else if (cell < t_n) dst[cell] = (uint16_t) posterior_bin(t_f[j], t_b[j], total, nb, &errbits);
                         }
                     }
                     uint32_t C1 = tcc.C1, C2 = tcc.C2;
@@ -2275,14 +2277,26 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                     if (j < nj) { /* (the lane's cell against a scalar bound, the step in the store's immediate offset: no
                                    * per-slot index registers) */
                         if (VEC == 1) {
-                            if (base_c < n_have - j * LG) dst[base_c + j * LG] = (uint16_t) posterior_bin(r_f[j], r_b[j], total, nb, &errbits);
+                            if (PAIRS) { /* the even cell of a unit writes the unit's bin */
+                                if (base_c < n_have - j * LG && (base_c & 1) == 0) dst[(base_c + j * LG) >> 1] = (uint16_t) posterior_bin(r_f[j], r_b[j], total, nb, &errbits);
+                            } else if (base_c < n_have - j * LG) dst[base_c + j * LG] = (uint16_t) posterior_bin(r_f[j], r_b[j], total, nb, &errbits);
                         } else {
                             const int left = n_have - (j * LG + base_c) * VEC; /* cells of this load inside the column */
                             if (left > 0) {
-                                uint32_t bq[VEC];
+                                if (PAIRS) { /* four cells = two units: the bins of cells 0 and 2 as one dword */
+                                    const uint32_t b0 = (uint32_t) posterior_bin(r_f[j * VEC], r_b[j * VEC], total, nb, &errbits);
+                                    const uint32_t b1 = left > 2 ? (uint32_t) posterior_bin(r_f[j * VEC + (VEC > 2 ? 2 : 0)], r_b[j * VEC + (VEC > 2 ? 2 : 0)], total, nb, &errbits) : 0u;
+#ifdef MRP_PRUNE_CHECK_PAIRS /* development: the twins' f and b really are equal */
+                                    if (left > 1 && (r_f[j * VEC] != r_f[j * VEC + 1] || r_b[j * VEC] != r_b[j * VEC + 1])) errbits |= MRP_ENGINE_ERR_STRUCTURE;
+                                    if (left > 3 && (r_f[j * VEC + 2] != r_f[j * VEC + 3] || r_b[j * VEC + 2] != r_b[j * VEC + 3])) errbits |= MRP_ENGINE_ERR_STRUCTURE;
+#endif
+                                    *reinterpret_cast<uint32_t *>(dst + (j * LG + base_c) * (VEC / 2)) = b0 | (b1 << 16);
+                                } else {
+                                    uint32_t bq[VEC];
 #pragma unroll
-                                for (int q = 0; q < VEC; q++) bq[q] = q < left ? (uint32_t) posterior_bin(r_f[j * VEC + q], r_b[j * VEC + q], total, nb, &errbits) : 0u;
-                                *reinterpret_cast<uint2 *>(dst + (j * LG + base_c) * VEC) = make_uint2(bq[0] | (bq[VEC > 1 ? 1 : 0] << 16), bq[VEC > 2 ? 2 : 0] | (bq[VEC > 3 ? 3 : 0] << 16));
+                                    for (int q = 0; q < VEC; q++) bq[q] = q < left ? (uint32_t) posterior_bin(r_f[j * VEC + q], r_b[j * VEC + q], total, nb, &errbits) : 0u;
+                                    *reinterpret_cast<uint2 *>(dst + (j * LG + base_c) * VEC) = make_uint2(bq[0] | (bq[VEC > 1 ? 1 : 0] << 16), bq[VEC > 2 ? 2 : 0] | (bq[VEC > 3 ? 3 : 0] << 16));
+                                }
                             }
                         }
                     }
@@ -2410,7 +2424,7 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
 }
 
 static size_t prune_lds_bytes(const PruneParams &p) {
-    const size_t cap = (size_t) ((p.max_cells + 3) & ~3);
+    const size_t cap = p.pairs ? (size_t) (((p.max_cells + 1) / 2 + 3) & ~3) : (size_t) ((p.max_cells + 3) & ~3);
     const size_t dwords = 4 * PRUNE_SP + PRUNE_SP + 4 * PRUNE_SP + 64 + 2 * 1024 + 512 + 512 + 2 * PRUNE_SP + 2 * PRUNE_SP + 512 + 512 + 4 * PRUNE_TAB * 128 + 512;
     return dwords * 4 + (size_t) (((p.max_merge + 127) >> 7) << 2) * 4 + 2 * cap * 2 + 16;
 }
