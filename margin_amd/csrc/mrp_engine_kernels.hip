@@ -27,6 +27,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <type_traits>
 
 #include "mrp_engine.h"
 #include "mrp_internal.h"
@@ -1569,7 +1570,107 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                     }
                 };
                 int n = 0;
-                if (keep_all) {
+                /* Columns of up to 64 NS candidates (NS = 1, 2, 4: nine columns in ten): the NS slots side by side in straight-line
+                 * code -- one fence for all their marks, their LDS round trips overlapped -- then either every candidate is kept
+                 * (emit in enumeration order; the list stage sorts) or the kept units are the first n of the sorted keys. */
+                auto small_col = [&](auto ns_tag) {
+                    constexpr int NS = decltype(ns_tag)::value;
+                    if (tot > 0) { /* marks: where this unit's range starts, and the slots it continues into */
+                        if (off < NS * WAVE) heads[off] = (uint32_t) lane + 1u;
+#pragma unroll
+                        for (int j = 1; j < NS; j++)
+                            if (off < j * WAVE && off + tot > j * WAVE) heads[j * WAVE] = (uint32_t) lane + 1u;
+                    }
+                    wave_lds_fence();
+                    uint32_t own[NS], key[NS], c1[NS], c2[NS], pe[NS];
+#pragma unroll
+                    for (int j = 0; j < NS; j++) { own[j] = heads[j * WAVE + lane]; heads[j * WAVE + lane] = 0u; }
+                    uint4 r[NS];
+                    bool in[NS];
+#pragma unroll
+                    for (int j = 0; j < NS; j++) {
+                        const uint64_t marks = __ballot(own[j] != 0u);
+                        const int first_owner = __builtin_amdgcn_readfirstlane((int) own[j]) - 1;
+                        const int owner = first_owner + mbcnt64(marks) + (own[j] != 0u ? 1 : 0) - 1;
+                        in[j] = j * WAVE + lane < L;
+                        r[j] = rec[in[j] ? owner & 63 : 0];
+                    }
+#pragma unroll
+                    for (int j = 0; j < NS; j++) {
+                        const uint32_t nbq = (r[j].x >> 14) & 0xFFu, sa = (r[j].y >> 14) & 0x7Fu, sb = (r[j].y >> 21) & 0x7Fu;
+                        const uint32_t t = (uint32_t) (j * WAVE + lane) - (r[j].y & 0x3FFFu);
+                        const uint32_t x = (uint32_t) (((float) t + 0.5f) * __uint_as_float(r[j].z)); /* exact: see slot() */
+                        const uint32_t y = t - x * nbq;
+                        c1[j] = listA[(sa + x) & 127u];
+                        c2[j] = listB[(sb + y) & 127u];
+                    }
+                    uint32_t ii[NS], jj[NS];
+#pragma unroll
+                    for (int j = 0; j < NS; j++) {
+                        const uint32_t par_c = (c1[j] & c_pa) | (c2[j] & c_sb);
+                        const uint32_t u = in[j] ? (c1[j] >> 1) * C2 + ((c2[j] ^ (c1[j] & c_xm)) >> c_sb) : 0u;
+                        pe[j] = ((r[j].x & 0x3FFFu) << 1) + ((((r[j].x >> 22) & 1u) ^ par_c) & i_pm);
+                        const uint32_t bin_ = bin_k[u];
+                        if (keep_all) { ii[j] = nxA[c1[j] & 127u]; jj[j] = nxB[c2[j] & 127u]; } /* (wave-uniform: asked for together with the bins) */
+                        key[j] = (!in[j] || (filt && par_c != 0u)) ? 0xFFFFFFFFu : ((bin_ << 14) | u);
+                    }
+                    if (keep_all) {
+                        SEC_COUNT(8);
+                        uint32_t mu2[NS], ent2[NS], old[NS];
+#pragma unroll
+                        for (int j = 0; j < NS; j++) {
+                            const bool take = key[j] != 0xFFFFFFFFu;
+                            const uint32_t par_c = (c1[j] & c_pa) | (c2[j] & c_sb);
+                            mu2[j] = has_next ? (ii[j] >> 1) * Mb + ((jj[j] ^ (ii[j] & o_xm)) >> o_sb) : 0u;
+                            const uint32_t par_m = (ii[j] & o_pa) | (jj[j] & o_sb);
+                            const uint32_t nxt_even = (mu2[j] << 1) + ((par_m ^ par_c) & o_pm);
+                            ent2[j] = mu2[j] | (ii[j] << 14) | (jj[j] << 21);
+                            const uint64_t am = __ballot(take);
+                            if (take) selb[(n + mbcnt64(am)) & 63] = make_uint2(key[j], nxt_even | (pe[j] << 16));
+                            n += __popcll(am);
+                            old[j] = 0xFFFFFFFFu;
+                            if (has_next && take) old[j] = atomicOr(&bmp_m[(mu2[j] >> 5) & 511u], 1u << (mu2[j] & 31u));
+                        }
+                        if (has_next) {
+#pragma unroll
+                            for (int j = 0; j < NS; j++) {
+                                const bool first = ((old[j] >> (mu2[j] & 31u)) & 1u) == 0u;
+                                const uint64_t fm = __ballot(first);
+                                if (first) kmn[(cm + mbcnt64(fm)) & 127] = ent2[j];
+                                cm += __popcll(fm);
+                            }
+                        }
+                        SEC(1);
+                    } else {
+                        SEC_COUNT(9);
+                        int g = Lu;
+                        if (!thr_all) {
+                            g = 0;
+#pragma unroll
+                            for (int j = 0; j < NS; j++) g += __popcll(__ballot(key[j] != 0xFFFFFFFFu && (int) (key[j] >> 14) <= p.thr_bin));
+                        }
+                        n = kept_units(g);
+                        wave_bitonic_sort_n<NS>(key, lane);
+                        const uint32_t *pvA = tA + 512, *pvB = tB + 512;
+                        /* n <= 64 units: the kept ones are in the first register.  The even cell of unit u and where it comes from: */
+                        const bool take = lane < n;
+                        const uint32_t u = take ? key[0] & 0x3FFFu : 0u;
+                        uint32_t d1, d2;
+                        if (a_cp) {
+                            const uint32_t q = (uint32_t) (((float) u + 0.5f) * __builtin_amdgcn_rcpf((float) (C2 ? C2 : 1u)));
+                            d1 = 2u * q; d2 = u - q * C2;
+                        } else if (b_cp) { d1 = 0u; d2 = 2u * u; }
+                        else { d1 = 0u; d2 = 0u; }
+                        d1 &= 127u; d2 &= 127u;
+                        const uint32_t prv = k > 0 ? pair_index(pvA[d1], pvB[d2], Pb, true, in_ap, in_bp) : 0u;
+                        emit(take, lane, key[0], d1, d2, prv);
+                        SEC(4);
+                    }
+                };
+                if (L <= WAVE) small_col(std::integral_constant<int, 1>());
+                else if (L <= 2 * WAVE) small_col(std::integral_constant<int, 2>());
+                else if (L <= 4 * WAVE) small_col(std::integral_constant<int, 4>());
+                else if (keep_all) {
                     SEC_COUNT(8);
 #pragma unroll 1
                     for (int q0 = 0; q0 < L; q0 += WAVE) {
@@ -1580,42 +1681,6 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                         n += __popcll(am);
                     }
                     SEC(1);
-                } else if (L <= 4 * WAVE) {
-                    /* up to four slots of candidate units: selection by SORTING (see the general chain below); what rides along
-                     * with a unit is derived again from its index for the kept ones */
-                    SEC_COUNT(9);
-                    uint32_t kk[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-                    {
-                        uint32_t c1, c2, pe;
-                        kk[0] = slot(0, c1, c2, pe);
-                        if (L > WAVE) kk[1] = slot(WAVE, c1, c2, pe);
-                        if (L > 2 * WAVE) kk[2] = slot(2 * WAVE, c1, c2, pe);
-                        if (L > 3 * WAVE) kk[3] = slot(3 * WAVE, c1, c2, pe);
-                    }
-                    int g = Lu;
-                    if (!thr_all) {
-                        g = 0;
-#pragma unroll
-                        for (int j = 0; j < 4; j++) g += __popcll(__ballot(kk[j] != 0xFFFFFFFFu && (int) (kk[j] >> 14) <= p.thr_bin));
-                    }
-                    n = kept_units(g);
-                    if (L <= 2 * WAVE) { uint32_t k2[2] = {kk[0], kk[1]}; wave_bitonic_sort_n<2>(k2, lane); kk[0] = k2[0]; }
-                    else wave_bitonic_sort_n<4>(kk, lane);
-                    const uint32_t *pvA = tA + 512, *pvB = tB + 512;
-                    {   /* n <= 64 units: the kept ones are in the first register.  The even cell of unit u and where it comes from: */
-                        const bool take = lane < n;
-                        const uint32_t u = take ? kk[0] & 0x3FFFu : 0u;
-                        uint32_t c1, c2;
-                        if (a_cp) {
-                            const uint32_t q = (uint32_t) (((float) u + 0.5f) * __builtin_amdgcn_rcpf((float) (C2 ? C2 : 1u)));
-                            c1 = 2u * q; c2 = u - q * C2;
-                        } else if (b_cp) { c1 = 0u; c2 = 2u * u; }
-                        else { c1 = 0u; c2 = 0u; }
-                        c1 &= 127u; c2 &= 127u;
-                        const uint32_t prv = k > 0 ? pair_index(pvA[c1], pvB[c2], Pb, true, in_ap, in_bp) : 0u;
-                        emit(take, lane, kk[0], c1, c2, prv);
-                    }
-                    SEC(4);
                 } else {
                     /* pass 1: histogram of the posterior bins */
                     if (lane == 0) sh[56 + b] = 1u; /* the table wave wipes this histogram before its next use */
