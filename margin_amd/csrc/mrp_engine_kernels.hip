@@ -1313,6 +1313,54 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
             }
             if (lane == 0) { sc.n_kept[lcol] = n; sh[36 + b] = (uint32_t) n; }
         };
+        /* PAIRS: stage 1 in two halves a column apart -- the posteriors of the merge cells are a gather from HBM (two microseconds
+         * under load, as long as a whole column of the chain on pairs): asked for when the selection of column kk is read (step
+         * kk + 1), used a step later, with the selection in registers meanwhile (the chain reuses its buffer). */
+        uint32_t p1_key = 0xFFFFFFFFu, p1_np = 0u, p1_fl = 0u;
+        int32_t p1_mf = 0, p1_mb = 0;
+        int p1_n = 0;
+        auto stage1_ask = [&](int kk, int64_t mcell_off) {
+            const int b = kk & 1;
+            const uint2 *selb = reinterpret_cast<const uint2 *>(sel) + b * 64; /* (bin << 14 | unit, next | prev << 16) */
+            p1_n = (int) sh[32 + b];
+            p1_fl = sh[44 + b]; /* bit 0: the column's cells come in pairs, 1: the merge cells after it, 2: those before it */
+            const uint2 mine = selb[lane];
+            p1_key = lane < p1_n ? (mine.x << 7) | (uint32_t) lane : 0xFFFFFFFFu; /* bin (10) | unit (14) | slot (7) */
+            p1_np = mine.y;
+            p1_mf = 0; p1_mb = 0;
+            if (kk + 1 < K && lane < p1_n) {
+                const uint32_t m = mine.y & 0xFFFFu;
+                p1_mf = d.merge_f32[mcell_off + m];
+                p1_mb = d.merge_b32[mcell_off + m];
+            }
+        };
+        auto stage1_finish = [&](int kk) {
+            const int b = kk & 1;
+            uint32_t *snp = s1 + b * 2 * PRUNE_SP, *sbin = snp + PRUNE_SP;
+            const int n = p1_n;
+            const uint32_t fl = p1_fl, o_pm = (fl >> 1) & 1u, i_pm = (fl >> 2) & 1u;
+            const int64_t lcol = h.col0 + kk;
+            const bool has_merge = kk + 1 < K;
+            uint32_t key[1] = {p1_key};
+            wave_bitonic_sort_n<1>(key, lane);
+            const uint32_t mbin = has_merge && lane < n ? (uint32_t) posterior_bin(p1_mf, p1_mb, total, nb, &errbits) : 0u;
+            /* what rides along with a unit comes from the lane that held it before the sort */
+            const uint32_t src = key[0] & 0x3Fu, u = (key[0] >> 7) & 0x3FFFu;
+            const uint32_t np_ = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (src << 2), (int) p1_np);
+            const uint32_t sb_ = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (src << 2), (int) mbin);
+            if (lane < n) {
+                if (fl & 1u) {
+                    *reinterpret_cast<uint32_t *>(sc.kept + lcol * S + 2 * lane) = (2u * u) | ((2u * u + 1u) << 16);
+                    *reinterpret_cast<uint2 *>(sc.kept_np + lcol * S + 2 * lane) = make_uint2(np_, np_ ^ o_pm ^ (i_pm << 16));
+                } else { /* a column of one cell */
+                    sc.kept[lcol * S + lane] = (uint16_t) u;
+                    sc.kept_np[lcol * S + lane] = np_;
+                }
+                snp[lane] = np_;
+                sbin[lane] = sb_;
+            }
+            if (lane == 0) { sc.n_kept[lcol] = (fl & 1u) ? 2 * n : n; sh[36 + b] = (uint32_t) n; sh[46 + b] = fl; }
+        };
         /* Stage 2 (wave 2, one column later): distinct next merge cells in order of first use, stable sort by posterior,
          * kept merge list to HBM. */
         auto lists_stage2 = [&](int kk) {
@@ -2141,31 +2189,61 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
             ROLE_CLK_DONE(0);
             SEC_DONE();
             lds_barrier();
+            if (PAIRS) lds_barrier(); /* (the list stages of the chain on pairs run three columns deep) */
         } else if (wave == 1) {
             int64_t mcell_prev = 0; /* first merge cell of the merge column after column k - 1 */
             SweepCol scur = k_load(d.scols + h.col0);
             lds_barrier();
             ROLE_CLK_INIT();
-            for (int k = 0; k < K; k++) {
-                if (k > 0) lists_stage1(k - 1, mcell_prev);
-                mcell_prev = scur.mcell_off;
-                if (k + 1 < K) scur = k_load(d.scols + h.col0 + k + 1);
-                ROLE_BARRIER();
+            if constexpr (PAIRS) {
+                for (int k = 0; k < K; k++) {
+                    if (k > 1) stage1_finish(k - 2);
+                    if (k > 0) stage1_ask(k - 1, mcell_prev);
+                    mcell_prev = scur.mcell_off;
+                    if (k + 1 < K) scur = k_load(d.scols + h.col0 + k + 1);
+                    ROLE_BARRIER();
+                }
+                ROLE_CLK_DONE(1);
+                if (K > 1) stage1_finish(K - 2);
+                stage1_ask(K - 1, mcell_prev);
+                lds_barrier();
+                stage1_finish(K - 1);
+                lds_barrier();
+            } else {
+                for (int k = 0; k < K; k++) {
+                    if (k > 0) lists_stage1(k - 1, mcell_prev);
+                    mcell_prev = scur.mcell_off;
+                    if (k + 1 < K) scur = k_load(d.scols + h.col0 + k + 1);
+                    ROLE_BARRIER();
+                }
+                ROLE_CLK_DONE(1);
+                lists_stage1(K - 1, mcell_prev);
+                lds_barrier();
             }
-            ROLE_CLK_DONE(1);
-            lists_stage1(K - 1, mcell_prev);
-            lds_barrier();
         } else if (wave == 2) {
             lds_barrier();
             ROLE_CLK_INIT();
-            for (int k = 0; k < K; k++) {
-                if (k > 1) lists_stage2(k - 2);
-                ROLE_BARRIER();
+            if constexpr (PAIRS) { /* a column later than the general chain: stage 1 takes two steps */
+                for (int k = 0; k < K; k++) {
+                    if (k > 2) lists_stage2(k - 3);
+                    ROLE_BARRIER();
+                }
+                ROLE_CLK_DONE(2);
+                if (K > 2) lists_stage2(K - 3);
+                lds_barrier();
+                if (K > 1) lists_stage2(K - 2);
+                lds_barrier();
+                lists_stage2(K - 1);
+            } else {
+                for (int k = 0; k < K; k++) {
+                    if (k > 1) lists_stage2(k - 2);
+                    ROLE_BARRIER();
+                }
+                ROLE_CLK_DONE(2);
+                if (K > 1) lists_stage2(K - 2);
+                lds_barrier();
+                lists_stage2(K - 1);
             }
-            ROLE_CLK_DONE(2);
-            if (K > 1) lists_stage2(K - 2);
-            lds_barrier();
-            lists_stage2(K - 1);
         } else if (wave == 3) {
             /* wave 3: the parents' transitions of the column after next.  Three columns are in the pipe: the tables of column
              * t are built from the registers while the transitions of column t + 1 and the descriptor of column t + 2 are in
@@ -2219,38 +2297,57 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                     }
                 }
             };
-            auto tab_build_side = [&](uint32_t *t5, const uint32_t (&rn)[2], uint32_t C, uint32_t P, uint32_t in_kind, uint32_t out_kind) {
-                uint32_t *cnt = t5, *start = t5 + 128, *list = t5 + 256, *nx = t5 + 384, *pv = t5 + 512;
-                const uint32_t G = P < 1u ? 1u : (P > 128u ? 128u : P);
-                cnt[lane] = 0u; cnt[lane + WAVE] = 0u;
-                wave_lds_fence();
-                uint32_t rank[2] = {0u, 0u}, grp_[2] = {0u, 0u};
+            /* inverted transition lists of both sides (cells grouped by the merge cell they come from: count, first entry, list),
+             * the two sides side by side between the same three LDS fences */
+            auto tab_build_sides = [&](uint32_t *tA5, uint32_t CA, uint32_t PA, uint32_t in_a, uint32_t out_a, uint32_t CB, uint32_t PB, uint32_t in_b, uint32_t out_b) {
+                uint32_t *t5[2] = {tA5, tA5 + PRUNE_TAB * 128};
+                const uint32_t C_[2] = {CA, CB}, in_[2] = {in_a, in_b}, out_[2] = {out_a, out_b};
+                const uint32_t G_[2] = {PA < 1u ? 1u : (PA > 128u ? 128u : PA), PB < 1u ? 1u : (PB > 128u ? 128u : PB)};
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const uint32_t c = (uint32_t) (lane + u * WAVE);
-                    if (c < C) {
-                        uint32_t pvi = in_kind == MRP_CONN_REAL ? (rn[u] >> 16) : (in_kind == MRP_CONN_IDENT ? c : 0u);
-                        const uint32_t nxi = out_kind == MRP_CONN_REAL ? (rn[u] & 0xFFFFu) : (out_kind == MRP_CONN_IDENT ? c : 0u);
-                        if (pvi >= G) { errbits |= MRP_ENGINE_ERR_RANGE; pvi = 0u; }
-                        pv[c] = pvi; nx[c] = nxi;
-                        grp_[u] = pvi;
-                        rank[u] = atomicAdd(&cnt[pvi], 1u);
+                for (int sd = 0; sd < 2; sd++) { t5[sd][lane] = 0u; t5[sd][lane + WAVE] = 0u; }
+                wave_lds_fence();
+                uint32_t rank[2][2] = {{0u, 0u}, {0u, 0u}}, grp_[2][2] = {{0u, 0u}, {0u, 0u}};
+#pragma unroll
+                for (int sd = 0; sd < 2; sd++) {
+                    uint32_t *cnt = t5[sd], *nx = t5[sd] + 384, *pv = t5[sd] + 512;
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const uint32_t c = (uint32_t) (lane + u * WAVE);
+                        const uint32_t rn = sd == 0 ? r_na[u] : r_nb[u];
+                        if (c < C_[sd]) {
+                            uint32_t pvi = in_[sd] == MRP_CONN_REAL ? (rn >> 16) : (in_[sd] == MRP_CONN_IDENT ? c : 0u);
+                            const uint32_t nxi = out_[sd] == MRP_CONN_REAL ? (rn & 0xFFFFu) : (out_[sd] == MRP_CONN_IDENT ? c : 0u);
+                            if (pvi >= G_[sd]) { errbits |= MRP_ENGINE_ERR_RANGE; pvi = 0u; }
+                            pv[c] = pvi; nx[c] = nxi;
+                            grp_[sd][u] = pvi;
+                            rank[sd][u] = atomicAdd(&cnt[pvi], 1u);
+                        }
                     }
                 }
                 wave_lds_fence();
-                /* exclusive scan of the group sizes (two per lane: groups lane and lane + 64) */
-                const int c0 = (int) cnt[lane], c1 = (int) cnt[lane + WAVE];
-                const int i0 = wave_incl_scan(c0, lane);
-                const int t0 = __shfl(i0, WAVE - 1, WAVE);
-                const int i1 = wave_incl_scan(c1, lane);
-                /* (the chain on pairs reads a group's first entry and size as one word) */
-                start[lane] = (uint32_t) (i0 - c0) | (PAIRS ? (uint32_t) c0 << 8 : 0u);
-                start[lane + WAVE] = (uint32_t) (t0 + i1 - c1) | (PAIRS ? (uint32_t) c1 << 8 : 0u);
+                /* exclusive scan of the group sizes (two per lane and side: groups lane and lane + 64) */
+                int c0[2], c1[2], i0[2], i1[2];
+#pragma unroll
+                for (int sd = 0; sd < 2; sd++) { c0[sd] = (int) t5[sd][lane]; c1[sd] = (int) t5[sd][lane + WAVE]; }
+#pragma unroll
+                for (int sd = 0; sd < 2; sd++) { i0[sd] = wave_incl_scan_bc(c0[sd]); i1[sd] = wave_incl_scan_bc(c1[sd]); }
+#pragma unroll
+                for (int sd = 0; sd < 2; sd++) {
+                    uint32_t *start = t5[sd] + 128;
+                    const int t0 = __builtin_amdgcn_readlane(i0[sd], WAVE - 1);
+                    /* (the chain on pairs reads a group's first entry and size as one word) */
+                    start[lane] = (uint32_t) (i0[sd] - c0[sd]) | (PAIRS ? (uint32_t) c0[sd] << 8 : 0u);
+                    start[lane + WAVE] = (uint32_t) (t0 + i1[sd] - c1[sd]) | (PAIRS ? (uint32_t) c1[sd] << 8 : 0u);
+                }
                 wave_lds_fence();
 #pragma unroll
-                for (int u = 0; u < 2; u++) {
-                    const uint32_t c = (uint32_t) (lane + u * WAVE);
-                    if (c < C) list[(start[grp_[u]] & 0xFFu) + rank[u]] = c;
+                for (int sd = 0; sd < 2; sd++) {
+                    uint32_t *start = t5[sd] + 128, *list = t5[sd] + 256;
+#pragma unroll
+                    for (int u = 0; u < 2; u++) {
+                        const uint32_t c = (uint32_t) (lane + u * WAVE);
+                        if (c < C_[sd]) list[(start[grp_[sd][u]] & 0xFFu) + rank[sd][u]] = c;
+                    }
                 }
             };
             auto tab_build = [&]() { /* tables of column tcol into buffer tcol & 1, from the registers loaded last time */
@@ -2273,8 +2370,7 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                     }
                     uint32_t C1 = tcc.C1, C2 = tcc.C2;
                     if (C1 > 128u || C2 > 128u) { errbits |= MRP_ENGINE_ERR_RANGE; C1 = C1 > 128u ? 128u : C1; C2 = C2 > 128u ? 128u : C2; }
-                    tab_build_side(tb, r_na, C1, tcc.Pa, tcc.in_a, tcc.out_a);
-                    tab_build_side(tb + PRUNE_TAB * 128, r_nb, C2, tcc.Pb, tcc.in_b, tcc.out_b);
+                    tab_build_sides(tb, C1, tcc.Pa, tcc.in_a, tcc.out_a, C2, tcc.Pb, tcc.in_b, tcc.out_b);
                 }
             };
 
@@ -2301,6 +2397,7 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
             }
             ROLE_CLK_DONE(3);
             lds_barrier();
+            if (PAIRS) lds_barrier();
         } else {
             /* bins groups (waves 4..): group g handles the columns g, g + 2, ...  A step of its loop stores the bins of the
              * column whose f and b sit in the registers and requests the column after next into the same registers; the
@@ -2393,6 +2490,7 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
             }
             if (gidx == 0) ROLE_CLK_DONE(4 + grp);
             lds_barrier();
+            if (PAIRS) lds_barrier();
         }
         __syncthreads(); /* also makes the lists above visible in global memory */
 
