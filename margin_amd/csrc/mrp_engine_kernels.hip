@@ -2496,7 +2496,66 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
 
         /* ---- stRPHmm_pruneBackwards hmm.c:1111-1158: lists of at most S entries, one wave; the lists of
          * column k - 1 are requested before column k is worked on ---- */
-        if (wave == 0) {
+        if (PAIRS && wave == 0) {
+            /* The lists in UNITS: entry i = cells 2 i, 2 i + 1 of the kept list (the list stages wrote a unit's cells next to each
+             * other; a column or merge column of one cell has a list of one -- an odd count), one entry per lane, the flags one
+             * per merge unit.  The merge cells the surviving cells come from are all in the forward pass's kept merge list (it
+             * keeps every merge cell a kept cell leads to, checked), so the flags set from the cells are the survivors of that list. */
+            struct ListsU { int nk, nm; uint32_t cc; uint2 cn; uint32_t mm; };
+            auto fetch = [&](int k) {
+                ListsU L;
+                L.nk = 0; L.nm = 0; L.cc = 0u; L.cn = make_uint2(0u, 0u); L.mm = 0u;
+                if (k >= 0) {
+                    const int64_t lc = h.col0 + k;
+                    L.nk = sc.n_kept[lc];
+                    L.nm = sc.n_keptm[lc];
+                    if (2 * lane < S) { /* (the counts are not known yet when the lists are requested: every slot below S is read) */
+                        L.cc = *reinterpret_cast<const uint32_t *>(sc.kept + lc * S + 2 * lane);
+                        L.cn = *reinterpret_cast<const uint2 *>(sc.kept_np + lc * S + 2 * lane);
+                        L.mm = *reinterpret_cast<const uint32_t *>(sc.keptm + lc * S + 2 * lane);
+                    }
+                }
+                return L;
+            };
+            uint32_t pm = 0u; /* merge unit of the merge column after column k this lane has flagged */
+            bool pmk = false;
+            ListsU cur = fetch(K - 1), nx1 = fetch(K - 2);
+            for (int k = K - 1; k >= 0; k--) {
+                const int64_t lcol = h.col0 + k;
+                const ListsU nx2 = fetch(k - 2);
+                const int sk = (cur.nk & 1) ? 0 : 1, so = (cur.nm & 1) ? 0 : 1; /* cells / merge cells after the column in pairs */
+                const int nku = cur.nk >> sk;
+                const bool keep = lane < nku && (k + 1 == K || flag_get((cur.cn.x & 0xFFFFu) >> so));
+                const uint64_t m0 = __ballot(keep);
+                const int ns = __popcll(m0);
+                if (pmk) flag_clr(pm);
+                if (ns != nku) {
+                    if (keep) {
+                        const int pos = mbcnt64(m0);
+                        *reinterpret_cast<uint32_t *>(sc.kept + lcol * S + 2 * pos) = cur.cc;
+                        *reinterpret_cast<uint2 *>(sc.kept_np + lcol * S + 2 * pos) = cur.cn;
+                    }
+                    if (lane == 0) sc.n_kept[lcol] = ns << sk;
+                }
+                if (k == 0) break;
+                /* merge column k - 1 keeps the merge cells some surviving cell comes from (:1141-1155) */
+                const int si = (nx1.nm & 1) ? 0 : 1;
+                if (keep) flag_set((cur.cn.x >> 16) >> si);
+                const int nmu = nx1.nm >> si;
+                const uint32_t mu_ = (nx1.mm & 0xFFFFu) >> si;
+                const bool mk = lane < nmu && flag_get(mu_);
+                const uint64_t q0 = __ballot(mk);
+                const int nms = __popcll(q0);
+                if (nms != nmu) {
+                    if (mk) *reinterpret_cast<uint32_t *>(sc.keptm + (lcol - 1) * S + 2 * mbcnt64(q0)) = nx1.mm;
+                    if (lane == 0) sc.n_keptm[lcol - 1] = nms << si;
+                }
+                pm = mu_; pmk = mk;
+                cur = nx1;
+                nx1 = nx2;
+            }
+            if (pmk) flag_clr(pm);
+        } else if (wave == 0) {
             uint32_t pm[2] = {0u, 0u}; /* kept merge cells of the merge column after column k: they own the flags */
             bool pmk[2] = {false, false};
             /* the lists of a column are requested two columns before they are used */
