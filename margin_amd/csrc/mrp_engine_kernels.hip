@@ -1521,10 +1521,11 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
             for (int k = 0; k < K; k++) {
                 SEC(7);
                 const int b = k & 1;
-                const uint2 cd = *reinterpret_cast<const uint2 *>(sh + 48 + 4 * b);
+                const uint4 cd = *reinterpret_cast<const uint4 *>(sh + 48 + 4 * b);
                 const int nkm = (int) sh[40 + b];
                 const uint32_t ent_ = kml[b * PRUNE_SP + lane];
                 const uint32_t cd0 = (uint32_t) __builtin_amdgcn_readfirstlane((int) cd.x), cd1 = (uint32_t) __builtin_amdgcn_readfirstlane((int) cd.y);
+                const uint32_t cd2 = (uint32_t) __builtin_amdgcn_readfirstlane((int) cd.z); /* the table wave's bits */
                 uint2 *selb = reinterpret_cast<uint2 *>(sel) + b * 64; /* selection of column k: (bin << 14 | unit, next | prev << 16 of the unit's even cell) */
                 const uint32_t *tA = tab + b * 2 * PRUNE_TAB * 128, *tB = tA + PRUNE_TAB * 128;
                 const uint32_t *csA = tA + 128, *listA = tA + 256, *nxA = tA + 384;
@@ -1535,15 +1536,14 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                 const uint32_t cflags = cd1 & 0xFFu;
                 const uint32_t C2 = (cd0 & 0xFFFFu) > 128u ? 128u : (cd0 & 0xFFFFu), Mb = cd0 >> 16, Pb = cd1 >> 16;
                 const bool a_cp = (cd1 & 0x100u) != 0, b_cp = (cd1 & 0x200u) != 0;
-                const bool out_ap = (cflags & MRP_XF_OUT_A_PAIRED) != 0, out_bp = (cflags & MRP_XF_OUT_B_PAIRED) != 0;
                 const bool in_ap = (cflags & MRP_XF_IN_A_PAIRED) != 0, in_bp = (cflags & MRP_XF_IN_B_PAIRED) != 0;
                 const bool has_next = k + 1 < K;
-                const uint32_t c_xm = (a_cp && b_cp) ? 1u : 0u, c_sb = (!a_cp && b_cp) ? 1u : 0u, c_pa = a_cp ? 1u : 0u;
-                const uint32_t o_xm = (out_ap && out_bp) ? 1u : 0u, o_sb = (!out_ap && out_bp) ? 1u : 0u, o_pa = out_ap ? 1u : 0u;
-                const uint32_t o_pm = (out_ap || out_bp) ? 1u : 0u, i_pm = (in_ap || in_bp) ? 1u : 0u;
-                const uint32_t i_pa = in_ap ? 1u : 0u, i_sb = (!in_ap && in_bp) ? 1u : 0u;
-                const int w_c = (a_cp || b_cp) ? 2 : 1;  /* cells per unit of this column */
-                const bool filt = i_pm == 0u && w_c == 2;  /* behind a merge column of one cell: both members are enumerated */
+                const uint32_t c_xm = cd2 & 1u, c_sb = (cd2 >> 1) & 1u, c_pa = (cd2 >> 2) & 1u;
+                const uint32_t o_xm = (cd2 >> 3) & 1u, o_sb = (cd2 >> 4) & 1u, o_pa = (cd2 >> 5) & 1u;
+                const uint32_t o_pm = (cd2 >> 6) & 1u, i_pm = (cd2 >> 7) & 1u;
+                const uint32_t i_pa = (cd2 >> 8) & 1u, i_sb = (cd2 >> 9) & 1u;
+                const int w_sh = (int) ((cd2 >> 10) & 1u), w_c = 1 << w_sh;  /* cells per unit of this column: 1 << w_sh */
+                const bool filt = ((cd2 >> 11) & 1u) != 0;  /* behind a merge column of one cell: both members are enumerated */
                 /* this lane's kept merge unit: the parents' cells one of its members links, as list ranges.  An entry of the
                  * list is unit | i << 14 | j << 21: the unit and the indices of that member on either side */
                 const bool has = lane < nkm;
@@ -1563,11 +1563,11 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                                                     __float_as_uint(rn), 0u);
                 }
                 const int Lu = filt ? L >> 1 : L;  /* linked units */
-                const int Lc = Lu * w_c;           /* linked cells */
+                const int Lc = Lu << w_sh;         /* linked cells */
                 SEC(0);
                 const bool thr_all = p.thr_bin >= nb - 1;
                 const bool keep_all = Lc <= p.min_p || (thr_all && Lc <= p.max_p); /* the loop of :1073-1079 drops nothing */
-                auto kept_units = [&](int g_units) -> int { return kept_count(Lc, g_units * w_c, p.min_p, p.max_p) / w_c; };
+                auto kept_units = [&](int g_units) -> int { return kept_count(Lc, g_units << w_sh, p.min_p, p.max_p) >> w_sh; };
                 /* candidates q0 .. q0 + 63: key = bin << 14 | unit (0xFFFFFFFF: none), the parent cells the enumeration met, and the
                  * merge cell the unit's EVEN cell comes from */
                 auto slot = [&](int q0, uint32_t &c1, uint32_t &c2, uint32_t &prv_even) -> uint32_t {
@@ -2357,6 +2357,15 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                         sh[48 + 4 * (tcol & 1)] = (uint32_t) tcc.C2 | ((uint32_t) tcc.Mb << 16);
                         sh[49 + 4 * (tcol & 1)] = (uint32_t) tcc.flags | ((tcc.a_part && tcc.d1 > 0) ? 0x100u : 0u) | ((tcc.b_part && tcc.d2 > 0) ? 0x200u : 0u) |
                                                   ((uint32_t) tcc.Pb << 16);
+                        if (PAIRS) { /* what the chain on pairs derives from these flags, as bits (see its unit() / parity() rule) */
+                            const bool a_cp = tcc.a_part && tcc.d1 > 0, b_cp = tcc.b_part && tcc.d2 > 0;
+                            const bool o_a = (tcc.flags & MRP_XF_OUT_A_PAIRED) != 0, o_b = (tcc.flags & MRP_XF_OUT_B_PAIRED) != 0;
+                            const bool i_a = (tcc.flags & MRP_XF_IN_A_PAIRED) != 0, i_b = (tcc.flags & MRP_XF_IN_B_PAIRED) != 0;
+                            sh[50 + 4 * (tcol & 1)] = ((a_cp && b_cp) ? 1u : 0u) | ((!a_cp && b_cp) ? 2u : 0u) | (a_cp ? 4u : 0u) | ((o_a && o_b) ? 8u : 0u) |
+                                                      ((!o_a && o_b) ? 16u : 0u) | (o_a ? 32u : 0u) | ((o_a || o_b) ? 64u : 0u) | ((i_a || i_b) ? 128u : 0u) |
+                                                      (i_a ? 256u : 0u) | ((!i_a && i_b) ? 512u : 0u) | ((a_cp || b_cp) ? 1024u : 0u) |
+                                                      ((!(i_a || i_b) && (a_cp || b_cp)) ? 2048u : 0u);
+                        }
                     }
                     if (W == 4) { /* the column's posterior bins */
                         uint16_t *dst = bins + (tcol & 1) * cap_c;
