@@ -65,6 +65,24 @@ def parse_args():
     return ap.parse_args()
 
 
+def insitu_rooflines(st):
+    """Per kernel family IN THE REAL STEP (not the replay): the algorithmic bytes the family is responsible for (SURVEY.md 8d:
+    recursion 16 B per cell + 32 B per merge cell + 8 B per column; prune: the 8 B per cell of f and b it ranks; cross product +
+    emission: the 8 B per cell of cost and transitions it writes) over the family's SUMMED device time of the step.  The
+    concurrent batches of a call run side by side, so the summed time exceeds the wall time and the rate is what one batch's
+    kernels get while sharing the device: roofline.path is the product of these terms and of the overlap."""
+    C, M, K = float(st.cells), float(st.merge_cells), float(st.columns)
+    fam = {"recursion": (16.0 * C + 32.0 * M + 8.0 * K, float(st.recursion_ms), "mrp_sweep_i32_kernel"),
+           "prune": (8.0 * C, float(st.prune_kernel_ms), "mrp_prune_kernel"),
+           "cross_product_emission": (8.0 * C, float(st.cross_emit_ms), "mrp_cross_emit_kernel (+ the final level's cross / emission kernels)")}
+    out = {}
+    for name, (b, ms, kern) in fam.items():
+        if ms > 0:
+            out[name] = dict(kernel=kern, algorithmic_bytes=b, summed_device_ms=ms, achieved=b / (ms * 1e-3) / 1e9, unit="GB/s",
+                             frac=b / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+    return out
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -142,15 +160,16 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    t0 = time.perf_counter()
+    t0, c0 = time.perf_counter(), time.process_time()
     st = None
     for _ in range(args.steps):
         st = step()
     barrier()
-    elapsed = time.perf_counter() - t0
+    elapsed, host_cpu = time.perf_counter() - t0, time.process_time() - c0
     elapsed, units_all = sharding.reduce_elapsed_and_units(dist, elapsed, units, device=reduce_dev)
-    value = units_all * args.steps / elapsed
-    ms_per_step = 1e3 * elapsed / args.steps
+    # (--steps 0: the counter passes of tools/collect_profiles_r04.sh, which want the replay leg's launches alone in the trace)
+    value = units_all * args.steps / elapsed if args.steps > 0 else 0.0
+    ms_per_step = 1e3 * elapsed / args.steps if args.steps > 0 else float("nan")
 
     cfg = dict(workload=f"configs[1]: synthetic 1 Mb chunk, {args.sites} het sites, {args.coverage:g}x ONT reads, shipped ONT haplotag params; "
                         f"{args.chunks} chunks per GPU phased end to end per step (mrp_phase_reads_many: all merge levels resident in HBM, final sweep, "
@@ -158,20 +177,43 @@ def main():
                chunks_per_gpu=args.chunks, units_per_gpu=int(units) // (n_gpus if single_process_multi else 1),
                parallelism=(f"1 process, {n_gpus} devices, host work queue (mrp_queue_phase_chunks), no collectives" if single_process_multi else
                             f"{world} process(es), one per GPU, chunks sharded by rank, no collectives"),
-               host_threads=host_threads, synth_s=t_synth)
+               host_threads=host_threads, host_cpu_s_per_step=host_cpu / max(1, args.steps), synth_s=t_synth)
     out = dict(metric="het-sites x reads phased/sec (30x ONT synthetic chunks, end to end: every merge level + final sweep)",
                value=value, unit="het-site-reads/s", n_gpus=n_gpus, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int32", data="synthetic", config=cfg)
-    if not single_process_multi:
+    if not single_process_multi and st is not None:
         out["step_detail"] = dict(resident=int(st.resident), fallback_chunks=int(st.fallback_chunks), levels=int(st.levels), hmms=int(st.hmms),
                                   columns=int(st.columns), cells=int(st.cells), merge_cells=int(st.merge_cells), device_ms=float(st.device_ms),
                                   cross_ms=float(st.cross_ms), sweep_ms=float(st.sweep_ms), prune_ms=float(st.prune_ms),
-                                  note="device_ms: summed HIP-event time of the levels' kernels of the last step (concurrent halves add up)")
-    else:
+                                  pack_ms=float(st.pack_ms), cross_emit_ms=float(st.cross_emit_ms), recursion_ms=float(st.recursion_ms),
+                                  prune_kernel_ms=float(st.prune_kernel_ms), compact_ms=float(st.compact_ms),
+                                  note="device_ms: summed HIP-event time of the levels' kernels of the last step (the concurrent batches of a call add up: "
+                                       "their kernels share the device); cross_ms / sweep_ms / prune_ms are the level's three event intervals (sweep_ms includes "
+                                       "packing and the one-pass cross product + emission, prune_ms the compaction), the *_ms after them the same time by kernel family")
+        out["insitu"] = insitu_rooflines(st)
+    elif st is not None:
         out["step_detail"] = dict(batches=int(st.batches), fallback_chunks=int(st.fallback_chunks),
                                   chunks_per_device=[int(st.chunks_per_device[d]) for d in range(n_gpus)],
                                   busy_ms_per_device=[float(st.busy_ms_per_device[d]) for d in range(n_gpus)],
                                   note="inputs in host memory: the upload of every batch is inside the timed region")
+
+    # ---- latency: what ONE chunk and EIGHT chunks of the headline workload cost end to end (BASELINE.json configs[1] is literally
+    # "a single 1 Mb chunk, one sweep": a caller with few chunks in hand sees this, not the many-chunk rate) ----------------
+    if not single_process_multi and rank == 0:
+        lat = {}
+        for m in (1, 8):
+            if m > len(dchunks):
+                continue
+            capi.phase_reads_many(ctx, dchunks[:m], chunks[:m], params, convert=False)
+            t1 = time.perf_counter()
+            reps = 5
+            for _ in range(reps):
+                capi.phase_reads_many(ctx, dchunks[:m], chunks[:m], params, convert=False)
+            dt = (time.perf_counter() - t1) / reps
+            lat[f"{m}_chunk{'s' if m > 1 else ''}"] = dict(ms_per_call=1e3 * dt, value=float(sum(c.units for c in chunks[:m])) / dt, unit="het-site-reads/s")
+        out["latency"] = dict(what="one mrp_phase_reads_many call over 1 and over 8 chunks of the headline workload, inputs resident in HBM, end to end", **lat)
+    if dist is not None:
+        dist.barrier()
 
     # ---- the same chunks from HOST memory through the work queue (PCIe-inclusive) --------------------------------
     if args.queue_runs > 0 and not single_process_multi:
@@ -216,17 +258,33 @@ def main():
             u = float(sum(c.units for c in cs))
             capi.phase_reads_many(ctx, dcs, cs, params, convert=False)
             barrier()
-            t1 = time.perf_counter()
+            t1, c1 = time.perf_counter(), time.process_time()
             for _ in range(args.shape_runs):
                 _, sst = capi.phase_reads_many(ctx, dcs, cs, params, convert=False)
             barrier()
-            el = time.perf_counter() - t1
+            el, cpu = time.perf_counter() - t1, time.process_time() - c1
             el, u_all = sharding.reduce_elapsed_and_units(dist, el, u, device=reduce_dev)
+            # latency: ONE chunk and EIGHT chunks per call (what a `margin phase -t N` user with few chunks in hand sees)
+            lat = {}
+            for m in (1, 8):
+                capi.phase_reads_many(ctx, dcs[:m], cs[:m], params, convert=False)
+                t2 = time.perf_counter()
+                for _ in range(5):
+                    capi.phase_reads_many(ctx, dcs[:m], cs[:m], params, convert=False)
+                lat[f"{m}_chunk{'s' if m > 1 else ''}"] = dict(ms_per_call=1e3 * (time.perf_counter() - t2) / 5,
+                                                              value=float(sum(c.units for c in cs[:m])) * 5 / (time.perf_counter() - t2))
             for d_ in dcs:
                 d_.close()
+            # the path's roofline fraction for this shape: algorithmic bytes of every sweep of the call (24 B per cell, 32 B per merge
+            # cell, 8 B per column; the profile bytes, a per cent of it, left out) over the wall time of the call
+            alg_b = 24.0 * float(sst.cells) + 32.0 * float(sst.merge_cells) + 8.0 * float(sst.columns)
+            ms_call = 1e3 * el / args.shape_runs
             out.setdefault("shapes", {})[name] = dict(what=what, chunks_per_gpu=n, value=u_all * args.shape_runs / el, unit="het-site-reads/s",
-                                                     ms_per_call=1e3 * el / args.shape_runs, runs=args.shape_runs, resident=int(sst.resident),
-                                                     fallback_chunks=int(sst.fallback_chunks))
+                                                     ms_per_call=ms_call, runs=args.shape_runs, resident=int(sst.resident),
+                                                     fallback_chunks=int(sst.fallback_chunks), host_cpu_s_per_call=cpu / args.shape_runs,
+                                                     path=dict(algorithmic_bytes=alg_b, achieved=alg_b / (ms_call * 1e-3) / 1e9, unit="GB/s",
+                                                               frac=alg_b / (ms_call * 1e-3) / 1e9 / HBM_PEAK_GBS),
+                                                     insitu=insitu_rooflines(sst), latency=lat)
         shape_leg("configs[2]", "chr20-like: 640 chunks of ~130 het sites (100 kb + margins), 30x ONT reads, one mrp_phase_reads_many call",
                   lambda s_: synth.make_ont_chunk(seed=50_000 + 1000 * rank + s_, region_bp=130 * 500, n_sites=130, coverage=args.coverage), 640)
         shape_leg("configs[4]", "HiFi-like: 48 chunks of 2 000 sites, 35x reads N(18 kb, 3 kb), 1 % allele error, 2-4 alleles per site "
@@ -285,7 +343,7 @@ def main():
         traffic, traffic_src = None, None
         import hashlib
         k_sha = hashlib.sha256(open(os.path.join(ROOT, "margin_amd", "csrc", "mrp_kernels.hip"), "rb").read()).hexdigest()
-        for tpath in (os.path.join(ROOT, "profiles", "r03", "traffic.json"), os.path.join(ROOT, "profiles", "r02", "traffic.json")):
+        for tpath in (os.path.join(ROOT, "profiles", "r04", "traffic.json"),):
             if traffic is None and os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if int(tj.get("chunks", -1)) == n_rec and tj.get("kernel_source_sha256") == k_sha:
@@ -297,7 +355,9 @@ def main():
                                # the same launch priced on the bytes that really crossed the HBM interface (the 32 B per merge
                                # cell of the algorithmic credit live in LDS): what the kernel sustains
                                frac_of_measured_traffic=(traffic / (sweep_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                               frac_note="frac = ALGORITHMIC bytes (SURVEY.md 8d) / kernel time / peak; the kernel moves fewer bytes than that credit",
+                               frac_note="frac = ALGORITHMIC bytes (SURVEY.md 8d: 16 B per cell, 32 B per merge cell, 8 B per column) / kernel time / peak. "
+                                         "traffic = HBM bytes of the same launch from the PMC counters: below the algorithmic credit when the merge cells' "
+                                         "32 B stay in LDS, as they do (frac_of_measured_traffic prices those bytes instead)",
                                algorithmic_bytes_per_launch=alg_sweep, kernel_ms=sweep_avg,
                                what=f"all {sweeps} forward/backward sweeps of {n_rec} chunks (every merge level + final) recorded by the hashing path and "
                                     f"replayed as ONE dependency-free batch: the kernels' throughput, not a phasing rate",

@@ -300,6 +300,9 @@ typedef struct mrp_phase_many_stats {
      * level and is two orders of magnitude slower; the first such call of a process also says so on stderr (MRP_QUIET=1
      * silences it). */
     char note[160];
+    /* device_ms by kernel family (summed HIP-event times; the concurrent batches of a call add up): profile byte packing,
+     * cross product + emission, forward/backward recursion, prune, compaction (+ the final level's trace back) */
+    double pack_ms, cross_emit_ms, recursion_ms, prune_kernel_ms, compact_ms;
 } mrp_phase_many_stats;
 
 /* bubbleGraph_phaseBubbleGraph (bubbleGraph.c:2673-2801) for n_chunks independent chunks in one call: the

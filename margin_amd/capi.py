@@ -109,7 +109,9 @@ class PhaseResult(C.Structure):
 class PhaseManyStats(C.Structure):
     _fields_ = [("resident", C.c_int32), ("fallback_chunks", C.c_int32), ("levels", C.c_int64), ("hmms", C.c_int64),
                 ("columns", C.c_int64), ("cells", C.c_int64), ("merge_cells", C.c_int64), ("device_ms", C.c_double),
-                ("cross_ms", C.c_double), ("sweep_ms", C.c_double), ("prune_ms", C.c_double), ("note", C.c_char * 160)]
+                ("cross_ms", C.c_double), ("sweep_ms", C.c_double), ("prune_ms", C.c_double), ("note", C.c_char * 160),
+                ("pack_ms", C.c_double), ("cross_emit_ms", C.c_double), ("recursion_ms", C.c_double), ("prune_kernel_ms", C.c_double),
+                ("compact_ms", C.c_double)]
 
 
 MAX_QUEUE_DEVICES = 16

@@ -1057,6 +1057,17 @@ int mrp_batch_stats(mrp_batch *b, mrp_launch_stats *out) {
     return MRP_OK;
 }
 
+/* the most recent launch by kernel family (ms): packing / bit planes, cross product + emission, recursion.  Called after the
+ * stream the launch ran on has been waited for. */
+void mrp_batch_last_launch_ms(mrp_batch *b, float *pack, float *emission, float *recursion) {
+    *pack = *emission = *recursion = 0.f;
+    if (!b || !b->launched || b->n_launches < 1) return;
+    const auto &ev = b->ev_ring[(size_t) ((b->n_launches - 1) % mrp_batch::EV_RING)];
+    (void) hipEventElapsedTime(pack, ev[0], ev[1]);
+    (void) hipEventElapsedTime(emission, ev[4], ev[3]);
+    (void) hipEventElapsedTime(recursion, ev[3], ev[2]);
+}
+
 int mrp_batch_download(mrp_batch *b) {
     if (!b) return fail(MRP_ERR_ARG, "batch is NULL");
     if (!b->launched) return fail(MRP_ERR_ARG, "mrp_batch_download before mrp_batch_launch");

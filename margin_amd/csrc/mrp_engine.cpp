@@ -89,7 +89,7 @@ struct mrp_engine_level_state {
     PruneParams pp{};
     double t_begin = 0, t_staged = 0, t_launch_ms = 0;
     hipEvent_t uploaded = nullptr; /* end of the uploads on the copy stream */
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; /* before / after the cross product, after the sweeps, after the compaction, [4] after the prune */
     ~mrp_engine_level_state() {
         if (uploaded) (void) hipEventDestroy(uploaded);
         for (auto &e_ : ev)
@@ -610,6 +610,16 @@ static int level_finish(mrp_engine *e) {
         e->stats.sweep_ms += t_sweep;
         e->stats.prune_ms += t_prune;
         e->stats.device_ms += t_cross + t_sweep + t_prune;
+        {   /* by kernel family: packing, cross product + emission, recursion (the batch's own events), prune, compaction */
+            float t_pack = 0, t_emit = 0, t_rec = 0, t_pr = 0;
+            mrp_batch_last_launch_ms(Lp->b, &t_pack, &t_emit, &t_rec);
+            if (!Lp->final_level) (void) hipEventElapsedTime(&t_pr, Lp->ev[2], Lp->ev[4]);
+            e->stats.pack_ms += t_pack;
+            e->stats.cross_emit_ms += t_cross + t_emit;
+            e->stats.recursion_ms += t_rec;
+            e->stats.prune_kernel_ms += Lp->final_level ? 0.0 : t_pr;
+            e->stats.compact_ms += Lp->final_level ? t_prune : t_prune - t_pr; /* (final level: the trace back) */
+        }
         e->segments.push_back(std::move(Lp->seg));
     }
     level_retire(e, Lp);
@@ -701,6 +711,7 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
         ENG_TRY(mrp_launch_traceback(b->dev, L->d_ph.p, n, L->d_err.p, L->d_err_hmm.p, s));
     } else {
         ENG_TRY(mrp_launch_prune(b->dev, L->d_cc.p, L->d_ph.p, n, L->pp, sc, s));
+        ENG_TRY(hipEventRecord(L->ev[4], s));
         ENG_TRY(mrp_launch_compact(b->dev, L->d_cc.p, L->d_ph.p, L->d_col_hmm.p, total_cols, L->pp, sc, s));
     }
     ENG_TRY(hipEventRecord(L->ev[3], s));

@@ -501,6 +501,7 @@ void mrp_engine_release_context_cache(mrp_context *ctx);
 int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *const *descs, mrp_chunk **out, mrp_chunk_block *blk);
 int mrp_host_threads_setting(void); /* what mrp_set_host_threads() was given, 0 if it was never called */
 /* host worker pools (mrp_api.cpp) */
+extern "C" void mrp_batch_last_launch_ms(struct mrp_batch *b, float *pack, float *emission, float *recursion);
 struct mrp_host_pool;
 mrp_host_pool *mrp_host_pool_create(int threads);
 void mrp_host_pool_destroy(mrp_host_pool *p);

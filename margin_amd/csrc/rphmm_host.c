@@ -2158,6 +2158,7 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
         stats->levels = es.levels; stats->hmms = es.hmms; stats->columns = es.columns; stats->cells = es.cells;
         stats->merge_cells = es.merge_cells;
         stats->device_ms = es.device_ms; stats->cross_ms = es.cross_ms; stats->sweep_ms = es.sweep_ms; stats->prune_ms = es.prune_ms;
+        stats->pack_ms = es.pack_ms; stats->cross_emit_ms = es.cross_emit_ms; stats->recursion_ms = es.recursion_ms; stats->prune_kernel_ms = es.prune_kernel_ms; stats->compact_ms = es.compact_ms;
     }
     const double t_clean = now_ms();
     for (int64_t c = 0; c < n_chunks; c++) { rhmm_destroy(st[c].hmm); free(st[c].discarded); free(st[c].tree.a); free(st[c].path); free(st[c].chosen); }
@@ -2247,6 +2248,7 @@ static void stats_add(mrp_phase_many_stats *stats, const mrp_phase_many_stats *s
     if (st->levels > stats->levels) stats->levels = st->levels;
     stats->hmms += st->hmms; stats->columns += st->columns; stats->cells += st->cells; stats->merge_cells += st->merge_cells;
     stats->device_ms += st->device_ms; stats->cross_ms += st->cross_ms; stats->sweep_ms += st->sweep_ms; stats->prune_ms += st->prune_ms;
+    stats->pack_ms += st->pack_ms; stats->cross_emit_ms += st->cross_emit_ms; stats->recursion_ms += st->recursion_ms; stats->prune_kernel_ms += st->prune_kernel_ms; stats->compact_ms += st->compact_ms;
     if (st->note[0] && !stats->note[0]) memcpy(stats->note, st->note, sizeof(stats->note));
 }
 
@@ -2369,6 +2371,8 @@ static int phase_many_once(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *
                 stats->merge_cells += q->stats.merge_cells;
                 stats->device_ms += q->stats.device_ms; stats->cross_ms += q->stats.cross_ms; stats->sweep_ms += q->stats.sweep_ms;
                 stats->prune_ms += q->stats.prune_ms;
+                stats->pack_ms += q->stats.pack_ms; stats->cross_emit_ms += q->stats.cross_emit_ms; stats->recursion_ms += q->stats.recursion_ms;
+                stats->prune_kernel_ms += q->stats.prune_kernel_ms; stats->compact_ms += q->stats.compact_ms;
             }
             free(q->chunks); free(q->reads); free(q->n_reads); free(q->out);
         }

@@ -103,6 +103,7 @@ typedef struct mrp_engine_stats {
     int64_t levels, hmms, columns, cells, merge_cells;
     double device_ms; /* summed over levels: cross + planes + emission + recursion + prune + compaction */
     double cross_ms, sweep_ms, prune_ms;
+    double pack_ms, cross_emit_ms, recursion_ms, prune_kernel_ms, compact_ms; /* the same time by kernel family */
 } mrp_engine_stats;
 
 /* MRP_ERR_UNSUPPORTED when the parameters are outside what the resident path handles (log-sum-exp mode,
