@@ -83,6 +83,7 @@ struct mrp_engine_level_state {
     bool any_pack = true, any_planes = true; /* columns for the byte packing kernel / the bit plane kernel */
     int seg_id = -1;
     bool fused = false; /* cross product and emission in one kernel, no partition array (merge levels, no ancestor model) */
+    bool units = false; /* the level's cell / merge cell arrays hold one entry per complement pair (MRP_XF_UNITS) */
     unsigned long long clk[12] = {0};
     mrp_xhmm *x = nullptr;
     int64_t n = 0, total_cols = 0, n_slots = 0, n_reads = 0;
@@ -477,6 +478,10 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         pp.max_merge = std::max(pp.max_merge, x[i].bound_max_merge);
     }
     if (ctx->test_hooks & 8) pp.pairs = 0; /* test hook: the general prune chain, for A/B parity with the chain on complement pairs */
+    /* one array entry per complement pair (MRP_XF_UNITS) where the one-pass cross product + emission kernel writes the level and
+     * the prune reads it by units; MRP_UNITS=0 (development) keeps one entry per cell */
+    L->units = L->fused && pp.pairs != 0 && !(getenv("MRP_UNITS") && getenv("MRP_UNITS")[0] == '0');
+    if (L->units) pp.pairs = 2;
     pp.pad = (ctx->test_hooks & 1) && e->stats.levels + (e->running ? 1 : 0) == 1 ? 1 : 0; /* test hook, see mrp_context_set_test_hooks */
 
     tm[tmi++] = eng_now();
@@ -604,8 +609,8 @@ static int level_finish(mrp_engine *e) {
         e->stats.levels += 1;
         e->stats.hmms += Lp->n;
         e->stats.columns += Lp->total_cols;
-        e->stats.cells += Lp->totals[0];
-        e->stats.merge_cells += Lp->totals[1];
+        e->stats.cells += Lp->totals[4];       /* the cross products' cells / merge cells (the arrays may hold units, mrp_engine.h) */
+        e->stats.merge_cells += Lp->totals[5];
         e->stats.cross_ms += t_cross;
         e->stats.sweep_ms += t_sweep;
         e->stats.prune_ms += t_prune;
@@ -640,8 +645,8 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
     lo.ccols = L->d_cc.p;
     ENG_TRY(hipStreamWaitEvent(s, L->uploaded, 0));
     ENG_TRY(mrp_launch_layout(L->d_plan.p, L->d_phmm.p, n, total_cols, b->d_chunks.p, e->pp.S,
-                              e->params.include_inverted_partitions ? MRP_XF_INVERTED : 0u, lo, s));
-    ENG_TRY(hipMemcpyAsync(L->totals, L->d_totals.p, 32, hipMemcpyDeviceToHost, s));
+                              (e->params.include_inverted_partitions ? MRP_XF_INVERTED : 0u) | (L->units ? MRP_XF_UNITS : 0u), lo, s));
+    ENG_TRY(hipMemcpyAsync(L->totals, L->d_totals.p, 48, hipMemcpyDeviceToHost, s));
     /* the one host wait of a level: it also ends the level before (its error flags are in) */
     int rc = level_finish(e);
     if (rc != MRP_OK) return rc;

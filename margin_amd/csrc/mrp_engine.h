@@ -26,6 +26,13 @@
 #define MRP_XF_OUT_B_PAIRED 4u
 #define MRP_XF_IN_A_PAIRED 8u
 #define MRP_XF_IN_B_PAIRED 16u
+/* The level's cell arrays hold UNITS: with inverted partitions every cell of a cross product column sits next to its complement
+ * (cells 2u, 2u + 1), with the same emission cost, f and b, and the twin's merge cells are the twins of its merge cells -- so the
+ * recursion over one member of each pair IS the recursion (max over the cells that feed a merge cell = max over the units that feed
+ * its unit).  cross product + emission writes cost and transitions once per unit (transition = merge UNIT index), the recursion
+ * kernel runs unchanged on arrays of half the size, the prune reads f and b per unit.  A column / merge column of one
+ * self-complementary cell is one unit.  Set for the fused merge levels when the prune runs on pairs (PruneParams.pairs == 2). */
+#define MRP_XF_UNITS 32u
 
 /* one column of stRPHmm_createCrossProductOfTwoAlignedHmm (hmm.c:534-750) */
 struct CrossCol {
@@ -70,8 +77,9 @@ struct PlanHmm {
     int64_t cost_bound;
 };
 struct LayoutTot {       /* per hmm, after the counting pass */
-    int64_t cells, merge;
+    int64_t cells, merge;    /* entries of the level's cell / merge cell arrays (units when MRP_XF_UNITS) */
     int32_t tiles_fast, tiles_gen, max_cells, max_merge;
+    int64_t acells, amerge;  /* cells / merge cells of the cross product itself (SURVEY.md 8d counts these) */
 };
 struct LayoutBase {      /* per hmm, after the scan over the hmms */
     int64_t cell0, mcell0, tile_fast0, tile_gen0;
@@ -80,7 +88,8 @@ struct LayoutOut {       /* everything the layout kernels write */
     uint16_t *dims;      /* [n_cols][4] C1, C2, Ma, Mb (scratch between the passes) */
     LayoutTot *tot;      /* [n_hmms] */
     LayoutBase *base;    /* [n_hmms] */
-    int64_t *totals;     /* [4] cells (padded to a multiple of 4 per hmm), merge cells, fast tiles, general tiles */
+    int64_t *totals;     /* [6] array entries for cells (padded to a multiple of 4 per hmm) and merge cells, fast tiles, general tiles; [4], [5]:
+                          * cells and merge cells of the cross products themselves (equal to [0], [1] up to the padding unless MRP_XF_UNITS) */
     DevHmm *hmms;
     DevCol *cols;
     SweepCol *scols;
@@ -139,7 +148,7 @@ hipError_t mrp_launch_structure(const StructureIn &in, hipStream_t stream);
 /* plan_dev / hmms_dev: PlanCol [n_cols], PlanHmm [n_hmms]; chunks_dev: the batch's DevChunk table; S: cells a pruned column
  * can have at most (parents' counts are clamped to it, so that a discarded parent cannot blow the level up) */
 hipError_t mrp_launch_layout(const PlanCol *plan_dev, const PlanHmm *hmms_dev, int64_t n_hmms, int64_t n_cols, const DevChunk *chunks_dev,
-                             int32_t S, uint32_t xflags, LayoutOut out, hipStream_t stream);
+                             int32_t S, uint32_t xflags, LayoutOut out, hipStream_t stream); /* xflags: MRP_XF_INVERTED, MRP_XF_UNITS */
 
 /* one cross product hmm of a level, as the prune kernels see it */
 struct PruneHmm {
@@ -159,7 +168,8 @@ struct PruneParams {
     int32_t thr_bin;        /* bins <= thr_bin have posterior >= minPosteriorProbabilityForPartition */
     int32_t max_cells, max_merge; /* largest column / merge column of the level (LDS sizing) */
     int32_t pad;            /* fault injection of the tests (mrp_context_set_test_hooks bit 0) */
-    int32_t pairs;          /* includeInvertedPartitions with even min_p / max_p: the prune chain runs on complement pairs */
+    int32_t pairs;          /* includeInvertedPartitions with even min_p / max_p: the prune chain runs on complement pairs; 2: and the
+                             * level's f / b / merge arrays hold units (MRP_XF_UNITS) */
     int32_t pad2;
 };
 

@@ -403,6 +403,12 @@ __global__ void __launch_bounds__(XE_WAVES * WAVE, XE_MIN_WAVES) mrp_cross_emit_
         const bool inv = (c.flags & MRP_XF_INVERTED) != 0;
         const uint32_t C1 = c.C1, C2 = c.C2, C = C1 * C2;
         const bool a_cells_paired = inv && c.a_part && c.d1 > 0, b_cells_paired = inv && c.b_part && c.d2 > 0;
+        /* MRP_XF_UNITS: one array entry per complement pair (the even cell's cost, its transitions as merge UNIT indices) */
+        const bool units = (c.flags & MRP_XF_UNITS) != 0;
+        const uint32_t ush = units && (a_cells_paired || b_cells_paired) ? 1u : 0u; /* entry of cell e: e >> ush, written for even e */
+        const uint32_t nsh = units && (c.flags & (MRP_XF_OUT_A_PAIRED | MRP_XF_OUT_B_PAIRED)) ? 1u : 0u;
+        const uint32_t psh = units && (c.flags & (MRP_XF_IN_A_PAIRED | MRP_XF_IN_B_PAIRED)) ? 1u : 0u;
+        auto np_entry = [&](uint32_t v) -> uint32_t { return ((v & 0xFFFFu) >> nsh) | (((v >> 16) >> psh) << 16); };
         /* slots per table fill: rows of the tables are padded to a multiple of four slots, the staging buffer holds XE_ROWS */
         const uint32_t Cs = C1 + C2;
         const uint32_t slot_room = (Cs >= 1u && Cs <= 256u) ? min((uint32_t) XE_ROWS, (XE_CAP / Cs) & ~3u) : 0u;
@@ -449,7 +455,7 @@ __global__ void __launch_bounds__(XE_WAVES * WAVE, XE_MIN_WAVES) mrp_cross_emit_
         if ((!c.a_part && C1 != 1u) || (!c.b_part && C2 != 1u) || C1 > 128u || C2 > 128u || (int) c.d1 + (int) c.d2 != dc.depth) bad |= MRP_ENGINE_ERR_RANGE;
         if (bad) { atomicOr(err, bad); atomicOr(err_hmm + col_hmm[col], bad); }
         if (__any(bad != 0)) { /* the level is discarded by the host; keep the arrays defined meanwhile */
-            for (uint32_t e = lane; e < C; e += WAVE) { cell_np[c.x_cell_off + e] = 0u; cell_cost[c.x_cell_off + e] = 0u; }
+            for (uint32_t e = lane; e < (C >> ush); e += WAVE) { cell_np[c.x_cell_off + e] = 0u; cell_cost[c.x_cell_off + e] = 0u; }
             continue;
         }
         const uint32_t *aoff = A_uni ? nullptr : chunks[dc.chunk].allele_offset + dc.site_start;
@@ -483,7 +489,8 @@ __global__ void __launch_bounds__(XE_WAVES * WAVE, XE_MIN_WAVES) mrp_cross_emit_
                 /* A site with more alleles than the tables hold for this many parent cells (rare): its cells are costed
                  * one by one from their merged partitions, straight from the packed bytes in HBM. */
                 const uint32_t A = A_uni ? A_uni : aoff[site0 + 1] - aoff[site0];
-                for (uint32_t e = lane; e < C; e += WAVE) {
+                for (uint32_t en = lane; en < (C >> ush); en += WAVE) {
+                    const uint32_t e = en << ush;
                     uint32_t c1, c2;
                     cross_cell(e, C2, inv, a_cells_paired, b_cells_paired, c1, c2);
                     const uint64_t P = cross_partition(c, c1, c2);
@@ -493,9 +500,9 @@ __global__ void __launch_bounds__(XE_WAVES * WAVE, XE_MIN_WAVES) mrp_cross_emit_
                         m1 = min(m1, t);
                         m2 = min(m2, slot_total[slot_g + a_] - t);
                     }
-                    const int64_t o = c.x_cell_off + e;
+                    const int64_t o = c.x_cell_off + en;
                     if (first_chunk) {
-                        cell_np[o] = xe_np(tra[c1], trb[c2]);
+                        cell_np[o] = np_entry(xe_np(tra[c1], trb[c2]));
                         cell_cost[o] = m1 + m2;
                     } else cell_cost[o] += m1 + m2;
                 }
@@ -604,7 +611,12 @@ __global__ void __launch_bounds__(XE_WAVES * WAVE, XE_MIN_WAVES) mrp_cross_emit_
                                     }
                             }
                         } else cost = xe_cost(pa, pb, nsl, ends);
-                        if (hv) {
+                        if (hv && units) { /* one entry per pair: a dword per lane and array, lanes along h */
+                            const int64_t o = c.x_cell_off + ((int64_t) r * C2 + h);
+                            if (first_chunk) cell_np[o] = np_entry(xe_np(tra[2u * r], tbh));
+                            else cost += cell_cost[o];
+                            cell_cost[o] = cost;
+                        } else if (hv) {
                             const int64_t o = c.x_cell_off + 2 * ((int64_t) r * C2 + h);
                             if (first_chunk) {
                                 const uint4 ta = *reinterpret_cast<const uint4 *>(tra + 2u * r); /* terms of cells 2r and 2r + 1 */
@@ -617,13 +629,14 @@ __global__ void __launch_bounds__(XE_WAVES * WAVE, XE_MIN_WAVES) mrp_cross_emit_
                     }
                 }
             } else {
-                for (uint32_t e = lane; e < C; e += WAVE) {
+                for (uint32_t en = lane; en < (C >> ush); en += WAVE) {
+                    const uint32_t e = en << ush;
                     uint32_t c1, c2;
                     cross_cell(e, C2, inv, a_cells_paired, b_cells_paired, c1, c2);
                     const uint32_t cost = xe_cost(tab + c1 * ST, tb + c2 * ST, nsl, ends);
-                    const int64_t o = c.x_cell_off + e;
+                    const int64_t o = c.x_cell_off + en;
                     if (first_chunk) {
-                        cell_np[o] = xe_np(tra[c1], trb[c2]);
+                        cell_np[o] = np_entry(xe_np(tra[c1], trb[c2]));
                         cell_cost[o] = cost;
                     } else cell_cost[o] += cost;
                 }
@@ -802,14 +815,15 @@ static __device__ __forceinline__ int wave_max_i32(int v) {
 
 /* pass 1, one wave per hmm: C1, C2, Ma, Mb of every column; per hmm the sums the scan needs */
 __global__ void __launch_bounds__(256) mrp_layout_count_kernel(const PlanCol *__restrict__ plan, const PlanHmm *__restrict__ ph, int64_t n_hmms,
-                                                               int32_t S, LayoutOut o) {
+                                                               int32_t S, uint32_t xflags, LayoutOut o) {
     const int lane = threadIdx.x & (WAVE - 1);
     const int64_t w = (int64_t) blockIdx.x * (blockDim.x / WAVE) + threadIdx.x / WAVE;
     if (w >= n_hmms) return;
     const PlanHmm h = ph[w];
     const bool ancestor = (h.flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) != 0;
-    int64_t cells = 0, merge = 0;
+    int64_t cells = 0, merge = 0, acells = 0, amerge = 0;
     int tf = 0, tg = 0, mc = 1, mm = 1;
+    const bool units = (xflags & MRP_XF_UNITS) != 0;
     for (int k = lane; k < h.n_cols; k += WAVE) {
         const PlanCol c = plan[h.col0 + k];
         const int C1 = layout_count(c.a_ncells, S), C2 = layout_count(c.b_ncells, S);
@@ -820,8 +834,12 @@ __global__ void __launch_bounds__(256) mrp_layout_count_kernel(const PlanCol *__
         }
         uint16_t *dm = o.dims + 4 * (h.col0 + k);
         dm[0] = (uint16_t) C1; dm[1] = (uint16_t) C2; dm[2] = (uint16_t) Ma; dm[3] = (uint16_t) Mb;
-        const int C = C1 * C2, M = Ma * Mb;
-        cells += C; merge += M;
+        const int Cf = C1 * C2, Mf = Ma * Mb;
+        /* MRP_XF_UNITS: a column some side of which has reads holds its cells in complement pairs, a merge column some side of
+         * which is paired likewise: one array entry per pair */
+        const int C = units && ((c.a_part && c.d1 > 0) || (c.b_part && c.d2 > 0)) ? Cf >> 1 : Cf;
+        const int M = units && !c.last && (c.out_a_paired || c.out_b_paired) ? Mf >> 1 : Mf;
+        cells += C; merge += M; acells += Cf; amerge += Mf;
         const int nt = (C + MRP_EMIT_TILE - 1) / MRP_EMIT_TILE;
         if (c.uniform_alleles != 0 && !ancestor) tf += nt; else tg += nt;
         mc = C > mc ? C : mc;
@@ -830,10 +848,13 @@ __global__ void __launch_bounds__(256) mrp_layout_count_kernel(const PlanCol *__
     /* (an hmm has at most 2^31 cells: checked on the host against the static bounds) */
     const int lo = wave_sum_i32((int) (cells & 0xFFFF)), hi = wave_sum_i32((int) (cells >> 16));
     const int mlo = wave_sum_i32((int) (merge & 0xFFFF)), mhi = wave_sum_i32((int) (merge >> 16));
+    const int alo = wave_sum_i32((int) (acells & 0xFFFF)), ahi = wave_sum_i32((int) (acells >> 16));
+    const int amlo = wave_sum_i32((int) (amerge & 0xFFFF)), amhi = wave_sum_i32((int) (amerge >> 16));
     tf = wave_sum_i32(tf); tg = wave_sum_i32(tg); mc = wave_max_i32(mc); mm = wave_max_i32(mm);
     if (lane == 0) {
         LayoutTot t;
         t.cells = ((int64_t) hi << 16) + lo; t.merge = ((int64_t) mhi << 16) + mlo;
+        t.acells = ((int64_t) ahi << 16) + alo; t.amerge = ((int64_t) amhi << 16) + amlo;
         t.tiles_fast = tf; t.tiles_gen = tg; t.max_cells = mc; t.max_merge = mm;
         o.tot[w] = t;
     }
@@ -841,21 +862,21 @@ __global__ void __launch_bounds__(256) mrp_layout_count_kernel(const PlanCol *__
 
 /* pass 2, one workgroup: where every hmm starts (cells padded to a multiple of 4 per hmm), the totals, the DevHmm records */
 __global__ void __launch_bounds__(1024) mrp_layout_scan_kernel(const PlanHmm *__restrict__ ph, int64_t n_hmms, LayoutOut o) {
-    __shared__ int64_t part[1024][4];
+    __shared__ int64_t part[1024][6];
     const int t = threadIdx.x;
     const int64_t per = (n_hmms + 1023) / 1024, lo = (int64_t) t * per, hi = lo + per < n_hmms ? lo + per : n_hmms;
-    int64_t s[4] = {0, 0, 0, 0};
+    int64_t s[6] = {0, 0, 0, 0, 0, 0};
     for (int64_t i = lo; i < hi; i++) {
         const LayoutTot x = o.tot[i];
-        s[0] += (x.cells + 3) & ~3ll; s[1] += x.merge; s[2] += x.tiles_fast; s[3] += x.tiles_gen;
+        s[0] += (x.cells + 3) & ~3ll; s[1] += x.merge; s[2] += x.tiles_fast; s[3] += x.tiles_gen; s[4] += x.acells; s[5] += x.amerge;
     }
-    for (int q = 0; q < 4; q++) part[t][q] = s[q];
+    for (int q = 0; q < 6; q++) part[t][q] = s[q];
     __syncthreads();
     if (t == 0) {
-        int64_t run[4] = {0, 0, 0, 0};
+        int64_t run[6] = {0, 0, 0, 0, 0, 0};
         for (int i = 0; i < 1024; i++)
-            for (int q = 0; q < 4; q++) { const int64_t v = part[i][q]; part[i][q] = run[q]; run[q] += v; }
-        for (int q = 0; q < 4; q++) o.totals[q] = run[q];
+            for (int q = 0; q < 6; q++) { const int64_t v = part[i][q]; part[i][q] = run[q]; run[q] += v; }
+        for (int q = 0; q < 6; q++) o.totals[q] = run[q];
     }
     __syncthreads();
     for (int q = 0; q < 4; q++) s[q] = part[t][q];
@@ -899,7 +920,9 @@ __global__ void __launch_bounds__(256) mrp_layout_fill_kernel(const PlanCol *__r
         const PlanCol c = plan[col];
         const uint16_t *dm = o.dims + 4 * col;
         const int C1 = in ? dm[0] : 0, C2 = in ? dm[1] : 0, Ma = in ? dm[2] : 0, Mb = in ? dm[3] : 0;
-        const int C = C1 * C2, M = Ma * Mb;
+        const bool units = (xflags & MRP_XF_UNITS) != 0; /* array entries per column: see mrp_layout_count_kernel */
+        const int C = units && ((c.a_part && c.d1 > 0) || (c.b_part && c.d2 > 0)) ? (C1 * C2) >> 1 : C1 * C2;
+        const int M = units && !c.last && (c.out_a_paired || c.out_b_paired) ? (Ma * Mb) >> 1 : Ma * Mb;
         const int nt = (C + MRP_EMIT_TILE - 1) / MRP_EMIT_TILE;
         const bool fast = c.uniform_alleles != 0 && !ancestor;
         int tc, tm, tf, tg;
@@ -949,7 +972,7 @@ hipError_t mrp_launch_layout(const PlanCol *plan_dev, const PlanHmm *hmms_dev, i
     if (n_hmms <= 0) return hipSuccess;
     (void) n_cols;
     const unsigned g = (unsigned) ((n_hmms + 3) / 4);
-    hipLaunchKernelGGL(mrp_layout_count_kernel, dim3(g), dim3(256), 0, stream, plan_dev, hmms_dev, n_hmms, S, out);
+    hipLaunchKernelGGL(mrp_layout_count_kernel, dim3(g), dim3(256), 0, stream, plan_dev, hmms_dev, n_hmms, S, xflags, out);
     hipLaunchKernelGGL(mrp_layout_scan_kernel, dim3(1), dim3(1024), 0, stream, hmms_dev, n_hmms, out);
     hipLaunchKernelGGL(mrp_layout_fill_kernel, dim3(g), dim3(256), 0, stream, plan_dev, hmms_dev, n_hmms, chunks_dev, xflags, out);
     return hipGetLastError();
@@ -1175,6 +1198,7 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
     extern __shared__ uint32_t lds[];
     const int S = p.S;
     const int nb = p.n_bins;
+    const bool units = PAIRS && p.pairs == 2; /* the level's f, b and merge arrays hold one entry per unit (MRP_XF_UNITS) */
     const int nb_r = 1024; /* 16 bins per lane of the cutoff search: bin b lives at (b & 15) * 64 + (b >> 4) */
     /* posterior bins in LDS, two columns: one per cell; PAIRS: one per unit (cells 2u, 2u + 1 tie) */
     const int cap_c = PAIRS ? ((p.max_cells + 1) / 2 + 3) & ~3 : (p.max_cells + 3) & ~3;
@@ -1329,7 +1353,7 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
             p1_np = mine.y;
             p1_mf = 0; p1_mb = 0;
             if (kk + 1 < K && lane < p1_n) {
-                const uint32_t m = mine.y & 0xFFFFu;
+                const uint32_t m = (mine.y & 0xFFFFu) >> (units ? (p1_fl >> 1) & 1u : 0u); /* (units: the merge arrays hold merge units) */
                 p1_mf = d.merge_f32[mcell_off + m];
                 p1_mb = d.merge_b32[mcell_off + m];
             }
@@ -2373,7 +2397,7 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
 #pragma unroll
                         for (int j = 0; j < (W == 4 ? CPT : 1); j++) {
                             const int cell = lane + j * WAVE;
-                            if (PAIRS) { if (cell < t_n && (cell & 1) == 0) dst[cell >> 1] = (uint16_t) posterior_bin(t_f[j], t_b[j], total, nb, &errbits); }
+                            if (PAIRS && !units) { if (cell < t_n && (cell & 1) == 0) dst[cell >> 1] = (uint16_t) posterior_bin(t_f[j], t_b[j], total, nb, &errbits); }
                             else if (cell < t_n) dst[cell] = (uint16_t) posterior_bin(t_f[j], t_b[j], total, nb, &errbits);
                         }
                     }
@@ -2448,13 +2472,13 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                     if (j < nj) { /* (the lane's cell against a scalar bound, the step in the store's immediate offset: no
                                    * per-slot index registers) */
                         if (VEC == 1) {
-                            if (PAIRS) { /* the even cell of a unit writes the unit's bin */
+                            if (PAIRS && !units) { /* the even cell of a unit writes the unit's bin */
                                 if (base_c < n_have - j * LG && (base_c & 1) == 0) dst[(base_c + j * LG) >> 1] = (uint16_t) posterior_bin(r_f[j], r_b[j], total, nb, &errbits);
                             } else if (base_c < n_have - j * LG) dst[base_c + j * LG] = (uint16_t) posterior_bin(r_f[j], r_b[j], total, nb, &errbits);
                         } else {
                             const int left = n_have - (j * LG + base_c) * VEC; /* cells of this load inside the column */
                             if (left > 0) {
-                                if (PAIRS) { /* four cells = two units: the bins of cells 0 and 2 as one dword */
+                                if (PAIRS && !units) { /* four cells = two units: the bins of cells 0 and 2 as one dword */
                                     const uint32_t b0 = (uint32_t) posterior_bin(r_f[j * VEC], r_b[j * VEC], total, nb, &errbits);
                                     const uint32_t b1 = left > 2 ? (uint32_t) posterior_bin(r_f[j * VEC + (VEC > 2 ? 2 : 0)], r_b[j * VEC + (VEC > 2 ? 2 : 0)], total, nb, &errbits) : 0u;
 #ifdef MRP_PRUNE_CHECK_PAIRS /* development: the twins' f and b really are equal */
@@ -2695,10 +2719,12 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, con
         if (pairs) hipLaunchKernelGGL((mrp_prune_kernel<T_, CPT_, NGRP_, VEC_, true>), grid, dim3(T_), lds, stream, in, hmms_dev, n_hmms, p, s);  \
         else hipLaunchKernelGGL((mrp_prune_kernel<T_, CPT_, NGRP_, VEC_, false>), grid, dim3(T_), lds, stream, in, hmms_dev, n_hmms, p, s);       \
     } while (0)
-    /* columns of at most 256 cells (the first merge levels: a few reads per hmm): four waves, the table wave writes the bins */
-    if (p.max_cells <= 4 * WAVE && !(force && force[0] == 's')) PRUNE_LAUNCH(256, 4, 1, 1);
-    else if (p.max_cells <= 2 * WAVE * 32) PRUNE_LAUNCH(512, 32, 2, 1);
-    else if (p.max_cells <= MRP_PRUNE_MID_CELLS && !(force && force[0] == 'b')) PRUNE_LAUNCH(512, 10, 1, 4);
+    /* what the bin-streaming waves hold per column: cells, or units when the level's arrays hold units (p.pairs == 2) */
+    const int held = p.pairs == 2 ? (p.max_cells + 1) / 2 : p.max_cells;
+    /* columns of at most 256 entries (the first merge levels: a few reads per hmm): four waves, the table wave writes the bins */
+    if (held <= 4 * WAVE && !(force && force[0] == 's')) PRUNE_LAUNCH(256, 4, 1, 1);
+    else if (held <= 2 * WAVE * 32) PRUNE_LAUNCH(512, 32, 2, 1);
+    else if (held <= MRP_PRUNE_MID_CELLS && !(force && force[0] == 'b')) PRUNE_LAUNCH(512, 10, 1, 4);
     else PRUNE_LAUNCH(1024, 36, 2, 1);
 #undef PRUNE_LAUNCH
     return hipGetLastError();
