@@ -117,8 +117,10 @@ def main():
     import numpy as np
     from margin_amd import capi, sharding, synth
 
-    if single_process_multi and capi.load().mrp_device_count() < n_gpus:
-        sys.exit(f"bench.py: --gpus {n_gpus} in one process, but only {capi.load().mrp_device_count()} device(s) are visible")
+    # rehearsal knob: the single-process path over an explicit device list (e.g. "0,0": two queue workers sharing one card)
+    queue_devices = [int(x) for x in os.environ["MRP_BENCH_DEVICES"].split(",")] if os.environ.get("MRP_BENCH_DEVICES") else list(range(n_gpus))
+    if single_process_multi and (len(queue_devices) != n_gpus or capi.load().mrp_device_count() <= max(queue_devices)):
+        sys.exit(f"bench.py: --gpus {n_gpus} in one process over devices {queue_devices}, but {capi.load().mrp_device_count()} device(s) are visible")
 
     params_dict = synth.shipped_phase_params()
     params = capi.Params.from_reference_names(params_dict)
@@ -148,7 +150,7 @@ def main():
 
     # ---- the timed region: every chunk phased end to end, K times -------------------------------------------------
     if single_process_multi:
-        queue = capi.Queue(list(range(n_gpus)))
+        queue = capi.Queue(queue_devices)
         descs = capi.chunk_descs(chunks)
         step = lambda: queue.phase(chunks, params, chunks_per_batch=args.queue_batch, descs=descs, convert=False)[1]
     else:

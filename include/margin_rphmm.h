@@ -55,7 +55,10 @@ const char *mrp_version(void);
 int mrp_device_count(void);
 
 /* Context: device + stream + reusable device workspace.  (No reference counterpart: the CPU
- * path allocates scratch per column, hmm.c:836,872.) */
+ * path allocates scratch per column, hmm.c:836,872.)  ONE HOST THREAD PER CONTEXT at a time: every entry point that takes a
+ * context (mrp_chunk_create, mrp_batch_*, mrp_fb_run, mrp_phase_reads*, mrp_get_rp_hmms*, ...) uses its streams, its event and
+ * its allocator cache without locking -- concurrent callers (phase.c:276 runs its chunk loop under OpenMP) take a context
+ * each, as the adaptor in integration/ does per thread; contexts are cheap and share the device's memory budget. */
 int mrp_context_create(int device, mrp_context **out);
 void mrp_context_destroy(mrp_context *ctx);
 int mrp_context_synchronize(mrp_context *ctx);

@@ -58,6 +58,21 @@ void mrp_chunk_host_view(const mrp_chunk *chunk, mrp_chunk_host *out) {
 }
 mrp_context *mrp_chunk_context(const mrp_chunk *chunk) { return chunk->ctx; }
 int mrp_context_device(const mrp_context *ctx) { return ctx->device; }
+/* Said once per process, when a call first runs concurrent batches: the runtime deals HIP streams onto GPU_MAX_HW_QUEUES hardware
+ * queues (default 4) and the kernels of streams that share a queue serialize -- eight concurrent batches on two streams each
+ * want 16 (mrp_runtime_init() before the first HIP call, or the variable in the environment). */
+void mrp_warn_hw_queues_once(int concurrent_batches) {
+    static std::atomic<int> said{0};
+    if (concurrent_batches <= 2 || getenv("MRP_QUIET")) return;
+    const char *q = getenv("GPU_MAX_HW_QUEUES");
+    const int have = q ? atoi(q) : 4;
+    if (have >= 2 * concurrent_batches || have >= 16) return;
+    if (said.exchange(1)) return;
+    fprintf(stderr, "margin_rphmm: %d concurrent batches (two streams each) on %d hardware queues (GPU_MAX_HW_QUEUES%s): their kernels share "
+                    "queues and serialize; call mrp_runtime_init() before the process's first HIP call, or set GPU_MAX_HW_QUEUES=16\n",
+            concurrent_batches, have, q ? "" : " unset, the runtime's default");
+}
+
 int mrp_context_set_grouped(mrp_context *ctx, int grouped) { const int was = ctx->grouped ? 1 : 0; ctx->grouped = grouped != 0; return was; }
 int64_t mrp_context_device_budget(mrp_context *ctx) { /* bytes the pools of the context's device may hold together */
     if (ctx->pool.device < 0 || hipSetDevice(ctx->device) != hipSuccess) return 0;

@@ -740,8 +740,9 @@ __global__ void __launch_bounds__(256) mrp_structure_kernel(StructureIn in) {
     const XDesc x = in.xd[lo - 1];
     const int k = (int) (col - x.col0);
     const bool last = k + 1 == x.n_cols;
-    const int32_t cs = in.col_start[col], ce = last ? x.ref_end : in.col_start[col + 1];
+    int32_t cs = in.col_start[col], ce = last ? x.ref_end : in.col_start[col + 1];
     int bad = (ce <= cs || cs < x.ref_start || ce > x.ref_end) ? 1 : 0;
+    if (bad) { cs = x.ref_start; ce = x.ref_end; } /* (the chunk's tables are read below whatever the flag says: inside the hmm's interval) */
     const mrp_xpar *pa = in.par + x.par0, *pb = pa + x.n_a;
     const SidePiece A = structure_side(in, pa, x.n_a, x.ref_end, cs, ce, &bad);
     const SidePiece B = structure_side(in, pb, x.n_b, x.ref_end, cs, ce, &bad);
@@ -749,6 +750,8 @@ __global__ void __launch_bounds__(256) mrp_structure_kernel(StructureIn in) {
     const int depth = (int) A.depth + (int) B.depth;
     if (depth > MRP_MAX_READ_PARTITIONING_DEPTH) bad = 1;
     const int64_t read_off = x.read0 + in.col_roff[col];
+    /* the host sized the column's slice of the read offsets from ITS depth: a disagreement must not run into the next column's */
+    if (!last && depth != in.col_roff[col + 1] - in.col_roff[col]) bad = 1;
     if (!bad) { /* the column's reads: side A's then side B's (partitions.c:21-28); profileSeq.c:41-47 */
         int64_t *dst = in.rbo + read_off;
         const uint32_t a_cs = ch.allele_offset[cs];

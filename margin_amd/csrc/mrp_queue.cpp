@@ -224,7 +224,7 @@ int mrp_queue_dry_run(int32_t n_devices, int32_t lanes, int64_t n_chunks, const 
 
 struct mrp_queue {
     std::vector<int32_t> devices;
-    /* one worker per device, each with: the context its batches are phased on, a second context on the same device whose
+    /* per lane (up to four per device): the context its batches are phased on, a second context on the same device whose
      * stream carries the uploads of the NEXT batch while the current one is phased, and its own host worker pool -- all
      * created by the worker on its first batch and kept between calls */
     std::vector<mrp_context *> ctx, stage_ctx; /* [device * lanes + lane] */

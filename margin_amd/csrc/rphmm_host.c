@@ -2351,6 +2351,7 @@ static int phase_many_once(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *
             if (!q->ctx) { q->rc = MRP_ERR_HIP; snprintf(q->err, sizeof(q->err), "%s", mrp_last_error()); }
         }
         const int was_grouped = mrp_context_set_grouped(ctx, 1); /* (the siblings always are) */
+        mrp_warn_hw_queues_once(G);
         for (int g = 1; g < G; g++)
             if (grp[g].ctx && pthread_create(&th[g], NULL, phase_group_main, &grp[g]) == 0) started[g] = 1;
         if (grp[0].ctx) phase_group_main(&grp[0]);

@@ -32,6 +32,7 @@ int mrp_context_device(const mrp_context *ctx);
 int mrp_context_set_grouped(mrp_context *ctx, int grouped); /* returns the previous setting */
 /* device memory of the context's pool: bytes cached for reuse, and what all pools of its device hold together (live + cached) */
 void mrp_context_pool_bytes(mrp_context *ctx, int64_t *cached, int64_t *device_held);
+void mrp_warn_hw_queues_once(int concurrent_batches); /* one stderr line per process when concurrent batches outnumber the hardware queues */
 uint64_t mrp_context_oom_events(mrp_context *ctx);   /* device allocations the driver refused for good on the context's device */
 int64_t mrp_context_device_budget(mrp_context *ctx); /* bytes all pools of the context's device may hold together; 0 = unknown */
 /* a further context (stream, allocator cache) on the same device, owned by ctx and destroyed with it; i = 0, 1, ... */

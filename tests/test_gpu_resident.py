@@ -572,3 +572,103 @@ def test_a_refused_device_allocation_redoes_the_call_in_two_halves(orc):
             assert (np.asarray(got[2][k]) == np.asarray(o[k])).all(), k
         for d in dch:
             d.close()
+
+
+def test_bench_shape_configs2_640_small_chunks_sampled_against_the_oracle(orc):
+    """bench.py's configs[2] leg at ITS size: 640 chunks of ~130 het sites (chr20 cut into 100 kb chunks) in one
+    mrp_phase_reads_many call with eight concurrent batches, 16 of the chunks against the oracle (every 40th: each batch of
+    the call is sampled twice), all of them by size-independent properties."""
+    n = 640
+    chunks = [synth.make_ont_chunk(seed=50_000 + s, region_bp=130 * 500, n_sites=130, coverage=30.0) for s in range(n)]
+    pd = _params()
+    params = capi.Params.from_reference_names(pd)
+    with capi.Context(0) as ctx:
+        dch = [capi.DeviceChunk.from_chunk(ctx, c) for c in chunks]
+        got, st = capi.phase_reads_many(ctx, dch, chunks, params)
+        assert st.resident == 1 and st.fallback_chunks == 0
+        for i in range(0, n, 40):
+            oc = orc.OracleChunk(chunks[i])
+            ref = oc.phase(pd)
+            oc.close()
+            for k in PHASE_KEYS:
+                assert (np.asarray(got[i][k]) == np.asarray(ref[k])).all(), (i, k)
+            assert got[i]["reads1"] == ref["reads1"] and got[i]["reads2"] == ref["reads2"], i
+        for c, g in zip(chunks, got):
+            assert len(set(g["reads1"]) & set(g["reads2"])) == 0 and len(g["reads1"]) + len(g["reads2"]) == len(c.reads)
+        for d in dch:
+            d.close()
+
+
+def test_bench_shape_configs4_full_size_hifi_chunk_equals_the_oracle(gpu_ctx, orc):
+    """bench.py's configs[4] leg at ITS chunk size: ONE HiFi-like chunk of 2 000 sites (35x reads N(18 kb, 3 kb), 1 % allele error,
+    2-4 alleles per site) against the oracle, array for array."""
+    chunk = synth.make_ont_chunk(seed=60_000, region_bp=2000 * 500, n_sites=2000, coverage=35.0, median_len=18_000.0, allele_error=0.01,
+                                 allele_choices=(2, 3, 4), allele_probs=(0.85, 0.1, 0.05), length_model="normal", normal_sd=3000.0)
+    pd = _params()
+    oc = orc.OracleChunk(chunk)
+    ref = oc.phase(pd)
+    oc.close()
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    (got,), st = capi.phase_reads_many(gpu_ctx, [dchunk], [chunk], capi.Params.from_reference_names(pd))
+    assert st.resident == 1 and st.fallback_chunks == 0
+    for k in PHASE_KEYS:
+        assert (np.asarray(got[k]) == np.asarray(ref[k])).all(), k
+    assert got["reads1"] == ref["reads1"] and got["reads2"] == ref["reads2"]
+    assert got["n_sweeps"] == ref["fb_calls"]
+    dchunk.close()
+
+
+@pytest.mark.parametrize("hooks,env", [(8, {}), (0, {"MRP_UNITS": "0"})], ids=["general_prune_chain", "pairs_chain_on_cell_arrays"])
+def test_prune_variants_agree_with_the_default_path_and_the_oracle(orc, hooks, env):
+    """The default resident path runs the prune chain on complement pairs over arrays that hold one entry per pair (MRP_XF_UNITS).
+    Two variants stay in the product (odd column limits / plain mode take the first, the two-kernel cross product + emission
+    path the second): the general chain with one entry per cell (test hook bit 3) and the pair chain over per-cell arrays
+    (MRP_UNITS=0, read at every level).  Both give the default path's results, which are the oracle's."""
+    pd = _params()
+    params = capi.Params.from_reference_names(pd)
+    chunks = [synth.make_ont_chunk(seed=820 + s, region_bp=120_000 + 40_000 * s, n_sites=240 + 80 * s, coverage=28.0 + 4 * s) for s in range(3)]
+    old = {k: os.environ.get(k) for k in env}
+    with capi.Context(0) as ctx:
+        dch = [capi.DeviceChunk.from_chunk(ctx, c) for c in chunks]
+        ref, st0 = capi.phase_reads_many(ctx, dch, chunks, params)
+        try:
+            os.environ.update(env)
+            ctx.set_test_hooks(hooks)
+            got, st = capi.phase_reads_many(ctx, dch, chunks, params)
+        finally:
+            ctx.set_test_hooks(0)
+            for k, v in old.items():
+                if v is None:
+                    os.environ.pop(k, None)
+                else:
+                    os.environ[k] = v
+        assert st.resident == 1 and st.fallback_chunks == 0 and st.cells == st0.cells and st.merge_cells == st0.merge_cells
+        for a, b in zip(ref, got):
+            for k in PHASE_KEYS:
+                assert (np.asarray(a[k]) == np.asarray(b[k])).all(), k
+            assert a["reads1"] == b["reads1"] and a["reads2"] == b["reads2"]
+        oc = orc.OracleChunk(chunks[1])
+        o = oc.phase(pd)
+        oc.close()
+        for k in PHASE_KEYS:
+            assert (np.asarray(got[1][k]) == np.asarray(o[k])).all(), k
+        for d in dch:
+            d.close()
+
+
+def test_odd_column_limits_take_the_general_prune_chain_and_equal_the_oracle(gpu_ctx, orc):
+    """maxPartitionsInAColumn = 51 (odd): a selection may cut a complement pair in two, so the engine keeps the general prune chain
+    (PruneParams.pairs = 0).  Where a pair IS cut, the next level's cross product finds a parent outside the pair order and that
+    chunk takes the hashing path (stats.fallback_chunks); either way the results are the oracle's."""
+    chunk = synth.make_ont_chunk(seed=877, region_bp=90_000, n_sites=180, coverage=30.0)
+    pd = _params(minPartitionsInAColumn=7, maxPartitionsInAColumn=51)
+    oc = orc.OracleChunk(chunk)
+    ref = oc.phase(pd)
+    oc.close()
+    dchunk = capi.DeviceChunk.from_chunk(gpu_ctx, chunk)
+    (got,), st = capi.phase_reads_many(gpu_ctx, [dchunk], [chunk], capi.Params.from_reference_names(pd))
+    assert st.resident == 1 and st.fallback_chunks in (0, 1)
+    for k in PHASE_KEYS:
+        assert (np.asarray(got[k]) == np.asarray(ref[k])).all(), k
+    assert got["reads1"] == ref["reads1"] and got["reads2"] == ref["reads2"]
+    dchunk.close()

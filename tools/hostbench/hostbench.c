@@ -15,6 +15,7 @@ int mrp_context_device(const mrp_context *ctx) { (void) ctx; return 0; }
 int mrp_context_set_grouped(mrp_context *ctx, int grouped) { (void) ctx; (void) grouped; return 0; }
 int64_t mrp_context_device_budget(mrp_context *ctx) { (void) ctx; return 0; }
 uint64_t mrp_context_oom_events(mrp_context *ctx) { (void) ctx; return 0; }
+void mrp_warn_hw_queues_once(int n) { (void) n; }
 int mrp_context_trim(mrp_context *ctx) { (void) ctx; return 0; }
 void mrp_context_pool_bytes(mrp_context *ctx, int64_t *cached, int64_t *device_held) { (void) ctx; *cached = 0; *device_held = 0; }
 mrp_context *mrp_context_sibling(mrp_context *ctx, int i) { (void) i; return ctx; }
