@@ -84,6 +84,7 @@ struct mrp_engine_level_state {
     int seg_id = -1;
     bool fused = false; /* cross product and emission in one kernel, no partition array (merge levels, no ancestor model) */
     bool units = false; /* the level's cell / merge cell arrays hold one entry per complement pair (MRP_XF_UNITS) */
+    int64_t n_mini = 0; /* hmms of the single-wave kernel: the last n_mini records of the level's PruneHmm array */
     unsigned long long clk[12] = {0};
     mrp_xhmm *x = nullptr;
     int64_t n = 0, total_cols = 0, n_slots = 0, n_reads = 0;
@@ -406,16 +407,27 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     *(SegDev *) (hb + o_seg) = sd;
 
     tm[tmi++] = eng_now();
+    /* one array entry per complement pair (MRP_XF_UNITS) where the one-pass cross product + emission kernel writes the level and
+     * the prune reads it by units; MRP_UNITS=0 (development) keeps one entry per cell.  (test hook bit 3: the general prune chain) */
+    L->units = L->fused && e->pp.pairs != 0 && !(ctx->test_hooks & 8) && !(getenv("MRP_UNITS") && getenv("MRP_UNITS")[0] == '0');
+    /* hmms whose columns hold at most 64 units and 64 merge units (the static bounds count cells) go through recursion, prune
+     * and compaction on ONE wave each (mrp_mini_kernel): the first merge levels, tens of thousands of hmms of a few cells.
+     * They sit at the end of the level's PruneHmm array.  MRP_MINI=0 (development) switches the class off. */
+    const bool mini_on = L->units && !(getenv("MRP_MINI") && getenv("MRP_MINI")[0] == '0');
+    auto is_mini = [&](int64_t i) { return mini_on && x[i].bound_max_cells <= 2 * MRP_MINI_MAX_UNITS && x[i].bound_max_merge <= 2 * MRP_MINI_MAX_UNITS; };
     /* the prune kernel walks one hmm per workgroup, its columns one after the other: longest hmms first */
     L->perm.resize((size_t) n);
     std::vector<int32_t> pos((size_t) n);
-    {   /* stable counting sort by descending number of columns */
+    L->n_mini = 0;
+    {   /* stable counting sort by descending number of columns, the single-wave class behind the others */
         int32_t max_cols = 1;
         for (int64_t i = 0; i < n; i++) max_cols = std::max(max_cols, x[i].n_cols);
-        std::vector<int64_t> at((size_t) max_cols + 2, 0);
-        for (int64_t i = 0; i < n; i++) at[(size_t) (max_cols - x[i].n_cols) + 1]++;
+        const size_t half = (size_t) max_cols + 1;
+        std::vector<int64_t> at(2 * half + 1, 0);
+        auto slot_of = [&](int64_t i) { return (size_t) (max_cols - x[i].n_cols) + (is_mini(i) ? half : 0); };
+        for (int64_t i = 0; i < n; i++) { at[slot_of(i) + 1]++; if (is_mini(i)) L->n_mini++; }
         for (size_t q = 1; q < at.size(); q++) at[q] += at[q - 1];
-        for (int64_t i = 0; i < n; i++) L->perm[(size_t) at[(size_t) (max_cols - x[i].n_cols)]++] = (int32_t) i;
+        for (int64_t i = 0; i < n; i++) L->perm[(size_t) at[slot_of(i)]++] = (int32_t) i;
         for (int64_t j = 0; j < n; j++) pos[(size_t) L->perm[(size_t) j]] = (int32_t) j;
     }
     /* per hmm records and the 8 bytes per column the host contributes (parallel) */
@@ -450,6 +462,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         std::vector<std::pair<int64_t, int32_t>> wide, mid, narrow;
         for (int64_t i = 0; i < n; i++) {
             const mrp_xhmm &q = x[i];
+            if (is_mini(i)) continue; /* swept by the single-wave kernel */
             if (q.bound_max_cells <= 256) narrow.push_back({-q.bound_cells, (int32_t) i});
             else if (q.bound_max_merge <= 4096) mid.push_back({-q.bound_cells, (int32_t) i});
             else wide.push_back({-q.bound_cells, (int32_t) i});
@@ -478,10 +491,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         pp.max_merge = std::max(pp.max_merge, x[i].bound_max_merge);
     }
     if (ctx->test_hooks & 8) pp.pairs = 0; /* test hook: the general prune chain, for A/B parity with the chain on complement pairs */
-    /* one array entry per complement pair (MRP_XF_UNITS) where the one-pass cross product + emission kernel writes the level and
-     * the prune reads it by units; MRP_UNITS=0 (development) keeps one entry per cell */
-    L->units = L->fused && pp.pairs != 0 && !(getenv("MRP_UNITS") && getenv("MRP_UNITS")[0] == '0');
-    if (L->units) pp.pairs = 2;
+    if (L->units) pp.pairs = 2; /* (decided above: the level's arrays hold one entry per complement pair) */
     pp.pad = (ctx->test_hooks & 1) && e->stats.levels + (e->running ? 1 : 0) == 1 ? 1 : 0; /* test hook, see mrp_context_set_test_hooks */
 
     tm[tmi++] = eng_now();
@@ -715,9 +725,11 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
     if (L->final_level) {
         ENG_TRY(mrp_launch_traceback(b->dev, L->d_ph.p, n, L->d_err.p, L->d_err_hmm.p, s));
     } else {
-        ENG_TRY(mrp_launch_prune(b->dev, L->d_cc.p, L->d_ph.p, n, L->pp, sc, s));
+        const int64_t n_reg = n - L->n_mini;
+        ENG_TRY(mrp_launch_mini(b->dev, L->d_cc.p, L->d_ph.p + n_reg, L->n_mini, n_reg, L->pp, sc, s));
+        ENG_TRY(mrp_launch_prune(b->dev, L->d_cc.p, L->d_ph.p, n_reg, L->pp, sc, s));
         ENG_TRY(hipEventRecord(L->ev[4], s));
-        ENG_TRY(mrp_launch_compact(b->dev, L->d_cc.p, L->d_ph.p, L->d_col_hmm.p, total_cols, L->pp, sc, s));
+        ENG_TRY(mrp_launch_compact(b->dev, L->d_cc.p, L->d_ph.p, L->d_col_hmm.p, total_cols, n_reg, L->pp, sc, s));
     }
     ENG_TRY(hipEventRecord(L->ev[3], s));
     if (L->final_level) {

@@ -208,6 +208,11 @@ hipError_t mrp_launch_traceback(const MrpBatchDev &d, const PruneHmm *hmms_dev, 
                                 hipStream_t stream);
 /* d.partition == NULL: the level was produced by mrp_launch_cross_emit, partitions of the kept cells come from the parents */
 hipError_t mrp_launch_compact(const MrpBatchDev &d, const CrossCol *ccols_dev, const PruneHmm *hmms_dev, const int32_t *col_hmm_dev, int64_t n_cols,
-                              PruneParams p, PruneScratch s, hipStream_t stream);
+                              int64_t n_hmms_here, PruneParams p, PruneScratch s, hipStream_t stream); /* columns of hmms at positions >= n_hmms_here are skipped */
+/* Recursion, prune and compaction of hmms whose columns hold at most 64 units and 64 merge units (MRP_XF_UNITS levels) by one wave
+ * each: hmms_dev[0 .. n_hmms) are the level's PruneHmm records from position hmm0 on (the error flags are indexed by position). */
+#define MRP_MINI_MAX_UNITS 64
+hipError_t mrp_launch_mini(const MrpBatchDev &d, const CrossCol *ccols_dev, const PruneHmm *hmms_dev, int64_t n_hmms, int64_t hmm0, PruneParams p,
+                           PruneScratch s, hipStream_t stream);
 
 #endif

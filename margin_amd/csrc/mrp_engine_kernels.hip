@@ -2734,10 +2734,294 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, con
 }
 
 /* ------------------------------------------------------------------------------------------ */
+/* small hmms: recursion, prune and compaction by ONE wave                                      */
+/* ------------------------------------------------------------------------------------------ */
+/*
+ * The first merge levels (coordination.c:341-409: 2 x 2 -> 4, 4 x 4 -> 16 cells) hold a per cent of the cells and a
+ * quarter of a batch's kernel time: tens of thousands of hmms of a handful of columns of a handful of cells, for which a
+ * workgroup per hmm and direction (recursion), a four-wave role pipeline with a barrier per column (prune) and a wave per
+ * column (compaction), each its own launch over its own descriptors, are almost pure fixed cost.  Here ONE wave takes an
+ * hmm whose columns hold at most 64 units (MRP_XF_UNITS: complement pairs) and at most 64 merge units through
+ *   stRPHmm_forward / stRPHmm_backward  hmm.c:827-929   lane = unit, the merge column in 64 words of LDS (ds_max)
+ *   stRPHmm_pruneForwards               hmm.c:1049-1109 kept merge units as ONE 64-bit mask; a unit is linked iff its bit is
+ *                                                        set; selection = the first n of the 64 sorted keys (bin, unit)
+ *   stRPHmm_pruneBackwards              hmm.c:1111-1158 the same masks from the right
+ *   filterMergeCells / relinkCells      hmm.c:964-1019  a merge cell's new index = the surviving merge cells below it
+ * with no barrier and no second launch; what a pass leaves for the next (f, posterior bins, the kept units) goes through
+ * the level's arrays in HBM / L2 (cell_f32, cell_b32 as the bins, the prune's kept list).  Same results as the three
+ * kernels it replaces (the test suite compares every level's pruned hmms with the oracle's).  Cell-level transition indices
+ * (which twin of a merge unit the even cell leads to) come from the parents' transitions, as in the prune chain.
+ */
+__global__ void __launch_bounds__(256) mrp_mini_kernel(MrpBatchDev d, const CrossCol *__restrict__ ccols, const PruneHmm *__restrict__ hmms,
+                                                       int64_t n_hmms, int64_t hmm0, PruneParams p, PruneScratch sc) {
+    __shared__ int32_t lds_m[4][2][WAVE];
+    __shared__ uint32_t lds_flag[4][WAVE];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / WAVE));
+    const int S = p.S, nb = p.n_bins;
+    const bool thr_all = p.thr_bin >= nb - 1;
+    uint32_t *flag = lds_flag[wave];
+    flag[lane] = 0u;
+    /* which merge units some lane of `who` names: a scatter through 64 words of LDS (left clean) */
+    auto units_named = [&](bool who, uint32_t unit) -> uint64_t {
+        if (who) flag[unit & 63u] = 1u;
+        wave_lds_fence();
+        const uint64_t m = __ballot(flag[lane] != 0u);
+        flag[lane] = 0u;
+        wave_lds_fence();
+        return m;
+    };
+    for (int64_t hi_ = (int64_t) blockIdx.x * 4 + wave; hi_ < n_hmms; hi_ += (int64_t) gridDim.x * 4) {
+        const PruneHmm h = k_load(hmms + hi_);
+        const int K = h.n_cols;
+        int errbits = 0;
+        int32_t *mcur = lds_m[wave][0], *mnxt = lds_m[wave][1];
+        /* The columns' descriptors 64 at a time, one column per lane (first cell relative to the hmm's, units, and the bits of the
+         * CrossCol the passes branch on); a pass gets a column's by v_readlane and asks for the NEXT column's data before it works
+         * on the current one: a column step then waits for LDS, not for HBM. */
+        const int64_t cell0 = k_load(d.scols + h.col0).cell_off;
+        uint32_t t_off = 0u, t_nu = 0u, t_fl = 0u;
+        auto load_block = [&](int k0) {
+            const int k = k0 + lane;
+            t_off = 0u; t_nu = 0u; t_fl = 0u;
+            if (k < K) {
+                const SweepCol *sc_ = d.scols + h.col0 + k;
+                const CrossCol *cc_ = ccols + h.col0 + k;
+                t_off = (uint32_t) (sc_->cell_off - cell0);
+                t_nu = (uint32_t) sc_->n_cells | ((uint32_t) sc_->n_merge << 16);
+                const bool paired = (cc_->a_part && cc_->d1 > 0) || (cc_->b_part && cc_->d2 > 0);
+                t_fl = (paired ? 1u : 0u) | ((k + 1 < K && (cc_->flags & (MRP_XF_OUT_A_PAIRED | MRP_XF_OUT_B_PAIRED))) ? 2u : 0u) |
+                       ((k > 0 && (cc_->flags & (MRP_XF_IN_A_PAIRED | MRP_XF_IN_B_PAIRED))) ? 4u : 0u);
+            }
+        };
+        auto col_off = [&](int k, int k0) -> int64_t { return cell0 + (int64_t) (uint32_t) __builtin_amdgcn_readlane((int) t_off, k - k0); };
+        auto col_nu = [&](int k, int k0) -> uint32_t { return (uint32_t) __builtin_amdgcn_readlane((int) t_nu, k - k0); };
+        auto col_fl = [&](int k, int k0) -> uint32_t { return (uint32_t) __builtin_amdgcn_readlane((int) t_fl, k - k0); };
+        {   /* every column within the single wave's reach */
+            bool bad = false;
+            for (int k0 = 0; k0 < K; k0 += WAVE) { load_block(k0); bad |= (t_nu & 0xFFFFu) > WAVE || (t_nu >> 16) > WAVE; }
+            if (__any(bad)) { if (lane == 0) { atomicOr(sc.err, MRP_ENGINE_ERR_RANGE); atomicOr(sc.err_hmm + hmm0 + hi_, MRP_ENGINE_ERR_RANGE); } continue; }
+        }
+        struct ColData { uint32_t cost, np; int32_t f, bin; };
+#ifdef PRUNE_EXP_CLOCK2 /* development: shader cycles of the four passes of the level's LONGEST hmm of this class (first record) */
+        uint64_t mt_[5]; mt_[0] = __builtin_amdgcn_s_memtime();
+#define MINI_T(i) mt_[i] = __builtin_amdgcn_s_memtime()
+#else
+#define MINI_T(i) do { } while (0)
+#endif
+        /* ---- stRPHmm_forward hmm.c:827-879 ---- */
+        int32_t total = MRP_NEG_I32;
+        for (int k0 = 0; k0 < K; k0 += WAVE) {
+            load_block(k0);
+            const int k1 = K < k0 + WAVE ? K : k0 + WAVE;
+            auto ask = [&](int k) -> ColData {
+                ColData r; r.f = 0; r.bin = 0;
+                const uint32_t nu = col_nu(k, k0) & 0xFFFFu;
+                const int64_t g = col_off(k, k0) + ((uint32_t) lane < nu ? lane : 0);
+                r.cost = d.cell_cost[g]; r.np = d.cell_np[g];
+                return r;
+            };
+            ColData nx = ask(k0);
+            for (int k = k0; k < k1; k++) {
+                const ColData cu = nx;
+                if (k + 1 < k1) nx = ask(k + 1);
+                const uint32_t nu = col_nu(k, k0) & 0xFFFFu;
+                const bool act = (uint32_t) lane < nu;
+                mnxt[lane] = MRP_NEG_I32;
+                const int32_t mfp = k == 0 ? 0 : mcur[(cu.np >> 16) & 63u];
+                const int32_t f = (k > 0 && mfp == MRP_NEG_I32) ? MRP_NEG_I32 : mfp - (int32_t) cu.cost; /* forwardCellCalc1 :791 */
+                if (act) d.cell_f32[col_off(k, k0) + lane] = f;
+                if (k + 1 < K) {
+                    wave_lds_fence();
+                    if (act && f != MRP_NEG_I32) atomicMax(&mnxt[cu.np & 63u], f);                      /* forwardCellCalc2 :814 */
+                    wave_lds_fence();
+                } else {
+                    int32_t v = act ? f : MRP_NEG_I32;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) { const int32_t t = __shfl_xor(v, o, WAVE); v = t > v ? t : v; }
+                    total = v;
+                }
+                int32_t *t_ = mcur; mcur = mnxt; mnxt = t_;
+            }
+        }
+        MINI_T(1);
+        /* ---- stRPHmm_backward hmm.c:910-929; a unit's posterior bin (total - f - b) replaces b in cell_b32 ---- */
+        for (int k0 = ((K - 1) / WAVE) * WAVE; k0 >= 0; k0 -= WAVE) {
+            load_block(k0);
+            const int k1 = K < k0 + WAVE ? K : k0 + WAVE;
+            auto ask = [&](int k) -> ColData {
+                ColData r; r.bin = 0;
+                const uint32_t nu = col_nu(k, k0) & 0xFFFFu;
+                const int64_t g = col_off(k, k0) + ((uint32_t) lane < nu ? lane : 0);
+                r.cost = d.cell_cost[g]; r.np = d.cell_np[g]; r.f = d.cell_f32[g];
+                return r;
+            };
+            ColData nx = ask(k1 - 1);
+            for (int k = k1 - 1; k >= k0; k--) {
+                const ColData cu = nx;
+                if (k > k0) nx = ask(k - 1);
+                const uint32_t nu = col_nu(k, k0) & 0xFFFFu;
+                const bool act = (uint32_t) lane < nu;
+                mnxt[lane] = MRP_NEG_I32;
+                const int32_t bv = k + 1 == K ? 0 : mcur[cu.np & 63u];
+                const int bin = posterior_bin(cu.f, bv, total, nb, &errbits);
+                if (act) d.cell_b32[col_off(k, k0) + lane] = bin;
+                if (k > 0) {
+                    wave_lds_fence();
+                    if (act && bv != MRP_NEG_I32) atomicMax(&mnxt[(cu.np >> 16) & 63u], bv - (int32_t) cu.cost); /* backwardCellCalc :881 */
+                    wave_lds_fence();
+                }
+                int32_t *t_ = mcur; mcur = mnxt; mnxt = t_;
+            }
+        }
+        MINI_T(2);
+        /* ---- stRPHmm_pruneForwards hmm.c:1049-1109 ---- */
+        uint64_t keptM = 0ull; /* kept merge units of the merge column before column k */
+        for (int k0 = 0; k0 < K; k0 += WAVE) {
+            load_block(k0);
+            const int k1 = K < k0 + WAVE ? K : k0 + WAVE;
+            auto ask = [&](int k) -> ColData {
+                ColData r; r.cost = 0u; r.f = 0;
+                const uint32_t nu = col_nu(k, k0) & 0xFFFFu;
+                const int64_t g = col_off(k, k0) + ((uint32_t) lane < nu ? lane : 0);
+                r.np = d.cell_np[g]; r.bin = d.cell_b32[g];
+                return r;
+            };
+            ColData nx = ask(k0);
+            for (int k = k0; k < k1; k++) {
+                const ColData cu = nx;
+                if (k + 1 < k1) nx = ask(k + 1);
+                const int64_t lcol = h.col0 + k;
+                const uint32_t nu = col_nu(k, k0) & 0xFFFFu;
+                const int w_sh = (int) (col_fl(k, k0) & 1u); /* cells per unit: 1 << w_sh */
+                const bool act = (uint32_t) lane < nu;
+                const bool linked = act && (k == 0 || ((keptM >> ((cu.np >> 16) & 63u)) & 1ull));
+                uint32_t key[1] = {linked ? ((uint32_t) cu.bin << 14) | (uint32_t) lane : 0xFFFFFFFFu};
+                const int L = __popcll(__ballot(linked));
+                const int gp = thr_all ? L : __popcll(__ballot(linked && cu.bin <= p.thr_bin));
+                const int n = kept_count(L << w_sh, gp << w_sh, p.min_p, p.max_p) >> w_sh;
+                wave_bitonic_sort_n<1>(key, lane); /* stable descending posterior: smaller bin first, then list order (:1043, :1071) */
+                const bool take = lane < n;
+                const uint32_t ku = key[0] & 63u;
+                const uint32_t np_k = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (ku << 2), (int) cu.np);
+                /* the kept units in posterior order, each with its transitions (units), for the pass from the right */
+                if (take) *reinterpret_cast<uint2 *>(sc.kept_np + lcol * S + 2 * lane) = make_uint2(ku, np_k);
+                if (lane == 0) sc.n_kept[lcol] = n;
+                if (k + 1 < K) keptM = units_named(take, np_k & 0xFFFFu); /* getLinkedMergeCells :989: every merge cell a kept cell leads to */
+            }
+        }
+        __threadfence_block();
+        MINI_T(3);
+        /* ---- stRPHmm_pruneBackwards hmm.c:1111-1158 + the pruned hmm in the resident layout; three columns in the pipe: the kept
+         * list of column k - 2 and the parents' cells of the kept units of column k - 1 are in flight while column k is written ---- */
+        struct Kept { int n; uint32_t ku, np; };
+        struct Par { CrossCol cc; uint32_t rna, rnb, c1, c2; uint64_t pa, pb; };
+        auto ask_kept = [&](int k) -> Kept {
+            Kept r; r.n = 0; r.ku = 0u; r.np = 0u;
+            if (k >= 0) {
+                const int64_t lcol = h.col0 + k;
+                r.n = sc.n_kept[lcol];
+                const uint2 v = 2 * lane < S ? *reinterpret_cast<const uint2 *>(sc.kept_np + lcol * S + 2 * lane) : make_uint2(0u, 0u);
+                r.ku = v.x & 63u; r.np = v.y;
+            }
+            return r;
+        };
+        auto ask_par = [&](int k, const Kept &kp) -> Par {
+            Par r; r.cc = CrossCol{}; r.rna = r.rnb = r.c1 = r.c2 = 0u; r.pa = r.pb = 0ull;
+            if (k >= 0) {
+                r.cc = k_load(ccols + h.col0 + k);
+                const bool a_cp = r.cc.a_part && r.cc.d1 > 0, b_cp = r.cc.b_part && r.cc.d2 > 0;
+                /* the unit's even cell (c1, c2): the order rule of cross_cell */
+                if (a_cp) { const uint32_t C2 = r.cc.C2 ? r.cc.C2 : 1u; const uint32_t q = (uint32_t) (((float) kp.ku + 0.5f) * __builtin_amdgcn_rcpf((float) C2)); r.c1 = 2u * q; r.c2 = kp.ku - q * C2; }
+                else if (b_cp) { r.c1 = 0u; r.c2 = 2u * kp.ku; }
+                const bool in = lane < kp.n;
+                if (in && r.cc.a_np) { r.rna = r.cc.a_np[r.c1 & 127u]; r.pa = r.cc.a_part[r.c1 & 127u]; }
+                if (in && r.cc.b_np) { r.rnb = r.cc.b_np[r.c2 & 127u]; r.pb = r.cc.b_part[r.c2 & 127u]; }
+            }
+            return r;
+        };
+        uint64_t aliveM = 0ull; /* surviving merge units of the merge column after column k */
+        Kept kp0 = ask_kept(K - 1);
+        Par pr0 = ask_par(K - 1, kp0);
+        Kept kp1 = ask_kept(K - 2);
+        for (int k = K - 1; k >= 0; k--) {
+            const Kept kp = kp0;
+            const Par pr = pr0;
+            kp0 = kp1;
+            pr0 = ask_par(k - 1, kp0);
+            kp1 = ask_kept(k - 2);
+            const CrossCol &cc = pr.cc;
+            const bool a_cp = cc.a_part && cc.d1 > 0, b_cp = cc.b_part && cc.d2 > 0;
+            const int w_sh = (a_cp || b_cp) ? 1 : 0;
+            const uint32_t o_pm = (k + 1 < K && (cc.flags & (MRP_XF_OUT_A_PAIRED | MRP_XF_OUT_B_PAIRED))) ? 1u : 0u;
+            const uint32_t i_pm = (k > 0 && (cc.flags & (MRP_XF_IN_A_PAIRED | MRP_XF_IN_B_PAIRED))) ? 1u : 0u;
+            const bool in = lane < kp.n;
+            const bool keep = in && (k + 1 == K || ((aliveM >> (kp.np & 63u)) & 1ull));
+            const uint64_t km = __ballot(keep);
+            const int ns = __popcll(km), pos = mbcnt64(km);
+            const uint64_t aliveP = k > 0 ? units_named(keep, kp.np >> 16) : 0ull; /* :1141-1155 */
+            if (keep) {
+                /* the even cell's transitions as CELL indices (which twin of the merge unit it leads to / comes from) */
+                uint32_t nxt = 0u, prv = 0u;
+                if (k + 1 < K) {
+                    const uint32_t ii = cc.out_a == MRP_CONN_REAL ? (pr.rna & 0xFFFFu) : (cc.out_a == MRP_CONN_IDENT ? pr.c1 : 0u);
+                    const uint32_t jj = cc.out_b == MRP_CONN_REAL ? (pr.rnb & 0xFFFFu) : (cc.out_b == MRP_CONN_IDENT ? pr.c2 : 0u);
+                    nxt = pair_index(ii, jj, cc.Mb, true, (cc.flags & MRP_XF_OUT_A_PAIRED) != 0, (cc.flags & MRP_XF_OUT_B_PAIRED) != 0);
+                }
+                if (k > 0) {
+                    const uint32_t ii = cc.in_a == MRP_CONN_REAL ? (pr.rna >> 16) : (cc.in_a == MRP_CONN_IDENT ? pr.c1 : 0u);
+                    const uint32_t jj = cc.in_b == MRP_CONN_REAL ? (pr.rnb >> 16) : (cc.in_b == MRP_CONN_IDENT ? pr.c2 : 0u);
+                    prv = pair_index(ii, jj, cc.Pb, true, (cc.flags & MRP_XF_IN_A_PAIRED) != 0, (cc.flags & MRP_XF_IN_B_PAIRED) != 0);
+                }
+                if ((nxt >> o_pm) != (kp.np & 0xFFFFu) || (prv >> i_pm) != (kp.np >> 16)) errbits |= MRP_ENGINE_ERR_RANGE; /* (the cross product kernel's view) */
+                /* filterMergeCells keeps the merge cells in their original relative order: new index = survivors below */
+                const uint32_t mu = nxt >> o_pm, pmu = prv >> i_pm;
+                const uint32_t new_next = k + 1 < K ? ((uint32_t) __popcll(aliveM & ((1ull << (mu & 63u)) - 1ull)) << o_pm) + (nxt & o_pm) : 0u;
+                const uint32_t new_prev = k > 0 ? ((uint32_t) __popcll(aliveP & ((1ull << (pmu & 63u)) - 1ull)) << i_pm) + (prv & i_pm) : 0u;
+                const uint64_t part = cc.d1 < 64 ? (pr.pa | (pr.pb << cc.d1)) : pr.pa; /* mergePartitionsOrMasks partitions.c:21-28 */
+                if (w_sh) {
+                    const int64_t o = (int64_t) k * S + 2 * pos;
+                    h.out_part[o] = part;
+                    h.out_part[o + 1] = ~part & accept_mask((uint32_t) cc.d1 + (uint32_t) cc.d2);
+                    h.out_np[o] = new_next | (new_prev << 16);
+                    h.out_np[o + 1] = (new_next ^ o_pm) | ((new_prev ^ i_pm) << 16);
+                } else {
+                    h.out_part[(int64_t) k * S + pos] = part;
+                    h.out_np[(int64_t) k * S + pos] = new_next | (new_prev << 16);
+                }
+            }
+            if (lane == 0) {
+                h.out_n_cells[k] = ns << w_sh;
+                h.out_n_merge[k] = k + 1 < K ? __popcll(aliveM) << o_pm : 0;
+            }
+            aliveM = aliveP;
+        }
+        MINI_T(4);
+#ifdef PRUNE_EXP_CLOCK2
+        if (hi_ == 0 && lane == 0) {
+            for (int i_ = 0; i_ < 4; i_++) atomicAdd((unsigned long long *) (sc.err + 4) + i_, (unsigned long long) (mt_[i_ + 1] - mt_[i_]));
+            atomicAdd((unsigned long long *) (sc.err + 4) + 8, (unsigned long long) K);
+        }
+#endif
+        if (p.pad && hmm0 + hi_ == 0) errbits |= MRP_ENGINE_ERR_MERGE; /* fault injection of the tests (mrp_context_set_test_hooks bit 0) */
+        if (errbits) { atomicOr(sc.err, errbits); atomicOr(sc.err_hmm + hmm0 + hi_, errbits); }
+    }
+}
+
+hipError_t mrp_launch_mini(const MrpBatchDev &d, const CrossCol *ccols_dev, const PruneHmm *hmms_dev, int64_t n_hmms, int64_t hmm0, PruneParams p,
+                           PruneScratch s, hipStream_t stream) {
+    if (n_hmms <= 0) return hipSuccess;
+    if (p.pairs != 2 || p.n_bins > 1024) return hipErrorInvalidValue;
+    const int64_t wgs = (n_hmms + 3) / 4;
+    hipLaunchKernelGGL(mrp_mini_kernel, dim3((unsigned) (wgs < (1 << 20) ? wgs : (1 << 20))), dim3(256), 0, stream, d, ccols_dev, hmms_dev, n_hmms, hmm0, p, s);
+    return hipGetLastError();
+}
+
+/* ------------------------------------------------------------------------------------------ */
 /* compaction: the pruned hmm in the resident layout                                           */
 /* ------------------------------------------------------------------------------------------ */
 __global__ void __launch_bounds__(256) mrp_compact_kernel(MrpBatchDev d, const CrossCol *__restrict__ ccols, const PruneHmm *__restrict__ hmms,
-                                                          const int32_t *__restrict__ col_hmm, int64_t n_cols, PruneParams p,
+                                                          const int32_t *__restrict__ col_hmm, int64_t n_cols, int32_t n_hmms_here, PruneParams p,
                                                           PruneScratch sc) {
     __shared__ uint32_t km_all[4][2 * PRUNE_SP]; /* per wave: the kept merge cells after and before the column (ascending) */
     const int lane = threadIdx.x & (WAVE - 1);
@@ -2758,6 +3042,7 @@ __global__ void __launch_bounds__(256) mrp_compact_kernel(MrpBatchDev d, const C
         return (uint32_t) lo;
     };
     for (int64_t lcol = (int64_t) blockIdx.x * (blockDim.x / WAVE) + wave; lcol < n_cols; lcol += stride) {
+        if (col_hmm[lcol] >= n_hmms_here) continue; /* (an hmm of the single-wave kernel: it wrote its pruned hmm itself) */
         const PruneHmm h = k_load(hmms + col_hmm[lcol]);
         const int k = (int) (lcol - h.col0);
         const int K = h.n_cols;
@@ -2906,10 +3191,10 @@ hipError_t mrp_launch_traceback(const MrpBatchDev &d, const PruneHmm *hmms_dev, 
 }
 
 hipError_t mrp_launch_compact(const MrpBatchDev &d, const CrossCol *ccols_dev, const PruneHmm *hmms_dev, const int32_t *col_hmm_dev, int64_t n_cols,
-                              PruneParams p, PruneScratch s, hipStream_t stream) {
-    if (n_cols <= 0) return hipSuccess;
+                              int64_t n_hmms_here, PruneParams p, PruneScratch s, hipStream_t stream) {
+    if (n_cols <= 0 || n_hmms_here <= 0) return hipSuccess;
     const int64_t wgs = (n_cols + 3) / 4;
     hipLaunchKernelGGL(mrp_compact_kernel, dim3((unsigned) (wgs < 65536 ? wgs : 65536)), dim3(256), 0, stream, d, ccols_dev, hmms_dev,
-                       col_hmm_dev, n_cols, p, s);
+                       col_hmm_dev, n_cols, (int32_t) n_hmms_here, p, s);
     return hipGetLastError();
 }
