@@ -2914,22 +2914,37 @@ __global__ void __launch_bounds__(256) mrp_mini_kernel(MrpBatchDev d, const Cros
         MINI_T(3);
         /* ---- stRPHmm_pruneBackwards hmm.c:1111-1158 + the pruned hmm in the resident layout; three columns in the pipe: the kept
          * list of column k - 2 and the parents' cells of the kept units of column k - 1 are in flight while column k is written ---- */
-        struct Kept { int n; uint32_t ku, np; };
+        struct Kept { int n; uint32_t ku, np; uint32_t dv; };
         struct Par { CrossCol cc; uint32_t rna, rnb, c1, c2; uint64_t pa, pb; };
+        /* the kept units of a column and -- as a vector load, lane l = dword l: a scalar load would be waited for on the spot,
+         * it shares its counter with the LDS traffic -- the column's CrossCol, both asked for two columns ahead */
         auto ask_kept = [&](int k) -> Kept {
-            Kept r; r.n = 0; r.ku = 0u; r.np = 0u;
+            Kept r; r.n = 0; r.ku = 0u; r.np = 0u; r.dv = 0u;
             if (k >= 0) {
                 const int64_t lcol = h.col0 + k;
                 r.n = sc.n_kept[lcol];
                 const uint2 v = 2 * lane < S ? *reinterpret_cast<const uint2 *>(sc.kept_np + lcol * S + 2 * lane) : make_uint2(0u, 0u);
                 r.ku = v.x & 63u; r.np = v.y;
+                if (lane < 16) r.dv = reinterpret_cast<const uint32_t *>(ccols + lcol)[lane];
             }
             return r;
         };
+        auto fld = [&](uint32_t v, int l) -> uint32_t { return (uint32_t) __builtin_amdgcn_readlane((int) v, l); };
         auto ask_par = [&](int k, const Kept &kp) -> Par {
             Par r; r.cc = CrossCol{}; r.rna = r.rnb = r.c1 = r.c2 = 0u; r.pa = r.pb = 0ull;
             if (k >= 0) {
-                r.cc = k_load(ccols + h.col0 + k);
+                const uint32_t dv = kp.dv;
+                CrossCol c = {};
+                c.a_part = reinterpret_cast<const uint64_t *>(((uint64_t) fld(dv, 1) << 32) | fld(dv, 0));
+                c.b_part = reinterpret_cast<const uint64_t *>(((uint64_t) fld(dv, 3) << 32) | fld(dv, 2));
+                c.a_np = reinterpret_cast<const uint32_t *>(((uint64_t) fld(dv, 5) << 32) | fld(dv, 4));
+                c.b_np = reinterpret_cast<const uint32_t *>(((uint64_t) fld(dv, 7) << 32) | fld(dv, 6));
+                const uint32_t w10 = fld(dv, 10), w11 = fld(dv, 11), w12 = fld(dv, 12), w13 = fld(dv, 13), w14 = fld(dv, 14);
+                c.C1 = (uint16_t) w10; c.C2 = (uint16_t) (w10 >> 16); c.Ma = (uint16_t) w11; c.Mb = (uint16_t) (w11 >> 16);
+                c.Pa = (uint16_t) w12; c.Pb = (uint16_t) (w12 >> 16);
+                c.d1 = (uint8_t) w13; c.d2 = (uint8_t) (w13 >> 8); c.out_a = (uint8_t) (w13 >> 16); c.out_b = (uint8_t) (w13 >> 24);
+                c.in_a = (uint8_t) w14; c.in_b = (uint8_t) (w14 >> 8); c.flags = (uint8_t) (w14 >> 16);
+                r.cc = c;
                 const bool a_cp = r.cc.a_part && r.cc.d1 > 0, b_cp = r.cc.b_part && r.cc.d2 > 0;
                 /* the unit's even cell (c1, c2): the order rule of cross_cell */
                 if (a_cp) { const uint32_t C2 = r.cc.C2 ? r.cc.C2 : 1u; const uint32_t q = (uint32_t) (((float) kp.ku + 0.5f) * __builtin_amdgcn_rcpf((float) C2)); r.c1 = 2u * q; r.c2 = kp.ku - q * C2; }
