@@ -85,6 +85,14 @@ struct mrp_engine_level_state {
     bool fused = false; /* cross product and emission in one kernel, no partition array (merge levels, no ancestor model) */
     bool units = false; /* the level's cell / merge cell arrays hold one entry per complement pair (MRP_XF_UNITS) */
     int64_t n_mini = 0; /* hmms of the single-wave kernel: the last n_mini records of the level's PruneHmm array */
+    /* genome fragments of a final level on the device (mrp_fragment_kernel): inputs staged, results fetched with the level's */
+    bool frag = false;
+    PinnedBuf frag_stage, frag_results;
+    DevBuf<FragHmm> d_frag_hmms; DevBuf<FragRead> d_frag_reads; DevBuf<int32_t> d_frag_by_pool, d_frag_disc, d_frag_lists, d_frag_work, d_frag_counts, d_frag_col_read, d_frag_col_cnt;
+    DevBuf<FragSite> d_frag_sites; DevBuf<uint64_t> d_frag_col_part; DevBuf<uint32_t> d_frag_read_key;
+    std::vector<FragHmm> frag_hmms;
+    int64_t frag_reads_total = 0, frag_disc_total = 0, frag_sites_total = 0, frag_list_total = 0;
+    FragSite *h_frag_sites = nullptr; int32_t *h_frag_lists = nullptr, *h_frag_counts = nullptr;
     unsigned long long clk[12] = {0};
     mrp_xhmm *x = nullptr;
     int64_t n = 0, total_cols = 0, n_slots = 0, n_reads = 0;
@@ -140,6 +148,9 @@ static void level_retire(mrp_engine *e, mrp_engine_level_state *L) {
     }
     L->seg.reset();
     L->d_plan.release(); L->d_xd.release(); L->d_par.release(); L->d_cstart.release(); L->d_croff.release(); L->d_phmm.release(); L->d_dims.release(); L->d_tot.release(); L->d_base.release(); L->d_totals.release();
+    L->d_frag_hmms.release(); L->d_frag_reads.release(); L->d_frag_by_pool.release(); L->d_frag_disc.release(); L->d_frag_lists.release(); L->d_frag_work.release();
+    L->d_frag_counts.release(); L->d_frag_col_read.release(); L->d_frag_col_cnt.release(); L->d_frag_sites.release(); L->d_frag_col_part.release(); L->d_frag_read_key.release();
+    L->frag = false;
     L->d_cc.release(); L->d_ph.release(); L->d_col_hmm.release(); L->d_nkept.release(); L->d_nkeptm.release(); L->d_err.release();
     L->d_err_hmm.release(); L->d_kept.release(); L->d_keptm.release(); L->d_kept_np.release();
     L->perm.clear();
@@ -539,6 +550,57 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         si.err = L->d_err.p; si.err_hmm = L->d_err_hmm.p;
         ENG_TRY(mrp_launch_structure(si, cs));
     }
+    L->frag = false;
+    if (final_level && n > 0) { /* genome fragments on the device: every hmm of the stage brings its chunk's reads */
+        bool all = !(getenv("MRP_FRAGMENTS") && getenv("MRP_FRAGMENTS")[0] == '0');
+        for (int64_t i = 0; i < n && all; i++) all = x[i].frag_reads && x[i].frag_by_pool && x[i].frag_sites && x[i].frag_reads1 && x[i].frag_reads2 && x[i].frag_n_reads > 0;
+        if (all) {
+            L->frag_hmms.resize((size_t) n);
+            int64_t r0 = 0, d0 = 0, s0 = 0, l0 = 0;
+            for (int64_t i = 0; i < n; i++) { /* (in the order of the level's PruneHmm array: the kernel indexes both alike) */
+                const mrp_xhmm &h = x[(size_t) L->perm[(size_t) i]];
+                FragHmm &f = L->frag_hmms[(size_t) i];
+                f.reads0 = r0; f.disc0 = d0; f.site0 = s0; f.list0 = l0; f.slot0 = read0[(size_t) L->perm[(size_t) i]];
+                f.n_reads = h.frag_n_reads; f.n_discarded = h.frag_n_discarded; f.ref_start = h.ref_start; f.length = h.ref_end - h.ref_start;
+                f.max_iterations = h.frag_iterations; f.pad = 0;
+                r0 += h.frag_n_reads; d0 += h.frag_n_discarded; s0 += f.length; l0 += 2 * (int64_t) h.frag_n_reads + 2;
+            }
+            L->frag_reads_total = r0; L->frag_disc_total = d0; L->frag_sites_total = s0; L->frag_list_total = l0;
+            auto al64 = [](size_t v) { return (v + 63) & ~(size_t) 63; };
+            const size_t o_fh = 0, o_fr = o_fh + al64(sizeof(FragHmm) * (size_t) n), o_fp = o_fr + al64(sizeof(FragRead) * (size_t) r0), o_fd = o_fp + al64(4 * (size_t) r0),
+                         o_fe = o_fd + al64(4 * (size_t) d0 + 4);
+            ENG_TRY(L->frag_stage.reserve(o_fe));
+            char *fb_ = (char *) L->frag_stage.p;
+            memcpy(fb_ + o_fh, L->frag_hmms.data(), sizeof(FragHmm) * (size_t) n);
+            FragRead *fr = (FragRead *) (fb_ + o_fr);
+            int32_t *fp = (int32_t *) (fb_ + o_fp), *fd = (int32_t *) (fb_ + o_fd);
+            mrp_parallel_for(n, 1, [&](int64_t i) {
+                const mrp_xhmm &h = x[(size_t) L->perm[(size_t) i]];
+                const FragHmm &f = L->frag_hmms[(size_t) i];
+                for (int32_t r = 0; r < h.frag_n_reads; r++) {
+                    FragRead &q = fr[f.reads0 + r];
+                    q.ref_start = h.frag_reads[r].ref_start; q.length = h.frag_reads[r].length; q.pool_offset = h.frag_reads[r].pool_offset;
+                }
+                memcpy(fp + f.reads0, h.frag_by_pool, 4 * (size_t) h.frag_n_reads);
+                if (h.frag_n_discarded > 0) memcpy(fd + f.disc0, h.frag_discarded, 4 * (size_t) h.frag_n_discarded);
+            });
+            L->d_frag_hmms.pool = pl; L->d_frag_reads.pool = pl; L->d_frag_by_pool.pool = pl; L->d_frag_disc.pool = pl; L->d_frag_lists.pool = pl; L->d_frag_work.pool = pl;
+            L->d_frag_counts.pool = pl; L->d_frag_col_read.pool = pl; L->d_frag_col_cnt.pool = pl; L->d_frag_sites.pool = pl; L->d_frag_col_part.pool = pl; L->d_frag_read_key.pool = pl;
+            ENG_TRY(L->d_frag_hmms.alloc((size_t) n)); ENG_TRY(L->d_frag_reads.alloc((size_t) r0)); ENG_TRY(L->d_frag_by_pool.alloc((size_t) r0));
+            ENG_TRY(L->d_frag_disc.alloc((size_t) d0 + 1)); ENG_TRY(L->d_frag_lists.alloc(2 * (size_t) l0)); ENG_TRY(L->d_frag_work.alloc(2 * (size_t) l0));
+            ENG_TRY(L->d_frag_counts.alloc(2 * (size_t) n)); ENG_TRY(L->d_frag_col_read.alloc((size_t) total_reads + 1)); ENG_TRY(L->d_frag_col_cnt.alloc(2 * (size_t) total_cols));
+            ENG_TRY(L->d_frag_sites.alloc((size_t) s0)); ENG_TRY(L->d_frag_col_part.alloc((size_t) total_cols)); ENG_TRY(L->d_frag_read_key.alloc(2 * (size_t) r0));
+            ENG_TRY(up(L->d_frag_hmms.p, fb_ + o_fh, sizeof(FragHmm) * (size_t) n));
+            ENG_TRY(up(L->d_frag_reads.p, fr, sizeof(FragRead) * (size_t) r0));
+            ENG_TRY(up(L->d_frag_by_pool.p, fp, 4 * (size_t) r0));
+            ENG_TRY(up(L->d_frag_disc.p, fd, 4 * (size_t) d0));
+            ENG_TRY(L->frag_results.reserve(al64(sizeof(FragSite) * (size_t) s0) + al64(8 * (size_t) l0) + al64(8 * (size_t) n)));
+            L->h_frag_sites = (FragSite *) L->frag_results.p;
+            L->h_frag_lists = (int32_t *) ((char *) L->frag_results.p + al64(sizeof(FragSite) * (size_t) s0));
+            L->h_frag_counts = (int32_t *) ((char *) L->h_frag_lists + al64(8 * (size_t) l0));
+            L->frag = true;
+        }
+    }
     ENG_TRY(hipEventRecord(L->uploaded, cs));
     /* which of the two packing kernels has columns to look at (they filter by PlaneCol.need_planes) */
     L->any_pack = !all_planes;
@@ -609,6 +671,21 @@ static int level_finish(mrp_engine *e) {
             Lp->x[i].hmm_forward = Lp->fb[(size_t) (2 * i)];
             Lp->x[i].hmm_backward = Lp->fb[(size_t) (2 * i + 1)];
             colbase += Lp->x[i].n_cols;
+        }
+        if (Lp->frag) { /* the genome fragments, in the order of the PruneHmm array */
+            mrp_parallel_for(Lp->n, 1, [&](int64_t j) {
+                mrp_xhmm &h = Lp->x[(size_t) Lp->perm[(size_t) j]];
+                const FragHmm &f = Lp->frag_hmms[(size_t) j];
+                h.frag_done = 0;
+                if (Lp->err_hmm[j] != 0) return;
+                const int cap = 2 * f.n_reads + 2;
+                const int n1 = Lp->h_frag_counts[2 * j], n2 = Lp->h_frag_counts[2 * j + 1];
+                if (n1 < 0 || n2 < 0 || n1 > cap || n2 > cap) return;
+                memcpy(h.frag_sites, Lp->h_frag_sites + f.site0, sizeof(FragSite) * (size_t) f.length);
+                memcpy(h.frag_reads1, Lp->h_frag_lists + 2 * f.list0, 4 * (size_t) n1);
+                memcpy(h.frag_reads2, Lp->h_frag_lists + 2 * f.list0 + cap, 4 * (size_t) n2);
+                h.frag_n1 = n1; h.frag_n2 = n2; h.frag_done = 1;
+            });
         }
     }
     if (rc == MRP_OK) {
@@ -724,6 +801,13 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
     ENG_TRY(hipEventRecord(L->ev[2], s));
     if (L->final_level) {
         ENG_TRY(mrp_launch_traceback(b->dev, L->d_ph.p, n, L->d_err.p, L->d_err_hmm.p, s));
+        if (L->frag) {
+            FragArrays fa{};
+            fa.hmms = L->d_frag_hmms.p; fa.reads = L->d_frag_reads.p; fa.by_pool = L->d_frag_by_pool.p; fa.discarded = L->d_frag_disc.p;
+            fa.sites = L->d_frag_sites.p; fa.lists = L->d_frag_lists.p; fa.work = L->d_frag_work.p; fa.counts = L->d_frag_counts.p;
+            fa.col_read = L->d_frag_col_read.p; fa.col_part = L->d_frag_col_part.p; fa.read_key = L->d_frag_read_key.p; fa.col_cnt = L->d_frag_col_cnt.p;
+            ENG_TRY(mrp_launch_fragments(b->dev, L->d_ph.p, n, fa, L->d_err.p, L->d_err_hmm.p, s));
+        }
     } else {
         const int64_t n_reg = n - L->n_mini;
         ENG_TRY(mrp_launch_mini(b->dev, L->d_cc.p, L->d_ph.p + n_reg, L->n_mini, n_reg, L->pp, sc, s));
@@ -736,6 +820,11 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
         ENG_TRY(hipMemcpyAsync(L->path_cell, seg->n_cells.p, sizeof(int32_t) * (size_t) total_cols, hipMemcpyDeviceToHost, s));
         ENG_TRY(hipMemcpyAsync(L->path_part, seg->part.p, sizeof(uint64_t) * (size_t) total_cols, hipMemcpyDeviceToHost, s));
         ENG_TRY(hipMemcpyAsync(L->fb, b->dev.hmm_fb, sizeof(double) * (size_t) (2 * n), hipMemcpyDeviceToHost, s));
+        if (L->frag) {
+            ENG_TRY(hipMemcpyAsync(L->h_frag_sites, L->d_frag_sites.p, sizeof(FragSite) * (size_t) L->frag_sites_total, hipMemcpyDeviceToHost, s));
+            ENG_TRY(hipMemcpyAsync(L->h_frag_lists, L->d_frag_lists.p, 8 * (size_t) L->frag_list_total, hipMemcpyDeviceToHost, s));
+            ENG_TRY(hipMemcpyAsync(L->h_frag_counts, L->d_frag_counts.p, 8 * (size_t) n, hipMemcpyDeviceToHost, s));
+        }
     }
     ENG_TRY(hipMemcpyAsync(L->err, L->d_err.p, 16, hipMemcpyDeviceToHost, s));
     ENG_TRY(hipMemcpyAsync(L->err_hmm, L->d_err_hmm.p, sizeof(int32_t) * (size_t) n, hipMemcpyDeviceToHost, s));

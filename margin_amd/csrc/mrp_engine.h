@@ -183,6 +183,38 @@ struct PruneScratch {
     int32_t *err_hmm;       /* [n_hmms] the same per hmm, indexed like the PruneHmm array */
 };
 
+/* ---- genome fragments of the final hmms on the device (emissions.c:246-343, genomeFragment.c:40-232, bubbleGraph.c:2761-2779) ----
+ * One record per final hmm (= per chunk); the arrays it points into are the level's own. */
+struct FragRead { int32_t ref_start, length; int64_t pool_offset; };
+struct FragSite { uint8_t ancestor, hap1, hap2, support1, support2, pad[3]; float genotype_prob, hap_prob1, hap_prob2; }; /* 20 B */
+struct FragHmm {
+    int64_t reads0;        /* first FragRead of the chunk's reads in the level's table; the same offset into by_pool */
+    int64_t disc0;         /* first entry of its discarded reads (coverage filter, coordination.c:443-488) */
+    int64_t site0;         /* first FragSite of its result */
+    int64_t list0;         /* its reads1 / reads2 results start at 2 x list0 in lists (capacity 2 n_reads + 2 each), its work lists in work */
+    int64_t slot0;         /* first entry of its per-(column, read) scratch (= its first entry in read_byte_off) */
+    int32_t n_reads, n_discarded;
+    int32_t ref_start, length;  /* sites of the fragment */
+    int32_t max_iterations;     /* roundsOfIterativeRefinement */
+    int32_t pad;
+};
+struct FragArrays {
+    const FragHmm *hmms;
+    const FragRead *reads;      /* per chunk, in the caller's read order */
+    const int32_t *by_pool;     /* per chunk: its read indices sorted by pool_offset (a column names a read by its profile bytes) */
+    const int32_t *discarded;
+    FragSite *sites;            /* out */
+    int32_t *lists;             /* out: per chunk 2 x (2 n_reads + 2): reads1, reads2 */
+    int32_t *work;              /* scratch: the same size, the lists of the round in progress */
+    int32_t *counts;            /* out: [n_hmms][2] entries of reads1 / reads2 */
+    int32_t *col_read;          /* scratch: read index per (column, slot), indexed like read_byte_off */
+    uint64_t *col_part;         /* scratch: current partition per column (the trace back's, then refined) */
+    uint32_t *read_key;         /* scratch: per read 2 x first sighting key, then the move flags */
+    int32_t *col_cnt;           /* scratch: per column 2 x first-sighting counts */
+};
+hipError_t mrp_launch_fragments(const MrpBatchDev &d, const PruneHmm *hmms_dev, int64_t n_hmms, FragArrays fa, int32_t *err, int32_t *err_hmm,
+                                hipStream_t stream);
+
 #define MRP_ENGINE_ERR_STRUCTURE 1 /* a parent is not in complement-pair order: closed-form cross product not valid */
 #define MRP_ENGINE_ERR_POSTERIOR 2 /* f + b > total (column.c:183 "invalid prob") */
 #define MRP_ENGINE_ERR_RANGE 4     /* index out of range */

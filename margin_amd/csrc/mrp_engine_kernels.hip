@@ -3197,6 +3197,236 @@ __global__ void __launch_bounds__(64) mrp_traceback_kernel(MrpBatchDev d, const 
     }
 }
 
+/* ------------------------------------------------------------------------------------------ */
+/* genome fragments                                                                            */
+/* ------------------------------------------------------------------------------------------ */
+/*
+ * stGenomeFragment_construct (genomeFragment.c:40-69), fillInPredictedGenome (emissions.c:246-343),
+ * stGenomeFragment_refineGenomeFragment (genomeFragment.c:165-232) and the re-adding of the coverage-filtered reads
+ * (bubbleGraph.c:2772-2779) for the final hmm of every chunk, one workgroup per chunk, right behind the trace back: through round 3
+ * this was a quarter of the host's CPU time (a flat copy of the final hmm rebuilt per chunk, then byte loops over columns x
+ * reads and reads x sites, up to ten rounds).  Everything is integer arithmetic on profile bytes and the site tables (the three
+ * "probabilities" are -(float) of an integer), so the results are the host's bit for bit; what needs care is ORDER:
+ *   reads1 / reads2      first sighting along the path (column, then slot) per set -- a read that inconsistent columns put on both
+ *                        sides is in both; a round keeps the stayers in order and appends the arrivals in the other list's order.
+ *                        First sightings are counted per column and prefix-summed; moves are stable compactions (block scans).
+ *   a column names its reads by the offsets of their profile bytes (read_byte_off); the read index comes from a binary search in
+ *   the chunk's reads sorted by pool offset.
+ */
+#define FRAG_T 256
+static __device__ int frag_block_excl_scan(int v, int *total, int *lds /* [FRAG_T / 64 + 1] */) {
+    const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
+    const int incl = wave_incl_scan_bc(v);
+    if (lane == WAVE - 1) lds[wave] = incl;
+    __syncthreads();
+    int base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < FRAG_T / WAVE; w++) { const int x = lds[w]; if (w < wave) base += x; tot += x; }
+    __syncthreads();
+    *total = tot;
+    return base + incl - v;
+}
+/* emissions.c:263-321 for the sites of one column with the given partition */
+static __device__ void frag_fill_column(const DevChunk &ch, const DevCol &c, const int64_t *rbo, uint64_t partition, FragSite *out, int32_t frag_start) {
+    const uint32_t first_allele = ch.allele_offset[c.site_start];
+    const uint32_t sup1 = (uint32_t) __popcll(partition), sup2 = (uint32_t) c.depth - sup1;
+    for (int s_ = 0; s_ < c.n_sites; s_++) {
+        const int site = c.site_start + s_;
+        const uint32_t A = ch.allele_number[site], so = ch.allele_offset[site] - first_allele;
+        const uint16_t *sub = ch.sub + ch.sub_offset[site], *prior = ch.prior + ch.allele_offset[site];
+        uint32_t h1[MRP_MAX_ALLELES], h2[MRP_MAX_ALLELES];
+        const uint32_t An = A <= MRP_MAX_ALLELES ? A : MRP_MAX_ALLELES;
+        for (uint32_t a = 0; a < An; a++) { h1[a] = 0u; h2[a] = 0u; }
+        for (int i = 0; i < c.depth; i++) { /* alleleLogHapProbabilities :144-154: byte sums over the reads of either side */
+            const uint8_t *b = ch.pool + rbo[i] + so;
+            const bool in1 = (partition >> i) & 1ull;
+            for (uint32_t a = 0; a < An; a++) { const uint32_t v = b[a]; if (in1) h1[a] += v; else h2[a] += v; }
+        }
+        uint32_t best = 0xFFFFFFFFu, anc = 0u; /* ancestorHapProbabilities :156-172, the ml ancestor allele :283-292 */
+        for (uint32_t i = 0; i < An; i++) {
+            uint32_t x = h1[0] + sub[i * A], y = h2[0] + sub[i * A];
+            for (uint32_t q = 1; q < An; q++) { x = min(x, h1[q] + sub[i * A + q]); y = min(y, h2[q] + sub[i * A + q]); }
+            const uint32_t j = x + y + prior[i];
+            if (j < best) { best = j; anc = i; }
+        }
+        uint32_t hap1 = 0u, hap2 = 0u, m1 = h1[0] + sub[anc * A], m2 = h2[0] + sub[anc * A]; /* getMLAllele :246-261 */
+        for (uint32_t i = 1; i < An; i++) {
+            if (h1[i] + sub[anc * A + i] < m1) { m1 = h1[i] + sub[anc * A + i]; hap1 = i; }
+            if (h2[i] + sub[anc * A + i] < m2) { m2 = h2[i] + sub[anc * A + i]; hap2 = i; }
+        }
+        FragSite o;
+        o.ancestor = (uint8_t) anc; o.hap1 = (uint8_t) hap1; o.hap2 = (uint8_t) hap2; o.support1 = (uint8_t) sup1; o.support2 = (uint8_t) sup2;
+        o.pad[0] = o.pad[1] = o.pad[2] = 0;
+        o.genotype_prob = -((float) best); o.hap_prob1 = -(float) h1[hap1]; o.hap_prob2 = -(float) h2[hap2];
+        out[site - frag_start] = o;
+    }
+}
+/* getLogProbOfReadGivenHaplotype genomeFragment.c:71-89 for both haplotypes: the byte sums (the log probabilities are minus these
+ * over 30; comparing the sums the other way round compares the doubles) */
+static __device__ void frag_read_sums(const DevChunk &ch, const FragRead &r, const FragSite *sites, int32_t start, int32_t length, uint32_t *s1, uint32_t *s2) {
+    int lo = start - r.ref_start, hi = start + length - r.ref_start;
+    if (lo < 0) lo = 0;
+    if (hi > r.length) hi = r.length;
+    const uint8_t *pool = ch.pool + r.pool_offset;
+    const uint32_t *ao = ch.allele_offset + r.ref_start;
+    const uint32_t first = ao[0];
+    const FragSite *st = sites + (r.ref_start - start);
+    uint32_t a = 0u, b = 0u;
+    for (int i = lo; i < hi; i++) {
+        const uint32_t o = ao[i] - first;
+        a += pool[o + st[i].hap1];
+        b += pool[o + st[i].hap2];
+    }
+    *s1 = a; *s2 = b;
+}
+__global__ void __launch_bounds__(FRAG_T) mrp_fragment_kernel(MrpBatchDev d, const PruneHmm *__restrict__ hmms, int64_t n_hmms, FragArrays fa,
+                                                              int32_t *__restrict__ err, int32_t *__restrict__ err_hmm) {
+    __shared__ int scan_lds[FRAG_T / WAVE + 1];
+    __shared__ int moved[2];
+    const int tid = threadIdx.x;
+    for (int64_t hi_ = blockIdx.x; hi_ < n_hmms; hi_ += gridDim.x) {
+        const PruneHmm h = hmms[hi_];
+        const FragHmm f = fa.hmms[hi_];
+        const int K = h.n_cols, nr = f.n_reads, cap = 2 * nr + 2;
+        const DevCol c0 = d.cols[h.col0];
+        const DevChunk ch = d.chunks[c0.chunk];
+        const FragRead *reads = fa.reads + f.reads0;
+        const int32_t *by_pool = fa.by_pool + f.reads0;
+        FragSite *sites = fa.sites + f.site0;
+        int32_t *l1 = fa.lists + 2 * f.list0, *l2 = l1 + cap, *w1 = fa.work + 2 * f.list0, *w2 = w1 + cap;
+        uint32_t *key1 = fa.read_key + 2 * f.reads0, *key2 = key1 + nr;
+        uint64_t *part = fa.col_part + h.col0;
+        int32_t *cnt1 = fa.col_cnt + 2 * h.col0, *cnt2 = cnt1 + K;
+        int bad = 0;
+        for (int r = tid; r < nr; r += FRAG_T) { key1[r] = 0xFFFFFFFFu; key2[r] = 0xFFFFFFFFu; }
+        __syncthreads();
+        /* the reads of every column (binary search of the byte offset among the chunk's reads), the path's partitions, and for
+         * every read where it is first seen on either side */
+        for (int k = tid; k < K; k += FRAG_T) {
+            const DevCol c = d.cols[h.col0 + k];
+            const uint64_t p = h.out_part[k];
+            part[k] = p;
+            const int64_t *rbo = d.read_byte_off + c.read_off;
+            const int64_t shift = (int64_t) ch.allele_offset[c.site_start];
+            for (int i = 0; i < c.depth; i++) {
+                const int64_t v = rbo[i]; /* = pool_offset + (allele_offset[site_start] - allele_offset[read start]) */
+                int lo = 0, hi = nr; /* last read (by pool offset) that starts at or before v */
+                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (reads[by_pool[mid]].pool_offset <= v) lo = mid; else hi = mid; }
+                const int rid = nr > 0 ? by_pool[lo] : 0;
+                const FragRead r = reads[rid];
+                if (nr <= 0 || r.pool_offset + (shift - (int64_t) ch.allele_offset[r.ref_start]) != v || c.site_start < r.ref_start || c.site_start >= r.ref_start + r.length) bad = 1;
+                fa.col_read[c.read_off + i] = rid;
+                atomicMin(((p >> i) & 1ull) ? &key1[rid] : &key2[rid], ((uint32_t) k << 6) | (uint32_t) i);
+            }
+        }
+        __syncthreads();
+        /* reads1 / reads2 in order of first sighting (genomeFragment.c:40-48, hmm.c:221-248): per column the first sightings ... */
+        for (int k = tid; k < K; k += FRAG_T) {
+            const DevCol c = d.cols[h.col0 + k];
+            const uint64_t p = part[k];
+            int a = 0, b = 0;
+            for (int i = 0; i < c.depth; i++) {
+                const int rid = fa.col_read[c.read_off + i];
+                const uint32_t key = ((uint32_t) k << 6) | (uint32_t) i;
+                if ((p >> i) & 1ull) a += key1[rid] == key; else b += key2[rid] == key;
+            }
+            cnt1[k] = a; cnt2[k] = b;
+        }
+        __syncthreads();
+        int n1 = 0, n2 = 0;
+        {   /* ... prefix sums over the columns (a thread owns a run of consecutive columns), then the lists */
+            const int per = (K + FRAG_T - 1) / FRAG_T, k0 = tid * per, k1 = k0 + per < K ? k0 + per : K;
+            int a = 0, b = 0;
+            for (int k = k0; k < k1; k++) { a += cnt1[k]; b += cnt2[k]; }
+            int base1 = frag_block_excl_scan(a, &n1, scan_lds), base2 = frag_block_excl_scan(b, &n2, scan_lds);
+            for (int k = k0; k < k1; k++) {
+                const DevCol c = d.cols[h.col0 + k];
+                const uint64_t p = part[k];
+                for (int i = 0; i < c.depth; i++) {
+                    const int rid = fa.col_read[c.read_off + i];
+                    const uint32_t key = ((uint32_t) k << 6) | (uint32_t) i;
+                    if ((p >> i) & 1ull) { if (key1[rid] == key) l1[base1++] = rid; }
+                    else if (key2[rid] == key) l2[base2++] = rid;
+                }
+            }
+        }
+        /* stGenomeFragment_construct: the predicted genome of every column */
+        for (int k = tid; k < K; k += FRAG_T) {
+            const DevCol c = d.cols[h.col0 + k];
+            frag_fill_column(ch, c, d.read_byte_off + c.read_off, part[k], sites, f.ref_start);
+        }
+        __syncthreads();
+        /* stGenomeFragment_refineGenomeFragment genomeFragment.c:165-232: key1 / key2 now hold the move flags of a round */
+        uint32_t *m12 = key1, *m21 = key2;
+        for (int it = 0; it < f.max_iterations; it++) {
+            for (int r = tid; r < nr; r += FRAG_T) { m12[r] = 0u; m21[r] = 0u; }
+            if (tid < 2) moved[tid] = 0;
+            __syncthreads();
+            for (int i = tid; i < n1 + n2; i += FRAG_T) { /* :126-151: reads more probably generated by the other haplotype */
+                const bool first_list = i < n1;
+                const int rid = first_list ? l1[i] : l2[i - n1];
+                uint32_t s1, s2;
+                frag_read_sums(ch, reads[rid], sites, f.ref_start, f.length, &s1, &s2);
+                if (first_list ? s1 > s2 : s2 > s1) { (first_list ? m12 : m21)[rid] = 1u; atomicAdd(&moved[first_list ? 0 : 1], 1); }
+            }
+            __syncthreads();
+            if (moved[0] + moved[1] == 0) break;
+            {   /* the stayers in order, then the arrivals in the other list's order (:199-203): four stable compactions */
+                const int tot = n1 + n2, per = (tot + FRAG_T - 1) / FRAG_T, i0 = tid * per, i1 = i0 + per < tot ? i0 + per : tot;
+                int stay1 = 0, stay2 = 0, go12 = 0, go21 = 0;
+                for (int i = i0; i < i1; i++) {
+                    if (i < n1) { if (m12[l1[i]]) go12++; else stay1++; }
+                    else { if (m21[l2[i - n1]]) go21++; else stay2++; }
+                }
+                int t_s1, t_s2, t_12, t_21;
+                int b_s1 = frag_block_excl_scan(stay1, &t_s1, scan_lds), b_s2 = frag_block_excl_scan(stay2, &t_s2, scan_lds);
+                int b_12 = frag_block_excl_scan(go12, &t_12, scan_lds), b_21 = frag_block_excl_scan(go21, &t_21, scan_lds);
+                for (int i = i0; i < i1; i++) {
+                    if (i < n1) { const int rid = l1[i]; if (m12[rid]) w2[t_s2 + b_12++] = rid; else w1[b_s1++] = rid; }
+                    else { const int rid = l2[i - n1]; if (m21[rid]) w1[t_s1 + b_21++] = rid; else w2[b_s2++] = rid; }
+                }
+                n1 = t_s1 + t_21; n2 = t_s2 + t_12;
+                int32_t *t_ = l1; l1 = w1; w1 = t_; t_ = l2; l2 = w2; w2 = t_;
+            }
+            __syncthreads();
+            for (int k = tid; k < K; k += FRAG_T) { /* :211-226: the moved reads change sides in every column that holds them */
+                const DevCol c = d.cols[h.col0 + k];
+                uint64_t flip = 0ull;
+                for (int i = 0; i < c.depth; i++) { const int rid = fa.col_read[c.read_off + i]; flip |= (uint64_t) (m12[rid] ^ m21[rid]) << i; }
+                if (!flip) continue;
+                part[k] ^= flip;
+                frag_fill_column(ch, c, d.read_byte_off + c.read_off, part[k], sites, f.ref_start);
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+        /* bubbleGraph.c:2772-2779: the reads the coverage filter took out go to the haplotype that explains them better, in order */
+        if (tid == 0) {
+            const int32_t *disc = fa.discarded + f.disc0;
+            for (int i = 0; i < f.n_discarded; i++) {
+                uint32_t s1, s2;
+                frag_read_sums(ch, reads[disc[i]], sites, f.ref_start, f.length, &s1, &s2);
+                if (s1 > s2) l2[n2++] = disc[i]; else l1[n1++] = disc[i];
+            }
+            fa.counts[2 * hi_] = n1; fa.counts[2 * hi_ + 1] = n2;
+            /* results at fixed places: reads1 in the first half of the chunk's block of fa.lists, reads2 in the second */
+            int32_t *o1 = fa.lists + 2 * f.list0, *o2 = o1 + cap;
+            if (l1 != o1) { /* (an odd number of rounds moved something: the lists sit in the work halves) */
+                for (int i = 0; i < n1; i++) o1[i] = l1[i];
+                for (int i = 0; i < n2; i++) o2[i] = l2[i];
+            }
+        }
+        if (__syncthreads_or(bad)) { if (tid == 0) { atomicOr(err, MRP_ENGINE_ERR_RANGE); atomicOr(err_hmm + hi_, MRP_ENGINE_ERR_RANGE); } }
+    }
+}
+
+hipError_t mrp_launch_fragments(const MrpBatchDev &d, const PruneHmm *hmms_dev, int64_t n_hmms, FragArrays fa, int32_t *err, int32_t *err_hmm,
+                                hipStream_t stream) {
+    if (n_hmms <= 0) return hipSuccess;
+    hipLaunchKernelGGL(mrp_fragment_kernel, dim3((unsigned) (n_hmms < 65536 ? n_hmms : 65536)), dim3(FRAG_T), 0, stream, d, hmms_dev, n_hmms, fa, err, err_hmm);
+    return hipGetLastError();
+}
+
 hipError_t mrp_launch_traceback(const MrpBatchDev &d, const PruneHmm *hmms_dev, int64_t n_hmms, int32_t *err, int32_t *err_hmm,
                                 hipStream_t stream) {
     if (n_hmms <= 0) return hipSuccess;

@@ -1970,6 +1970,10 @@ typedef struct {
     rleaf *leaves;       /* leaf shadows of all reads of the chunk */
     int rc;
     char err[256];
+    /* the genome fragment as the device leaves it (mrp_xhmm.frag_*): 20 bytes per site, the two read lists */
+    int32_t *by_pool, *frag_reads1, *frag_reads2;
+    void *frag_sites;
+    int32_t frag_n1, frag_n2, frag_done;
 } many_state;
 
 typedef struct {
@@ -2041,11 +2045,50 @@ static void many_final_shadow(int64_t c, void *arg) {
     x->n_cells = m->path;
     x->path_part = m->chosen;
     m->w.n_sweeps += 1; /* bubbleGraph.c:2749 */
+    {   /* the genome fragment on the device, behind the trace back: the chunk's reads, their order by pool offset (a column names a
+         * read by where its profile bytes are), the reads the coverage filter took out */
+        const int64_t nr = m->w.n_reads;
+        m->by_pool = xmalloc(sizeof(int32_t) * (size_t) (nr + 1));
+        int sorted = 1;
+        for (int64_t i = 0; i < nr; i++) { m->by_pool[i] = (int32_t) i; if (i > 0 && m->w.reads[i].pool_offset < m->w.reads[i - 1].pool_offset) sorted = 0; }
+        if (!sorted) { /* (rare: callers lay the profiles out in read order) insertion into a keyed array, then a plain sort */
+            keyed *a = xmalloc(sizeof(keyed) * (size_t) (nr + 1)), *t = xmalloc(sizeof(keyed) * (size_t) (nr + 1));
+            for (int64_t i = 0; i < nr; i++) { a[i].idx = i; a[i].key = -(double) m->w.reads[i].pool_offset; } /* keyed_sort_desc: descending key */
+            keyed_sort_desc(a, nr, t);
+            for (int64_t i = 0; i < nr; i++) m->by_pool[i] = (int32_t) a[i].idx;
+            free(a); free(t);
+        }
+        const int64_t len = (int64_t) x->ref_end - x->ref_start;
+        m->frag_sites = xmalloc(20 * (size_t) (len + 1));
+        m->frag_reads1 = xmalloc(sizeof(int32_t) * (size_t) (2 * nr + 2));
+        m->frag_reads2 = xmalloc(sizeof(int32_t) * (size_t) (2 * nr + 2));
+        x->frag_reads = m->w.reads; x->frag_n_reads = (int32_t) nr; x->frag_by_pool = m->by_pool;
+        x->frag_discarded = m->discarded; x->frag_n_discarded = (int32_t) m->nd;
+        x->frag_iterations = (int32_t) ctl->params->rounds_of_iterative_refinement;
+        x->frag_sites = m->frag_sites; x->frag_reads1 = m->frag_reads1; x->frag_reads2 = m->frag_reads2;
+        x->frag_n1 = x->frag_n2 = 0; x->frag_done = 0;
+    }
 }
 static void many_finish(int64_t c, void *arg) {
     many_ctl *ctl = arg;
     many_state *m = &ctl->st[c];
     if (m->w.failed) ctl->out[c] = NULL; /* redone by the caller on the hashing path */
+    else if (m->hmm && m->frag_done) { /* the fragment came from the device: widen it into the result's arrays */
+        const int32_t start = m->hmm->ref_start, len = m->hmm->ref_length;
+        mrp_phase_result *g = result_new(start, len, m->w.n_reads);
+        const struct { uint8_t anc, h1, h2, s1, s2, pad[3]; float gp, p1, p2; } *fs = m->frag_sites;
+        for (int32_t q = 0; q < len; q++) {
+            const uint64_t A = m->w.ch.allele_number[start + q], h1 = fs[q].h1, h2 = fs[q].h2;
+            g->ancestor_string[q] = fs[q].anc; g->haplotype_string1[q] = h1; g->haplotype_string2[q] = h2;
+            g->genotype_string[q] = h1 < h2 ? h1 * A + h2 : h2 * A + h1;
+            g->genotype_probs[q] = fs[q].gp; g->haplotype_probs1[q] = fs[q].p1; g->haplotype_probs2[q] = fs[q].p2;
+            g->reads_supporting_haplotype1[q] = fs[q].s1; g->reads_supporting_haplotype2[q] = fs[q].s2;
+        }
+        memcpy(g->reads1, m->frag_reads1, sizeof(int32_t) * (size_t) m->frag_n1); g->n_reads1 = m->frag_n1;
+        memcpy(g->reads2, m->frag_reads2, sizeof(int32_t) * (size_t) m->frag_n2); g->n_reads2 = m->frag_n2;
+        g->hmm_forward = m->fwd; g->hmm_backward = m->bwd; g->n_sweeps = m->w.n_sweeps;
+        ctl->out[c] = g;
+    }
     else if (m->hmm) {
         mrp_hmm *flat = r_expand(&m->w, m->hmm, 0);
         if (!flat) { m->rc = MRP_ERR_ARG; snprintf(m->err, sizeof(m->err), "%s", mrp_last_error()); return; }
@@ -2115,6 +2158,8 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
         for (int64_t c = 0; c < n_chunks; c++)
             if (st[c].hmm) {
                 st[c].fwd = xh[st[c].final_index].hmm_forward; st[c].bwd = xh[st[c].final_index].hmm_backward;
+                st[c].frag_done = rc == MRP_OK ? xh[st[c].final_index].frag_done : 0;
+                st[c].frag_n1 = xh[st[c].final_index].frag_n1; st[c].frag_n2 = xh[st[c].final_index].frag_n2;
                 if (rc == MRP_OK && xh[st[c].final_index].err != 0) st[c].w.failed = 1;
             }
         free(xh);
@@ -2161,7 +2206,10 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
         stats->pack_ms = es.pack_ms; stats->cross_emit_ms = es.cross_emit_ms; stats->recursion_ms = es.recursion_ms; stats->prune_kernel_ms = es.prune_kernel_ms; stats->compact_ms = es.compact_ms;
     }
     const double t_clean = now_ms();
-    for (int64_t c = 0; c < n_chunks; c++) { rhmm_destroy(st[c].hmm); free(st[c].discarded); free(st[c].tree.a); free(st[c].path); free(st[c].chosen); }
+    for (int64_t c = 0; c < n_chunks; c++) {
+        rhmm_destroy(st[c].hmm); free(st[c].discarded); free(st[c].tree.a); free(st[c].path); free(st[c].chosen);
+        free(st[c].by_pool); free(st[c].frag_sites); free(st[c].frag_reads1); free(st[c].frag_reads2);
+    }
     r_free_tree(&tree);
     for (int64_t c = 0; c < n_chunks; c++) free(st[c].leaves);
     free(st);

@@ -94,6 +94,18 @@ typedef struct mrp_xhmm {
     /* MRP_ENGINE_ERR_* bits the kernels raised for this hmm; non-zero (structure / merge): its results are not valid and
      * the chunk it belongs to has to be redone on the hashing path */
     int32_t err;
+    /* mrp_engine_final_stage, optional (frag_reads != NULL for EVERY hmm of the stage): the genome fragment of the traced-back
+     * path on the device -- stGenomeFragment_construct, the refinement rounds and the re-adding of the coverage-filtered reads
+     * (genomeFragment.c:40-232, bubbleGraph.c:2761-2779).  In: the chunk's reads, their indices sorted by pool_offset, the
+     * filtered-out reads in the order bubbleGraph.c:2772 walks them.  Out (caller-allocated): 20 bytes per site of
+     * [ref_start, ref_end) (ancestor, hap1, hap2, reads on either side as bytes; three floats), reads1 / reads2 (capacity
+     * 2 n_reads + 2 each) and their lengths; frag_done = 1 when they were filled. */
+    const struct mrp_read *frag_reads;
+    const int32_t *frag_by_pool, *frag_discarded;
+    int32_t frag_n_reads, frag_n_discarded, frag_iterations;
+    void *frag_sites;
+    int32_t *frag_reads1, *frag_reads2;
+    int32_t frag_n1, frag_n2, frag_done;
 } mrp_xhmm;
 
 /* static upper bound of the cells one side contributes to a cross product column: a pruned column has at most S cells,
