@@ -3213,7 +3213,8 @@ __global__ void __launch_bounds__(64) mrp_traceback_kernel(MrpBatchDev d, const 
  *   a column names its reads by the offsets of their profile bytes (read_byte_off); the read index comes from a binary search in
  *   the chunk's reads sorted by pool offset.
  */
-#define FRAG_T 256
+#define FRAG_T 512
+#define FRAG_LDS_READS 6144 /* pool offsets of up to this many reads of a chunk are searched in LDS */
 static __device__ int frag_block_excl_scan(int v, int *total, int *lds /* [FRAG_T / 64 + 1] */) {
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
     const int incl = wave_incl_scan_bc(v);
@@ -3283,6 +3284,7 @@ __global__ void __launch_bounds__(FRAG_T) mrp_fragment_kernel(MrpBatchDev d, con
                                                               int32_t *__restrict__ err, int32_t *__restrict__ err_hmm) {
     __shared__ int scan_lds[FRAG_T / WAVE + 1];
     __shared__ int moved[2];
+    __shared__ int64_t pool_sorted[FRAG_LDS_READS]; /* the reads' pool offsets in ascending order */
     const int tid = threadIdx.x;
     for (int64_t hi_ = blockIdx.x; hi_ < n_hmms; hi_ += gridDim.x) {
         const PruneHmm h = hmms[hi_];
@@ -3298,7 +3300,8 @@ __global__ void __launch_bounds__(FRAG_T) mrp_fragment_kernel(MrpBatchDev d, con
         uint64_t *part = fa.col_part + h.col0;
         int32_t *cnt1 = fa.col_cnt + 2 * h.col0, *cnt2 = cnt1 + K;
         int bad = 0;
-        for (int r = tid; r < nr; r += FRAG_T) { key1[r] = 0xFFFFFFFFu; key2[r] = 0xFFFFFFFFu; }
+        const bool in_lds = nr <= FRAG_LDS_READS;
+        for (int r = tid; r < nr; r += FRAG_T) { key1[r] = 0xFFFFFFFFu; key2[r] = 0xFFFFFFFFu; if (in_lds) pool_sorted[r] = reads[by_pool[r]].pool_offset; }
         __syncthreads();
         /* the reads of every column (binary search of the byte offset among the chunk's reads), the path's partitions, and for
          * every read where it is first seen on either side */
@@ -3311,7 +3314,8 @@ __global__ void __launch_bounds__(FRAG_T) mrp_fragment_kernel(MrpBatchDev d, con
             for (int i = 0; i < c.depth; i++) {
                 const int64_t v = rbo[i]; /* = pool_offset + (allele_offset[site_start] - allele_offset[read start]) */
                 int lo = 0, hi = nr; /* last read (by pool offset) that starts at or before v */
-                while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (reads[by_pool[mid]].pool_offset <= v) lo = mid; else hi = mid; }
+                if (in_lds) { while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (pool_sorted[mid] <= v) lo = mid; else hi = mid; } }
+                else { while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (reads[by_pool[mid]].pool_offset <= v) lo = mid; else hi = mid; } }
                 const int rid = nr > 0 ? by_pool[lo] : 0;
                 const FragRead r = reads[rid];
                 if (nr <= 0 || r.pool_offset + (shift - (int64_t) ch.allele_offset[r.ref_start]) != v || c.site_start < r.ref_start || c.site_start >= r.ref_start + r.length) bad = 1;
