@@ -163,38 +163,67 @@ static inline uint64_t invert_partition(uint64_t p, int64_t depth) { return acce
 #define SHADOW_CLASSES 20 /* 512 B .. 256 MB */
 static struct { pthread_mutex_t mu; void **stack; int64_t n, cap; } g_shadow[SHADOW_CLASSES];
 static pthread_once_t g_shadow_once = PTHREAD_ONCE_INIT;
-static void shadow_pool_init(void) { for (int i = 0; i < SHADOW_CLASSES; i++) pthread_mutex_init(&g_shadow[i].mu, NULL); }
 static int shadow_class(size_t bytes) {
     int c = 0;
     while (((size_t) 1 << (c + SHADOW_MIN_LOG)) < bytes) c++;
     return c;
 }
-/* per-thread front of the pool (the worker threads are persistent): the shared stacks are touched a batch at a time */
-#define SHADOW_TL 16
-static __thread struct { void *slot[SHADOW_CLASSES][SHADOW_TL]; int n[SHADOW_CLASSES]; } t_shadow;
-static void *shadow_alloc(size_t bytes, int *cls_out) {
+/* per-thread front of the pool: the shared stacks are touched a batch at a time.  The fronts are large for the small classes
+ * -- a level of the first merges makes tens of thousands of blocks of 512 B .. 2 KB on the worker threads and the thread that
+ * drives the batch gives the parents' blocks back: everything flows through the shared stack, and with fronts of 16 the
+ * class mutex was taken every eighth block by 24 threads (a fifth of a call's host CPU time in futex calls). */
+#define SHADOW_TL 256
+#define SHADOW_TL_LARGE 16
+#define SHADOW_SMALL_CLASSES 6 /* up to 16 KB */
+static inline int shadow_front(int c) { return c < SHADOW_SMALL_CLASSES ? SHADOW_TL : SHADOW_TL_LARGE; }
+typedef struct { void *slot[SHADOW_CLASSES][SHADOW_TL]; int n[SHADOW_CLASSES]; int keyed; } shadow_tl;
+static __thread shadow_tl t_shadow;
+static pthread_key_t g_shadow_key;
+static void shadow_spill(int c, shadow_tl *f, int keep) { /* front -> shared stack */
+    pthread_mutex_lock(&g_shadow[c].mu);
+    if (g_shadow[c].n + f->n[c] > g_shadow[c].cap) {
+        while (g_shadow[c].n + f->n[c] > g_shadow[c].cap) g_shadow[c].cap = g_shadow[c].cap ? 2 * g_shadow[c].cap : 1024;
+        void **grown = realloc(g_shadow[c].stack, sizeof(void *) * (size_t) g_shadow[c].cap);
+        if (!grown) { fprintf(stderr, "margin_rphmm: out of host memory\n"); abort(); }
+        g_shadow[c].stack = grown;
+    }
+    while (f->n[c] > keep) g_shadow[c].stack[g_shadow[c].n++] = f->slot[c][--f->n[c]];
+    pthread_mutex_unlock(&g_shadow[c].mu);
+}
+static void shadow_thread_exit(void *arg) { /* a thread ends (the threads of a call's concurrent batches do): its front goes back */
+    shadow_tl *f = arg;
+    for (int c = 0; c < SHADOW_CLASSES; c++) if (f->n[c] > 0) shadow_spill(c, f, 0);
+}
+static void shadow_pool_init(void) {
+    for (int i = 0; i < SHADOW_CLASSES; i++) pthread_mutex_init(&g_shadow[i].mu, NULL);
+    (void) pthread_key_create(&g_shadow_key, shadow_thread_exit);
+}
+static inline void shadow_thread_enter(void) {
     pthread_once(&g_shadow_once, shadow_pool_init);
+    if (!t_shadow.keyed) { t_shadow.keyed = 1; (void) pthread_setspecific(g_shadow_key, &t_shadow); }
+}
+static void *shadow_alloc(size_t bytes, int *cls_out) {
     const int c = shadow_class(bytes);
     if (c >= SHADOW_CLASSES) { *cls_out = -1; return xmalloc(bytes); }
     *cls_out = c;
-    if (t_shadow.n[c] == 0) { /* refill: up to half a front from the shared stack */
-        pthread_mutex_lock(&g_shadow[c].mu);
-        while (t_shadow.n[c] < SHADOW_TL / 2 && g_shadow[c].n > 0) t_shadow.slot[c][t_shadow.n[c]++] = g_shadow[c].stack[--g_shadow[c].n];
-        pthread_mutex_unlock(&g_shadow[c].mu);
-    }
     if (t_shadow.n[c] > 0) return t_shadow.slot[c][--t_shadow.n[c]];
-    return xmalloc((size_t) 1 << (c + SHADOW_MIN_LOG));
+    shadow_thread_enter();
+    /* refill: up to half a front from the shared stack */
+    pthread_mutex_lock(&g_shadow[c].mu);
+    while (t_shadow.n[c] < shadow_front(c) / 2 && g_shadow[c].n > 0) t_shadow.slot[c][t_shadow.n[c]++] = g_shadow[c].stack[--g_shadow[c].n];
+    pthread_mutex_unlock(&g_shadow[c].mu);
+    if (t_shadow.n[c] > 0) return t_shadow.slot[c][--t_shadow.n[c]];
+    const int was = t_ar.active; /* (never from the scratch arena: the block outlives the merge) */
+    t_ar.active = 0;
+    void *p = xmalloc((size_t) 1 << (c + SHADOW_MIN_LOG));
+    t_ar.active = was;
+    return p;
 }
 static void shadow_release(void *p, int cls) {
     if (cls < 0) { free(p); return; }
-    if (t_shadow.n[cls] == SHADOW_TL) { /* spill half of the front */
-        pthread_mutex_lock(&g_shadow[cls].mu);
-        if (g_shadow[cls].n + SHADOW_TL / 2 > g_shadow[cls].cap) {
-            g_shadow[cls].cap = g_shadow[cls].cap ? 2 * g_shadow[cls].cap : 256;
-            g_shadow[cls].stack = xrealloc(g_shadow[cls].stack, sizeof(void *) * (size_t) g_shadow[cls].cap);
-        }
-        while (t_shadow.n[cls] > SHADOW_TL / 2) g_shadow[cls].stack[g_shadow[cls].n++] = t_shadow.slot[cls][--t_shadow.n[cls]];
-        pthread_mutex_unlock(&g_shadow[cls].mu);
+    if (t_shadow.n[cls] == shadow_front(cls)) { /* spill half of the front */
+        shadow_thread_enter();
+        shadow_spill(cls, &t_shadow, shadow_front(cls) / 2);
     }
     t_shadow.slot[cls][t_shadow.n[cls]++] = p;
 }
@@ -1380,10 +1409,17 @@ typedef struct rhmm {
 static void rhmm_destroy(rhmm *h) {
     if (h && h->pool_class != 0) shadow_release(h, h->pool_class - 1);
 }
+/* A tiling path is either a vector of its own (heap) or the head of ONE block of the shadow pool that also holds its array and
+ * the lists of the merge that made it (level_prepare): cap = -(size class + 2) marks the latter. */
+static void r_path_release(r_hmm_vec *tp) {
+    if (!tp) return;
+    if (tp->cap < -1) { shadow_release(tp, (int) (-tp->cap - 2)); return; }
+    free(tp->a); free(tp);
+}
 static void r_free_path(r_hmm_vec *tp, int destroy_hmms) {
     if (!tp) return;
     if (destroy_hmms) for (int64_t i = 0; i < tp->n; i++) rhmm_destroy(tp->a[i]);
-    free(tp->a); free(tp);
+    r_path_release(tp);
 }
 
 /* stRPHmm_construct (hmm.c:97-133): one column {1, 0} over the read's sites.  All leaves of a chunk live in one block. */
@@ -1398,8 +1434,8 @@ static void r_leaf_init(rleaf *l, const world *w, int32_t read) {
     l->starts[0] = r->ref_start; l->roff[0] = 0; l->roff[1] = 1; l->reads[0] = read;
     h->starts = l->starts; h->roff = l->roff; h->reads = l->reads;
 }
-static rleaf *r_leaves_of_chunk(const world *w) {
-    rleaf *lv = xmalloc(sizeof(rleaf) * (size_t) (w->n_reads + 1));
+static rleaf *r_leaves_of_chunk(const world *w, int *cls) { /* (a block of the shadow pool: a few hundred KB, warm from the call before) */
+    rleaf *lv = shadow_alloc(sizeof(rleaf) * (size_t) (w->n_reads + 1), cls);
     for (int64_t i = 0; i < w->n_reads; i++) r_leaf_init(&lv[i], w, (int32_t) i);
     return lv;
 }
@@ -1614,11 +1650,28 @@ static int r_prepare_merge(const world *w, int32_t stride, r_hmm_vec *tp1, r_hmm
     r_comp_vec comps = r_overlapping_components(w, tp1, tp2);
     ar_off();
     T_ADD(0, tq);
-    free(tp1->a); free(tp1); free(tp2->a); free(tp2);
+    r_path_release(tp1); r_path_release(tp2);
     int rc = MRP_OK;
     for (int64_t i = 0; i < comps.n; i++) {
         r_component *comp = comps.a[i];
-        if (rc == MRP_OK) {
+        if (rc == MRP_OK && comp->members.n == 1) { /* nothing overlaps it: passes through (coordination.c:317-322) */
+            VEC_PUSH(*res, comp->members.a[0]);
+        } else if (rc == MRP_OK && comp->members.n == 2) {
+            /* two hmms that overlap -- the common case -- are two tiling paths of one hmm each, the smaller one by stRPHmm_cmpFn
+             * first (getTilingPaths sorts, coordination.c:186-190): no lists to build */
+            rhmm *m0 = comp->members.a[0], *m1 = comp->members.a[1];
+            if (r_hmm_cmp(w, m0, m1) > 0) { rhmm *t_ = m0; m0 = m1; m1 = t_; }
+            rhmm *ma[1] = {m0}, *mb[1] = {m1};
+            const r_hmm_vec va = {ma, 1, 1}, vb = {mb, 1, 1};
+            const int32_t S = m0->ref_start < m1->ref_start ? m0->ref_start : m1->ref_start;
+            const int32_t Ea = m0->ref_start + m0->ref_length, Eb = m1->ref_start + m1->ref_length;
+            xbuild xb = {NULL, w};
+            tq = tcpu_ms();
+            rc = r_cross_build(w, &va, &vb, S, Ea > Eb ? Ea : Eb, stride, &xb.x);
+            T_ADD(2, tq);
+            VEC_PUSH(*garbage, m0); VEC_PUSH(*garbage, m1);
+            if (rc == MRP_OK) { VEC_PUSH(*xs, xb); VEC_PUSH(*res, xb.x); }
+        } else if (rc == MRP_OK) {
             tq = tcpu_ms();
             ar_on();
             r_path_vec sub = r_tiling_paths_from(w, comp->members.a, comp->members.n);
@@ -1714,24 +1767,45 @@ typedef struct {
     r_hmm_vec *res;
     xbuild_vec xs;
     r_hmm_vec garbage;
-    int rc;
+    int rc, res_class;
+    void *big_block;
     char err[256];
 } level_item;
 static void level_prepare(int64_t i, void *arg) {
     level_item *it = &((level_item *) arg)[i];
     rnode *nd = &it->t->a[it->node];
-    it->res = xcalloc(1, sizeof(*it->res));
     r_hmm_vec *l = it->t->a[nd->left].path, *r = it->t->a[nd->right].path;
     it->t->a[nd->left].path = NULL; it->t->a[nd->right].path = NULL;
+    {   /* the merged path, the cross products to build and the parents to drop: at most one entry per hmm of the two paths each.
+         * ONE block of the shadow pool, owned by the path (released when the next level consumes it; the other two lists are
+         * read by the thread that drives the batch before that) -- no malloc / free across threads */
+        const int64_t cap = l->n + r->n + 1;
+        const size_t o_res = (sizeof(r_hmm_vec) + 15) & ~(size_t) 15, o_xs = o_res + sizeof(rhmm *) * (size_t) cap,
+                     o_garbage = o_xs + sizeof(xbuild) * (size_t) cap, bytes = o_garbage + sizeof(rhmm *) * (size_t) cap;
+        int cls = 0;
+        char *blk = shadow_alloc(bytes, &cls);
+        it->res = (r_hmm_vec *) blk;
+        it->res->a = (rhmm **) (blk + o_res); it->res->n = 0; it->res->cap = cap;
+        it->xs.a = (xbuild *) (blk + o_xs); it->xs.n = 0; it->xs.cap = cap;
+        it->garbage.a = (rhmm **) (blk + o_garbage); it->garbage.n = 0; it->garbage.cap = cap;
+        it->res_class = cls;
+    }
     it->rc = r_prepare_merge(nd->w, it->stride, l, r, it->res, &it->xs, &it->garbage);
+    if (it->res_class >= 0) it->res->cap = -(int64_t) it->res_class - 2;
+    else { /* (a path beyond the pool's largest class: an ordinary vector again) */
+        r_hmm_vec *v = xcalloc(1, sizeof(*v));
+        v->a = xmalloc(sizeof(rhmm *) * (size_t) (it->res->n + 1)); memcpy(v->a, it->res->a, sizeof(rhmm *) * (size_t) it->res->n);
+        v->n = it->res->n; v->cap = it->res->n + 1;
+        it->big_block = it->res; it->res = v;
+    }
     if (it->rc != MRP_OK) snprintf(it->err, sizeof(it->err), "%s", mrp_last_error());
 }
 static void level_drop_garbage(int64_t i, void *arg) { /* the parents' shadows of one merge */
     level_item *it = &((level_item *) arg)[i];
     for (int64_t j = 0; j < it->garbage.n; j++) rhmm_destroy(it->garbage.a[j]);
-    free(it->garbage.a);
-    it->garbage.a = NULL;
+    it->garbage.a = NULL; /* (the list is part of the path's block) */
     it->garbage.n = 0;
+    if (it->big_block) { free(it->big_block); it->big_block = NULL; }
 }
 static void level_finish(int64_t i, void *arg) {
     level_item *it = &((level_item *) arg)[i];
@@ -1804,8 +1878,7 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
         n_x = 0;
         for (int64_t i = 0; i < n_items; i++) {
             for (int64_t j = 0; j < items[i].xs.n; j++) xb[n_x++] = items[i].xs.a[j];
-            free(items[i].xs.a);
-            items[i].xs.a = NULL;
+            items[i].xs.a = NULL; /* (part of the path's block) */
         }
         for (int64_t i = 0; i < n_x; i++) {
             r_describe(xb[i].w, xb[i].x, flags, &xh[i]);
@@ -1935,7 +2008,8 @@ int mrp_get_rp_hmms_resident(mrp_context *ctx, const mrp_chunk *chunk, const mrp
     mrp_engine *e = NULL;
     rc = mrp_engine_create(ctx, params, &e);
     if (rc != MRP_OK) return rc;
-    rleaf *leaves = r_leaves_of_chunk(&w);
+    int leaves_class = -1;
+    rleaf *leaves = r_leaves_of_chunk(&w, &leaves_class);
     rnode_vec tree = {0};
     rhmm **picked = xmalloc(sizeof(*picked) * (size_t) (n + 1));
     for (int64_t i = 0; i < n; i++) picked[i] = &leaves[read_index[i]].h;
@@ -1950,7 +2024,7 @@ int mrp_get_rp_hmms_resident(mrp_context *ctx, const mrp_chunk *chunk, const mrp
         if (rc == MRP_OK) { *n_out = tree.a[root].path->n; *hmms_out = res; }
     }
     r_free_tree(&tree);
-    free(leaves);
+    shadow_release(leaves, leaves_class);
     mrp_engine_destroy(e);
     return rc;
 }
@@ -1968,6 +2042,7 @@ typedef struct {
     double fwd, bwd;
     int64_t final_index;
     rleaf *leaves;       /* leaf shadows of all reads of the chunk */
+    int leaves_class;
     int rc;
     char err[256];
     /* the genome fragment as the device leaves it (mrp_xhmm.frag_*): 20 bytes per site, the two read lists */
@@ -1998,7 +2073,7 @@ static void many_setup(int64_t c, void *arg) {
     m->rc = world_init(&m->w, ctl->ctx, ctl->chunks[c], ctl->reads[c], ctl->n_reads[c], NULL);
     if (m->rc == MRP_OK && ctl->n_reads[c] > 0) {
         const int64_t nr = ctl->n_reads[c];
-        m->leaves = r_leaves_of_chunk(&m->w);
+        m->leaves = r_leaves_of_chunk(&m->w, &m->leaves_class);
         /* every getTilingPaths of the chunk (coverage filter, either strand) starts by sorting its hmms with stRPHmm_cmpFn
          * (coordination.c:186-190): the leaves are sorted once, subsets keep the order */
         rhmm **sorted = xmalloc(sizeof(*sorted) * (size_t) (nr + 1));
@@ -2211,7 +2286,7 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
         free(st[c].by_pool); free(st[c].frag_sites); free(st[c].frag_reads1); free(st[c].frag_reads2);
     }
     r_free_tree(&tree);
-    for (int64_t c = 0; c < n_chunks; c++) free(st[c].leaves);
+    for (int64_t c = 0; c < n_chunks; c++) if (st[c].leaves) shadow_release(st[c].leaves, st[c].leaves_class);
     free(st);
     const double t_eng = now_ms();
     mrp_engine_destroy(e);

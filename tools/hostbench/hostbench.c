@@ -7,7 +7,9 @@
 #include "../../margin_amd/csrc/rphmm_host.c"
 
 struct mrp_chunk { mrp_chunk_host h; };
-struct mrp_engine { int n_segs; int64_t cols; };
+struct mrp_engine { int n_segs; int64_t cols; uint64_t hash; };
+static uint64_t g_hash; /* of everything the engine is told: a structural change that alters a level shows here */
+static inline uint64_t hmix(uint64_t h, uint64_t v) { h ^= v + 0x9E3779B97F4A7C15ull + (h << 6) + (h >> 2); return h * 0xff51afd7ed558ccdULL; }
 static __thread char g_err[512];
 void mrp_chunk_host_view(const mrp_chunk *chunk, mrp_chunk_host *out) { *out = chunk->h; }
 mrp_context *mrp_chunk_context(const mrp_chunk *chunk) { (void) chunk; return (mrp_context *) 8; }
@@ -21,7 +23,8 @@ void mrp_context_pool_bytes(mrp_context *ctx, int64_t *cached, int64_t *device_h
 mrp_context *mrp_context_sibling(mrp_context *ctx, int i) { (void) i; return ctx; }
 int mrp_set_error(int code, const char *fmt, ...) { va_list ap; va_start(ap, fmt); vsnprintf(g_err, sizeof g_err, fmt, ap); va_end(ap); return code; }
 const char *mrp_last_error(void) { return g_err; }
-int mrp_host_threads(void) { return 1; }
+static int g_threads = 1;
+int mrp_host_threads(void) { return g_threads; }
 int mrp_context_phase_groups(const mrp_context *ctx) { (void) ctx; return 1; }
 void mrp_pool_set_priority(int p) { (void) p; }
 void mrp_pool_set_tag(int t) { (void) t; }
@@ -29,13 +32,12 @@ long long mrp_pool_tag_cpu_ns(int tag) { (void) tag; return 0; }
 long long mrp_pool_task_cpu_ns(void) { return 0; }
 long long mrp_pool_task_cpu_ns_this_thread(void) { return 0; }
 void mrp_pool_adopt(void *p) { (void) p; }
-static int g_threads = 1;
 typedef struct { int64_t n, grain; void (*fn)(int64_t, void *); void *arg; int64_t next; } pjob;
 static void *pworker(void *a) { pjob *j = a; for (;;) { int64_t lo = __atomic_fetch_add(&j->next, j->grain, __ATOMIC_RELAXED); if (lo >= j->n) return NULL;
     int64_t hi = lo + j->grain < j->n ? lo + j->grain : j->n; for (int64_t i = lo; i < hi; i++) j->fn(i, j->arg); } }
 void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void *), void *arg) {
     if (g_threads <= 1) { for (int64_t i = 0; i < n; i++) fn(i, arg); return; }
-    pjob j = {n, grain < 1 ? 1 : grain, fn, arg, 0};
+    pjob j = {n, grain < 1 ? 1 : grain, fn, arg, 0}; if (getenv("HB_DEBUG")) fprintf(stderr, "pool_run n=%lld grain=%lld threads=%d\n", (long long) n, (long long) grain, g_threads);
     pthread_t th[64];
     for (int t = 1; t < g_threads; t++) pthread_create(&th[t], NULL, pworker, &j);
     pworker(&j);
@@ -44,13 +46,21 @@ void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void *), void *a
 int mrp_fb_run(mrp_context *ctx, int64_t n, const mrp_hmm_job *jobs) { (void) ctx; (void) n; (void) jobs; return MRP_ERR_NO_DEVICE; }
 int mrp_batch_add(mrp_batch *b, const mrp_hmm_job *job) { (void) b; (void) job; return MRP_ERR_NO_DEVICE; }
 int mrp_engine_create(mrp_context *ctx, const mrp_params *params, mrp_engine **out) { (void) ctx; (void) params; *out = calloc(1, sizeof(mrp_engine)); return MRP_OK; }
-void mrp_engine_destroy(mrp_engine *e) { (free)(e); }
+void mrp_engine_destroy(mrp_engine *e) { g_hash = e->hash; (free)(e); }
 int32_t mrp_engine_stride(const mrp_engine *e) { (void) e; return 100; }
 int mrp_engine_locate(const mrp_engine *e, int32_t seg, int64_t col0, const uint64_t **a, const uint32_t **b, const int32_t **c, const int32_t **d) { (void) e; (void) seg; (void) col0; *a = NULL; *b = NULL; *c = NULL; *d = NULL; return MRP_OK; }
 static int stage(mrp_engine *e, int64_t n, mrp_xhmm *x, int final) {
     int64_t col = 0;
-    for (int64_t i = 0; i < n; i++) { x[i].seg = e->n_segs; x[i].col0 = col; col += x[i].n_cols; x[i].err = 0;
-        if (final) { for (int k = 0; k < x[i].n_cols; k++) { x[i].n_cells[k] = 0; x[i].path_part[k] = 0; } } }
+    for (int64_t i = 0; i < n; i++) {
+        uint64_t h = e->hash;
+        h = hmix(h, (uint64_t) x[i].ref_start); h = hmix(h, (uint64_t) x[i].ref_end); h = hmix(h, (uint64_t) x[i].n_cols); h = hmix(h, (uint64_t) x[i].n_a); h = hmix(h, (uint64_t) x[i].n_b);
+        h = hmix(h, (uint64_t) x[i].bound_cells); h = hmix(h, (uint64_t) x[i].bound_merge); h = hmix(h, (uint64_t) x[i].depth_sites); h = hmix(h, (uint64_t) x[i].bound_max_cells); h = hmix(h, (uint64_t) x[i].bound_max_merge);
+        for (int k = 0; k < x[i].n_cols; k++) { h = hmix(h, (uint64_t) x[i].col_start[k]); h = hmix(h, (uint64_t) x[i].col_read_off[k + 1]); }
+        for (int k = 0; k < x[i].n_a + x[i].n_b; k++) { const mrp_xpar *q = &x[i].par[k]; h = hmix(h, (uint64_t) q->start); h = hmix(h, (uint64_t) q->end); h = hmix(h, (uint64_t) q->n_cols); h = hmix(h, (uint64_t) q->seg); h = hmix(h, (uint64_t) q->col0); }
+        e->hash = h;
+        x[i].seg = e->n_segs; x[i].col0 = col; col += x[i].n_cols; x[i].err = 0;
+        if (final) { for (int k = 0; k < x[i].n_cols; k++) { x[i].n_cells[k] = 0; x[i].path_part[k] = 0; }
+            if (x[i].frag_sites) { memset(x[i].frag_sites, 0, 20 * (size_t) (x[i].ref_end - x[i].ref_start)); x[i].frag_n1 = x[i].frag_n2 = 0; x[i].frag_done = 1; } } } /* (as the device leaves it) */
     e->n_segs++; e->cols += col;
     return MRP_OK;
 }
@@ -108,8 +118,8 @@ int main(int argc, char **argv) {
         clock_gettime(CLOCK_MONOTONIC, &a); clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &ca);
         int rc = phase_many_resident((mrp_context *) 8, n, cp, rp, nr, &P, out, &st);
         clock_gettime(CLOCK_MONOTONIC, &b); clock_gettime(CLOCK_PROCESS_CPUTIME_ID, &cb);
-        printf("run %d: rc %d (%s) %lld chunks, %lld units, wall %.1f ms, cpu %.1f ms, columns %lld, levels %lld\n", r, rc, rc ? g_err : "ok", (long long) n, (long long) units,
-               1e3 * (b.tv_sec - a.tv_sec) + 1e-6 * (b.tv_nsec - a.tv_nsec), 1e3 * (cb.tv_sec - ca.tv_sec) + 1e-6 * (cb.tv_nsec - ca.tv_nsec), (long long) st.columns, (long long) st.levels);
+        printf("run %d: rc %d (%s) %lld chunks, %lld units, wall %.1f ms, cpu %.1f ms, columns %lld, levels %lld, structure hash %016llx\n", r, rc, rc ? g_err : "ok", (long long) n, (long long) units,
+               1e3 * (b.tv_sec - a.tv_sec) + 1e-6 * (b.tv_nsec - a.tv_nsec), 1e3 * (cb.tv_sec - ca.tv_sec) + 1e-6 * (cb.tv_nsec - ca.tv_nsec), (long long) st.columns, (long long) st.levels, (unsigned long long) g_hash);
         for (int64_t c = 0; c < n; c++) { mrp_phase_result_destroy(out[c]); out[c] = NULL; }
     }
     return 0;

@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--check-oracle", type=int, default=0)
     ap.add_argument("--groups", type=int, default=1, help="phase the chunks as this many concurrent batches (one host thread + context each)")
     ap.add_argument("--hifi", action="store_true", help="HiFi-like chunks (SURVEY.md 8d configs 3-5): 35x, reads N(18 kb, 3 kb), 1 %% allele error, 2-4 alleles per site")
+    ap.add_argument("--sample", default="", help="CPU sampling profile of the timed runs after the first into this file (tools/sampler)")
     args = ap.parse_args()
     pd = synth.shipped_phase_params()
     params = capi.Params.from_reference_names(pd)
@@ -64,14 +65,21 @@ def main():
             dt = time.perf_counter() - t0
             print(f"run {r} ({G} concurrent batches): {dt * 1e3:.1f} ms wall, {units / dt:.3e} units/s, device_ms per batch "
                   f"{[round(x[1].device_ms, 1) for x in res]}", flush=True)
+    sampler = None
     for r in range(args.repeat):
         last = r + 1 == args.repeat
+        if args.sample and r == 1:
+            import ctypes
+            sampler = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "sampler", "libcpusampler.so"))
+            sampler.cpusampler_start(250)
         t0, c0 = time.perf_counter(), time.process_time()
         got, st = capi.phase_reads_many(ctx, dchunks, chunks, params, convert=last)
         dt, cpu = time.perf_counter() - t0, time.process_time() - c0
         print(f"run {r}: {dt * 1e3:.1f} ms wall, {units / dt:.3e} units/s, host cpu {cpu * 1e3:.0f} ms, resident={st.resident} levels={st.levels} hmms={st.hmms} "
               f"cols={st.columns} cells={st.cells} device_ms={st.device_ms:.2f} (cross {st.cross_ms:.2f} sweep {st.sweep_ms:.2f} "
               f"prune {st.prune_ms:.2f})", flush=True)
+    if sampler is not None:
+        sampler.cpusampler_stop(args.sample.encode())
     for i in range(min(args.check_host, args.chunks)):
         t0 = time.perf_counter()
         host = capi.phase_reads(ctx, dchunks[i], chunks[i], params)
