@@ -331,8 +331,10 @@ int mrp_phase_reads_many(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *co
  * off).  Chunks are independent until stitching: no collective, no traffic between devices.  A device may be listed more
  * than once (two workers sharing it). */
 #define MRP_MAX_QUEUE_DEVICES 16
-#define MRP_QUEUE_DEFAULT_BATCH 192 /* batch size when the caller passes 0 and the queue is longer than 640 chunks per device, both counted in chunks of
+#define MRP_QUEUE_DEFAULT_BATCH 192 /* batch size when the caller passes 0 and the queue is longer than MRP_QUEUE_SHORT_CHUNKS chunks per device, both counted in chunks of
                                      * MRP_QUEUE_UNITS_PER_CHUNK units (a shorter queue is one batch per device; smaller batches at the end) */
+#define MRP_QUEUE_SHORT_CHUNKS 1280 /* a queue of up to this many yardstick chunks per device is ONE call per device (round 4: 1 152 chunks 200 ms
+                                     * as one call, 219 ms as eight batches on four lanes; 2 304 chunks: the same either way) */
 #define MRP_QUEUE_UNITS_PER_CHUNK 60000 /* (read, het site) units of the 1 Mb, 30x chunk the batch sizes were measured on: the library's own batches
                                          * are cut by units, so that 3 000 chunks of 130 sites make the call that 192 chunks of 2 000 sites make */
 typedef struct mrp_chunk_desc {     /* one genome chunk in host memory: what mrp_chunk_create and mrp_phase_reads take */

@@ -368,8 +368,8 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
             return mrp_set_error(MRP_ERR_UNSUPPORTED, "device-resident hmm %lld is outside the kernels' range", (long long) i);
         col0[(size_t) i] = total_cols; read0[(size_t) i] = total_reads; slot0[(size_t) i] = total_slots; par0[(size_t) i] = total_par;
         total_cols += h.n_cols;
-        total_reads += h.col_read_off[h.n_cols];
-        total_slots += ch->allele_offset[(size_t) h.ref_end] - ch->allele_offset[(size_t) h.ref_start];
+        total_reads += h.n_col_reads; /* (= col_read_off[n_cols] and the allele slots of the interval, as the caller counted them: this loop */
+        total_slots += h.n_slots;     /*  runs on the thread that feeds the device and stays inside the descriptions) */
         total_par += h.n_a + h.n_b;
     }
     col0[(size_t) n] = total_cols;

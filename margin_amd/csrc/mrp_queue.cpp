@@ -42,8 +42,8 @@ struct QueuePlan {
 /* phase.c:257-263: sort by estimated size, largest first; then cut into batches of consecutive chunks.
  * chunks_per_batch >= 1: batches of that many chunks.  0: the library's choice for n_workers pulling threads on n_devices
  * devices.  A batch is one mrp_phase_reads_many call; a call begins and ends with host work and walks its merge levels one
- * after the other, the top ones bound by per-column latency whatever the number of chunks.  A short queue (up to 640 chunks
- * of the 1 Mb kind per device; sizes are counted in units, below) is ONE batch per device: the call runs it as eight concurrent batches of its own (576 chunks: 170-182 ms).  A
+ * after the other, the top ones bound by per-column latency whatever the number of chunks.  A short queue (up to 1 280 chunks
+ * of the 1 Mb kind per device -- 640 through round 3, when a device held twice as much per chunk; sizes are counted in units, below) is ONE batch per device: the call runs it as eight concurrent batches of its own (576 chunks: 170-182 ms).  A
  * longer one is handed out in batches of MRP_QUEUE_DEFAULT_BATCH chunks to the lanes of the devices (four per device, each
  * call two concurrent batches: the same eight in flight, but at different levels -- while one lane is in its host-bound
  * head or its latency-bound top levels the others stream; measured on 2 304 chunks: 153-160 ms per 576 against 174-177 for
@@ -59,14 +59,16 @@ QueuePlan plan_queue(int64_t n, const int64_t *cost, int64_t chunks_per_batch, i
      * BASELINE.json configs[1] (60 000 units) as the yardstick the policy was measured on: what a call costs the device and
      * what it keeps there grow with its units, not with its chunks -- 192 chunks of 130 sites would be a call of 9 ms. */
     const int64_t unit_chunk = MRP_QUEUE_UNITS_PER_CHUNK;
-    const int64_t big = MRP_QUEUE_DEFAULT_BATCH * unit_chunk, short_queue = 640 * unit_chunk;
+    int64_t short_chunks = MRP_QUEUE_SHORT_CHUNKS;
+    if (const char *ev = getenv("MRP_QUEUE_SHORT_CHUNKS")) { const long v = atol(ev); if (v > 0) short_chunks = v; } /* (development) */
+    const int64_t big = MRP_QUEUE_DEFAULT_BATCH * unit_chunk, short_queue = short_chunks * unit_chunk;
     auto units = [&](int64_t pos) { return std::max<int64_t>(1, cost[p.order[(size_t) pos]]); };
     int64_t total = 0;
     for (int64_t i = 0; i < n; i++) total += units(i);
     if (chunks_per_batch >= 1) {
         for (int64_t o = 0; o < n; o += chunks_per_batch) p.batch_off.push_back(o);
     } else if (total <= (int64_t) n_devices * short_queue) {
-        /* up to 640 yardstick chunks per device ONE call per device is the fastest */
+        /* up to MRP_QUEUE_SHORT_CHUNKS yardstick chunks per device ONE call per device is the fastest */
         const int64_t parts = std::min<int64_t>(n, n_devices);
         /* these batches all start at once: deal the chunks out in stripes (batch b takes the b-th, (b + parts)-th, ... of the
          * cost order), so that every batch gets its share of the expensive ones -- consecutive runs of a largest-first order

@@ -1768,6 +1768,7 @@ typedef struct {
     xbuild_vec xs;
     r_hmm_vec garbage;
     int rc, res_class;
+    int64_t x0;        /* where the item's cross products start in the level's list */
     void *big_block;
     char err[256];
 } level_item;
@@ -1821,18 +1822,32 @@ static void r_describe(const world *w, const rhmm *x, uint32_t flags, mrp_xhmm *
     d->col_start = x->starts; d->col_read_off = x->roff;
     d->bound_cells = x->bound_cells; d->bound_merge = x->bound_merge; d->depth_sites = x->depth_sites;
     d->bound_max_cells = x->bound_max_cells; d->bound_max_merge = x->bound_max_merge;
+    d->n_col_reads = x->roff[x->n_cols];
+    d->n_slots = (int64_t) w->ch.allele_offset[x->ref_start + x->ref_length] - (int64_t) w->ch.allele_offset[x->ref_start];
+}
+typedef struct { level_item *items; mrp_xhmm *xh; xbuild *xb; uint32_t flags; } level_gather_ctl;
+static void level_gather(int64_t i, void *arg) {
+    const level_gather_ctl *g = arg;
+    const level_item *it = &g->items[i];
+    for (int64_t j = 0; j < it->xs.n; j++) {
+        g->xb[it->x0 + j] = it->xs.a[j];
+        r_describe(it->xs.a[j].w, it->xs.a[j].x, g->flags, &g->xh[it->x0 + j]);
+    }
 }
 /* what the host keeps of a level while it is on the device */
 typedef struct {
     level_item *items; int64_t n_items;
     mrp_xhmm *xh; xbuild *xb; int64_t n_x;
+    int cls_items, cls_xh, cls_xb; /* the three lists are blocks of the shadow pool (megabytes per level: warm instead of mapped afresh) */
 } level_run;
 static void level_run_settle(level_run *r, int rc_ok) { /* the level has ended: its error flags are in */
     for (int64_t i = 0; i < r->n_x; i++)
         /* outside what the kernels handle (a parent not in complement-pair order, ...): the later levels leave this
          * chunk out, its caller redoes it on the hashing path */
         if (rc_ok && r->xh[i].err != 0) ((world *) r->xb[i].w)->failed = 1;
-    free(r->xh); free(r->xb); free(r->items);
+    if (r->xh) shadow_release(r->xh, r->cls_xh);
+    if (r->xb) shadow_release(r->xb, r->cls_xb);
+    if (r->items) shadow_release(r->items, r->cls_items);
     memset(r, 0, sizeof(*r));
 }
 /* pending: if not NULL the last level is left running (the caller stages what comes next beside it, then launches / ends and
@@ -1862,7 +1877,9 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
         int64_t n_items = 0;
         for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > 0 && lvl[i] == h && !t->a[i].w->failed) n_items++;
         if (n_items == 0) continue;
-        level_item *items = xcalloc((size_t) n_items + 1, sizeof(*items));
+        int cls_items = -1, cls_xh = -1, cls_xb = -1;
+        level_item *items = shadow_alloc(sizeof(*items) * ((size_t) n_items + 1), &cls_items);
+        memset(items, 0, sizeof(*items) * ((size_t) n_items + 1));
         n_items = 0;
         for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > 0 && lvl[i] == h && !t->a[i].w->failed) { items[n_items].t = t; items[n_items].node = i; items[n_items].stride = stride; n_items++; }
         /* the merges of a level touch disjoint nodes: structure in parallel, device work as one batch */
@@ -1873,17 +1890,16 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
             n_x += items[i].xs.n;
             if (items[i].rc != MRP_OK && rc == MRP_OK) rc = mrp_set_error(items[i].rc, "%s", items[i].err);
         }
-        mrp_xhmm *xh = xcalloc((size_t) n_x + 1, sizeof(*xh));
-        xbuild *xb = xcalloc((size_t) n_x + 1, sizeof(*xb));
+        mrp_xhmm *xh = shadow_alloc(sizeof(*xh) * ((size_t) n_x + 1), &cls_xh);
+        xbuild *xb = shadow_alloc(sizeof(*xb) * ((size_t) n_x + 1), &cls_xb);
         n_x = 0;
-        for (int64_t i = 0; i < n_items; i++) {
-            for (int64_t j = 0; j < items[i].xs.n; j++) xb[n_x++] = items[i].xs.a[j];
-            items[i].xs.a = NULL; /* (part of the path's block) */
+        for (int64_t i = 0; i < n_items; i++) { items[i].x0 = n_x; n_x += items[i].xs.n; }
+        {   /* the level as the engine is told about it, in node order (worker threads: the shadows are in their caches) */
+            level_gather_ctl gc = {items, xh, xb, flags};
+            mrp_pool_set_tag(3); mrp_pool_run(n_items, n_items > 512 ? n_items / 256 : 1, level_gather, &gc); mrp_pool_set_tag(0);
         }
-        for (int64_t i = 0; i < n_x; i++) {
-            r_describe(xb[i].w, xb[i].x, flags, &xh[i]);
-            ((world *) xb[i].w)->n_sweeps += 1; /* coordination.c:312: one forward/backward per overlap component */
-        }
+        for (int64_t i = 0; i < n_items; i++) /* coordination.c:312: one forward/backward per overlap component */
+            ((world *) t->a[items[i].node].w)->n_sweeps += (int) items[i].xs.n, items[i].xs.a = NULL; /* (the list is part of the path's block) */
         const double tb = now_ms();
         if (rc == MRP_OK) rc = mrp_engine_level_stage(e, n_x, xh);
         const double tc = now_ms();
@@ -1907,6 +1923,7 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
             fprintf(stderr, "    host level %d: prepare %.2f ms, gather %.2f, stage %.2f, sort %.2f | launch (waits for the level before) %.2f | settle+garbage %.2f\n",
                     h, ta - t0, tb - ta, tc - tb, t1 - tc, t2 - t1, now_ms() - t2);
         prev.items = items; prev.n_items = n_items; prev.xh = xh; prev.xb = xb; prev.n_x = n_x;
+        prev.cls_items = cls_items; prev.cls_xh = cls_xh; prev.cls_xb = cls_xb;
     }
     if (pending && rc == MRP_OK) {
         *pending = prev;

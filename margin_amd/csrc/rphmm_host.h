@@ -82,6 +82,7 @@ typedef struct mrp_xhmm {
      * the device from the parents' counts */
     int64_t bound_cells, bound_merge;
     int64_t depth_sites;          /* sum over the columns of depth x sites */
+    int64_t n_col_reads, n_slots; /* col_read_off[n_cols]; allele slots of [ref_start, ref_end) (so that staging a level reads the descriptions only) */
     int32_t bound_max_cells, bound_max_merge;
     /* results, known as soon as the level is staged: where the pruned hmm will be */
     int32_t seg;

@@ -62,7 +62,7 @@ def test_whole_genome_queue_on_eight_devices_is_balanced():
     assert (per_device > 0).all()
     imbalance = per_device.max() / per_device.mean() - 1.0
     assert imbalance <= 0.02, (imbalance, per_device.tolist())
-    # this queue (2.4e8 units) is below 640 yardstick chunks per device: ONE striped batch per device, one lane each
+    # this queue (2.4e8 units) is below 1 280 yardstick chunks per device: ONE striped batch per device, one lane each
     assert len(set(worker.tolist())) == devices and (worker % lanes == 0).all()
     # one device: the batches follow the queue's order and are cut by UNITS (192 chunks of 60 000 units = 1.152e7 per batch: ~1 480 of
     # these small chunks), not by chunk count
@@ -76,7 +76,7 @@ def test_whole_genome_queue_on_eight_devices_is_balanced():
 
 
 def test_long_queue_on_eight_devices_takes_the_guided_schedule_and_stays_balanced():
-    """More than 640 yardstick chunks (60 000 units) per device: the multi-device branch of the plan -- batches of at most 192
+    """More than 1 280 yardstick chunks (60 000 units) per device: the multi-device branch of the plan -- batches of at most 192
     yardstick chunks, shrinking towards the end (what is left / twice the lanes, at least a quarter batch: a lane holds the batch
     it phases and the one it took ahead) -- handed out dynamically to 8 devices x 4 lanes.  The stand-in calls sleep in
     proportion to their units; every lane of every device takes work and the devices end within 4 % of the mean cost."""
@@ -86,7 +86,7 @@ def test_long_queue_on_eight_devices_takes_the_guided_schedule_and_stays_balance
     depth = np.clip(rng.normal(30, 6, size=n), 5, 64)
     cost = (sites * depth * 2.0).astype(np.int64)
     lanes, devices = 4, 8
-    assert cost.sum() > devices * 640 * 60_000
+    assert cost.sum() > devices * 1280 * 60_000
     usec = 4.0e5 * devices * lanes / float(cost.sum())  # about 0.4 s of stand-in work per lane
     worker, seq = capi.queue_dry_run(devices, lanes, cost, 0, usec_per_cost=usec)
     assert sorted(seq.tolist()) == list(range(n)) and (worker >= 0).all()
@@ -173,12 +173,12 @@ def test_two_workers_on_one_device_phase_every_chunk(orc):
 
 
 def test_library_batches_are_cut_by_units_for_mixed_chunk_sizes():
-    """chunks_per_batch = 0 on one device: 900 chunks of the 1 Mb kind (~60 000 units) mixed with 6 000 of the 100 kb kind (~4 000
-    units) and a few without reads.  More than 640 yardstick chunks of work, so the queue is cut into batches of about
+    """chunks_per_batch = 0 on one device: 1 200 chunks of the 1 Mb kind (~60 000 units) mixed with 6 000 of the 100 kb kind (~4 000
+    units) and a few without reads.  More than 1 280 yardstick chunks of work, so the queue is cut into batches of about
     192 x 60 000 units each, in cost order: the first batches hold ~190 large chunks, the last ones thousands of small ones; every
     chunk is in exactly one batch."""
     rng = np.random.default_rng(5)
-    cost = np.concatenate([rng.integers(50_000, 70_000, size=900), rng.integers(2_000, 6_000, size=6_000), np.zeros(7, dtype=np.int64)]).astype(np.int64)
+    cost = np.concatenate([rng.integers(50_000, 70_000, size=1200), rng.integers(2_000, 6_000, size=6_000), np.zeros(7, dtype=np.int64)]).astype(np.int64)
     rng.shuffle(cost)
     order, batch = capi.queue_plan(cost, 0)
     assert sorted(order.tolist()) == list(range(len(cost)))
@@ -189,4 +189,4 @@ def test_library_batches_are_cut_by_units_for_mixed_chunk_sizes():
     assert len(per_batch) == n_batches
     assert (np.abs(per_batch[:-1] / target - 1.0) < 0.01).all() and 0.5 * target <= per_batch[-1] <= 1.5 * target
     sizes = np.bincount(batch)
-    assert 160 <= sizes[0] <= 230 and sizes[-1] > 1000
+    assert 140 <= sizes[0] <= 230 and sizes[-1] > 1000

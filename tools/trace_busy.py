@@ -37,3 +37,23 @@ for r in sel:
     tot[n] = tot.get(n, 0.0) + (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 print(f"kernels {len(sel)}, span {(t1 - t0) / 1e6:.2f} ms, device busy (union) {busy / 1e6:.2f} ms = {100.0 * busy / (t1 - t0):.1f} %, summed durations {sum(tot.values()):.2f} ms")
 print("summed durations (ms):", {k: round(v, 2) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])})
+# timeline: per 10 ms of the call, how many kernels run on average, what share of the device's thread slots their grids could fill
+# (grid threads / (256 CUs x 2 048), at most 1 per kernel: an upper bound, LDS and registers limit it further) and who they are
+CAP = 256 * 2048.0
+BIN = 10e6
+nb = int((t1 - t0) / BIN) + 1
+run = [0.0] * nb; fill = [0.0] * nb; who = [dict() for _ in range(nb)]
+for r in sel:
+    s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+    g = min(1.0, float(r["Grid_Size_X"]) * float(r.get("Grid_Size_Y", 1) or 1) / CAP)
+    n = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("mrp_", "").replace("_kernel", "")
+    b = int((s - t0) / BIN)
+    while b < nb and t0 + b * BIN < e:
+        ov = min(e, t0 + (b + 1) * BIN) - max(s, t0 + b * BIN)
+        if ov > 0:
+            run[b] += ov / BIN; fill[b] += g * ov / BIN; who[b][n] = who[b].get(n, 0.0) + g * ov / BIN
+        b += 1
+print("timeline (10 ms bins): kernels running | thread slots their grids could fill (1 = the whole device) | largest shares")
+for b in range(nb):
+    top = sorted(who[b].items(), key=lambda kv: -kv[1])[:4]
+    print(f"  {10 * b:4d} ms  {run[b]:5.1f}  {fill[b]:5.2f}  " + ", ".join(f"{k} {v:.2f}" for k, v in top))
