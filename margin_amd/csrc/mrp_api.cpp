@@ -646,14 +646,24 @@ extern "C" long long mrp_pool_tag_cpu_ns(int tag) { return g_pool_tag_cpu_ns[tag
 namespace {
 thread_local int t_pool_priority = 0;
 thread_local int t_pool_tag = 0;
+/* The indices of a loop are dealt out from MRP_POOL_RANGES contiguous ranges, and a thread starts with the range of its own
+ * number before it helps with the others: the loops of a batch's levels run over the same chunks in the same order, so the
+ * thread that built a chunk's hmms at one level mostly meets them again at the next (their blocks are in its cache, or its
+ * neighbours') instead of wherever a single shared counter sends it. */
+#define MRP_POOL_RANGES 16
+struct alignas(64) PoolRange { std::atomic<int64_t> next{0}; int64_t end = 0; };
 struct PoolJob {
     void (*fn)(int64_t, void *);
     void *arg;
     int64_t n, grain;
     int prio = 0, tag = 0;
-    std::atomic<int64_t> next{0}, done{0};
+    PoolRange range[MRP_POOL_RANGES];
+    std::atomic<int64_t> done{0};
+    std::atomic<int> exhausted{0}; /* ranges that have nothing left to hand out */
     int active = 0; /* workers currently holding the pointer (under Pool::mu) */
+    bool has_work() const { return exhausted.load(std::memory_order_relaxed) < MRP_POOL_RANGES; }
 };
+thread_local int t_pool_slot = -1; /* the calling thread's number in its pool: workers 0 .. threads - 2, a posting thread threads - 1 */
 }  // namespace
 /* One pool serves the process by default (mrp_set_host_threads); a work queue gives every device its own (mrp_queue.cpp:
  * the reference's axis is "every core works", phase.c:276-279 -- eight devices on one shared pool of sixteen threads would
@@ -674,12 +684,18 @@ struct mrp_host_pool {
             ~Acc() { timespec b; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &b); const long long d = (b.tv_sec - a.tv_sec) * 1000000000ll + (b.tv_nsec - a.tv_nsec);
                      g_pool_task_cpu_ns.fetch_add(d); g_pool_tag_cpu_ns[tag & 15].fetch_add(d); t_pool_task_cpu_ns += d; }
         } acc(j->tag);
-        for (;;) {
-            const int64_t lo = j->next.fetch_add(j->grain);
-            if (lo >= j->n) return;
-            const int64_t hi = std::min(j->n, lo + j->grain);
-            for (int64_t i = lo; i < hi; i++) j->fn(i, j->arg);
-            j->done.fetch_add(hi - lo);
+        const int home = (t_pool_slot >= 0 ? t_pool_slot : 0) % MRP_POOL_RANGES;
+        for (int k = 0; k < MRP_POOL_RANGES; k++) {
+            PoolRange &r = j->range[(home + k) % MRP_POOL_RANGES];
+            for (;;) {
+                if (r.next.load(std::memory_order_relaxed) >= r.end) break;
+                const int64_t lo = r.next.fetch_add(j->grain);
+                if (lo >= r.end) break;
+                const int64_t hi = std::min(r.end, lo + j->grain);
+                if (lo + j->grain >= r.end) j->exhausted.fetch_add(1); /* (took the range's last grain: exactly one thread does) */
+                for (int64_t i = lo; i < hi; i++) j->fn(i, j->arg);
+                j->done.fetch_add(hi - lo);
+            }
         }
     }
     void worker() {
@@ -687,7 +703,7 @@ struct mrp_host_pool {
         for (;;) {
             PoolJob *j = nullptr;
             for (PoolJob *q : jobs)
-                if (q->next.load() < q->n && (!j || q->prio < j->prio)) j = q;
+                if (q->has_work() && (!j || q->prio < j->prio)) j = q;
             if (!j) {
                 if (stop) return;
                 cv_work.wait(lk);
@@ -703,7 +719,7 @@ struct mrp_host_pool {
     }
     void ensure(int n_workers) {
         std::lock_guard<std::mutex> lk(mu);
-        while ((int) workers.size() < n_workers) workers.emplace_back([this] { worker(); });
+        while ((int) workers.size() < n_workers) { const int slot = (int) workers.size(); workers.emplace_back([this, slot] { t_pool_slot = slot; worker(); }); }
     }
     ~mrp_host_pool() {
         {
@@ -736,6 +752,17 @@ extern "C" void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void 
     P.ensure(threads - 1);
     PoolJob j;
     j.fn = fn; j.arg = arg; j.n = n; j.grain = grain; j.prio = t_pool_priority; j.tag = t_pool_tag;
+    {   /* ranges of whole grains; the empty ones (a short loop) count as exhausted from the start */
+        const int64_t grains = (n + grain - 1) / grain;
+        int empty = 0;
+        for (int r = 0; r < MRP_POOL_RANGES; r++) {
+            const int64_t lo = std::min(n, grains * r / MRP_POOL_RANGES * grain), hi = std::min(n, grains * (r + 1) / MRP_POOL_RANGES * grain);
+            j.range[r].next.store(lo); j.range[r].end = hi;
+            if (lo >= hi) empty++;
+        }
+        j.exhausted.store(empty);
+    }
+    if (t_pool_slot < 0) t_pool_slot = threads - 1;
     {
         std::lock_guard<std::mutex> lk(P.mu);
         P.jobs.push_back(&j);

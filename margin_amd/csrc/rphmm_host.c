@@ -1747,6 +1747,20 @@ static int r_tree_of_sorted(rnode_vec *t, const world *w, rhmm *const *hmms, int
                       (long long) np, MRP_MAX_READ_PARTITIONING_DEPTH, (long long) params->max_coverage_depth);
         return -1;
     }
+    /* the leaf paths as blocks of the shadow pool: the merge that consumes one (another thread, a level later) gives a block back
+     * to its own front instead of freeing into this thread's malloc arena */
+    for (int64_t i = 0; i < paths.n; i++) {
+        r_hmm_vec *tp = paths.a[i];
+        const size_t o_a = (sizeof(r_hmm_vec) + 15) & ~(size_t) 15;
+        int cls = 0;
+        char *blk = shadow_alloc(o_a + sizeof(rhmm *) * (size_t) (tp->n + 1), &cls);
+        if (cls < 0) { free(blk); continue; } /* (beyond the pool's classes: stays as it is) */
+        r_hmm_vec *v = (r_hmm_vec *) blk;
+        v->a = (rhmm **) (blk + o_a); v->n = tp->n; v->cap = -(int64_t) cls - 2;
+        memcpy(v->a, tp->a, sizeof(rhmm *) * (size_t) tp->n);
+        free(tp->a); free(tp);
+        paths.a[i] = v;
+    }
     const int root = r_tree_of_paths(t, w, paths.a, paths.n);
     free(paths.a);
     return root;
