@@ -1470,7 +1470,7 @@ static void r_filter_reads_by_coverage_depth(const world *w, rhmm *const *sorted
  * stRPHmm_alignColumns hmm.c:396-462). */
 typedef struct { const r_hmm_vec *tp; int64_t i; int32_t k, pos, E; } piter;
 typedef struct { int32_t end, depth; uint8_t out; } rpiece; /* out: connector that leaves the piece at its own end */
-static int piter_next(piter *it, rpiece *p) {
+static inline __attribute__((always_inline)) int piter_next(piter *it, rpiece *p) {
     if (it->i < it->tp->n) {
         const rhmm *h = it->tp->a[it->i];
         if (it->k == 0 && h->ref_start > it->pos) { /* gap: depth 0, one cell; (0, 0) merge column behind it (hmm.c:324-345) */
@@ -1528,6 +1528,10 @@ static int r_cross_build(const world *w, const r_hmm_vec *a, const r_hmm_vec *b,
         h->n_reads = (int32_t) n_reads;
         h->first_read = n_reads > 0 ? h->reads[0] : -1;
     }
+    /* mrp_side_bound for every depth, once per thread and stride */
+    static __thread int32_t sb_stride = -1;
+    static __thread int32_t sb[MRP_MAX_READ_PARTITIONING_DEPTH + 2];
+    if (sb_stride != stride) { for (int d = 0; d <= MRP_MAX_READ_PARTITIONING_DEPTH + 1; d++) sb[d] = (int32_t) mrp_side_bound(d, stride); sb_stride = stride; }
     piter ia = {a, 0, 0, S, E}, ib = {b, 0, 0, S, E};
     rpiece pa, pb;
     if (!piter_next(&ia, &pa) || !piter_next(&ib, &pb)) { rhmm_destroy(h); return mrp_set_error(MRP_ERR_ARG, "cross product of an empty interval"); }
@@ -1545,13 +1549,13 @@ static int r_cross_build(const world *w, const r_hmm_vec *a, const r_hmm_vec *b,
         h->starts[n] = pos;
         h->roff[n] = (int32_t) D;
         D += depth;
-        const int64_t C = mrp_side_bound(d1, stride) * mrp_side_bound(d2, stride);
+        const int64_t C = (int64_t) sb[d1] * sb[d2];
         h->bound_cells += C;
         if (C > h->bound_max_cells) h->bound_max_cells = (int32_t) C;
         h->depth_sites += (int64_t) depth * (end - pos);
         if (end < E) { /* merge column hmm.c:686-740: a piece that is cut leaves through an accept-mask connector (column.c:86-101) */
             const uint8_t oa = pa.end > end ? MRP_CONN_IDENT : pa.out, ob = pb.end > end ? MRP_CONN_IDENT : pb.out;
-            const int64_t Ma = oa == MRP_CONN_ZERO ? 1 : mrp_side_bound(d1, stride), Mb = ob == MRP_CONN_ZERO ? 1 : mrp_side_bound(d2, stride);
+            const int64_t Ma = oa == MRP_CONN_ZERO ? 1 : sb[d1], Mb = ob == MRP_CONN_ZERO ? 1 : sb[d2];
             h->bound_merge += Ma * Mb;
             if (Ma * Mb > h->bound_max_merge) h->bound_max_merge = (int32_t) (Ma * Mb);
         }
