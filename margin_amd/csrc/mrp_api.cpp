@@ -53,7 +53,7 @@ void mrp_chunk_host_view(const mrp_chunk *chunk, mrp_chunk_host *out) {
     out->sub_offset = chunk->sub_offset.data();
     out->sub = chunk->sub.data();
     out->prior = chunk->prior.data();
-    out->pool = chunk->pool.data();
+    out->pool = chunk->pool_host;
     out->pool_bytes = chunk->pool_bytes;
 }
 mrp_context *mrp_chunk_context(const mrp_chunk *chunk) { return chunk->ctx; }
@@ -192,7 +192,8 @@ int mrp_context_synchronize(mrp_context *ctx) {
 
 /* host half of a chunk: validation, prefix sums, host copies of everything (the caller's arrays may go after the call) */
 static int chunk_host_init(mrp_context *ctx, int64_t n_sites, const uint32_t *allele_number, const uint16_t *substitution_log_probs,
-                           const uint16_t *allele_prior_log_probs, const uint8_t *profile_pool, int64_t pool_bytes, mrp_chunk **out) {
+                           const uint16_t *allele_prior_log_probs, const uint8_t *profile_pool, int64_t pool_bytes, mrp_chunk **out,
+                           bool copy_pool = true) {
     if (!ctx || !out || n_sites < 0 || pool_bytes < 0 || (n_sites > 0 && !allele_number) ||
         (pool_bytes > 0 && !profile_pool))
         return fail(MRP_ERR_ARG, "mrp_chunk_create: bad arguments");
@@ -230,7 +231,8 @@ static int chunk_host_init(mrp_context *ctx, int64_t n_sites, const uint32_t *al
     std::vector<uint16_t> &sub = ch->sub, &prior = ch->prior;
     sub.assign(soff, 0);
     prior.assign(off, 0);
-    if (pool_bytes > 0) ch->pool.assign(profile_pool, profile_pool + pool_bytes);
+    if (pool_bytes > 0 && copy_pool) ch->pool.assign(profile_pool, profile_pool + pool_bytes);
+    ch->pool_host = ch->pool.data(); /* (copy_pool = false: set by the caller, who keeps the bytes elsewhere) */
     if (substitution_log_probs) sub.assign(substitution_log_probs, substitution_log_probs + soff);
     if (allele_prior_log_probs) prior.assign(allele_prior_log_probs, allele_prior_log_probs + off);
     for (uint16_t v : sub) ch->max_sub = std::max<uint32_t>(ch->max_sub, v);
@@ -293,7 +295,8 @@ int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *co
     std::vector<std::string> msgs((size_t) n);
     mrp_parallel_for(n, 4, [&](int64_t i) {
         const mrp_chunk_desc &c = *descs[i];
-        rcs[(size_t) i] = chunk_host_init(ctx, c.n_sites, c.allele_number, c.substitution_log_probs, c.allele_prior_log_probs, c.profile_pool, c.pool_bytes, &out[i]);
+        /* (the profile bytes -- nine tenths of a chunk -- are copied ONCE, into the page-locked block below, which outlives the chunk) */
+        rcs[(size_t) i] = chunk_host_init(ctx, c.n_sites, c.allele_number, c.substitution_log_probs, c.allele_prior_log_probs, c.profile_pool, c.pool_bytes, &out[i], false);
         if (rcs[(size_t) i] != MRP_OK) msgs[(size_t) i] = mrp_last_error();
     });
     int rc = MRP_OK;
@@ -304,7 +307,7 @@ int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *co
     for (int64_t i = 0; i < n && rc == MRP_OK; i++) {
         const mrp_chunk *ch = out[i];
         off[(size_t) i + 1] = off[(size_t) i] + al(4 * ch->allele_number.size()) + al(4 * ch->allele_offset.size()) + al(4 * ch->sub_offset.size()) +
-                              al(4 * ch->same_until.size()) + al(2 * ch->sub.size()) + al(2 * ch->prior.size()) + al(ch->pool.size());
+                              al(4 * ch->same_until.size()) + al(2 * ch->sub.size()) + al(2 * ch->prior.size()) + al((size_t) ch->pool_bytes);
     }
     hipError_t e = hipSuccess;
     if (rc == MRP_OK) {
@@ -326,7 +329,8 @@ int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *co
             ch->dev.same_until = (const int32_t *) put(ch->same_until.data(), 4 * ch->same_until.size());
             ch->dev.sub = (const uint16_t *) put(ch->sub.data(), 2 * ch->sub.size());
             ch->dev.prior = (const uint16_t *) put(ch->prior.data(), 2 * ch->prior.size());
-            ch->dev.pool = (const uint8_t *) put(ch->pool.data(), ch->pool.size());
+            ch->pool_host = (const uint8_t *) (hb + o);
+            ch->dev.pool = (const uint8_t *) put(descs[i]->profile_pool, (size_t) ch->pool_bytes);
         });
         if (off[(size_t) n] > 0) e = hipMemcpyAsync(db, hb, off[(size_t) n], hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipEventRecord(blk->ready, ctx->stream);

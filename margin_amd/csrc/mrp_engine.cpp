@@ -444,6 +444,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     /* per hmm records and the 8 bytes per column the host contributes (parallel) */
     mrp_pool_set_tag(8); mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
         mrp_xhmm &h = x[i];
+        if (i + 3 < n) { __builtin_prefetch(x[i + 3].col_start); __builtin_prefetch(x[i + 3].col_read_off); __builtin_prefetch(x[i + 3].par); }
         const int K = h.n_cols;
         const int64_t colbase = col0[(size_t) i];
         XDesc &d = xd[i];

@@ -356,6 +356,7 @@ struct mrp_chunk {
     std::vector<int32_t> same_until; /* [n_sites] first site after i whose allele count differs from site i's (n_sites if none) */
     std::vector<uint16_t> sub, prior; /* host copies for the structural code (rphmm_host.c) */
     std::vector<uint8_t> pool;
+    const uint8_t *pool_host = nullptr; /* the profile bytes on the host: pool.data(), or the copy in the page-locked block of a work queue's batch */
     uint32_t max_sub = 0, max_prior = 0, max_alleles = 1;
     DevBuf<uint32_t> d_allele_number, d_allele_offset, d_sub_offset;
     DevBuf<int32_t> d_same_until;

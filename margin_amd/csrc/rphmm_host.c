@@ -1500,8 +1500,9 @@ static inline __attribute__((always_inline)) int piter_next(piter *it, rpiece *p
 static int r_cross_build(const world *w, const r_hmm_vec *a, const r_hmm_vec *b, int32_t S, int32_t E, int32_t stride, rhmm **out) {
     (void) w;
     int64_t cap = 2, n_reads = 0;
-    for (int64_t i = 0; i < a->n; i++) { cap += a->a[i]->n_cols + 1; n_reads += a->a[i]->n_reads; }
-    for (int64_t i = 0; i < b->n; i++) { cap += b->a[i]->n_cols + 1; n_reads += b->a[i]->n_reads; }
+    /* (the parents were written a level ago, often by another core: their arrays are asked for while the sizes are added up) */
+    for (int64_t i = 0; i < a->n; i++) { const rhmm *p = a->a[i]; cap += p->n_cols + 1; n_reads += p->n_reads; __builtin_prefetch(p->starts); __builtin_prefetch(p->roff); __builtin_prefetch(p->reads); }
+    for (int64_t i = 0; i < b->n; i++) { const rhmm *p = b->a[i]; cap += p->n_cols + 1; n_reads += p->n_reads; __builtin_prefetch(p->starts); __builtin_prefetch(p->roff); __builtin_prefetch(p->reads); }
     const size_t o_starts = (sizeof(rhmm) + 7) & ~(size_t) 7, o_roff = o_starts + 4 * (size_t) cap, o_reads = o_roff + 4 * (size_t) (cap + 1),
                  o_par = (o_reads + 4 * (size_t) n_reads + 7) & ~(size_t) 7, bytes = o_par + sizeof(mrp_xpar) * (size_t) (a->n + b->n);
     int cls = 0;
@@ -1648,7 +1649,7 @@ static double tcpu_ms(void) {
     struct timespec t; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t); return 1e3 * (double) t.tv_sec + 1e-6 * (double) t.tv_nsec;
 }
 #define T_ADD(slot, t0) do { if (g_prepare_timing) __atomic_fetch_add(&g_ns[slot], (int64_t) ((tcpu_ms() - (t0)) * 1e6), __ATOMIC_RELAXED); } while (0)
-static int r_prepare_merge(const world *w, int32_t stride, r_hmm_vec *tp1, r_hmm_vec *tp2, r_hmm_vec *res, xbuild_vec *xs, r_hmm_vec *garbage) {
+static int r_prepare_merge(const world *w, int32_t stride, r_hmm_vec *tp1, r_hmm_vec *tp2, r_hmm_vec *res, xbuild_vec *xs) {
     double tq = tcpu_ms();
     ar_on();
     r_comp_vec comps = r_overlapping_components(w, tp1, tp2);
@@ -1673,7 +1674,9 @@ static int r_prepare_merge(const world *w, int32_t stride, r_hmm_vec *tp1, r_hmm
             tq = tcpu_ms();
             rc = r_cross_build(w, &va, &vb, S, Ea > Eb ? Ea : Eb, stride, &xb.x);
             T_ADD(2, tq);
-            VEC_PUSH(*garbage, m0); VEC_PUSH(*garbage, m1);
+            /* the parents' shadows are no longer needed (their cells stay in the engine's segments; what the engine was told of
+             * them it copied when their level was staged): back to THIS thread's front of the pool, warm for its next hmm */
+            rhmm_destroy(m0); rhmm_destroy(m1);
             if (rc == MRP_OK) { VEC_PUSH(*xs, xb); VEC_PUSH(*res, xb.x); }
         } else if (rc == MRP_OK) {
             tq = tcpu_ms();
@@ -1691,10 +1694,8 @@ static int r_prepare_merge(const world *w, int32_t stride, r_hmm_vec *tp1, r_hmm
                 tq = tcpu_ms();
                 rc = r_cross_build(w, a, b, S, E, stride, &xb.x);
                 T_ADD(2, tq);
-                /* the parents' shadows are no longer needed; their cells stay in the engine's segments */
-                /* (freed by the caller's thread while the device works) */
-                for (int64_t t = 0; t < a->n; t++) VEC_PUSH(*garbage, a->a[t]);
-                for (int64_t t = 0; t < b->n; t++) VEC_PUSH(*garbage, b->a[t]);
+                for (int64_t t = 0; t < a->n; t++) rhmm_destroy(a->a[t]);
+                for (int64_t t = 0; t < b->n; t++) rhmm_destroy(b->a[t]);
                 if (rc == MRP_OK) { VEC_PUSH(*xs, xb); VEC_PUSH(*res, xb.x); }
             } else if (sub.n == 1 && sub.a[0]->n == 1) {
                 VEC_PUSH(*res, sub.a[0]->a[0]);
@@ -1784,7 +1785,6 @@ typedef struct {
     int32_t stride;
     r_hmm_vec *res;
     xbuild_vec xs;
-    r_hmm_vec garbage;
     int rc, res_class;
     int64_t x0;        /* where the item's cross products start in the level's list */
     void *big_block;
@@ -1795,21 +1795,20 @@ static void level_prepare(int64_t i, void *arg) {
     rnode *nd = &it->t->a[it->node];
     r_hmm_vec *l = it->t->a[nd->left].path, *r = it->t->a[nd->right].path;
     it->t->a[nd->left].path = NULL; it->t->a[nd->right].path = NULL;
-    {   /* the merged path, the cross products to build and the parents to drop: at most one entry per hmm of the two paths each.
-         * ONE block of the shadow pool, owned by the path (released when the next level consumes it; the other two lists are
-         * read by the thread that drives the batch before that) -- no malloc / free across threads */
+    {   /* the merged path and the cross products to build: at most one entry per hmm of the two paths each.  ONE block of the
+         * shadow pool, owned by the path (released when the next level consumes it; the list of cross products is read by the
+         * thread that drives the batch before that) -- no malloc / free across threads */
         const int64_t cap = l->n + r->n + 1;
         const size_t o_res = (sizeof(r_hmm_vec) + 15) & ~(size_t) 15, o_xs = o_res + sizeof(rhmm *) * (size_t) cap,
-                     o_garbage = o_xs + sizeof(xbuild) * (size_t) cap, bytes = o_garbage + sizeof(rhmm *) * (size_t) cap;
+                     bytes = o_xs + sizeof(xbuild) * (size_t) cap;
         int cls = 0;
         char *blk = shadow_alloc(bytes, &cls);
         it->res = (r_hmm_vec *) blk;
         it->res->a = (rhmm **) (blk + o_res); it->res->n = 0; it->res->cap = cap;
         it->xs.a = (xbuild *) (blk + o_xs); it->xs.n = 0; it->xs.cap = cap;
-        it->garbage.a = (rhmm **) (blk + o_garbage); it->garbage.n = 0; it->garbage.cap = cap;
         it->res_class = cls;
     }
-    it->rc = r_prepare_merge(nd->w, it->stride, l, r, it->res, &it->xs, &it->garbage);
+    it->rc = r_prepare_merge(nd->w, it->stride, l, r, it->res, &it->xs);
     if (it->res_class >= 0) it->res->cap = -(int64_t) it->res_class - 2;
     else { /* (a path beyond the pool's largest class: an ordinary vector again) */
         r_hmm_vec *v = xcalloc(1, sizeof(*v));
@@ -1819,11 +1818,8 @@ static void level_prepare(int64_t i, void *arg) {
     }
     if (it->rc != MRP_OK) snprintf(it->err, sizeof(it->err), "%s", mrp_last_error());
 }
-static void level_drop_garbage(int64_t i, void *arg) { /* the parents' shadows of one merge */
+static void level_drop_garbage(int64_t i, void *arg) { /* (the parents' shadows went back to the pool in r_prepare_merge) */
     level_item *it = &((level_item *) arg)[i];
-    for (int64_t j = 0; j < it->garbage.n; j++) rhmm_destroy(it->garbage.a[j]);
-    it->garbage.a = NULL; /* (the list is part of the path's block) */
-    it->garbage.n = 0;
     if (it->big_block) { free(it->big_block); it->big_block = NULL; }
 }
 static void level_finish(int64_t i, void *arg) {
@@ -1848,6 +1844,7 @@ static void level_gather(int64_t i, void *arg) {
     const level_gather_ctl *g = arg;
     const level_item *it = &g->items[i];
     for (int64_t j = 0; j < it->xs.n; j++) {
+        if (j + 4 < it->xs.n) { __builtin_prefetch(it->xs.a[j + 4].x); __builtin_prefetch((const char *) it->xs.a[j + 4].x + 64); }
         g->xb[it->x0 + j] = it->xs.a[j];
         r_describe(it->xs.a[j].w, it->xs.a[j].x, g->flags, &g->xh[it->x0 + j]);
     }
@@ -1930,10 +1927,7 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
         if (rc == MRP_OK) rc = mrp_engine_level_launch(e);
         else (void) mrp_engine_level_end(e);
         level_run_settle(&prev, rc == MRP_OK);
-        /* while the device works: drop the parents' shadows */
         const double t2 = now_ms();
-        /* (on this thread: the blocks go back to the shadow pool through one thread's front instead of sixteen fighting for
-         * the pool's locks -- 30 ms of CPU per call instead of 180) */
         for (int64_t i = 0; i < n_items; i++) level_drop_garbage(i, items);
         (void) t2;
         g_t_prepare += t1 - t0; g_t_level += now_ms() - t1;

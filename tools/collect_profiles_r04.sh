@@ -51,16 +51,21 @@ if has levels; then  # 5. the levels of the resident pipeline: one batch (per-di
   python3 $R/tools/trace_busy.py $O/t_g8b 8 > $O/pipeline_busy_1152chunks_8batches.txt
   rm -rf $O/t_lv $O/t_g8 $O/t_g8b
 fi
-if has host; then    # 6. host threads: the same call with 16, 8, 6 and 4 threads in the library's pool (wall, process CPU time)
-  for t in 16 8 6 4; do
-    ( cd $R && MRP_HOST_THREADS=$t timeout -k 10 300 python3 tools/pipeline_probe.py --chunks 576 --repeat 5 --check-host 0 > $O/probe_576_t$t.log 2>&1 ) || exit 1
+if has host; then    # 6. host threads: the same 1 152-chunk call with 16, 12, 8, 6 and 4 threads in the library's pool (wall, process CPU time),
+                     #    and a CPU sampling profile of the call's host side (tools/sampler: no perf on these boxes)
+  for t in 16 12 8 6 4; do
+    ( cd $R && MRP_HOST_THREADS=$t timeout -k 10 300 python3 tools/pipeline_probe.py --chunks 1152 --repeat 5 --check-host 0 > $O/probe_1152_t$t.log 2>&1 ) || exit 1
   done
-  ( cd $R && timeout -k 10 300 python3 tools/pipeline_probe.py --chunks 1152 --repeat 4 --check-host 0 > $O/probe_1152_t16.log 2>&1 ) || exit 1
-  ( cd $O && grep -H "^run" probe_576_t16.log probe_576_t8.log probe_576_t6.log probe_576_t4.log probe_1152_t16.log > probe_runs.txt )
+  ( cd $R && timeout -k 10 300 python3 tools/pipeline_probe.py --chunks 576 --repeat 5 --check-host 0 > $O/probe_576_t16.log 2>&1 ) || exit 1
+  ( cd $O && grep -H "^run" probe_1152_t16.log probe_1152_t12.log probe_1152_t8.log probe_1152_t6.log probe_1152_t4.log probe_576_t16.log > probe_runs.txt )
+  ( cd $R && gcc -O2 -g -shared -fPIC -o tools/sampler/libcpusampler.so tools/sampler/cpusampler.c -lpthread &&
+    timeout -k 10 400 python3 tools/pipeline_probe.py --chunks 1152 --repeat 8 --check-host 0 --sample $O/host.samples > $O/host_sample.log 2>&1 &&
+    python3 tools/sampler/resolve.py $O/host.samples 40 | cut -c1-160 > $O/host_profile.txt; rm -f $O/host.samples ) || exit 1
 fi
 if has queue; then   # 7. the work queue from host memory: one batch beside the resident call, and a long queue
   ( cd $R && timeout -k 10 600 python3 tools/queue_probe.py --runs 4 2>&1 | grep " ms" > $O/queue_probe.txt ) || exit 1
   ( cd $R && timeout -k 10 600 python3 tools/queue_long.py --chunks 2304 2>&1 | grep "queue:\|resident:" > $O/queue_long.txt ) || exit 1
+  ( cd $R && timeout -k 10 600 python3 tools/queue_long.py --chunks 4608 --skip-resident 1 2>&1 | grep "queue:" >> $O/queue_long.txt ) || exit 1
   ( cd $R && timeout -k 10 600 python3 tools/adaptor_probe.py --chunks 8 --threads 8 > $O/adaptor_probe.txt 2>&1 ) || exit 1
 fi
 if has clocks && [ -f $R/alt_lib/libmargin_rphmm_clk1.so ]; then  # 8. in-kernel clocks of the prune kernel (development builds with -DPRUNE_EXP_CLOCK / -DPRUNE_EXP_CLOCK2)
