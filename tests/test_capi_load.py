@@ -84,7 +84,20 @@ def test_host_worker_pool_runs_every_index_once():
             if hits != [1] * n:
                 errors.append((seed, r, n))
 
-    threads = [threading.Thread(target=caller, args=(s,)) for s in range(3)]
+    def big(seed):  # loops longer than the pool's ranges: every range, whole grains, the clamped last one
+        for n, grain in ((1, 7), (15, 1), (16, 1), (17, 3), (255, 16), (1000, 64), (4097, 1), (5000, 7)):
+            hits = [0] * n
+            lock = threading.Lock()
+
+            def body(i, _arg):
+                with lock:
+                    hits[i] += 1
+            cb = CB(body)
+            lib.mrp_pool_run(n, grain, cb, None)
+            if hits != [1] * n:
+                errors.append((seed, "big", n, grain))
+
+    threads = [threading.Thread(target=caller, args=(s,)) for s in range(3)] + [threading.Thread(target=big, args=(9,))]
     for t in threads:
         t.start()
     for t in threads:

@@ -25,3 +25,20 @@ def test_host_structure_of_whole_chunks_is_consistent(tmp_path, threads):
     # the same chunks give the same structure in every run and for any number of host threads
     cols = {l.split("columns ")[1].split(",")[0] for l in lines}
     assert len(cols) == 1 and int(cols.pop()) > 1000
+    # ... and everything the engine is told (intervals, column boundaries, read offsets, parents, static bounds) hashes alike
+    hashes = {l.split("structure hash ")[1].strip() for l in lines}
+    assert len(hashes) == 1
+    _HASHES.setdefault("h", set()).update(hashes)
+    assert len(_HASHES["h"]) == 1, "the level descriptions depend on the number of host threads"
+
+
+_HASHES = {}
+
+
+def test_tiling_paths_in_one_pass_equal_the_reference_walk():
+    """getTilingPaths (coordination.c:19-55, 186-222) builds path after path; the product deals the sorted hmms out in one first-fit
+    pass.  hostbench --selftest compares the two on 400 random interval sets (nested, touching, equal intervals; up to 2 500 hmms),
+    and checks the radix / insertion sort of stRPHmm_cmpFn on the way."""
+    subprocess.check_call(["make", "-C", HB, "hostbench"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    out = subprocess.check_output([os.path.join(HB, "hostbench"), "--selftest"], text=True)
+    assert out.strip() == "selftest ok", out

@@ -72,8 +72,52 @@ int mrp_engine_fetch(mrp_engine *e, void *dst, const void *src, int64_t bytes) {
 int mrp_engine_sync(mrp_engine *e) { (void) e; return MRP_OK; }
 void mrp_engine_get_stats(const mrp_engine *e, mrp_engine_stats *out) { memset(out, 0, sizeof *out); out->columns = e->cols; out->levels = e->n_segs; }
 
+/* --selftest: r_tiling_paths_sorted (one first-fit pass) against the walk of getTilingPaths as the reference does it -- path after
+ * path, each time the first unused hmm that starts at or behind the end of the path's last one (coordination.c:19-55, 186-222) -- on
+ * random interval sets in stRPHmm_cmpFn order: nested, touching, equal, sparse and 60 deep. */
+static int selftest(void) {
+    uint64_t rng = 12345;
+    #define RND() (rng = rng * 6364136223846793005ull + 1442695040888963407ull, (uint32_t) (rng >> 33))
+    for (int round = 0; round < 400; round++) {
+        const int n = 1 + (int) (RND() % (round < 200 ? 40 : 2500));
+        const int span = 1 + (int) (RND() % 3000), maxlen = 1 + (int) (RND() % (round % 3 ? 400 : 30));
+        rhmm *h = calloc((size_t) n, sizeof *h);
+        rhmm **sorted = calloc((size_t) n, sizeof *sorted);
+        for (int i = 0; i < n; i++) { h[i].ref_start = (int32_t) (RND() % (uint32_t) span); h[i].ref_length = 1 + (int32_t) (RND() % (uint32_t) maxlen); h[i].first_read = -1; sorted[i] = &h[i]; }
+        world w; memset(&w, 0, sizeof w);
+        r_sort_hmms(&w, sorted, n);
+        for (int i = 1; i < n; i++) if (r_hmm_cmp(&w, sorted[i - 1], sorted[i]) > 0) { printf("selftest: sort order broken in round %d\n", round); return 1; }
+        r_path_vec got = r_tiling_paths_sorted(sorted, n);
+        /* the reference's walk */
+        uint8_t *used = calloc((size_t) n, 1);
+        int remaining = n, first = 0, path = 0, bad = 0;
+        while (remaining > 0 && !bad) {
+            while (used[first]) first++;
+            int cur = first, k = 0;
+            if (path >= got.n) { bad = 1; break; }
+            for (;;) {
+                if (k >= got.a[path]->n || got.a[path]->a[k] != sorted[cur]) { bad = 1; break; }
+                used[cur] = 1; remaining--; k++;
+                int nxt = -1;
+                for (int j = cur + 1; j < n; j++) if (!used[j] && sorted[cur]->ref_start + sorted[cur]->ref_length <= sorted[j]->ref_start) { nxt = j; break; }
+                if (nxt < 0) break;
+                cur = nxt;
+            }
+            if (!bad && k != got.a[path]->n) bad = 1;
+            path++;
+        }
+        if (!bad && path != got.n) bad = 1;
+        if (bad) { printf("selftest: tiling paths differ from the reference's walk in round %d (n = %d)\n", round, n); return 1; }
+        for (int64_t i = 0; i < got.n; i++) r_free_path(got.a[i], 0);
+        free(got.a); free(used); free(sorted); free(h);
+    }
+    printf("selftest ok\n");
+    return 0;
+}
+
 int main(int argc, char **argv) {
-    if (argc < 2) { fprintf(stderr, "usage: hostbench chunks.bin [repeat] [threads]\n"); return 2; }
+    if (argc >= 2 && strcmp(argv[1], "--selftest") == 0) return selftest();
+    if (argc < 2) { fprintf(stderr, "usage: hostbench chunks.bin [repeat] [threads] | hostbench --selftest\n"); return 2; }
     const int repeat = argc > 2 ? atoi(argv[2]) : 3;
     g_threads = argc > 3 ? atoi(argv[3]) : 1;
     FILE *f = fopen(argv[1], "rb");
