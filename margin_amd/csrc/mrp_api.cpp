@@ -287,7 +287,7 @@ int mrp_chunk_create(mrp_context *ctx, int64_t n_sites, const uint32_t *allele_n
  * one event ends it.  Nothing is waited for here: the first device work that reads a chunk waits for the event on its stream
  * (mrp_engine.cpp) or on the host (mrp_chunk::host_wait).  Per chunk this replaces seven allocations and seven pageable
  * copies (30 ms for 288 chunks) by a share of one. */
-int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *const *descs, mrp_chunk **out, mrp_chunk_block *blk) {
+int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *const *descs, mrp_chunk **out, mrp_chunk_block *blk, int groups) {
     if (!ctx || n < 0 || !blk || (n > 0 && (!descs || !out))) return fail(MRP_ERR_ARG, "mrp_chunk_block_create: bad arguments");
     for (int64_t i = 0; i < n; i++) out[i] = nullptr;
     HIP_TRY(hipSetDevice(ctx->device));
@@ -303,10 +303,17 @@ int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *co
     for (int64_t i = 0; i < n && rc == MRP_OK; i++)
         if (rcs[(size_t) i] != MRP_OK) rc = fail(rcs[(size_t) i], "%s", msgs[(size_t) i].c_str());
     auto al = [](size_t v) { return (v + 255) & ~(size_t) 255; };
-    std::vector<size_t> off((size_t) n + 1, 0);
-    for (int64_t i = 0; i < n && rc == MRP_OK; i++) {
-        const mrp_chunk *ch = out[i];
-        off[(size_t) i + 1] = off[(size_t) i] + al(4 * ch->allele_number.size()) + al(4 * ch->allele_offset.size()) + al(4 * ch->sub_offset.size()) +
+    if (groups < 1 || n < 4 * (int64_t) groups) groups = 1;
+    /* the order of the chunks in the block: group 0's (chunks 0, groups, 2 groups, ...), then group 1's, ... */
+    std::vector<int64_t> order; order.reserve((size_t) n);
+    std::vector<int64_t> group_first((size_t) groups + 1, 0);
+    for (int g = 0; g < groups; g++) { group_first[(size_t) g] = (int64_t) order.size(); for (int64_t i = g; i < n; i += groups) order.push_back(i); }
+    group_first[(size_t) groups] = n;
+    std::vector<size_t> off((size_t) n + 1, 0), at_of((size_t) n, 0); /* off: by position in the block; at_of: by chunk */
+    for (int64_t k = 0; k < n && rc == MRP_OK; k++) {
+        const mrp_chunk *ch = out[order[(size_t) k]];
+        at_of[(size_t) order[(size_t) k]] = off[(size_t) k];
+        off[(size_t) k + 1] = off[(size_t) k] + al(4 * ch->allele_number.size()) + al(4 * ch->allele_offset.size()) + al(4 * ch->sub_offset.size()) +
                               al(4 * ch->same_until.size()) + al(2 * ch->sub.size()) + al(2 * ch->prior.size()) + al((size_t) ch->pool_bytes);
     }
     hipError_t e = hipSuccess;
@@ -315,13 +322,21 @@ int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *co
         e = blk->host.reserve(off[(size_t) n] + 256);
         if (e == hipSuccess) e = blk->dev.alloc(off[(size_t) n] + 256);
         if (e == hipSuccess && !blk->ready) e = hipEventCreateWithFlags(&blk->ready, hipEventBlockingSync | hipEventDisableTiming);
+        while (e == hipSuccess && (int) blk->group_ready.size() < groups) {
+            hipEvent_t ev = nullptr;
+            e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming);
+            if (e == hipSuccess) blk->group_ready.push_back(ev);
+        }
     }
     if (rc == MRP_OK && e == hipSuccess) {
         char *hb = (char *) blk->host.p;
         uint8_t *db = blk->dev.p;
-        mrp_parallel_for(n, 4, [&](int64_t i) {
+        for (int g = 0; g < groups && e == hipSuccess; g++) { /* group by group: the copy of one runs beside the staging of the next */
+        const int64_t g_n = group_first[(size_t) g + 1] - group_first[(size_t) g];
+        mrp_parallel_for(g_n, 4, [&](int64_t k) {
+            const int64_t i = order[(size_t) (group_first[(size_t) g] + k)];
             mrp_chunk *ch = out[i];
-            size_t o = off[(size_t) i];
+            size_t o = at_of[(size_t) i];
             auto put = [&](const void *src, size_t bytes) { const size_t at = o; if (bytes) memcpy(hb + at, src, bytes); o += al(bytes); return db + at; };
             ch->dev.allele_number = (const uint32_t *) put(ch->allele_number.data(), 4 * ch->allele_number.size());
             ch->dev.allele_offset = (const uint32_t *) put(ch->allele_offset.data(), 4 * ch->allele_offset.size());
@@ -332,7 +347,10 @@ int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *co
             ch->pool_host = (const uint8_t *) (hb + o);
             ch->dev.pool = (const uint8_t *) put(descs[i]->profile_pool, (size_t) ch->pool_bytes);
         });
-        if (off[(size_t) n] > 0) e = hipMemcpyAsync(db, hb, off[(size_t) n], hipMemcpyHostToDevice, ctx->stream);
+            const size_t lo = off[(size_t) group_first[(size_t) g]], hi = off[(size_t) group_first[(size_t) g + 1]];
+            if (hi > lo) e = hipMemcpyAsync(db + lo, hb + lo, hi - lo, hipMemcpyHostToDevice, ctx->stream);
+            if (e == hipSuccess) e = hipEventRecord(blk->group_ready[(size_t) g], ctx->stream);
+        }
         if (e == hipSuccess) e = hipEventRecord(blk->ready, ctx->stream);
         if (e == hipSuccess && getenv("MRP_TIMING_UPLOAD")) { /* diagnosis only: waits for the copy */
             const auto t0 = std::chrono::steady_clock::now();
@@ -341,7 +359,7 @@ int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *co
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         }
         if (e == hipSuccess)
-            for (int64_t i = 0; i < n; i++) { out[i]->ready = blk->ready; out[i]->owns_ready = false; out[i]->ready_pending.store(true); }
+            for (int64_t i = 0; i < n; i++) { out[i]->ready = blk->group_ready[(size_t) (i % groups)]; out[i]->owns_ready = false; out[i]->ready_pending.store(true); }
     }
     if (rc == MRP_OK && e != hipSuccess) rc = fail(MRP_ERR_HIP, "chunk block upload failed: %s", hipGetErrorString(e));
     if (rc != MRP_OK)

@@ -401,9 +401,11 @@ struct PinnedBuf {
 struct mrp_chunk_block {
     PinnedBuf host;
     DevBuf<uint8_t> dev;
-    hipEvent_t ready = nullptr;
+    hipEvent_t ready = nullptr;              /* end of the whole upload */
+    std::vector<hipEvent_t> group_ready;     /* end of the upload of every group of chunks (the chunks of a group are contiguous in the block) */
     ~mrp_chunk_block() {
         if (ready) { (void) hipEventSynchronize(ready); (void) hipEventDestroy(ready); }
+        for (hipEvent_t e : group_ready) if (e) (void) hipEventDestroy(e);
     }
 };
 
@@ -499,7 +501,10 @@ int mrp_batch_add_impl(mrp_batch *b, const mrp_hmm_job *job, bool resident, int6
 extern "C" void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void *), void *arg);
 /* releases what mrp_engine.cpp parked in the context (mrp_context_destroy) */
 void mrp_engine_release_context_cache(mrp_context *ctx);
-int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *const *descs, mrp_chunk **out, mrp_chunk_block *blk);
+/* groups > 1: chunk i belongs to group i % groups (the concurrent batches mrp_phase_reads_many will deal the chunks to); the block is
+ * laid out and uploaded group by group, and a chunk is ready when its group's copy has ended -- the first batch's kernels need not wait
+ * for the last batch's bytes */
+int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *const *descs, mrp_chunk **out, mrp_chunk_block *blk, int groups = 1);
 int mrp_host_threads_setting(void); /* what mrp_set_host_threads() was given, 0 if it was never called */
 /* host worker pools (mrp_api.cpp) */
 extern "C" void mrp_batch_last_launch_ms(struct mrp_batch *b, float *pack, float *emission, float *recursion);

@@ -392,7 +392,9 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
         if (!blk) blk = new (std::nothrow) mrp_chunk_block();
         std::vector<const mrp_chunk_desc *> dl((size_t) st->count);
         for (int64_t i = 0; i < st->count; i++) dl[(size_t) i] = &chunks[plan.order[(size_t) (st->first + i)]];
-        const int rc = blk ? mrp_chunk_block_create(sc, st->count, dl.data(), st->dch.data(), blk) : mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
+        /* (uploaded in the groups the call will deal the chunks to: its first batch starts on the device when an eighth of the bytes is there) */
+        const int rc = blk ? mrp_chunk_block_create(sc, st->count, dl.data(), st->dch.data(), blk, mrp_phase_groups_for(q->ctx[(size_t) w], st->count))
+                           : mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
         if (rc != MRP_OK) errs[(size_t) w] = mrp_last_error();
         if (timing) fprintf(stderr, "  [%7.1f] queue lane %d: batch %lld (%lld chunks) staged in %.1f ms\n", since(), w, (long long) b, (long long) st->count,
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count());

@@ -2391,6 +2391,16 @@ static void *hashing_main(void *p) {
     }
 }
 
+/* the concurrent batches a call over n_chunks chunks is split into (chunk i goes to batch i % G) */
+int mrp_phase_groups_for(const mrp_context *ctx, int64_t n_chunks) {
+    int G = mrp_context_phase_groups(ctx); /* mrp_context_set_phase_groups; 0 (default): by batch size */
+    if (G <= 0) G = n_chunks < 192 ? (int) (n_chunks / 12 > 4 ? 4 : n_chunks / 12) : 8;
+    if (G < 1) G = 1;
+    if (G > 16) G = 16;
+    if (n_chunks < 4 * G) G = 1;
+    return G;
+}
+
 static int phase_many_once(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *const *chunks, const mrp_read *const *reads,
                            const int64_t *n_reads, const mrp_params *params, mrp_phase_result **out, mrp_phase_many_stats *stats);
 
@@ -2473,14 +2483,10 @@ static int phase_many_once(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *
     for (int64_t c = 0; c < n_chunks; c++) out[c] = NULL;
     /* the levels of a batch alternate host work (structure, descriptors) and device work; two interleaved halves of the
      * chunks, each with its own context and host thread, keep both busy */
-    int G = mrp_context_phase_groups(ctx); /* mrp_context_set_phase_groups; 0 (default): by batch size */
+    int G = mrp_phase_groups_for(ctx, n_chunks);
     /* measured on MI355X (bench.py --chunks N --phase-groups G, two streams a batch): 48 chunks 45.3 ms with 2 batches, 42.5
      * with 4; 96: 52.3 with 4, 54.8 with 8; 144: 66.4 / 68.0; 192: 80.2 / 78.6; 288: 104.5 / 96.9; 432: 139.9 with 6, 130.5
      * with 8; 576 with 8: 169.5 (2.04e8 units/s, the best rate; 768: 243 ms).  More than 8 would share hardware queues. */
-    if (G <= 0) G = n_chunks < 192 ? (int) (n_chunks / 12 > 4 ? 4 : n_chunks / 12) : 8;
-    if (G < 1) G = 1;
-    if (G > 16) G = 16;
-    if (n_chunks < 4 * G) G = 1;
     int rc = MRP_OK;
     if (G == 1) {
         rc = phase_many_resident(ctx, n_chunks, chunks, reads, n_reads, params, out, stats);

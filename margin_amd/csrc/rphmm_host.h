@@ -41,6 +41,7 @@ int mrp_set_error(int code, const char *fmt, ...);
 /* host worker threads for structural code and descriptor building (mrp_set_host_threads, default min(16, cores)) */
 int mrp_host_threads(void);
 int mrp_context_phase_groups(const mrp_context *ctx);
+int mrp_phase_groups_for(const mrp_context *ctx, int64_t n_chunks); /* concurrent batches of a mrp_phase_reads_many call over n_chunks (chunk i: batch i % G) */
 int mrp_context_test_hooks(const mrp_context *ctx);
 /* urgency of the parallel loops the calling thread posts to the host worker pool from now on (smaller = served first) */
 void mrp_pool_set_priority(int p);

@@ -32,6 +32,7 @@ long long mrp_pool_tag_cpu_ns(int tag) { (void) tag; return 0; }
 long long mrp_pool_task_cpu_ns(void) { return 0; }
 long long mrp_pool_task_cpu_ns_this_thread(void) { return 0; }
 void mrp_pool_adopt(void *p) { (void) p; }
+void *mrp_pool_current(void) { return NULL; }
 typedef struct { int64_t n, grain; void (*fn)(int64_t, void *); void *arg; int64_t next; } pjob;
 static void *pworker(void *a) { pjob *j = a; for (;;) { int64_t lo = __atomic_fetch_add(&j->next, j->grain, __ATOMIC_RELAXED); if (lo >= j->n) return NULL;
     int64_t hi = lo + j->grain < j->n ? lo + j->grain : j->n; for (int64_t i = lo; i < hi; i++) j->fn(i, j->arg); } }
