@@ -494,6 +494,9 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         plan_class(wide, b->order_wide, ord_w, &b->max_merge_wide);
         plan_class(mid, b->order_mid, ord_m, &b->max_merge_mid);
         plan_class(narrow, b->order_narrow, ord_n, &b->max_merge_narrow);
+        if (L->units) { /* the merge columns of a unit level hold one entry per pair (the bounds count cells): half the LDS per workgroup */
+            b->max_merge_wide = (b->max_merge_wide + 1) / 2 + 1; b->max_merge_mid = (b->max_merge_mid + 1) / 2 + 1; b->max_merge_narrow = (b->max_merge_narrow + 1) / 2 + 1;
+        }
     }
     PruneParams &pp = L->pp;
     pp = e->pp;
