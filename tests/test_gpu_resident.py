@@ -672,3 +672,38 @@ def test_odd_column_limits_take_the_general_prune_chain_and_equal_the_oracle(gpu
         assert (np.asarray(got[k]) == np.asarray(ref[k])).all(), k
     assert got["reads1"] == ref["reads1"] and got["reads2"] == ref["reads2"]
     dchunk.close()
+
+
+def test_results_do_not_depend_on_the_host_threads(gpu_ctx, orc):
+    """The host side of a level runs on a pool whose threads start every loop with a range of their own, keep per-thread fronts of
+    the block pool and give the parents' blocks back as they merge them.  Size-independent property: the same 64 chunks (eight
+    concurrent batches) phased with 1, 3 and 16 pool threads give the same results, array for array; a sample against the oracle."""
+    chunks = [synth.make_ont_chunk(seed=7000 + s, region_bp=150_000, n_sites=300, coverage=30.0) for s in range(64)]
+    pd = _params()
+    params = capi.Params.from_reference_names(pd)
+    dchunks = [capi.DeviceChunk.from_chunk(gpu_ctx, c) for c in chunks]
+    lib = capi.load()
+    results = []
+    try:
+        for threads in (1, 3, 16):
+            lib.mrp_set_host_threads(threads)
+            for _ in range(2):  # (the second call of a setting runs on the blocks the first one left in the pool)
+                got, st = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
+            assert st.resident == 1 and st.fallback_chunks == 0
+            results.append(got)
+    finally:
+        lib.mrp_set_host_threads(16)
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            for k in PHASE_KEYS:
+                assert (np.asarray(a[k]) == np.asarray(b[k])).all(), k
+            assert a["reads1"] == b["reads1"] and a["reads2"] == b["reads2"] and a["n_sweeps"] == b["n_sweeps"]
+    for i in (0, 31, 63):
+        oc = orc.OracleChunk(chunks[i])
+        ref = oc.phase(pd)
+        oc.close()
+        for k in PHASE_KEYS:
+            assert (np.asarray(results[0][i][k]) == np.asarray(ref[k])).all(), k
+        assert results[0][i]["reads1"] == ref["reads1"] and results[0][i]["reads2"] == ref["reads2"]
+    for d in dchunks:
+        d.close()
