@@ -83,6 +83,35 @@ def insitu_rooflines(st):
     return out
 
 
+def bind_near_device(device):
+    """sched_setaffinity to /sys/bus/pci/devices/<bus id of the device>/local_cpulist (intersected with the CPUs the process may
+    use); returns what was done, for the JSON line"""
+    try:
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        buf = ctypes.create_string_buffer(64)
+        if hip.hipDeviceGetPCIBusId(buf, 63, int(device)) != 0:
+            return "none (no PCI bus id)"
+        bus = buf.value.decode().lower()
+        with open(f"/sys/bus/pci/devices/{bus}/local_cpulist") as f:
+            text = f.read().strip()
+        near = set()
+        for tok in text.split(","):
+            if "-" in tok:
+                lo, hi = tok.split("-")
+                near.update(range(int(lo), int(hi) + 1))
+            elif tok:
+                near.add(int(tok))
+        allowed = os.sched_getaffinity(0)
+        want = near & allowed
+        if len(want) < 8 or want == allowed:
+            return f"none (local_cpulist of {bus} leaves {len(want)} of the {len(allowed)} usable CPUs)"
+        os.sched_setaffinity(0, want)
+        return f"{len(want)} CPUs next to {bus}"
+    except Exception as e:  # no sysfs entry, a container without the call, ...
+        return f"none ({type(e).__name__})"
+
+
 def main():
     args = parse_args()
     rank = int(os.environ.get("RANK", "0"))
@@ -113,6 +142,13 @@ def main():
             dist.init_process_group(backend=backend)
     elif torch.cuda.is_available():
         torch.cuda.set_device(local_rank)
+
+    # one rank per GPU on a node with several sockets: the rank's threads (this process's, the library's pool, the runtime's) stay on the
+    # CPUs next to its device, as the library's work queue does for its workers -- staging buffers and the hmm shadows are then local
+    # memory.  Only inside what the process may use anyway, and never down to a handful of CPUs.
+    cpu_binding = "none"
+    if world > 1 and os.environ.get("MRP_BENCH_AFFINITY", "1") != "0":
+        cpu_binding = bind_near_device(local_rank)
 
     import numpy as np
     from margin_amd import capi, sharding, synth
@@ -179,7 +215,7 @@ def main():
                chunks_per_gpu=args.chunks, units_per_gpu=int(units) // (n_gpus if single_process_multi else 1),
                parallelism=(f"1 process, {n_gpus} devices, host work queue (mrp_queue_phase_chunks), no collectives" if single_process_multi else
                             f"{world} process(es), one per GPU, chunks sharded by rank, no collectives"),
-               host_threads=host_threads, host_cpu_s_per_step=host_cpu / max(1, args.steps), synth_s=t_synth)
+               host_threads=host_threads, host_cpu_s_per_step=host_cpu / max(1, args.steps), synth_s=t_synth, cpu_binding=cpu_binding)
     out = dict(metric="het-sites x reads phased/sec (30x ONT synthetic chunks, end to end: every merge level + final sweep)",
                value=value, unit="het-site-reads/s", n_gpus=n_gpus, steps=args.steps, warmup=args.warmup, ms_per_step=ms_per_step,
                higher_is_better=True, scaling="weak", vs_baseline=None, dtype="int32", data="synthetic", config=cfg)
