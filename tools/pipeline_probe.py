@@ -34,6 +34,10 @@ def main():
     args = ap.parse_args()
     pd = synth.shipped_phase_params()
     params = capi.Params.from_reference_names(pd)
+    if os.environ.get("MRP_PROBE_BIND"):  # the CPUs next to the device, as bench.py's ranks do
+        import bench
+        capi.load().mrp_device_count()
+        print("cpu binding:", bench.bind_near_device(0), flush=True)
     ctx = capi.Context(0)
     ctx.set_test_hooks(int(os.environ.get("MRP_TEST_HOOKS", "0")))  # bit 1: separate cross product / emission kernels (A/B)
     if os.environ.get("MRP_PHASE_GROUPS"):
