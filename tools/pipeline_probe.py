@@ -81,7 +81,8 @@ def main():
         dt, cpu = time.perf_counter() - t0, time.process_time() - c0
         print(f"run {r}: {dt * 1e3:.1f} ms wall, {units / dt:.3e} units/s, host cpu {cpu * 1e3:.0f} ms, resident={st.resident} levels={st.levels} hmms={st.hmms} "
               f"cols={st.columns} cells={st.cells} device_ms={st.device_ms:.2f} (cross {st.cross_ms:.2f} sweep {st.sweep_ms:.2f} "
-              f"prune {st.prune_ms:.2f})", flush=True)
+              f"prune {st.prune_ms:.2f}; pack {st.pack_ms:.2f} cross+emission {st.cross_emit_ms:.2f} recursion {st.recursion_ms:.2f} prune kernels {st.prune_kernel_ms:.2f} "
+              f"compaction {st.compact_ms:.2f})", flush=True)
     if sampler is not None:
         sampler.cpusampler_stop(args.sample.encode())
     for i in range(min(args.check_host, args.chunks)):
