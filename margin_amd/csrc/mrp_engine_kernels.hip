@@ -3112,10 +3112,24 @@ __global__ void __launch_bounds__(256) mrp_compact_kernel(MrpBatchDev d, const C
 /* ------------------------------------------------------------------------------------------ */
 __global__ void __launch_bounds__(64) mrp_traceback_kernel(MrpBatchDev d, const PruneHmm *__restrict__ hmms, int64_t n_hmms,
                                                            int32_t *__restrict__ err, int32_t *__restrict__ err_hmm) {
+    /* The chosen cells of the last TB_TILE columns: the walk itself neither stores to global memory nor gathers the chosen cell's
+     * partition (a load whose address is the step's own result: with it in the loop every step waited a memory latency for the one
+     * before); both happen a tile at a time, a column per lane, coalesced. */
+    constexpr int TB_TILE = 1024;
+    __shared__ int32_t chosen[TB_TILE];
     const int lane = threadIdx.x;
     for (int64_t hi = blockIdx.x; hi < n_hmms; hi += gridDim.x) {
         const PruneHmm h = k_load(hmms + hi);
         const int K = h.n_cols;
+        auto flush = [&](int k_lo, int k_hi) { /* columns [k_lo, k_hi): chosen[k - k_lo] -> out_n_cells, out_part */
+            wave_lds_fence();
+            for (int k = k_lo + lane; k < k_hi; k += WAVE) {
+                const int32_t bi = chosen[k - k_lo];
+                h.out_n_cells[k] = bi;
+                h.out_part[k] = d.partition[d.scols[h.col0 + k].cell_off + bi];
+            }
+            wave_lds_fence();
+        };
         uint32_t want = 0; /* merge cell the chosen cell of column k + 1 comes from */
         /* The walk is a chain of dependent steps (the chosen cell names the merge cell the next column is filtered by), but
          * what a step READS does not depend on the chain: the descriptor of a column is requested two steps ahead and its
@@ -3180,16 +3194,14 @@ __global__ void __launch_bounds__(64) mrp_traceback_kernel(MrpBatchDev d, const 
                     best_i = 0;
                 }
             }
-            if (lane == 0) {
-                h.out_n_cells[k] = best_i;
-                h.out_part[k] = d.partition[col.cell_off + best_i];
-            }
+            if (lane == 0) chosen[k & (TB_TILE - 1)] = best_i;
             if (small) {
                 const uint32_t from = best_i < WAVE ? cur.np[0] : cur.np[1];
                 want = (uint32_t) __shfl((int) from, best_i & (WAVE - 1), WAVE) >> 16;
             } else {
                 want = d.cell_np[col.cell_off + best_i] >> 16;
             }
+            if ((k & (TB_TILE - 1)) == 0) flush(k, min(K, k + TB_TILE)); /* (the tile [k, k + TB_TILE) is complete: the walk goes downwards) */
             col = col_m1;
             col_m1 = col_m2;
             cur = nxt;
