@@ -3225,7 +3225,7 @@ __global__ void __launch_bounds__(64) mrp_traceback_kernel(MrpBatchDev d, const 
  *   a column names its reads by the offsets of their profile bytes (read_byte_off); the read index comes from a binary search in
  *   the chunk's reads sorted by pool offset.
  */
-#define FRAG_T 512
+#define FRAG_T 1024
 #define FRAG_LDS_READS 6144 /* pool offsets of up to this many reads of a chunk are searched in LDS */
 static __device__ int frag_block_excl_scan(int v, int *total, int *lds /* [FRAG_T / 64 + 1] */) {
     const int lane = threadIdx.x & (WAVE - 1), wave = threadIdx.x / WAVE;
