@@ -863,26 +863,35 @@ __global__ void __launch_bounds__(256) mrp_layout_count_kernel(const PlanCol *__
     }
 }
 
-/* pass 2, one workgroup: where every hmm starts (cells padded to a multiple of 4 per hmm), the totals, the DevHmm records */
+/* pass 2, one workgroup: where every hmm starts (cells padded to a multiple of 4 per hmm), the totals, the DevHmm records.  A thread
+ * owns a run of consecutive hmms; the 1 024 partial sums are scanned inside the waves and across them through LDS (thread 0 used to add
+ * them up one after the other: 60 us on the launch path of every level, however small). */
+static __device__ __forceinline__ int64_t wave_incl_scan_i64(int64_t v, int lane) {
+#pragma unroll
+    for (int o = 1; o < WAVE; o <<= 1) { const int64_t t = __shfl_up(v, o, WAVE); if (lane >= o) v += t; }
+    return v;
+}
 __global__ void __launch_bounds__(1024) mrp_layout_scan_kernel(const PlanHmm *__restrict__ ph, int64_t n_hmms, LayoutOut o) {
-    __shared__ int64_t part[1024][6];
-    const int t = threadIdx.x;
+    __shared__ int64_t wsum[16][6];
+    const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
     const int64_t per = (n_hmms + 1023) / 1024, lo = (int64_t) t * per, hi = lo + per < n_hmms ? lo + per : n_hmms;
     int64_t s[6] = {0, 0, 0, 0, 0, 0};
     for (int64_t i = lo; i < hi; i++) {
         const LayoutTot x = o.tot[i];
         s[0] += (x.cells + 3) & ~3ll; s[1] += x.merge; s[2] += x.tiles_fast; s[3] += x.tiles_gen; s[4] += x.acells; s[5] += x.amerge;
     }
-    for (int q = 0; q < 6; q++) part[t][q] = s[q];
+    int64_t incl[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) { incl[q] = wave_incl_scan_i64(s[q], lane); if (lane == WAVE - 1) wsum[wave][q] = incl[q]; }
     __syncthreads();
-    if (t == 0) {
-        int64_t run[6] = {0, 0, 0, 0, 0, 0};
-        for (int i = 0; i < 1024; i++)
-            for (int q = 0; q < 6; q++) { const int64_t v = part[i][q]; part[i][q] = run[q]; run[q] += v; }
-        for (int q = 0; q < 6; q++) o.totals[q] = run[q];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        int64_t before = 0, all = 0;
+#pragma unroll
+        for (int w = 0; w < 16; w++) { const int64_t y = wsum[w][q]; if (w < wave) before += y; all += y; }
+        s[q] = before + incl[q] - s[q]; /* exclusive: what the threads before this one hold */
+        if (t == 0) o.totals[q] = all;
     }
-    __syncthreads();
-    for (int q = 0; q < 4; q++) s[q] = part[t][q];
     for (int64_t i = lo; i < hi; i++) {
         const LayoutTot x = o.tot[i];
         const PlanHmm h = ph[i];
