@@ -68,6 +68,8 @@ if has queue; then   # 7. the work queue from host memory: one batch beside the 
   ( cd $R && timeout -k 10 600 python3 tools/queue_long.py --chunks 4608 --skip-resident 1 2>&1 | grep "queue:" >> $O/queue_long.txt ) || exit 1
   ( cd $R && timeout -k 10 600 python3 tools/adaptor_probe.py --chunks 8 --threads 8 > $O/adaptor_probe.txt 2>&1 ) || exit 1
 fi
+# (alt_lib/ is listed in .gpurunignore since the end of round 4: to run this part again, build the two libraries -- tools/clk1_probe.sh,
+#  tools/clk2_probe.sh say how -- and take alt_lib/ out of .gpurunignore for that call)
 if has clocks && [ -f $R/alt_lib/libmargin_rphmm_clk1.so ]; then  # 8. in-kernel clocks of the prune kernel (development builds with -DPRUNE_EXP_CLOCK / -DPRUNE_EXP_CLOCK2)
   ( cd $R && bash tools/clk1_probe.sh r04 > $O/prune_role_clocks.txt 2>&1 && bash tools/clk2_probe.sh r04 > $O/prune_chain_sections.txt 2>&1 ) || exit 1
 fi
