@@ -74,6 +74,8 @@ void mrp_warn_hw_queues_once(int concurrent_batches) {
 }
 
 int mrp_context_set_grouped(mrp_context *ctx, int grouped) { const int was = ctx->grouped ? 1 : 0; ctx->grouped = grouped != 0; return was; }
+void mrp_context_set_concurrent_batches(mrp_context *ctx, int n) { ctx->concurrent_batches = n < 1 ? 1 : n; }
+int mrp_context_calls_sharing_device(const mrp_context *ctx) { return ctx->calls_sharing_device; }
 int64_t mrp_context_device_budget(mrp_context *ctx) { /* bytes the pools of the context's device may hold together */
     if (ctx->pool.device < 0 || hipSetDevice(ctx->device) != hipSuccess) return 0;
     const size_t b = DevPoolRegistry::get().budget_of(ctx->pool.device);
@@ -1068,7 +1070,14 @@ int mrp_batch_launch(mrp_batch *b) {
         HIP_TRY(hipStreamWaitEvent(a0, ctx->fork, 0));
         HIP_TRY(hipStreamWaitEvent(a1, ctx->fork, 0));
     }
-    const int t_wide = 512, t_mid = 512, t_narrow = 64; /* workgroup sizes of the recursion kernel's classes (measured; in the
+    /* Wide and mid hmms: 512 threads walk an hmm fastest, but the kernel's 128 registers then allow two workgroups to a CU.  When the
+     * concurrent batches of a call together bring more such workgroups than the device has slots for (the top levels of a
+     * 1 152-chunk call: 2 304 on 512 slots), 256 threads -- four to a CU -- get them through sooner: -3 % per call, A/B on one box;
+     * a single batch, whose hmms all find a slot, stays at 512 (+4 % with 256). */
+    const int64_t chains = 2 * (int64_t) (b->order_wide.size() + b->order_mid.size()) * (int64_t) ctx->concurrent_batches;
+    const int t_chain = chains > 2 * 256 ? 256 : 512;
+    const int t_wide = t_chain, t_mid = t_chain, t_narrow = 64;
+    /* workgroup sizes of the recursion kernel's classes (measured; in the
                                                          * concurrent batches of a call 64 to 512 threads for the mid class make no difference) */
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_wide.p, (int64_t) b->order_wide.size(), t_wide, b->max_merge_wide, s));
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_mid.p, (int64_t) b->order_mid.size(), t_mid, b->max_merge_mid, a0));

@@ -275,6 +275,8 @@ struct mrp_context {
      * eight batches of a call); a context on its own runs them side by side on two more. */
     hipStream_t aux[2] = {nullptr, nullptr};
     bool grouped = false;
+    int concurrent_batches = 1; /* how many batches of a mrp_phase_reads_many call run side by side on the device (this context's is one of them) */
+    int calls_sharing_device = 1; /* a work queue's lanes: this many calls run on the device at a time (set on the lane's context) */
     hipError_t side_streams(hipStream_t *a0, hipStream_t *a1) {
         if (grouped) { *a0 = *a1 = stream; return hipSuccess; }
         for (int i = 0; i < 2; i++)

@@ -370,6 +370,7 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
         }
         if (r != MRP_OK) { errs[(size_t) w] = mrp_last_error(); return r; }
         if (lanes > 1) (void) mrp_context_set_grouped(q->ctx[(size_t) w], 1); /* the lanes of a device are concurrent batches of it */
+        q->ctx[(size_t) w]->calls_sharing_device = n_batches > (int64_t) n_devices ? active_lanes : 1;
         lane_state[(size_t) w].caller_pool = mrp_pool_current(); /* (lane 0 may run on the caller's thread: its pool comes back at the end) */
         mrp_pool_adopt(q->pools[(size_t) d]);
         /* the lanes of a device share it: a call of a long queue runs 8 / lanes concurrent batches, the one call of a short

@@ -2509,6 +2509,7 @@ static int phase_many_once(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *
             if (!q->ctx) { q->rc = MRP_ERR_HIP; snprintf(q->err, sizeof(q->err), "%s", mrp_last_error()); }
         }
         const int was_grouped = mrp_context_set_grouped(ctx, 1); /* (the siblings always are) */
+        for (int g = 0; g < G; g++) if (grp[g].ctx) mrp_context_set_concurrent_batches(grp[g].ctx, G * mrp_context_calls_sharing_device(ctx));
         mrp_warn_hw_queues_once(G);
         for (int g = 1; g < G; g++)
             if (grp[g].ctx && pthread_create(&th[g], NULL, phase_group_main, &grp[g]) == 0) started[g] = 1;
@@ -2518,6 +2519,7 @@ static int phase_many_once(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *
             else if (grp[g].ctx) phase_group_main(&grp[g]); /* thread creation failed: run it here */
         }
         mrp_context_set_grouped(ctx, was_grouped);
+        for (int g = 0; g < G; g++) if (grp[g].ctx) mrp_context_set_concurrent_batches(grp[g].ctx, 1);
         for (int g = 0; g < G; g++) {
             phase_group *q = &grp[g];
             if (q->rc != MRP_OK && (rc == MRP_OK || rc == MRP_ERR_UNSUPPORTED)) rc = mrp_set_error(q->rc, "%s", q->err);

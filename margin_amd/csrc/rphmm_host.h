@@ -30,6 +30,8 @@ mrp_context *mrp_chunk_context(const mrp_chunk *chunk);
 int mrp_context_device(const mrp_context *ctx);
 /* the context is one of several concurrent batches of its device: no side streams (mrp_internal.h) */
 int mrp_context_set_grouped(mrp_context *ctx, int grouped); /* returns the previous setting */
+void mrp_context_set_concurrent_batches(mrp_context *ctx, int n); /* how many batches of the call share the device (launch shapes of the chain kernels) */
+int mrp_context_calls_sharing_device(const mrp_context *ctx); /* calls a work queue runs on the context's device at a time (1 outside a queue) */
 /* device memory of the context's pool: bytes cached for reuse, and what all pools of its device hold together (live + cached) */
 void mrp_context_pool_bytes(mrp_context *ctx, int64_t *cached, int64_t *device_held);
 void mrp_warn_hw_queues_once(int concurrent_batches); /* one stderr line per process when concurrent batches outnumber the hardware queues */

@@ -15,6 +15,8 @@ void mrp_chunk_host_view(const mrp_chunk *chunk, mrp_chunk_host *out) { *out = c
 mrp_context *mrp_chunk_context(const mrp_chunk *chunk) { (void) chunk; return (mrp_context *) 8; }
 int mrp_context_device(const mrp_context *ctx) { (void) ctx; return 0; }
 int mrp_context_set_grouped(mrp_context *ctx, int grouped) { (void) ctx; (void) grouped; return 0; }
+void mrp_context_set_concurrent_batches(mrp_context *ctx, int n) { (void) ctx; (void) n; }
+int mrp_context_calls_sharing_device(const mrp_context *ctx) { (void) ctx; return 1; }
 int64_t mrp_context_device_budget(mrp_context *ctx) { (void) ctx; return 0; }
 uint64_t mrp_context_oom_events(mrp_context *ctx) { (void) ctx; return 0; }
 void mrp_warn_hw_queues_once(int n) { (void) n; }
