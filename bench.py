@@ -100,7 +100,7 @@ def run_queue_child(args):
     cmd = [sys.executable, os.path.abspath(__file__), "--queue-child", "--chunks", str(args.chunks), "--sites", str(args.sites),
            "--coverage", str(args.coverage), "--queue-runs", str(args.queue_runs), "--queue-batch", str(args.queue_batch), "--threads", str(args.threads)]
     try:
-        res = subprocess.run(cmd, capture_output=True, text=True, timeout=900)
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
         for line in reversed(res.stdout.splitlines()):
             if line.startswith("{") and "queue_child" in line:
                 return json.loads(line)
