@@ -334,21 +334,21 @@ int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *co
         char *hb = (char *) blk->host.p;
         uint8_t *db = blk->dev.p;
         for (int g = 0; g < groups && e == hipSuccess; g++) { /* group by group: the copy of one runs beside the staging of the next */
-        const int64_t g_n = group_first[(size_t) g + 1] - group_first[(size_t) g];
-        mrp_parallel_for(g_n, 4, [&](int64_t k) {
-            const int64_t i = order[(size_t) (group_first[(size_t) g] + k)];
-            mrp_chunk *ch = out[i];
-            size_t o = at_of[(size_t) i];
-            auto put = [&](const void *src, size_t bytes) { const size_t at = o; if (bytes) memcpy(hb + at, src, bytes); o += al(bytes); return db + at; };
-            ch->dev.allele_number = (const uint32_t *) put(ch->allele_number.data(), 4 * ch->allele_number.size());
-            ch->dev.allele_offset = (const uint32_t *) put(ch->allele_offset.data(), 4 * ch->allele_offset.size());
-            ch->dev.sub_offset = (const uint32_t *) put(ch->sub_offset.data(), 4 * ch->sub_offset.size());
-            ch->dev.same_until = (const int32_t *) put(ch->same_until.data(), 4 * ch->same_until.size());
-            ch->dev.sub = (const uint16_t *) put(ch->sub.data(), 2 * ch->sub.size());
-            ch->dev.prior = (const uint16_t *) put(ch->prior.data(), 2 * ch->prior.size());
-            ch->pool_host = (const uint8_t *) (hb + o);
-            ch->dev.pool = (const uint8_t *) put(descs[i]->profile_pool, (size_t) ch->pool_bytes);
-        });
+            const int64_t g_n = group_first[(size_t) g + 1] - group_first[(size_t) g];
+            mrp_parallel_for(g_n, 4, [&](int64_t k) {
+                const int64_t i = order[(size_t) (group_first[(size_t) g] + k)];
+                mrp_chunk *ch = out[i];
+                size_t o = at_of[(size_t) i];
+                auto put = [&](const void *src, size_t bytes) { const size_t at = o; if (bytes) memcpy(hb + at, src, bytes); o += al(bytes); return db + at; };
+                ch->dev.allele_number = (const uint32_t *) put(ch->allele_number.data(), 4 * ch->allele_number.size());
+                ch->dev.allele_offset = (const uint32_t *) put(ch->allele_offset.data(), 4 * ch->allele_offset.size());
+                ch->dev.sub_offset = (const uint32_t *) put(ch->sub_offset.data(), 4 * ch->sub_offset.size());
+                ch->dev.same_until = (const int32_t *) put(ch->same_until.data(), 4 * ch->same_until.size());
+                ch->dev.sub = (const uint16_t *) put(ch->sub.data(), 2 * ch->sub.size());
+                ch->dev.prior = (const uint16_t *) put(ch->prior.data(), 2 * ch->prior.size());
+                ch->pool_host = (const uint8_t *) (hb + o);
+                ch->dev.pool = (const uint8_t *) put(descs[i]->profile_pool, (size_t) ch->pool_bytes);
+            });
             const size_t lo = off[(size_t) group_first[(size_t) g]], hi = off[(size_t) group_first[(size_t) g + 1]];
             if (hi > lo) e = hipMemcpyAsync(db + lo, hb + lo, hi - lo, hipMemcpyHostToDevice, ctx->stream);
             if (e == hipSuccess) e = hipEventRecord(blk->group_ready[(size_t) g], ctx->stream);
