@@ -129,6 +129,7 @@ struct LaneHooks {
     std::function<int(int)> begin;                     /* lane */
     std::function<int(int, int64_t)> prefetch;         /* lane, batch: may run on another thread than phase */
     std::function<int(int, int64_t)> phase;            /* lane, batch */
+    std::function<void(int, int64_t)> retire;          /* lane, batch: after phase AND after the prefetch that ran beside it has ended */
     std::function<void(int, int64_t)> discard;         /* lane, batch: a prefetched batch that will not be phased */
     std::function<void(int)> end;
 };
@@ -163,6 +164,7 @@ int run_lanes(int n_devices, int lanes, int active_lanes, int64_t n_batches, con
             }
             rc = hk.phase(w, cur);
             if (stager.joinable()) stager.join();
+            if (hk.retire) hk.retire(w, cur); /* (what the batch held goes back with no other thread of the lane at work) */
             if (inline_stage) prc = hk.prefetch(w, nb);
             if (rc != MRP_OK) { fail(rc); if (nb < n_batches && hk.discard) hk.discard(w, nb); break; }
             cur = nb < n_batches ? nb : -1;
@@ -327,7 +329,8 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
     const int64_t n_batches = (int64_t) plan.batch_off.size() - 1;
     if (stats) stats->batches = n_batches;
 
-    std::vector<std::string> errs((size_t) n_workers);
+    /* one error text per lane and ROLE: the call (phase) and the upload of the next batch (prefetch) run on two threads at a time */
+    std::vector<std::string> errs((size_t) n_workers), stage_errs((size_t) n_workers);
     struct PerDev { int64_t chunks = 0, units = 0, fallback = 0; double busy_ms = 0, stage_wait_ms = 0; };
     std::vector<PerDev> per((size_t) n_workers);
     std::mutex pool_mu;
@@ -338,7 +341,8 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
     /* the chunks of one batch on the device (uploads queued on the staging context's stream; the chunks carry the event that
      * ends the upload, the first device work that reads one waits for it) */
     struct Staged {
-        int64_t batch = -1, first = 0, count = 0;
+        std::atomic<int64_t> batch{-1}; /* (the call's thread looks its batch up while the stager fills the lane's OTHER slot) */
+        int64_t first = 0, count = 0;
         std::vector<mrp_chunk *> dch;
     };
     struct Lane { Staged st[2]; int n_staged = 0; void *caller_pool = nullptr; };
@@ -353,7 +357,7 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
     };
     auto staged_of = [&](int w, int64_t b) -> Staged * {
         Lane &L = lane_state[(size_t) w];
-        return L.st[0].batch == b ? &L.st[0] : (L.st[1].batch == b ? &L.st[1] : nullptr);
+        return L.st[0].batch.load() == b ? &L.st[0] : (L.st[1].batch.load() == b ? &L.st[1] : nullptr);
     };
     LaneHooks hk;
     hk.begin = [&](int w) {
@@ -385,8 +389,9 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
         Lane &L = lane_state[(size_t) w];
         const int parity = L.n_staged++ & 1;
         Staged *st = &L.st[parity];
-        st->batch = b; st->first = plan.batch_off[(size_t) b]; st->count = plan.batch_off[(size_t) b + 1] - st->first;
+        st->first = plan.batch_off[(size_t) b]; st->count = plan.batch_off[(size_t) b + 1] - st->first;
         st->dch.assign((size_t) st->count, nullptr);
+        st->batch.store(b);
         mrp_context *sc = q->stage_ctx[(size_t) w];
         sc->pool.reclaim(); /* the block of the batch before last was emptied after its call returned */
         mrp_chunk_block *&blk = q->blocks[(size_t) w * 2 + (size_t) parity];
@@ -396,7 +401,7 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
         /* (uploaded in the groups the call will deal the chunks to: its first batch starts on the device when an eighth of the bytes is there) */
         const int rc = blk ? mrp_chunk_block_create(sc, st->count, dl.data(), st->dch.data(), blk, mrp_phase_groups_for(q->ctx[(size_t) w], st->count))
                            : mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
-        if (rc != MRP_OK) errs[(size_t) w] = mrp_last_error();
+        if (rc != MRP_OK) stage_errs[(size_t) w] = mrp_last_error();
         if (timing) fprintf(stderr, "  [%7.1f] queue lane %d: batch %lld (%lld chunks) staged in %.1f ms\n", since(), w, (long long) b, (long long) st->count,
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ts0).count());
         return rc;
@@ -425,9 +430,15 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
         if (r == MRP_OK) { per[(size_t) w].chunks += count; per[(size_t) w].fallback += ps.resident ? ps.fallback_chunks : count; }
         if (timing) fprintf(stderr, "  [%7.1f] queue lane %d: batch %lld phased in %.1f ms\n", since(), w, (long long) b,
                             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
-        drop(cur);
         per[(size_t) w].busy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         return r;
+    };
+    /* the batch's chunks live on the lane's STAGING context, on which the stager thread makes the next batch's block while the call
+     * runs: they are destroyed after that thread has ended (one host thread per context, include/margin_rphmm.h) */
+    hk.retire = [&](int w, int64_t b) {
+        const auto t0 = std::chrono::steady_clock::now();
+        if (Staged *st = staged_of(w, b)) drop(st);
+        per[(size_t) w].busy_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
     };
     hk.end = [&](int w) { mrp_pool_adopt(lane_state[(size_t) w].caller_pool); };
     /* before the first thread of a worker is created (they inherit it): the CPUs next to its device */
@@ -449,6 +460,8 @@ int mrp_queue_phase_chunks(mrp_queue *q, int64_t n_chunks, const mrp_chunk_desc 
     if (rc != MRP_OK) {
         for (int64_t i = 0; i < n_chunks; i++) { mrp_phase_result_destroy(out[i]); out[i] = nullptr; }
         for (auto &e : errs)
+            if (!e.empty()) return mrp_set_error(rc, "%s", e.c_str());
+        for (auto &e : stage_errs)
             if (!e.empty()) return mrp_set_error(rc, "%s", e.c_str());
         return mrp_set_error(rc, "work queue stopped");
     }

@@ -198,16 +198,18 @@ static void shadow_pool_init(void) {
     for (int i = 0; i < SHADOW_CLASSES; i++) pthread_mutex_init(&g_shadow[i].mu, NULL);
     (void) pthread_key_create(&g_shadow_key, shadow_thread_exit);
 }
-static inline void shadow_thread_enter(void) {
+static inline void shadow_thread_enter(void) { /* every thread that holds blocks in its front is registered: its front is spilled when it ends */
+    if (__builtin_expect(t_shadow.keyed, 1)) return;
     pthread_once(&g_shadow_once, shadow_pool_init);
-    if (!t_shadow.keyed) { t_shadow.keyed = 1; (void) pthread_setspecific(g_shadow_key, &t_shadow); }
+    t_shadow.keyed = 1;
+    (void) pthread_setspecific(g_shadow_key, &t_shadow);
 }
 static void *shadow_alloc(size_t bytes, int *cls_out) {
     const int c = shadow_class(bytes);
     if (c >= SHADOW_CLASSES) { *cls_out = -1; return xmalloc(bytes); }
     *cls_out = c;
-    if (t_shadow.n[c] > 0) return t_shadow.slot[c][--t_shadow.n[c]];
     shadow_thread_enter();
+    if (t_shadow.n[c] > 0) return t_shadow.slot[c][--t_shadow.n[c]];
     /* refill: up to half a front from the shared stack */
     pthread_mutex_lock(&g_shadow[c].mu);
     while (t_shadow.n[c] < shadow_front(c) / 2 && g_shadow[c].n > 0) t_shadow.slot[c][t_shadow.n[c]++] = g_shadow[c].stack[--g_shadow[c].n];
@@ -221,8 +223,8 @@ static void *shadow_alloc(size_t bytes, int *cls_out) {
 }
 static void shadow_release(void *p, int cls) {
     if (cls < 0) { free(p); return; }
+    shadow_thread_enter(); /* (a thread that only ever releases -- a batch's own thread, the clean-up of a call -- used to keep its front for good) */
     if (t_shadow.n[cls] == shadow_front(cls)) { /* spill half of the front */
-        shadow_thread_enter();
         shadow_spill(cls, &t_shadow, shadow_front(cls) / 2);
     }
     t_shadow.slot[cls][t_shadow.n[cls]++] = p;
