@@ -10,13 +10,18 @@ ancestor model, trace back, genome fragments and the read bipartition -- everyth
 profile sequences on.  Inputs (profile bytes, site tables) are resident in HBM when the timed region starts.
 `value` = het-sites x reads of all chunks x steps / wall time: the rate at which chunks are actually phased.
 
-Beside it, as evidence for the kernels (not as the headline):
-  roofline      the forward/backward recursion kernel (the kernel that moves the algorithmic bytes of SURVEY.md 8d) replayed
-                over ALL sweeps of the same chunks as one batch: HIP-event duration per launch against its algorithmic bytes;
-                `traffic` = HBM bytes of that launch from the committed rocprofv3 PMC pass (profiles/r02/traffic.json);
-                `path` = the algorithmic bytes of all sweeps over the wall time of the real step.
+Beside it:
+  roofline      THE PATH: algorithmic bytes of every sweep of the timed step (24 B per cell, 32 B per merge cell, 8 B
+                per column, counted by the engine while the step runs) over the wall time of the step, against the HBM peak;
+                `traffic` = HBM bytes that really cross the interface per step, from the committed rocprofv3 PMC passes over every
+                kernel of a 96-chunk batch in situ (profiles/r05/path_traffic.json, stamped with the kernel sources' hash);
+                `insitu` = the same arithmetic per kernel family with the family's summed device time (HIP events of the step);
+                `replay` = kernel evidence only: the recursion kernel over ALL sweeps of 96 chunks as one dependency-free batch.
+  parity        the results of the LAST timed step for 16 of its chunks against the oracle's results for the same chunks (the
+                cpu_baseline leg computes them anyway); the shape legs sample 8 chunks each the same way
   queue         the same chunks through the host work queue from HOST memory (upload included, PCIe-inclusive rate)
-  shapes        the chunk shapes of BASELINE.json configs[2] (640 x ~130 sites) and configs[4] (HiFi, 2-4 alleles) through the same call
+  shapes        the chunk shapes of BASELINE.json configs[2] (640 x ~130 sites), configs[4] (HiFi, 2-4 alleles) through the same call, and
+                configs[3]/8: one GPU's share of a whole genome (3 900 chunks of ~130 sites) from HOST memory through the work queue
   alignment     the pair-HMM kernel family that produces the profile bytes
   cpu_baseline  the oracle (CPU restatement of the reference) on a bounded sample of the same chunks, N = 1 only
 
@@ -51,18 +56,21 @@ def parse_args():
     ap.add_argument("--coverage", type=float, default=30.0)
     ap.add_argument("--threads", type=int, default=int(os.environ.get("MRP_BENCH_THREADS", "0")))
     ap.add_argument("--phase-groups", type=int, default=0,
-                    help="concurrent batches inside mrp_phase_reads_many (0: the library's choice, one per 24 chunks up to 4)")
+                    help="concurrent batches inside mrp_phase_reads_many (0: the library's choice, one per 12 chunks up to 4, eight from 192 chunks on)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true", help="skip the kernel replay leg (it needs ~20 s of host work to record the sweeps)")
     ap.add_argument("--roofline-steps", type=int, default=20)
     ap.add_argument("--roofline-chunks", type=int, default=96, help="chunks whose sweeps the kernel replay leg records (host work: ~0.2 s per chunk)")
     ap.add_argument("--queue-runs", type=int, default=3, help="runs of the host-memory work queue leg (0: skip)")
-    ap.add_argument("--queue-batch", type=int, default=0, help="chunks per batch of the queue leg (0: the library's default, 96)")
+    ap.add_argument("--queue-batch", type=int, default=0, help="chunks per batch of the queue leg (0: the library's choice: one call per device up to 1 280 chunks of this kind, batches of at most 192 beyond)")
     ap.add_argument("--shape-runs", type=int, default=3, help="runs of the configs[2] / configs[4] shape legs (0: skip)")
     ap.add_argument("--align-chunks", type=int, default=4, help="chunks whose read x allele pairs the alignment leg scores (0: skip)")
     ap.add_argument("--align-runs", type=int, default=3)
     ap.add_argument("--sum-chunks", type=int, default=16, help="chunks whose sweeps the log-sum-exp leg replays (0: skip)")
+    ap.add_argument("--genome-chunks", type=int, default=3900, help="chunks of the configs[3]/8 leg: one GPU's eighth of a 31 000-chunk genome (0: skip)")
+    ap.add_argument("--parity-chunks", type=int, default=16, help="chunks of the timed step whose results are compared with the oracle's (needs the cpu_baseline leg)")
     ap.add_argument("--queue-child", action="store_true", help="(internal) run the work queue leg alone and print its runs as one JSON line")
+    ap.add_argument("--queue-device", type=int, default=0, help="(internal) device of the queue child")
     return ap.parse_args()
 
 
@@ -82,7 +90,7 @@ def queue_child(args):
     for c in chunks:
         capi.read_records(c)
     descs = capi.chunk_descs(chunks)
-    q = capi.Queue([0])
+    q = capi.Queue([args.queue_device])
     for _ in range(2):
         q.phase(chunks, params, chunks_per_batch=args.queue_batch, descs=descs, convert=False)
     runs = []
@@ -94,19 +102,82 @@ def queue_child(args):
     print(json.dumps(dict(queue_child=True, runs_ms=runs, batches=int(qst.batches), units=float(sum(c.units for c in chunks)))))
 
 
-def run_queue_child(args):
-    """parent side: None if the child could not be run (the in-process leg is then the only one)"""
+def run_queue_child(args, device):
+    """parent side -> (result dict or None, how the leg was run: "child" or "child-failed: <reason>")"""
     import subprocess
     cmd = [sys.executable, os.path.abspath(__file__), "--queue-child", "--chunks", str(args.chunks), "--sites", str(args.sites),
-           "--coverage", str(args.coverage), "--queue-runs", str(args.queue_runs), "--queue-batch", str(args.queue_batch), "--threads", str(args.threads)]
+           "--coverage", str(args.coverage), "--queue-runs", str(args.queue_runs), "--queue-batch", str(args.queue_batch), "--threads", str(args.threads),
+           "--queue-device", str(device)]
     try:
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=300)
-        for line in reversed(res.stdout.splitlines()):
-            if line.startswith("{") and "queue_child" in line:
-                return json.loads(line)
-    except Exception:
+    except subprocess.TimeoutExpired:
+        return None, "child-failed: no result within 300 s"
+    except OSError as e:
+        return None, f"child-failed: {type(e).__name__}: {e}"
+    if res.returncode != 0:
+        return None, f"child-failed: exit code {res.returncode}: {res.stderr.strip().splitlines()[-1][:200] if res.stderr.strip() else 'no stderr'}"
+    for line in reversed(res.stdout.splitlines()):
+        if line.startswith("{") and "queue_child" in line:
+            return json.loads(line), "child"
+    return None, "child-failed: no result line on stdout"
+
+
+def cpu_model():
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.lower().startswith("model name"):
+                    return line.split(":", 1)[1].strip()
+    except OSError:
         pass
-    return None
+    return "unknown"
+
+
+PHASE_KEYS = ("hap1", "hap2", "genotype", "ancestor", "support1", "support2", "genotype_probs", "hap_probs1", "hap_probs2")
+
+
+def same_phasing(a, b):
+    """haplotype strings, genotypes, per-site supports and probabilities, and the read bipartition in order: bit for bit"""
+    import numpy as np
+    return (a["ref_start"], a["length"]) == (b["ref_start"], b["length"]) and all((np.asarray(a[k]) == np.asarray(b[k])).all() for k in PHASE_KEYS) \
+        and a["reads1"] == b["reads1"] and a["reads2"] == b["reads2"]
+
+
+def oracle_phase_sample(chunks, params_dict, n_threads):
+    """the oracle (test infrastructure: the checker and the CPU baseline, never the product) over these chunks, one per thread ->
+    (results, wall seconds, [(seconds, seconds inside forward/backward, sweeps) per chunk])"""
+    from oracle import orc
+
+    def one(c):
+        oc = orc.OracleChunk(c)
+        t1 = time.perf_counter()
+        r = oc.phase(params_dict)
+        dt = time.perf_counter() - t1
+        oc.close()
+        return r, (dt, r["fb_seconds"], r["fb_calls"])
+
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(max_workers=max(1, n_threads)) as ex:
+        res = list(ex.map(one, chunks))
+    return [r[0] for r in res], time.perf_counter() - t0, [r[1] for r in res]
+
+
+def path_traffic(n_chunks_per_step, workload_sites):
+    """HBM bytes that really cross the interface per step: sum over EVERY kernel of one 96-chunk batch in situ of (2 x FETCH_SIZE +
+    WRITE_SIZE) x 1024 (separate --pmc passes; gfx950 tallies a wide coalesced read at one half, MI355X_MICROARCH.md), scaled by the
+    step's chunks.  Read from the committed summary of the round's profile run, which is stamped with the hash of the kernel sources
+    it was measured on: a stale file is ignored rather than quoted.  -> (bytes per step or None, source)"""
+    import hashlib
+    tpath = os.path.join(ROOT, "profiles", "r05", "path_traffic.json")
+    if not os.path.exists(tpath) or workload_sites != 2000:
+        return None, None
+    tj = json.load(open(tpath))
+    h = hashlib.sha256()
+    for f in ("mrp_kernels.hip", "mrp_engine_kernels.hip"):
+        h.update(open(os.path.join(ROOT, "margin_amd", "csrc", f), "rb").read())
+    if tj.get("kernel_sources_sha256") != h.hexdigest():
+        return None, "profiles/r05/path_traffic.json is older than the kernel sources: not quoted"
+    return float(tj["hbm_bytes_per_batch"]) * n_chunks_per_step / float(tj["chunks"]), tj.get("source")
 
 
 def insitu_rooflines(st):
@@ -166,9 +237,9 @@ def main():
     n_gpus = args.gpus
     # the work queue leg in a fresh process, BEFORE this one touches the GPU (a process that has initialised the GPU must not start
     # another program); one rank only: the ranks of a multi-GPU launch keep the in-process leg, whose runs they can bracket by barriers
-    fresh_queue = None
+    fresh_queue, queue_process = None, "in-process"
     if world == 1 and n_gpus == 1 and args.queue_runs > 0 and args.steps > 0 and "MRP_BENCH_DEVICES" not in os.environ:
-        fresh_queue = run_queue_child(args)
+        fresh_queue, queue_process = run_queue_child(args, local_rank)
     # one rank per GPU (the driver's launch), or one process that drives the N devices through the library's queue
     if world != 1 and world != n_gpus:
         sys.exit(f"bench.py: --gpus {n_gpus} but WORLD_SIZE={world}: launch one rank per GPU (torch.distributed.run --nproc-per-node {n_gpus}) "
@@ -236,29 +307,36 @@ def main():
     reduce_dev = "cuda" if (dist is not None and dist.get_backend() == "nccl") else None
 
     # ---- the timed region: every chunk phased end to end, K times -------------------------------------------------
+    # parity stamp: the results of the LAST timed step for the first chunks stay unconverted until the clock has stopped
+    n_parity = min(args.parity_chunks, len(chunks)) if (rank == 0 and not args.no_cpu_baseline and n_gpus == 1) else 0
     if single_process_multi:
         queue = capi.Queue(queue_devices)
         descs = capi.chunk_descs(chunks)
-        step = lambda: queue.phase(chunks, params, chunks_per_batch=args.queue_batch, descs=descs, convert=False)[1]
+        step = lambda defer=(): queue.phase(chunks, params, chunks_per_batch=args.queue_batch, descs=descs, convert=False, defer=defer)
     else:
         ctx = capi.Context(local_rank)
         ctx.set_phase_groups(args.phase_groups)
         dchunks = [capi.DeviceChunk.from_chunk(ctx, c) for c in chunks]
         many_args = capi.phase_many_args(dchunks, chunks)  # (the call's argument arrays: built once, not per step)
-        step = lambda: capi.phase_reads_many(ctx, dchunks, chunks, params, convert=False, prepared=many_args)[1]
+        step = lambda defer=(): capi.phase_reads_many(ctx, dchunks, chunks, params, convert=False, prepared=many_args, defer=defer)
     for _ in range(args.warmup):
         step()
     barrier()
     t0, c0 = time.perf_counter(), time.process_time()
-    st = None
-    for _ in range(args.steps):
-        st = step()
+    st, step_results, step_ms = None, None, []
+    for k_ in range(args.steps):
+        t_s = time.perf_counter()
+        step_results, st = step(range(n_parity) if k_ + 1 == args.steps else ())
+        step_ms.append(1e3 * (time.perf_counter() - t_s))
     barrier()
     elapsed, host_cpu = time.perf_counter() - t0, time.process_time() - c0
     elapsed, units_all = sharding.reduce_elapsed_and_units(dist, elapsed, units, device=reduce_dev)
-    # (--steps 0: the counter passes of tools/collect_profiles_r04.sh, which want the replay leg's launches alone in the trace)
+    gpu_sample = [step_results[i].get() for i in range(n_parity)] if step_results is not None else []
+    step_results = None
+    # (--steps 0: the counter passes of tools/collect_profiles_r05.sh, which want the replay leg's launches alone in the trace)
     value = units_all * args.steps / elapsed if args.steps > 0 else 0.0
     ms_per_step = 1e3 * elapsed / args.steps if args.steps > 0 else float("nan")
+    median_step_ms = sorted(step_ms)[len(step_ms) // 2] if step_ms else float("nan")
 
     cfg = dict(workload=f"configs[1]: synthetic 1 Mb chunk, {args.sites} het sites, {args.coverage:g}x ONT reads, shipped ONT haplotag params; "
                         f"{args.chunks} chunks per GPU phased end to end per step (mrp_phase_reads_many: all merge levels resident in HBM, final sweep, "
@@ -279,6 +357,24 @@ def main():
                                   note="device_ms: summed HIP-event time of the levels' kernels of the last step (the concurrent batches of a call add up: "
                                        "their kernels share the device); cross_ms / sweep_ms / prune_ms are the level's three event intervals (sweep_ms includes "
                                        "packing and the one-pass cross product + emission, prune_ms the compaction), the *_ms after them the same time by kernel family")
+        out["step_detail"]["median_step_ms"] = median_step_ms
+        # ---- roofline: THE PATH.  Algorithmic bytes of every sweep of the step (B = sum 24 C_k + 32 M_k + 8 per column; the
+        # profile bytes D_k Al_k, under one per cent, are left out), counted by the engine on the hmms it really built, over the wall
+        # time of the step.  (The engine's counters are those of the last step; every step phases the same chunks.)
+        if args.steps > 0:
+            alg_step = 24.0 * float(st.cells) + 32.0 * float(st.merge_cells) + 8.0 * float(st.columns)
+            ach = alg_step / (ms_per_step * 1e-3) / 1e9
+            traffic, traffic_src = path_traffic(args.chunks, args.sites)
+            out["roofline"] = dict(bound="hbm", kernel="the whole step: every kernel of mrp_phase_reads_many (dominant families under `insitu`)",
+                                   achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
+                                   frac_of_measured_traffic=(traffic / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                                   algorithmic_bytes_per_step=alg_step, ms_per_step=ms_per_step,
+                                   frac_note="frac = ALGORITHMIC bytes of the step (24 B per cell, 32 B per merge cell, 8 B per column, SURVEY.md 8d) / wall time of "
+                                             "the step / HBM peak: the path's figure, end to end.  traffic = HBM bytes that really cross the interface per step "
+                                             "(PMC, every kernel in situ; the merge cells' 32 B live in LDS and the level arrays hold one entry per complement pair, "
+                                             "so it is below the algorithmic credit).  insitu: per kernel family, its algorithmic bytes over its summed device time in "
+                                             "the step.  replay: kernel evidence only (a dependency-free launch of the recursion kernel), not the path",
+                                   insitu=insitu_rooflines(st))
         out["insitu"] = insitu_rooflines(st)
     elif st is not None:
         out["step_detail"] = dict(batches=int(st.batches), fallback_chunks=int(st.fallback_chunks),
@@ -324,20 +420,26 @@ def main():
         # the median run (every run is listed): a run that meets a cold allocator after another tenant's memory pressure takes seconds
         q_el = sorted(q_ms)[len(q_ms) // 2] * 1e-3
         q_el, q_units = sharding.reduce_elapsed_and_units(dist, q_el, units, device=reduce_dev)
+        # both legs by the same statistic: the MEDIAN run of the queue over the MEDIAN step of the resident leg (vs_resident); the ratio to the
+        # headline value (a mean over the steps, as the contract asks) is listed beside it
+        res_rate = units_all / (median_step_ms * 1e-3) if world == 1 and args.steps > 0 else value
         out["queue"] = dict(what="mrp_queue_phase_chunks: the same chunks from HOST memory (PCIe-inclusive): sorted by estimated cost, pulled in "
                                  "batches by one worker per device, the next batch's site tables and profile bytes uploaded on a second stream "
                                  "while the current batch is phased",
                             value=q_units / q_el, unit="het-site-reads/s", ms_per_run=1e3 * q_el, runs_ms=[round(x, 1) for x in q_ms],
-                            batches=int(qst.batches), runs=args.queue_runs, vs_resident=(q_units / q_el) / value)
+                            batches=int(qst.batches), runs=args.queue_runs, vs_resident=(q_units / q_el) / res_rate, vs_value=(q_units / q_el) / value,
+                            statistic="median run / median step of the resident leg", process=queue_process)
         if fresh_queue is not None and fresh_queue.get("runs_ms"):
             # the same leg from a process of its own (run_queue_child): that is what a caller of the queue sees; the in-process runs above
             # come second in a process whose first family of contexts -- closed by now -- was the resident leg's
             f_ms = sorted(fresh_queue["runs_ms"])[len(fresh_queue["runs_ms"]) // 2]
             same = dict(value=out["queue"]["value"], ms_per_run=out["queue"]["ms_per_run"], runs_ms=out["queue"]["runs_ms"], vs_resident=out["queue"]["vs_resident"],
                         note="the leg run in THIS process after the resident leg: the second family of contexts of a process runs 3-6 % slower at this size, whichever it is")
-            out["queue"].update(value=fresh_queue["units"] / (f_ms * 1e-3), ms_per_run=f_ms, runs_ms=[round(x, 1) for x in fresh_queue["runs_ms"]],
-                                batches=int(fresh_queue["batches"]), vs_resident=(fresh_queue["units"] / (f_ms * 1e-3)) / value,
-                                process="a process of its own, started before this one touched the GPU (a caller of the queue holds no other contexts)",
+            f_rate = fresh_queue["units"] / (f_ms * 1e-3)
+            out["queue"].update(value=f_rate, ms_per_run=f_ms, runs_ms=[round(x, 1) for x in fresh_queue["runs_ms"]],
+                                batches=int(fresh_queue["batches"]), vs_resident=f_rate / res_rate, vs_value=f_rate / value,
+                                process="child: a process of its own on the same device, started before this one touched the GPU (a caller of the queue holds no other "
+                                        "contexts); median of its runs after two warm-up calls",
                                 same_process=same)
         q.close()
         ctx = capi.Context(local_rank)
@@ -348,7 +450,16 @@ def main():
     if not single_process_multi:
         ctx.trim()
     if args.shape_runs > 0 and not single_process_multi:
-        def shape_leg(name, what, make, n):
+        do_parity = rank == 0 and not args.no_cpu_baseline and n_gpus == 1
+
+        def parity_of(cs, got, idx):
+            """the oracle over the sampled chunks against the device results of the leg's last call"""
+            ref, _, _ = oracle_phase_sample([cs[i] for i in idx], params_dict, min(16, os.cpu_count() or 1))
+            ok = sum(1 for r, i in zip(ref, idx) if same_phasing(got[i].get(), r))
+            return dict(identical=f"{ok}/{len(idx)}", chunks=[int(i) for i in idx],
+                        against="oracle/rphmm_oracle.c phasing the same chunks end to end (haplotype strings, genotypes, supports, probabilities, read bipartition)")
+
+        def shape_leg(name, what, make, n, sample=8):
             with ThreadPoolExecutor(max_workers=n_threads) as ex:
                 cs = list(ex.map(make, range(n)))
             for c in cs:
@@ -356,10 +467,11 @@ def main():
             dcs = [capi.DeviceChunk.from_chunk(ctx, c) for c in cs]
             u = float(sum(c.units for c in cs))
             capi.phase_reads_many(ctx, dcs, cs, params, convert=False)
+            idx = sorted({(j * max(1, n // sample)) % n for j in range(sample)}) if do_parity else []
             barrier()
             t1, c1 = time.perf_counter(), time.process_time()
-            for _ in range(args.shape_runs):
-                _, sst = capi.phase_reads_many(ctx, dcs, cs, params, convert=False)
+            for r_ in range(args.shape_runs):
+                got, sst = capi.phase_reads_many(ctx, dcs, cs, params, convert=False, defer=idx if r_ + 1 == args.shape_runs else ())
             barrier()
             el, cpu = time.perf_counter() - t1, time.process_time() - c1
             el, u_all = sharding.reduce_elapsed_and_units(dist, el, u, device=reduce_dev)
@@ -384,13 +496,60 @@ def main():
                                                      path=dict(algorithmic_bytes=alg_b, achieved=alg_b / (ms_call * 1e-3) / 1e9, unit="GB/s",
                                                                frac=alg_b / (ms_call * 1e-3) / 1e9 / HBM_PEAK_GBS),
                                                      insitu=insitu_rooflines(sst), latency=lat)
-        shape_leg("configs[2]", "chr20-like: 640 chunks of ~130 het sites (100 kb + margins), 30x ONT reads, one mrp_phase_reads_many call",
-                  lambda s_: synth.make_ont_chunk(seed=50_000 + 1000 * rank + s_, region_bp=130 * 500, n_sites=130, coverage=args.coverage), 640)
+            if idx:
+                out["shapes"][name]["parity"] = parity_of(cs, got, idx)
+            return cs, alg_b
+
+        small = lambda s_: synth.make_ont_chunk(seed=50_000 + 1000 * rank + s_, region_bp=130 * 500, n_sites=130, coverage=args.coverage)
+        shape_leg("configs[2]", "chr20-like: 640 chunks of ~130 het sites (100 kb + margins), 30x ONT reads, one mrp_phase_reads_many call", small, 640)
         shape_leg("configs[4]", "HiFi-like: 48 chunks of 2 000 sites, 35x reads N(18 kb, 3 kb), 1 % allele error, 2-4 alleles per site "
                                 "(shipped ONT haplotag parameters; phase_vcf mode differs in I/O only)",
                   lambda s_: synth.make_ont_chunk(seed=60_000 + 1000 * rank + s_, region_bp=args.sites * 500, n_sites=args.sites, coverage=35.0, median_len=18_000.0,
                                                   allele_error=0.01, allele_choices=(2, 3, 4), allele_probs=(0.85, 0.1, 0.05), length_model="normal",
                                                   normal_sd=3000.0), 48)
+        if args.genome_chunks > 0:
+            # configs[3]/8: one GPU's share of a whole genome -- BASELINE.json configs[3] is ~31 000 chunks of 100 kb (htsIntegration.c:151-179) over
+            # eight GPUs -- from HOST memory through the work queue on this device: what a `margin phase` run over a genome asks of one GPU.
+            # The bytes of the path come from one resident call over the same chunks (the same hmms; the queue's statistics do not carry them).
+            n_g = args.genome_chunks
+            with ThreadPoolExecutor(max_workers=n_threads) as ex:
+                gcs = list(ex.map(small, range(n_g)))
+            for c in gcs:
+                capi.read_records(c)
+            gu = float(sum(c.units for c in gcs))
+            gd = [capi.DeviceChunk.from_chunk(ctx, c) for c in gcs]
+            capi.phase_reads_many(ctx, gd, gcs, params, convert=False)
+            t1 = time.perf_counter()
+            _, gst = capi.phase_reads_many(ctx, gd, gcs, params, convert=False)
+            g_res_ms = 1e3 * (time.perf_counter() - t1)
+            for d_ in gd:
+                d_.close()
+            ctx.trim()
+            g_alg = 24.0 * float(gst.cells) + 32.0 * float(gst.merge_cells) + 8.0 * float(gst.columns)
+            gq = capi.Queue([local_rank])
+            gdescs = capi.chunk_descs(gcs)
+            gq.phase(gcs, params, chunks_per_batch=0, descs=gdescs, convert=False)
+            gidx = sorted({(j * max(1, n_g // 16)) % n_g for j in range(16)}) if do_parity else []
+            barrier()
+            g_ms, g_cpu0 = [], time.process_time()
+            for r_ in range(max(1, args.shape_runs)):
+                t1 = time.perf_counter()
+                ggot, gqst = gq.phase(gcs, params, chunks_per_batch=0, descs=gdescs, convert=False, defer=gidx if r_ + 1 == max(1, args.shape_runs) else ())
+                barrier()
+                g_ms.append(1e3 * (time.perf_counter() - t1))
+            g_cpu = (time.process_time() - g_cpu0) / len(g_ms)
+            g_el = sorted(g_ms)[len(g_ms) // 2] * 1e-3
+            g_el, gu_all = sharding.reduce_elapsed_and_units(dist, g_el, gu, device=reduce_dev)
+            out["shapes"]["configs[3]/8"] = dict(
+                what=f"one GPU's eighth of a whole genome: {n_g} chunks of ~130 het sites, 30x ONT reads, from HOST memory through mrp_queue_phase_chunks on one device "
+                     "(upload inside the timed region; batches cut by units, four lanes)",
+                chunks_per_gpu=n_g, value=gu_all / g_el, unit="het-site-reads/s", ms_per_run=1e3 * g_el, runs_ms=[round(x, 1) for x in g_ms], batches=int(gqst.batches),
+                fallback_chunks=int(gqst.fallback_chunks), host_cpu_s_per_run=g_cpu,
+                path=dict(algorithmic_bytes=g_alg, achieved=g_alg / g_el / 1e9, unit="GB/s", frac=g_alg / g_el / 1e9 / HBM_PEAK_GBS),
+                resident_call=dict(ms_per_call=g_res_ms, value=gu / (g_res_ms * 1e-3), note="the same chunks resident in HBM, ONE mrp_phase_reads_many call"))
+            if gidx:
+                out["shapes"]["configs[3]/8"]["parity"] = parity_of(gcs, ggot, gidx)
+            gq.close()
 
     # ---- kernel evidence: all sweeps of the same chunks replayed as one batch (rank 0) ---------------------------
     if not args.no_roofline and rank == 0 and not single_process_multi:
@@ -437,38 +596,36 @@ def main():
         alg = float(s.algorithmic_bytes)
         alg_sweep = 16.0 * C + 32.0 * M + 8.0 * K
         achieved = alg_sweep / (sweep_avg * 1e-3) / 1e9
-        # HBM bytes of one launch from the PMC counters: measured by tools/collect_profiles_r03.sh on this workload and stamped
+        # HBM bytes of one launch from the PMC counters: measured by tools/collect_profiles_r05.sh on this workload and stamped
         # with the hash of the kernel source it was measured on -- a stale file is ignored rather than quoted
         traffic, traffic_src = None, None
         import hashlib
         k_sha = hashlib.sha256(open(os.path.join(ROOT, "margin_amd", "csrc", "mrp_kernels.hip"), "rb").read()).hexdigest()
-        for tpath in (os.path.join(ROOT, "profiles", "r04", "traffic.json"),):
+        for tpath in (os.path.join(ROOT, "profiles", "r05", "traffic.json"), os.path.join(ROOT, "profiles", "r04", "traffic.json")):
             if traffic is None and os.path.exists(tpath):
                 tj = json.load(open(tpath))
                 if int(tj.get("chunks", -1)) == n_rec and tj.get("kernel_source_sha256") == k_sha:
                     traffic, traffic_src = float(tj["sweep_kernel_hbm_bytes_per_launch"]), tj.get("source")
         replay_ms = 1e3 * r_el / done
         rec_units = float(sum(c.units for c in chunks[:n_rec]))
-        out["roofline"] = dict(bound="hbm", kernel="mrp_sweep_i32_kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
-                               frac=achieved / HBM_PEAK_GBS, traffic=traffic, traffic_source=traffic_src,
-                               # the same launch priced on the bytes that really crossed the HBM interface (the 32 B per merge
-                               # cell of the algorithmic credit live in LDS): what the kernel sustains
-                               frac_of_measured_traffic=(traffic / (sweep_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
-                               frac_note="frac = ALGORITHMIC bytes (SURVEY.md 8d: 16 B per cell, 32 B per merge cell, 8 B per column) / kernel time / peak. "
-                                         "traffic = HBM bytes of the same launch from the PMC counters: below the algorithmic credit when the merge cells' "
-                                         "32 B stay in LDS, as they do (frac_of_measured_traffic prices those bytes instead)",
-                               algorithmic_bytes_per_launch=alg_sweep, kernel_ms=sweep_avg,
-                               what=f"all {sweeps} forward/backward sweeps of {n_rec} chunks (every merge level + final) recorded by the hashing path and "
-                                    f"replayed as ONE dependency-free batch: the kernels' throughput, not a phasing rate",
-                               moved_bytes_model=24.0 * C + 8.0 * M,
-                               replay=dict(ms_per_launch=replay_ms, units_per_s=rec_units / (replay_ms * 1e-3), planes_ms=planes_avg, emission_ms=emis_avg,
-                                           sweep_ms=sweep_avg, algorithmic_bytes=alg, frac=alg / (replay_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                           emission_kernel=dict(algorithmic_bytes=8.0 * C, achieved=8.0 * C / (emis_avg * 1e-3) / 1e9),
-                                           host_record_s=t_build),
-                               # the path's fraction: algorithmic bytes of every sweep of a step over the wall time of the REAL step
-                               path=dict(algorithmic_bytes=alg * args.chunks / n_rec, ms_per_step=ms_per_step,
-                                         achieved=alg * args.chunks / n_rec / (ms_per_step * 1e-3) / 1e9,
-                                         frac=alg * args.chunks / n_rec / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS))
+        replay = dict(kernel="mrp_sweep_i32_kernel", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS,
+                      traffic=traffic, traffic_source=traffic_src,
+                      # the same launch priced on the bytes that really crossed the HBM interface (the 32 B per merge
+                      # cell of the algorithmic credit live in LDS): what the kernel sustains
+                      frac_of_measured_traffic=(traffic / (sweep_avg * 1e-3) / 1e9 / HBM_PEAK_GBS) if traffic else None,
+                      frac_note="KERNEL EVIDENCE, NOT THE PATH: ALGORITHMIC bytes (SURVEY.md 8d: 16 B per cell, 32 B per merge cell, 8 B per column) of ONE "
+                                "dependency-free launch of the recursion kernel / its HIP-event time / peak.  traffic = HBM bytes of the same launch from the PMC counters",
+                      algorithmic_bytes_per_launch=alg_sweep, kernel_ms=sweep_avg,
+                      what=f"all {sweeps} forward/backward sweeps of {n_rec} chunks (every merge level + final) recorded by the hashing path and "
+                           f"replayed as ONE dependency-free batch on per-cell arrays: the kernel's throughput, not a phasing rate",
+                      moved_bytes_model=24.0 * C + 8.0 * M, ms_per_launch=replay_ms, units_per_s=rec_units / (replay_ms * 1e-3), planes_ms=planes_avg,
+                      emission_ms=emis_avg, sweep_ms=sweep_avg, algorithmic_bytes=alg, whole_launch_frac=alg / (replay_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      emission_kernel=dict(algorithmic_bytes=8.0 * C, achieved=8.0 * C / (emis_avg * 1e-3) / 1e9), host_record_s=t_build)
+        if "roofline" in out:
+            out["roofline"]["replay"] = replay
+        else:  # (--steps 0: the counter passes of the profile script run the replay alone)
+            out["roofline"] = dict(bound="hbm", kernel="mrp_sweep_i32_kernel (replay only: no step was timed)", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s",
+                                   frac=achieved / HBM_PEAK_GBS, traffic=traffic, replay=replay)
         big.close()
         for d_ in keep:
             d_.close()
@@ -560,26 +717,24 @@ def main():
         # CPU baseline: the oracle (C restatement of the reference's linked-list/hash implementation, -O3 -mpopcnt) phasing
         # one chunk per thread -- the reference's own parallel axis (phase.c:276) -- on a bounded sample of the same chunks,
         # end to end like the GPU value (tiling paths, every merge level with prune, final sweep, trace back, fragments).
-        from oracle import orc
         n_thr = max(1, min(16, os.cpu_count() or 1, len(chunks)))
-
-        def cpu_one(c):
-            oc = orc.OracleChunk(c)
-            t1 = time.perf_counter()
-            r = oc.phase(params_dict)
-            dt = time.perf_counter() - t1
-            oc.close()
-            return dt, r["fb_seconds"], r["fb_calls"]
-
-        t_cpu = time.perf_counter()
-        with ThreadPoolExecutor(max_workers=n_thr) as ex:
-            res = list(ex.map(cpu_one, chunks[:n_thr]))
-        t_cpu = time.perf_counter() - t_cpu
-        sample_units = sum(c.units for c in chunks[:n_thr])
+        n_cpu = max(n_thr, n_parity)
+        ref_res, t_cpu, res = oracle_phase_sample(chunks[:n_cpu], params_dict, n_thr)
+        sample_units = sum(c.units for c in chunks[:n_cpu])
         out["cpu_baseline"] = dict(value=sample_units / t_cpu, unit="het-site-reads/s", cores=n_thr, kind="port",
-                                   sample=f"{n_thr} of {len(chunks)} chunks, one per thread, phased end to end by the oracle: {t_cpu:.1f} s wall "
+                                   sample=f"{n_cpu} of {len(chunks)} chunks, one per thread, phased end to end by the oracle: {t_cpu:.1f} s wall "
                                           f"({sum(r[2] for r in res)} sweeps; {max(r[1] for r in res):.2f} s of the slowest thread inside forward/backward)",
-                                   per_core=chunks[0].units / res[0][0])
+                                   per_core=chunks[0].units / res[0][0], cpu_model=cpu_model(), host_cpus=os.cpu_count(),
+                                   usable_cpus=len(os.sched_getaffinity(0)))
+        # parity stamp of the TIMED STEP: its results for the same chunks (taken from the last timed step, converted after the clock stopped)
+        if gpu_sample:
+            ok = sum(1 for g_, r_ in zip(gpu_sample, ref_res) if same_phasing(g_, r_))
+            out["parity"] = dict(identical=f"{ok}/{len(gpu_sample)}", chunks=list(range(len(gpu_sample))),
+                                 what=f"results of the last timed step ({args.chunks} chunks in one mrp_phase_reads_many call) for its first {len(gpu_sample)} chunks against "
+                                      "oracle/rphmm_oracle.c phasing the same chunks end to end: haplotype strings, genotypes, supports, probabilities and the read "
+                                      "bipartition (HP tags) in order, bit for bit",
+                                 shapes={k: v["parity"]["identical"] for k, v in out.get("shapes", {}).items() if "parity" in v},
+                                 alignment=out.get("alignment", {}).get("cpu_baseline", {}).get("identical_to_gpu"))
     if rank == 0:
         print(json.dumps(out))
     if single_process_multi:

@@ -610,9 +610,23 @@ def phase_many_args(dchunks: Sequence[DeviceChunk], chunks: Sequence):
     return ch, rd, nr, keep
 
 
-def phase_reads_many(ctx: Context, dchunks: Sequence[DeviceChunk], chunks: Sequence, params: Params, convert: bool = True, prepared=None):
+class DeferredResult:
+    """an mrp_phase_result the caller converts later (outside a timed region): .get() -> result dict, once"""
+
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def get(self):
+        d = _phase_result_dict(self.ptr.contents)
+        load().mrp_phase_result_destroy(self.ptr)
+        self.ptr = None
+        return d
+
+
+def phase_reads_many(ctx: Context, dchunks: Sequence[DeviceChunk], chunks: Sequence, params: Params, convert: bool = True, prepared=None, defer=()):
     """mrp_phase_reads_many -> (list of result dicts, PhaseManyStats).  convert=False skips the Python copies of the
-    results (timing runs); prepared = phase_many_args(dchunks, chunks)."""
+    results (timing runs); the results of the chunks listed in `defer` come back as DeferredResult whatever `convert` says;
+    prepared = phase_many_args(dchunks, chunks)."""
     L = load()
     n = len(chunks)
     ch, rd, nr, _keep = prepared if prepared is not None else phase_many_args(dchunks, chunks)
@@ -620,7 +634,11 @@ def phase_reads_many(ctx: Context, dchunks: Sequence[DeviceChunk], chunks: Seque
     st = PhaseManyStats()
     _check(L.mrp_phase_reads_many(ctx.h, n, ch, rd, nr, C.byref(params), res, C.byref(st)))
     out = []
+    later = set(defer)
     for i in range(n):
+        if i in later:
+            out.append(DeferredResult(res[i]))
+            continue
         out.append(_phase_result_dict(res[i].contents) if convert else None)
         L.mrp_phase_result_destroy(res[i])
     return out, st
@@ -675,7 +693,7 @@ class Queue:
         self.h = C.c_void_p()
         _check(load().mrp_queue_create(C.cast(dev, C.c_void_p), len(devices), C.byref(self.h)))
 
-    def phase(self, chunks, params: Params, chunks_per_batch: int = 48, descs=None, convert: bool = True):
+    def phase(self, chunks, params: Params, chunks_per_batch: int = 48, descs=None, convert: bool = True, defer=()):
         L = load()
         n = len(chunks)
         arr, _keep = descs if descs is not None else chunk_descs(chunks)
@@ -683,7 +701,11 @@ class Queue:
         st = QueueStats()
         _check(L.mrp_queue_phase_chunks(self.h, n, arr, C.byref(params), chunks_per_batch, res, C.byref(st)))
         out = []
+        later = set(defer)
         for i in range(n):
+            if i in later:
+                out.append(DeferredResult(res[i]))
+                continue
             out.append(_phase_result_dict(res[i].contents) if convert else None)
             L.mrp_phase_result_destroy(res[i])
         return out, st
