@@ -16,7 +16,7 @@ PHASE_KEYS = ("hap1", "hap2", "genotype", "ancestor", "support1", "support2", "g
 REASONS = ["Same", "NoHet", "MissingConcordancy", "UnlikelyConcordancy", "Discordancy"]
 
 
-@pytest.mark.parametrize("seed,n_chunks,min_phred,ps_params", [(1, 4, 0, (1, 0.0, 0.5)), (6, 4, 3, (14, 0.02, 0.08)), (8, 3, 0, (12, 0.05, 0.05))])
+@pytest.mark.parametrize("seed,n_chunks,min_phred,ps_params", [(1, 4, 0, (1, 0.0, 0.5)), (6, 4, 3, (14, 0.02, 0.08)), (8, 4, 0, (12, 0.05, 0.05))])
 def test_adjacent_chunks_phase_stitch_and_phase_sets_equal_the_oracle_chain(gpu_ctx, orc, seed, n_chunks, min_phred, ps_params):
     from oracle import frame_oracle as fo
     overlap = 40
@@ -48,7 +48,6 @@ def test_adjacent_chunks_phase_stitch_and_phase_sets_equal_the_oracle_chain(gpu_
         assert (sw, counts) == (ref["switched"][c], ref["counts"][c]), c
         switched.append(sw)
         # the read sets stitching carries to the next chunk (addToHapReadsSeen, stitching.c:244-283)
-        assert stitch.size(1) == len(ref["stitcher"].readsInHap1) if c + 1 == len(chunks) else True
         for i in range(len(chunk.reads)):
             if hap[i] in (1, 2) and phred[i] > min_phred:
                 hap_of.setdefault(ids[c][i], []).append((hap[i] - 1) ^ int(sw))
@@ -58,7 +57,7 @@ def test_adjacent_chunks_phase_stitch_and_phase_sets_equal_the_oracle_chain(gpu_
     for name, p in ref["stitcher"].readsInHap2.items():
         assert stitch.lookup(2, name) == p
     stitch.close()
-    assert any(switched[1:]) or seed == 3  # the seeds were chosen so that stitching does flip a chunk
+    assert any(switched[1:])  # the seeds were chosen (on the oracle chain, tests/test_chain_oracle.py) so that stitching does flip a chunk
 
     variants = ch.stitched_variants(chunks, windows, ids, got, switched, overlap)
     sets = capi.phase_sets(variants, *ps_params)
