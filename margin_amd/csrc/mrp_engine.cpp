@@ -790,7 +790,7 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
         ENG_TRY(hipEventRecord(L->ev[0], s));
         ENG_TRY(hipEventRecord(L->ev[1], s));
         b->pre_sweep = [L](hipStream_t st) -> hipError_t {
-            return mrp_launch_cross_emit(L->d_cc.p, L->b->dev, L->d_err.p, L->d_col_hmm.p, L->d_err_hmm.p, st);
+            return mrp_launch_cross_emit(L->d_cc.p, L->b->dev, L->d_err.p, L->d_col_hmm.p, L->d_err_hmm.p, L->pp.max_cells, 2 * L->n_mini > L->n, st);
         };
     } else {
         b->pre_sweep = nullptr;

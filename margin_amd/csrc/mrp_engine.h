@@ -229,7 +229,8 @@ hipError_t mrp_launch_cross(const CrossCol *cols_dev, int64_t n_cols, uint64_t *
 /* Cross product and emission in one pass (merge levels without the ancestor substitution model): writes d.cell_np and
  * d.cell_cost from the parents' cells and the packed profile bytes (d.slot_bytes, d.slot_total); no partition array. */
 hipError_t mrp_launch_cross_emit(const CrossCol *cols_dev, const MrpBatchDev &d, int32_t *err, const int32_t *col_hmm_dev, int32_t *err_hmm,
-                                 hipStream_t stream);
+                                 int32_t level_max_cells /* largest column of the level by the static bounds: sizes the kernel's tables */,
+                                 bool mostly_narrow /* most hmms of the level hold at most 64 array entries per column */, hipStream_t stream);
 /* ccols_dev: the level's cross product descriptors, indexed like the batch's columns (the prune kernel enumerates the
  * cells linked to a kept merge cell from the parents' transition arrays) */
 hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, const PruneHmm *hmms_dev, int64_t n_hmms, PruneParams p,

@@ -27,6 +27,7 @@
 #include <stdint.h>
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 #include "mrp_engine.h"
@@ -207,9 +208,18 @@ hipError_t mrp_launch_cross(const CrossCol *cols_dev, int64_t n_cols, uint64_t *
 #ifndef XE_WAVES
 #define XE_WAVES 1
 #endif
-#ifndef XE_CAP
-#define XE_CAP 832 /* table dwords per wave: 200 parent cells (two pruned columns of 100) x 4 allele slots, 128 x 6; with 25 KB of LDS
-                    * per workgroup six workgroups = 24 waves share a CU (1 024 dwords: five; -9 % on the kernel) */
+/* Table dwords per wave, chosen per launch (dynamic LDS): XE_CAP_NARROW for the levels whose columns all take the table-free path
+ * below (200 parent cells x 4 allele slots would still fit: a column that needs the tables after all fills them several times) --
+ * 6.4 KB per one-wave workgroup, the registers' 20 waves per CU fit; XE_CAP_WIDE where two pruned columns of 100 cells meet: 8 slots
+ * = 4 biallelic sites per fill instead of 2 (a column of more sites walks its cells once per fill, adding to the costs already
+ * stored), 9.7 KB, 16 waves per CU.  Measured per 96-chunk batch, widest level / the two above it / the three below it:
+ * 832 dwords 1.39 / 0.65 + 0.48 / 0.37-0.39 ms; 1 248: 1.24 / 0.64 + 0.49 / 0.39-0.41; 1 664: 1.06 / 0.60 + 0.48 / 0.35-0.44;
+ * 2 496: 1.16 / 0.78 + 0.47 / 0.48-0.59; 3 328: 1.26 / 0.84 + 0.58 / 0.54-0.69. */
+#ifndef XE_CAP_NARROW
+#define XE_CAP_NARROW 832
+#endif
+#ifndef XE_CAP_WIDE
+#define XE_CAP_WIDE 1664
 #endif
 #ifndef XE_ROWS
 #define XE_ROWS 16 /* allele slots staged per table fill */
@@ -319,6 +329,7 @@ static __device__ __forceinline__ void xe_stage_transitions(const CrossCol &c, b
 }
 /* verify_side over a side of at most 128 parent cells held in registers (entry e = lane + 64 u; its complement e ^ 1 sits in
  * the neighbouring lane) */
+template <int NU = 2>
 static __device__ __forceinline__ int xe_verify_side(bool have, const uint64_t *P, const uint32_t *np, uint32_t C, uint32_t depth, uint32_t M_out,
                                                      uint32_t M_in, uint32_t out_kind, uint32_t in_kind, bool inv, bool out_paired, bool in_paired,
                                                      int lane) {
@@ -328,7 +339,7 @@ static __device__ __forceinline__ int xe_verify_side(bool have, const uint64_t *
     if (cells_paired && (C & 1u)) return MRP_ENGINE_ERR_STRUCTURE;
     const uint64_t acc = accept_mask(depth);
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < NU; u++) {
         const uint32_t e = (uint32_t) lane + (uint32_t) u * WAVE;
         const uint32_t v = np[u], nx = v & 0xFFFFu, pv = v >> 16;
         const uint32_t v_other = (uint32_t) __shfl_xor((int) v, 1, WAVE);
@@ -363,6 +374,99 @@ static __device__ __forceinline__ uint32_t xe_np(uint2 a, uint2 b) { /* next | p
     return nxt | (prv << 16);
 }
 
+/* ---- narrow columns: at most 64 array entries and at most 64 parent cells per side (the first merge levels: a few cells per
+ * column, long runs of sites) ----
+ * No tables: entry `lane` of the column is a cell (c1, c2) whose merged partition P the lane holds; its cost over one allele slot is
+ * getLogProbOfAllele (emissions.c:125-138) evaluated directly, Sum_w v_dot4(bytes of reads 4w..4w+3, bits of P expanded to 0/1
+ * bytes).  The packed bytes of a slot are the same 64 bytes for every lane.  A chunk of up to 16 slots (whole sites) is requested
+ * at once: FOUR coalesced loads -- lane l of load g holds dword l & 15 of slot 4 g + (l >> 4) -- and one for the byte sums, all in
+ * flight together (one round trip per 16 slots; scalar loads, tried first, return out of order and the compiler waits for each
+ * slot's row in turn); a slot's words then reach every lane through v_readlane (wave-uniform operands of the v_dot4).  Per site the
+ * minima over its alleles of hap1 and of hap2 = total - hap1 (emissions.c:144-154, :174-185, :205-207).  With the table kernel a
+ * column of the first merge levels cost ~1 900 instructions whatever its cells (two table fills through LDS, transition terms, a
+ * grid walk), two thirds of them on the scalar unit; this path has neither LDS traffic nor a second pass. */
+/* The same cost with the lanes along the SLOTS (biallelic sites, a column of few cells and many sites: the first merge level's
+ * columns hold two to four cells and up to sixty sites): lane l keeps the packed bytes of slot l of a chunk of 64 -- every lane its own
+ * 16 x NW4 bytes, the wave a contiguous 4 KB --; for each cell of the column (its partition broadcast through a scalar pair) one
+ * v_dot4 chain per lane gives hap1 of all 64 slots at once, the two alleles of a site sit in neighbouring lanes (one DPP swap for the
+ * minima) and the sites are summed across the wave.  Per cell and 32 sites some 35 instructions, where a lane per cell takes 17 per
+ * slot.  Returns, in lane e, the cost of cell e over the chunk. */
+static __device__ __forceinline__ uint32_t xe_wave_sum_u32(uint32_t v) {
+    int x = (int) v;
+    x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true);  /* row_shr:1 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true);
+    x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); /* row_bcast:15 into rows 1 and 3 */
+    x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); /* row_bcast:31 into rows 2 and 3 */
+    return (uint32_t) __builtin_amdgcn_readlane(x, WAVE - 1);
+}
+template <int NW4>
+static __device__ __forceinline__ uint32_t xe_slots_chunk(const uint32_t *__restrict__ slot_bytes, const uint32_t *__restrict__ slot_total, int64_t slot0,
+                                                          uint32_t nsl, uint32_t U, uint64_t P, int lane) {
+    const bool have = (uint32_t) lane < nsl;
+    const uint4 *rp = reinterpret_cast<const uint4 *>(slot_bytes + (slot0 + (have ? (uint32_t) lane : 0u)) * 16);
+    uint4 row[NW4];
+#pragma unroll
+    for (int k = 0; k < NW4; k++) row[k] = rp[k];
+    const uint32_t tot = slot_total[slot0 + (have ? (uint32_t) lane : 0u)];
+    uint32_t mine = 0;
+    for (uint32_t e = 0; e < U; e++) { /* wave-uniform */
+        const uint64_t Pe = ((uint64_t) (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) (P >> 32), (int) e) << 32) |
+                            (uint32_t) __builtin_amdgcn_readlane((int) (uint32_t) P, (int) e);
+        uint32_t t = 0;
+#pragma unroll
+        for (int k = 0; k < NW4; k++) {
+            const uint32_t bits = (uint32_t) (Pe >> (16 * k)) & 0xFFFFu; /* scalar: the expansion runs on the scalar unit */
+            t = __builtin_amdgcn_udot4(row[k].x, ((bits & 0xFu) * 0x00204081u) & 0x01010101u, t, false);
+            t = __builtin_amdgcn_udot4(row[k].y, (((bits >> 4) & 0xFu) * 0x00204081u) & 0x01010101u, t, false);
+            t = __builtin_amdgcn_udot4(row[k].z, (((bits >> 8) & 0xFu) * 0x00204081u) & 0x01010101u, t, false);
+            t = __builtin_amdgcn_udot4(row[k].w, ((bits >> 12) * 0x00204081u) & 0x01010101u, t, false);
+        }
+        const uint32_t h2 = tot - t;
+        const uint32_t o1 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t, 0xB1, 0xf, 0xf, false);  /* quad_perm [1,0,3,2]: the site's other allele */
+        const uint32_t o2 = (uint32_t) __builtin_amdgcn_update_dpp(0, (int) h2, 0xB1, 0xf, 0xf, false);
+        const uint32_t v = (have && (lane & 1) == 0) ? min(t, o1) + min(h2, o2) : 0u;
+        const uint32_t sum = xe_wave_sum_u32(v);
+        mine += (uint32_t) lane == e ? sum : 0u;
+    }
+    return mine;
+}
+
+template <int NW4>
+static __device__ __forceinline__ uint32_t xe_narrow_chunk(const uint32_t *__restrict__ slot_bytes, const uint32_t *__restrict__ slot_total, int64_t slot0,
+                                                           uint32_t nsl, uint32_t ends, const uint32_t (&sel)[16], int lane, uint32_t &m1, uint32_t &m2) {
+    const uint32_t grp = (uint32_t) lane >> 4, dw = (uint32_t) lane & 15u;
+    uint32_t r[4] = {0u, 0u, 0u, 0u};
+#pragma unroll
+    for (int g = 0; g < 4; g++)
+        if (4u * (uint32_t) g < nsl) r[g] = slot_bytes[(slot0 + min(4u * (uint32_t) g + grp, nsl - 1u)) * 16 + dw];
+    const uint32_t tot_v = slot_total[slot0 + min((uint32_t) lane, nsl - 1u)];
+    uint32_t cost = 0;
+#pragma unroll
+    for (int g = 0; g < 4; g++) {
+        if (4u * (uint32_t) g < nsl) { /* wave-uniform */
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                const uint32_t sidx = 4u * (uint32_t) g + (uint32_t) j;
+                const bool valid = sidx < nsl;
+                const bool last = valid && ((ends >> sidx) & 1u) != 0u;
+                uint32_t t = 0;
+#pragma unroll
+                for (int k = 0; k < 4 * NW4; k++) t = __builtin_amdgcn_udot4((uint32_t) __builtin_amdgcn_readlane((int) r[g], j * 16 + k), sel[k], t, false);
+                const uint32_t tt = (uint32_t) __builtin_amdgcn_readlane((int) tot_v, g * 4 + j);
+                const uint32_t n1 = min(m1, t), n2 = min(m2, tt - t);
+                m1 = valid ? n1 : m1;
+                m2 = valid ? n2 : m2;
+                cost += last ? m1 + m2 : 0u;
+                m1 = last ? 0xFFFFFFFFu : m1;
+                m2 = last ? 0xFFFFFFFFu : m2;
+            }
+        }
+    }
+    return cost;
+}
+
 #ifdef XE_CLOCK /* development: where a wave of mrp_cross_emit_kernel spends its time (summed over the waves of a launch, clock ticks) */
 #define XE_T(i) do { const uint64_t t_ = __builtin_amdgcn_s_memtime(); xe_sec[i] += t_ - xe_t; xe_t = t_; } while (0)
 #else
@@ -374,21 +478,35 @@ struct __attribute__((packed, aligned(4))) xe_u32x2 { uint32_t x, y; };
 #ifndef XE_MIN_WAVES
 #define XE_MIN_WAVES 1
 #endif
-__global__ void __launch_bounds__(XE_WAVES * WAVE, XE_MIN_WAVES) mrp_cross_emit_kernel(const CrossCol *__restrict__ ccols, const DevCol *__restrict__ cols,
+#ifndef XE_FAST2_ON
+#define XE_FAST2_ON 1 /* (development: 0 keeps the general grid walk for biallelic unit levels) */
+#endif
+#ifndef XE_SLOTS_ON
+#define XE_SLOTS_ON 1 /* (development: 0 keeps a lane per cell for every narrow column) */
+#endif
+#ifndef XE_NARROW_ON
+#define XE_NARROW_ON 1 /* (development: 0 sends every column through the tables) */
+#endif
+/* MODE 1: the narrow columns only (no tables, no LDS, two thirds of the registers: eight waves per SIMD wait for their descriptors and
+ * parent cells side by side); MODE 2: the columns that need the tables; a wave that meets a column of the other kind ends behind the
+ * column's descriptor.  MODE 0: both kinds in one launch.  The first merge levels, whose hmms are nearly all small, take MODE 1 (and
+ * MODE 2 behind it unless the static bounds say every column is narrow); the levels of wide columns take MODE 0 -- a pass of waves
+ * that only skip costs them 70-90 us per 190 000 columns, more than their few narrow columns gain from the leaner kernel. */
+template <int MODE>
+__global__ void __launch_bounds__(XE_WAVES * WAVE, MODE == 1 ? 8 : XE_MIN_WAVES) mrp_cross_emit_kernel(const CrossCol *__restrict__ ccols, const DevCol *__restrict__ cols,
                                                                          const DevChunk *__restrict__ chunks, int64_t n_cols,
                                                                          const uint32_t *__restrict__ slot_bytes,
                                                                          const uint32_t *__restrict__ slot_total,
                                                                          uint32_t *__restrict__ cell_np, uint32_t *__restrict__ cell_cost,
                                                                          int32_t *__restrict__ err, const int32_t *__restrict__ col_hmm,
-                                                                         int32_t *__restrict__ err_hmm) {
-    __shared__ __attribute__((aligned(16))) uint32_t tab_all[XE_WAVES][XE_CAP];
-    __shared__ __attribute__((aligned(16))) uint32_t row_all[XE_WAVES][XE_ROWS * 16];
-    __shared__ uint32_t tot_all[XE_WAVES][XE_ROWS];
-    __shared__ __attribute__((aligned(16))) uint2 tr_all[XE_WAVES][256]; /* transition terms of the parent cells, see xe_stage_transitions */
+                                                                         int32_t *__restrict__ err_hmm, uint32_t cap) {
+    /* per wave: tables [cap] | packed bytes of a fill [XE_ROWS * 16] | their byte sums [XE_ROWS] | transition terms of the parent cells
+     * [256 uint2], see xe_stage_transitions */
+    extern __shared__ __attribute__((aligned(16))) uint32_t xe_lds[];
     const int lane = threadIdx.x & (WAVE - 1);
     const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / WAVE));
-    uint32_t *tab = tab_all[wave], *rowbuf = row_all[wave], *totbuf = tot_all[wave];
-    uint2 *tra = tr_all[wave], *trb = tr_all[wave] + 128;
+    uint32_t *tab = xe_lds + (size_t) wave * (cap + XE_ROWS * 16 + XE_ROWS + 512), *rowbuf = tab + cap, *totbuf = rowbuf + XE_ROWS * 16;
+    uint2 *tra = reinterpret_cast<uint2 *>(totbuf + XE_ROWS), *trb = tra + 128;
 #ifdef XE_CLOCK
     uint64_t xe_sec[8] = {0, 0, 0, 0, 0, 0, 0, 0}, xe_t = __builtin_amdgcn_s_memtime();
 #endif
@@ -411,10 +529,115 @@ __global__ void __launch_bounds__(XE_WAVES * WAVE, XE_MIN_WAVES) mrp_cross_emit_
         auto np_entry = [&](uint32_t v) -> uint32_t { return ((v & 0xFFFFu) >> nsh) | (((v >> 16) >> psh) << 16); };
         /* slots per table fill: rows of the tables are padded to a multiple of four slots, the staging buffer holds XE_ROWS */
         const uint32_t Cs = C1 + C2;
-        const uint32_t slot_room = (Cs >= 1u && Cs <= 256u) ? min((uint32_t) XE_ROWS, (XE_CAP / Cs) & ~3u) : 0u;
+        const uint32_t slot_room = (Cs >= 1u && Cs <= 256u) ? min((uint32_t) XE_ROWS, (cap / Cs) & ~3u) : 0u;
         const uint32_t A_uni = (dc.flags >> 8) & 0xFFu; /* allele count shared by the column's sites, 0 if they differ (layout kernel) */
         const int w4_all = (dc.depth + 15) >> 4;
         const int w4_a = ((int) c.d1 + 15) >> 4, w4_b = (int) c.d1 >> 4;
+        /* narrow column: every array entry and every parent cell has a lane of its own */
+        const bool narrow = (C >> ush) <= (uint32_t) WAVE && C1 <= (uint32_t) WAVE && C2 <= (uint32_t) WAVE && XE_NARROW_ON;
+        if (MODE == 1 ? !narrow : (MODE == 2 && narrow)) continue;
+        if (MODE != 2 && narrow) {
+            const bool have_a = c.a_part != nullptr, have_b = c.b_part != nullptr;
+            const bool ia = have_a && (uint32_t) lane < C1, ib = have_b && (uint32_t) lane < C2;
+            uint32_t npa[2] = {ia ? c.a_np[lane] : 0u, 0u}, npb[2] = {ib ? c.b_np[lane] : 0u, 0u};
+            uint64_t Pa[2] = {ia ? c.a_part[lane] : 0ull, 0ull}, Pb[2] = {ib ? c.b_part[lane] : 0ull, 0ull};
+            XE_T(1);
+            int bad = xe_verify_side<1>(have_a, Pa, npa, C1, c.d1, c.Ma, c.Pa, c.out_a, c.in_a, inv,
+                                        (c.flags & MRP_XF_OUT_A_PAIRED) != 0, (c.flags & MRP_XF_IN_A_PAIRED) != 0, lane);
+            bad |= xe_verify_side<1>(have_b, Pb, npb, C2, c.d2, c.Mb, c.Pb, c.out_b, c.in_b, inv,
+                                     (c.flags & MRP_XF_OUT_B_PAIRED) != 0, (c.flags & MRP_XF_IN_B_PAIRED) != 0, lane);
+            if ((!c.a_part && C1 != 1u) || (!c.b_part && C2 != 1u) || (int) c.d1 + (int) c.d2 != dc.depth) bad |= MRP_ENGINE_ERR_RANGE;
+            if (bad) { atomicOr(err, bad); atomicOr(err_hmm + col_hmm[col], bad); }
+            const uint32_t U = C >> ush;
+            if (__any(bad != 0)) { /* the level is discarded by the host; keep the arrays defined meanwhile */
+                if ((uint32_t) lane < U) { cell_np[c.x_cell_off + lane] = 0u; cell_cost[c.x_cell_off + lane] = 0u; }
+                continue;
+            }
+            /* the lane's cell, its parents' partitions and transitions (from the lanes that hold them) */
+            uint32_t c1, c2;
+            cross_cell(((uint32_t) lane < U ? (uint32_t) lane : 0u) << ush, C2, inv, a_cells_paired, b_cells_paired, c1, c2);
+            const uint32_t n1 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (c1 << 2), (int) npa[0]);
+            const uint32_t n2 = (uint32_t) __builtin_amdgcn_ds_bpermute((int) (c2 << 2), (int) npb[0]);
+            const uint64_t p1 = ((uint64_t) (uint32_t) __builtin_amdgcn_ds_bpermute((int) (c1 << 2), (int) (uint32_t) (Pa[0] >> 32)) << 32) |
+                                (uint32_t) __builtin_amdgcn_ds_bpermute((int) (c1 << 2), (int) (uint32_t) Pa[0]);
+            const uint64_t p2 = ((uint64_t) (uint32_t) __builtin_amdgcn_ds_bpermute((int) (c2 << 2), (int) (uint32_t) (Pb[0] >> 32)) << 32) |
+                                (uint32_t) __builtin_amdgcn_ds_bpermute((int) (c2 << 2), (int) (uint32_t) Pb[0]);
+            const uint64_t P = c.d1 < 64 ? (p1 | (p2 << c.d1)) : p1; /* mergePartitionsOrMasks, partitions.c:21-28 */
+            const uint32_t npv = np_entry(cross_np(c, inv, c1, c2, n1, n2));
+            XE_T(2);
+            /* the sites in chunks of whole sites of at most 16 slots; `ends` marks the last allele slot of every site */
+            const uint32_t *aoff = A_uni ? nullptr : chunks[dc.chunk].allele_offset + dc.site_start;
+            uint32_t sel[16];
+#pragma unroll
+            for (int w = 0; w < 16; w++) sel[w] = ((uint32_t) ((P >> (4 * w)) & 0xFull) * 0x00204081u) & 0x01010101u;
+            uint32_t cost = 0, site0 = 0, sl0 = 0, m1 = 0xFFFFFFFFu, m2 = 0xFFFFFFFFu;
+            if (A_uni == 2u && 2u * U < 2u * (uint32_t) dc.n_sites && XE_SLOTS_ON) { /* few cells, many sites: lanes along the slots */
+                const uint32_t n_slots = 2u * (uint32_t) dc.n_sites;
+                for (uint32_t s0 = 0; s0 < n_slots; s0 += WAVE) {
+                    const uint32_t nsl = min((uint32_t) WAVE, n_slots - s0);
+                    const int64_t sg = dc.slot_off + s0;
+                    switch (w4_all) {
+                    case 0: case 1: cost += xe_slots_chunk<1>(slot_bytes, slot_total, sg, nsl, U, P, lane); break;
+                    case 2: cost += xe_slots_chunk<2>(slot_bytes, slot_total, sg, nsl, U, P, lane); break;
+                    case 3: cost += xe_slots_chunk<3>(slot_bytes, slot_total, sg, nsl, U, P, lane); break;
+                    default: cost += xe_slots_chunk<4>(slot_bytes, slot_total, sg, nsl, U, P, lane); break;
+                    }
+                }
+                site0 = (uint32_t) dc.n_sites;
+            }
+            while (site0 < (uint32_t) dc.n_sites) {
+                uint32_t cnt, nsl, ends = 0;
+                if (A_uni && A_uni <= 16u) {
+                    cnt = min((uint32_t) dc.n_sites - site0, 16u / A_uni);
+                    nsl = cnt * A_uni;
+                    if (A_uni == 2u) ends = 0xAAAAu & ((1u << nsl) - 1u);
+                    else for (uint32_t s_ = 1; s_ <= cnt; s_++) ends |= 1u << (s_ * A_uni - 1u);
+                } else { /* lane s looks at the end of site site0 + s */
+                    const uint32_t *ao = A_uni ? chunks[dc.chunk].allele_offset + dc.site_start : aoff;
+                    const uint32_t base = ao[site0];
+                    const bool have = site0 + (uint32_t) lane < (uint32_t) dc.n_sites;
+                    const uint32_t end = have ? ao[site0 + lane + 1] - base : 0xFFFFFFFFu;
+                    const bool fits = have && end <= 16u;
+                    cnt = (uint32_t) __popcll(__ballot(fits));
+                    nsl = cnt ? (uint32_t) __builtin_amdgcn_readlane((int) end, (int) cnt - 1) : 0u;
+                    ends = (fits && end >= 1u) ? 1u << (end - 1u) : 0u;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) ends |= (uint32_t) __shfl_xor((int) ends, o, WAVE);
+                    if (cnt == 0) { /* a site of more than 16 alleles: slot by slot, the site ends with its last slot */
+                        cnt = 1u;
+                        nsl = ao[site0 + 1] - base;
+                        const int64_t sg = dc.slot_off + sl0;
+                        for (uint32_t a_ = 0; a_ < nsl; a_++) {
+                            const uint32_t t = slot_dot(slot_bytes + (sg + a_) * 16, P, 0, w4_all);
+                            m1 = min(m1, t);
+                            m2 = min(m2, slot_total[sg + a_] - t);
+                        }
+                        cost += m1 + m2; m1 = 0xFFFFFFFFu; m2 = 0xFFFFFFFFu;
+                        site0 += 1u; sl0 += nsl;
+                        continue;
+                    }
+                }
+                nsl = (uint32_t) __builtin_amdgcn_readfirstlane((int) nsl); /* (wave-uniform by construction; said again for the compiler) */
+                ends = (uint32_t) __builtin_amdgcn_readfirstlane((int) ends);
+                const int64_t sg = dc.slot_off + sl0;
+                switch (w4_all) {
+                case 0: case 1: cost += xe_narrow_chunk<1>(slot_bytes, slot_total, sg, nsl, ends, sel, lane, m1, m2); break;
+                case 2: cost += xe_narrow_chunk<2>(slot_bytes, slot_total, sg, nsl, ends, sel, lane, m1, m2); break;
+                case 3: cost += xe_narrow_chunk<3>(slot_bytes, slot_total, sg, nsl, ends, sel, lane, m1, m2); break;
+                default: cost += xe_narrow_chunk<4>(slot_bytes, slot_total, sg, nsl, ends, sel, lane, m1, m2); break;
+                }
+                site0 += cnt;
+                sl0 += nsl;
+            }
+            XE_T(3);
+            if ((uint32_t) lane < U) {
+                cell_np[c.x_cell_off + lane] = npv;
+                cell_cost[c.x_cell_off + lane] = cost;
+            }
+            XE_T(4);
+            continue;
+        }
+        if constexpr (MODE != 1) {
         /* Everything the column needs from HBM is requested HERE, in one round trip behind the two descriptors: the parents'
          * transitions and partitions (parent cells lane and lane + 64 of either side stay in the lane's registers: the pair
          * order check, the transition terms and the table rows all start from them) and, when the column's sites share their
@@ -568,9 +791,81 @@ __global__ void __launch_bounds__(XE_WAVES * WAVE, XE_MIN_WAVES) mrp_cross_emit_
                     }
                 }
             }
+            /* biallelic sites, unit level (the shipped ONT parameters: every level above the first): the cells' loop below takes the
+             * slots four at a time without looking at `ends`; the rows' padding up to a multiple of four slots is zeroed (a pad pair
+             * then costs 0 + 0) */
+            const bool fast2 = units && a_cells_paired && A_uni == 2u && XE_FAST2_ON;
+            if (fast2 && ST > nsl)
+                for (uint32_t i = lane; i < Cs; i += WAVE) {
+                    uint32_t *rw = tab + i * ST; /* (side B's rows follow side A's: tb = tab + C1 * ST) */
+                    for (uint32_t s_ = nsl; s_ < ST; s_++) rw[s_] = 0u;
+                }
             wave_lds_fence();
             XE_T(3); /* table fill */
-            if (a_cells_paired) {
+            if (fast2) {
+                /* the grid walk of the general branch below -- row r = pair (2r, 2r + 1) of side A cells, lane = side B cell h -- with
+                 * everything that does not depend on the row hoisted: the lane's table row (up to 16 slots in registers), its two
+                 * transition terms per direction, and the store addresses, which advance by a constant.  Per unit: an add and half a
+                 * packed min per slot, two adds per site, seven operations for the transitions. */
+                const uint32_t W = C2 >= 33u ? 64u : (C2 >= 17u ? 32u : (C2 >= 9u ? 16u : (C2 >= 5u ? 8u : (C2 >= 3u ? 4u : (C2 >= 2u ? 2u : 1u)))));
+                const uint32_t wsh = 31u - (uint32_t) __builtin_clz(W), R = WAVE >> wsh;
+                const uint32_t hl = (uint32_t) lane & (W - 1u), rl = (uint32_t) lane >> wsh, rows = C1 >> 1;
+                const uint32_t nq = ST >> 2;
+                for (uint32_t hb = 0; hb < C2; hb += WAVE) {
+                    const uint32_t h = hb + hl;
+                    const bool hv = h < C2;
+                    const uint32_t hc = hv ? h : 0u;
+                    const uint2 tbh = trb[hc];
+                    const uint32_t bn_lo = tbh.x & 0xFFFFu, bn_hi = tbh.x >> 16, bp_lo = tbh.y & 0xFFFFu, bp_hi = tbh.y >> 16;
+                    const uint32_t *pb = tb + hc * ST;
+                    uint4 bq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) bq[q] = (uint32_t) q < nq ? *reinterpret_cast<const uint4 *>(pb + 4 * q) : make_uint4(0, 0, 0, 0);
+                    uint32_t *pn = cell_np + c.x_cell_off + ((int64_t) rl * C2 + h), *pc = cell_cost + c.x_cell_off + ((int64_t) rl * C2 + h);
+                    const uint32_t stride = R * C2;
+                    /* two rows per step (r and r + R), their table rows and transition terms requested together; NQ = groups of four
+                     * slots, a compile-time constant per instantiation: the body is straight-line code */
+                    auto walk = [&](auto nq_tag) {
+                        constexpr int NQ = decltype(nq_tag)::value;
+                        constexpr bool TWO = NQ <= 2; /* (two rows of 12 or 16 slots in flight cost the fifth wave per SIMD its registers) */
+                        for (uint32_t r = rl; r < rows; r += (TWO ? 2u : 1u) * R) {
+                            const uint32_t r2 = r + R;
+                            const bool v2 = TWO && r2 < rows;
+                            const uint32_t r2c = v2 ? r2 : r;
+                            const uint32_t *pa0 = tab + 2u * r * ST, *pa1 = tab + 2u * r2c * ST;
+                            uint4 a0[NQ], a1[TWO ? NQ : 1];
+#pragma unroll
+                            for (int q = 0; q < NQ; q++) { a0[q] = *reinterpret_cast<const uint4 *>(pa0 + 4 * q); if (TWO) a1[q] = *reinterpret_cast<const uint4 *>(pa1 + 4 * q); }
+                            const uint2 ta0 = tra[2u * r], ta1 = TWO ? tra[2u * r2c] : make_uint2(0u, 0u);
+                            uint32_t cost0 = 0, cost1 = 0;
+#pragma unroll
+                            for (int q = 0; q < NQ; q++) {
+                                const uint32_t m01 = pk_min_u16(a0[q].x + bq[q].x, a0[q].y + bq[q].y), m23 = pk_min_u16(a0[q].z + bq[q].z, a0[q].w + bq[q].w);
+                                cost0 += (m01 & 0xFFFFu) + (m01 >> 16) + (m23 & 0xFFFFu) + (m23 >> 16);
+                                if (TWO) {
+                                    const uint32_t n01 = pk_min_u16(a1[q].x + bq[q].x, a1[q].y + bq[q].y), n23 = pk_min_u16(a1[q].z + bq[q].z, a1[q].w + bq[q].w);
+                                    cost1 += (n01 & 0xFFFFu) + (n01 >> 16) + (n23 & 0xFFFFu) + (n23 >> 16);
+                                }
+                            }
+                            const uint32_t nx0 = (ta0.x & 0x7FFFFFFFu) + ((int32_t) ta0.x < 0 ? bn_hi : bn_lo), pv0 = (ta0.y & 0x7FFFFFFFu) + ((int32_t) ta0.y < 0 ? bp_hi : bp_lo);
+                            const uint32_t nx1 = (ta1.x & 0x7FFFFFFFu) + ((int32_t) ta1.x < 0 ? bn_hi : bn_lo), pv1 = (ta1.y & 0x7FFFFFFFu) + ((int32_t) ta1.y < 0 ? bp_hi : bp_lo);
+                            if (hv) {
+                                if (first_chunk) { pn[0] = (nx0 >> nsh) | ((pv0 >> psh) << 16); if (v2) pn[stride] = (nx1 >> nsh) | ((pv1 >> psh) << 16); }
+                                else { cost0 += pc[0]; if (v2) cost1 += pc[stride]; }
+                                pc[0] = cost0;
+                                if (v2) pc[stride] = cost1;
+                            }
+                            pn += (TWO ? 2u : 1u) * stride; pc += (TWO ? 2u : 1u) * stride;
+                        }
+                    };
+                    switch (nq) {
+                    case 1: walk(std::integral_constant<int, 1>()); break;
+                    case 2: walk(std::integral_constant<int, 2>()); break;
+                    case 3: walk(std::integral_constant<int, 3>()); break;
+                    default: walk(std::integral_constant<int, 4>()); break;
+                    }
+                }
+            } else if (a_cells_paired) {
                 /* The cells of the column are a grid: row r = pair (2r, 2r + 1) of side A cells, position h = side B cell;
                  * cells e = 2 (r C2 + h) and e + 1 are complements and share their cost.  A lane keeps ONE h: its side B
                  * table row and transition terms stay in registers while it walks down the rows; with C2 <= 32 a wave
@@ -657,6 +952,7 @@ __global__ void __launch_bounds__(XE_WAVES * WAVE, XE_MIN_WAVES) mrp_cross_emit_
             }
             fill_and_cost(false, Qa[0], Qa[1], Qb[0], Qb[1]);
         }
+        } /* MODE != 1 */
     }
 #ifdef XE_CLOCK
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -666,11 +962,26 @@ __global__ void __launch_bounds__(XE_WAVES * WAVE, XE_MIN_WAVES) mrp_cross_emit_
 }
 
 hipError_t mrp_launch_cross_emit(const CrossCol *cols_dev, const MrpBatchDev &d, int32_t *err, const int32_t *col_hmm_dev, int32_t *err_hmm,
-                                 hipStream_t stream) {
+                                 int32_t level_max_cells, bool mostly_narrow, hipStream_t stream) {
     if (d.n_cols <= 0) return hipSuccess;
-    const int64_t wgs = (d.n_cols + XE_WAVES - 1) / XE_WAVES;
-    hipLaunchKernelGGL(mrp_cross_emit_kernel, dim3((unsigned) (wgs < (1 << 20) ? wgs : (1 << 20))), dim3(XE_WAVES * WAVE), 0, stream, cols_dev,
-                       d.cols, d.chunks, d.n_cols, d.slot_bytes, d.slot_total, const_cast<uint32_t *>(d.cell_np), d.cell_cost, err, col_hmm_dev, err_hmm);
+    int64_t wgs = (d.n_cols + XE_WAVES - 1) / XE_WAVES;
+    /* level_max_cells: the level's largest cross product column by the host's static bounds; up to 128 cells (64 array entries of a
+     * unit level) every column has a lane per entry */
+    uint32_t cap = level_max_cells > 2 * WAVE && !mostly_narrow ? XE_CAP_WIDE : XE_CAP_NARROW;
+    static const long xe_cap = getenv("MRP_XE_CAP") ? atol(getenv("MRP_XE_CAP")) : 0; /* (development) */
+    if (xe_cap >= 256 && xe_cap <= 8192) cap = (uint32_t) xe_cap & ~3u;
+    const size_t lds = (size_t) XE_WAVES * (cap + XE_ROWS * 16 + XE_ROWS + 512) * sizeof(uint32_t);
+    const dim3 grid((unsigned) (wgs < (1 << 20) ? wgs : (1 << 20)));
+    if (mostly_narrow && XE_NARROW_ON) {
+        hipLaunchKernelGGL(mrp_cross_emit_kernel<1>, grid, dim3(XE_WAVES * WAVE), 0, stream, cols_dev, d.cols, d.chunks, d.n_cols, d.slot_bytes, d.slot_total,
+                           const_cast<uint32_t *>(d.cell_np), d.cell_cost, err, col_hmm_dev, err_hmm, cap);
+        /* (a column of at most 64 cells is narrow whatever its parents: they have no more cells than it has) */
+        if (level_max_cells > WAVE)
+            hipLaunchKernelGGL(mrp_cross_emit_kernel<2>, grid, dim3(XE_WAVES * WAVE), lds, stream, cols_dev, d.cols, d.chunks, d.n_cols, d.slot_bytes, d.slot_total,
+                               const_cast<uint32_t *>(d.cell_np), d.cell_cost, err, col_hmm_dev, err_hmm, cap);
+    } else
+        hipLaunchKernelGGL(mrp_cross_emit_kernel<0>, grid, dim3(XE_WAVES * WAVE), lds, stream, cols_dev, d.cols, d.chunks, d.n_cols, d.slot_bytes, d.slot_total,
+                           const_cast<uint32_t *>(d.cell_np), d.cell_cost, err, col_hmm_dev, err_hmm, cap);
     return hipGetLastError();
 }
 
