@@ -66,7 +66,7 @@ struct mrp_engine_level_state {
     DevBuf<uint16_t> d_dims;
     DevBuf<LayoutTot> d_tot;
     DevBuf<LayoutBase> d_base;
-    DevBuf<int64_t> d_totals;
+    DevBuf<int64_t> d_totals, d_tile_sums;
     DevBuf<CrossCol> d_cc;
     DevBuf<PruneHmm> d_ph;
     DevBuf<int32_t> d_col_hmm, d_nkept, d_nkeptm, d_err, d_err_hmm;
@@ -147,7 +147,7 @@ static void level_retire(mrp_engine *e, mrp_engine_level_state *L) {
         L->b = nullptr;
     }
     L->seg.reset();
-    L->d_plan.release(); L->d_xd.release(); L->d_par.release(); L->d_cstart.release(); L->d_croff.release(); L->d_phmm.release(); L->d_dims.release(); L->d_tot.release(); L->d_base.release(); L->d_totals.release();
+    L->d_plan.release(); L->d_xd.release(); L->d_par.release(); L->d_cstart.release(); L->d_croff.release(); L->d_phmm.release(); L->d_dims.release(); L->d_tot.release(); L->d_base.release(); L->d_totals.release(); L->d_tile_sums.release();
     L->d_frag_hmms.release(); L->d_frag_reads.release(); L->d_frag_by_pool.release(); L->d_frag_disc.release(); L->d_frag_lists.release(); L->d_frag_work.release();
     L->d_frag_counts.release(); L->d_frag_col_read.release(); L->d_frag_col_cnt.release(); L->d_frag_sites.release(); L->d_frag_col_part.release(); L->d_frag_read_key.release();
     L->frag = false;
@@ -513,13 +513,14 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     /* device side of the description + the descriptor arrays the structure and layout kernels fill */
     b->bind_pool(pl);
     L->d_plan.pool = pl; L->d_xd.pool = pl; L->d_par.pool = pl; L->d_cstart.pool = L->d_croff.pool = pl;
-    L->d_phmm.pool = pl; L->d_dims.pool = pl; L->d_tot.pool = pl; L->d_base.pool = pl; L->d_totals.pool = pl;
+    L->d_phmm.pool = pl; L->d_dims.pool = pl; L->d_tot.pool = pl; L->d_base.pool = pl; L->d_totals.pool = pl; L->d_tile_sums.pool = pl;
     L->d_cc.pool = pl; L->d_ph.pool = pl; L->d_col_hmm.pool = L->d_nkept.pool = L->d_nkeptm.pool = L->d_err.pool = L->d_err_hmm.pool = pl;
     L->d_kept.pool = L->d_keptm.pool = pl; L->d_kept_np.pool = pl;
     ENG_TRY(L->d_plan.alloc((size_t) total_cols)); ENG_TRY(L->d_xd.alloc((size_t) n)); ENG_TRY(L->d_par.alloc((size_t) total_par));
     ENG_TRY(L->d_cstart.alloc((size_t) total_cols + 1)); ENG_TRY(L->d_croff.alloc((size_t) total_cols));
     ENG_TRY(L->d_phmm.alloc((size_t) n)); ENG_TRY(L->d_dims.alloc(4 * (size_t) total_cols));
     ENG_TRY(L->d_tot.alloc((size_t) n)); ENG_TRY(L->d_base.alloc((size_t) n)); ENG_TRY(L->d_totals.alloc(8));
+    ENG_TRY(L->d_tile_sums.alloc(6 * (((size_t) n + 255) / 256)));
     ENG_TRY(L->d_cc.alloc((size_t) total_cols)); ENG_TRY(L->d_ph.alloc((size_t) n)); ENG_TRY(L->d_col_hmm.alloc((size_t) total_cols));
     ENG_TRY(L->d_err.alloc(64)); ENG_TRY(L->d_err_hmm.alloc((size_t) n));
     ENG_TRY(b->d_hmms.alloc((size_t) n)); ENG_TRY(b->d_cols.alloc((size_t) total_cols)); ENG_TRY(b->d_scols.alloc((size_t) total_cols));
@@ -731,7 +732,7 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
     const int64_t n = L->n, total_cols = L->total_cols;
     const double t0 = eng_now();
     LayoutOut lo{};
-    lo.dims = L->d_dims.p; lo.tot = L->d_tot.p; lo.base = L->d_base.p; lo.totals = L->d_totals.p;
+    lo.dims = L->d_dims.p; lo.tot = L->d_tot.p; lo.base = L->d_base.p; lo.totals = L->d_totals.p; lo.tile_sums = L->d_tile_sums.p;
     lo.hmms = b->d_hmms.p; lo.cols = b->d_cols.p; lo.scols = b->d_scols.p; lo.pcols = b->d_pcols.p; lo.tilecols = b->d_tilecols.p;
     lo.ccols = L->d_cc.p;
     ENG_TRY(hipStreamWaitEvent(s, L->uploaded, 0));

@@ -88,6 +88,7 @@ struct LayoutOut {       /* everything the layout kernels write */
     uint16_t *dims;      /* [n_cols][4] C1, C2, Ma, Mb (scratch between the passes) */
     LayoutTot *tot;      /* [n_hmms] */
     LayoutBase *base;    /* [n_hmms] */
+    int64_t *tile_sums;  /* [ceil(n_hmms / 256)][6] scratch of the scan over the hmms */
     int64_t *totals;     /* [6] array entries for cells (padded to a multiple of 4 per hmm) and merge cells, fast tiles, general tiles; [4], [5]:
                           * cells and merge cells of the cross products themselves (equal to [0], [1] up to the padding unless MRP_XF_UNITS) */
     DevHmm *hmms;

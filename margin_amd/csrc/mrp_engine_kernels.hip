@@ -1174,46 +1174,95 @@ __global__ void __launch_bounds__(256) mrp_layout_count_kernel(const PlanCol *__
     }
 }
 
-/* pass 2, one workgroup: where every hmm starts (cells padded to a multiple of 4 per hmm), the totals, the DevHmm records.  A thread
- * owns a run of consecutive hmms; the 1 024 partial sums are scanned inside the waves and across them through LDS (thread 0 used to add
- * them up one after the other: 60 us on the launch path of every level, however small). */
+/* pass 2: where every hmm starts (cells padded to a multiple of 4 per hmm), the totals, the DevHmm records -- an exclusive scan over the
+ * hmms' sums in two small kernels of 256-thread workgroups, a tile of 256 hmms each:
+ *   mrp_layout_tiles_kernel   the six sums of every tile (coalesced: thread i reads hmm 256 t + i);
+ *   mrp_layout_scan_kernel    tile t adds up the tiles before it (at most a few hundred: 37 000 hmms are 145 tiles), scans its own 256
+ *                             hmms in LDS and writes their bases and DevHmm records; the last tile writes the totals.
+ * Through round 4 this was ONE workgroup of 1 024 threads walking the hmms in runs (two passes of strided 48-byte reads, 128 registers
+ * and 48 spilled): 20-240 us alone -- and, needing a CU's whole register file to start, 1 ms on average once the device was full of
+ * other batches' chain workgroups, on the critical path of every level (62 ms of summed kernel time per 1 152-chunk step). */
+#define LAYOUT_TILE 256
+static __device__ __forceinline__ void layout_sums_of(const LayoutTot &x, int64_t (&v)[6]) {
+    v[0] = (x.cells + 3) & ~3ll; v[1] = x.merge; v[2] = x.tiles_fast; v[3] = x.tiles_gen; v[4] = x.acells; v[5] = x.amerge;
+}
 static __device__ __forceinline__ int64_t wave_incl_scan_i64(int64_t v, int lane) {
 #pragma unroll
     for (int o = 1; o < WAVE; o <<= 1) { const int64_t t = __shfl_up(v, o, WAVE); if (lane >= o) v += t; }
     return v;
 }
-__global__ void __launch_bounds__(1024) mrp_layout_scan_kernel(const PlanHmm *__restrict__ ph, int64_t n_hmms, LayoutOut o) {
-    __shared__ int64_t wsum[16][6];
+__global__ void __launch_bounds__(LAYOUT_TILE) mrp_layout_tiles_kernel(int64_t n_hmms, LayoutOut o, int64_t *__restrict__ tile_sums) {
+    __shared__ int64_t wsum[LAYOUT_TILE / WAVE][6];
     const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
-    const int64_t per = (n_hmms + 1023) / 1024, lo = (int64_t) t * per, hi = lo + per < n_hmms ? lo + per : n_hmms;
-    int64_t s[6] = {0, 0, 0, 0, 0, 0};
-    for (int64_t i = lo; i < hi; i++) {
-        const LayoutTot x = o.tot[i];
-        s[0] += (x.cells + 3) & ~3ll; s[1] += x.merge; s[2] += x.tiles_fast; s[3] += x.tiles_gen; s[4] += x.acells; s[5] += x.amerge;
-    }
-    int64_t incl[6];
-#pragma unroll
-    for (int q = 0; q < 6; q++) { incl[q] = wave_incl_scan_i64(s[q], lane); if (lane == WAVE - 1) wsum[wave][q] = incl[q]; }
-    __syncthreads();
+    const int64_t i = (int64_t) blockIdx.x * LAYOUT_TILE + t;
+    int64_t v[6] = {0, 0, 0, 0, 0, 0};
+    if (i < n_hmms) layout_sums_of(o.tot[i], v);
 #pragma unroll
     for (int q = 0; q < 6; q++) {
-        int64_t before = 0, all = 0;
+        int64_t x = v[q];
 #pragma unroll
-        for (int w = 0; w < 16; w++) { const int64_t y = wsum[w][q]; if (w < wave) before += y; all += y; }
-        s[q] = before + incl[q] - s[q]; /* exclusive: what the threads before this one hold */
-        if (t == 0) o.totals[q] = all;
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, WAVE);
+        if (lane == 0) wsum[wave][q] = x;
     }
-    for (int64_t i = lo; i < hi; i++) {
-        const LayoutTot x = o.tot[i];
+    __syncthreads();
+    if (t < 6) {
+        int64_t x = 0;
+#pragma unroll
+        for (int w = 0; w < LAYOUT_TILE / WAVE; w++) x += wsum[w][t];
+        tile_sums[(int64_t) blockIdx.x * 6 + t] = x;
+    }
+}
+__global__ void __launch_bounds__(LAYOUT_TILE) mrp_layout_scan_kernel(const PlanHmm *__restrict__ ph, int64_t n_hmms, LayoutOut o,
+                                                                      const int64_t *__restrict__ tile_sums) {
+    __shared__ int64_t wsum[LAYOUT_TILE / WAVE][6];
+    __shared__ int64_t before[6];
+    const int t = threadIdx.x, lane = t & (WAVE - 1), wave = t / WAVE;
+    const int64_t tile = blockIdx.x, i = tile * LAYOUT_TILE + t;
+    /* the tiles before this one */
+    int64_t pre[6] = {0, 0, 0, 0, 0, 0};
+    for (int64_t j = t; j < tile; j += LAYOUT_TILE)
+#pragma unroll
+        for (int q = 0; q < 6; q++) pre[q] += tile_sums[j * 6 + q];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        int64_t x = pre[q];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_xor(x, off, WAVE);
+        if (lane == 0) wsum[wave][q] = x;
+    }
+    __syncthreads();
+    if (t < 6) {
+        int64_t x = 0;
+#pragma unroll
+        for (int w = 0; w < LAYOUT_TILE / WAVE; w++) x += wsum[w][t];
+        before[t] = x;
+    }
+    __syncthreads();
+    /* this tile's hmms */
+    LayoutTot x{};
+    int64_t v[6] = {0, 0, 0, 0, 0, 0}, incl[6];
+    if (i < n_hmms) { x = o.tot[i]; layout_sums_of(x, v); }
+#pragma unroll
+    for (int q = 0; q < 6; q++) { incl[q] = wave_incl_scan_i64(v[q], lane); if (lane == WAVE - 1) wsum[wave][q] = incl[q]; }
+    __syncthreads();
+    int64_t excl[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) {
+        int64_t bw = before[q], all = before[q];
+#pragma unroll
+        for (int w = 0; w < LAYOUT_TILE / WAVE; w++) { const int64_t y = wsum[w][q]; if (w < wave) bw += y; all += y; }
+        excl[q] = bw + incl[q] - v[q];
+        if (tile == (int64_t) gridDim.x - 1 && t == 0) o.totals[q] = all;
+    }
+    if (i < n_hmms) {
         const PlanHmm h = ph[i];
         LayoutBase b;
-        b.cell0 = s[0]; b.mcell0 = s[1]; b.tile_fast0 = s[2]; b.tile_gen0 = s[3];
+        b.cell0 = excl[0]; b.mcell0 = excl[1]; b.tile_fast0 = excl[2]; b.tile_gen0 = excl[3];
         o.base[i] = b;
         DevHmm d;
         d.col0 = h.col0; d.n_cols = h.n_cols; d.flags = h.flags; d.max_merge = x.max_merge; d.max_cells = x.max_cells;
         d.wide_idx = 0; d.pad = 0; d.n_cells = x.cells; d.n_merge = x.merge; d.cost_bound = h.cost_bound;
         o.hmms[i] = d;
-        s[0] += (x.cells + 3) & ~3ll; s[1] += x.merge; s[2] += x.tiles_fast; s[3] += x.tiles_gen;
     }
 }
 
@@ -1296,7 +1345,9 @@ hipError_t mrp_launch_layout(const PlanCol *plan_dev, const PlanHmm *hmms_dev, i
     (void) n_cols;
     const unsigned g = (unsigned) ((n_hmms + 3) / 4);
     hipLaunchKernelGGL(mrp_layout_count_kernel, dim3(g), dim3(256), 0, stream, plan_dev, hmms_dev, n_hmms, S, xflags, out);
-    hipLaunchKernelGGL(mrp_layout_scan_kernel, dim3(1), dim3(1024), 0, stream, hmms_dev, n_hmms, out);
+    const unsigned tiles = (unsigned) ((n_hmms + LAYOUT_TILE - 1) / LAYOUT_TILE);
+    hipLaunchKernelGGL(mrp_layout_tiles_kernel, dim3(tiles), dim3(LAYOUT_TILE), 0, stream, n_hmms, out, out.tile_sums);
+    hipLaunchKernelGGL(mrp_layout_scan_kernel, dim3(tiles), dim3(LAYOUT_TILE), 0, stream, hmms_dev, n_hmms, out, out.tile_sums);
     hipLaunchKernelGGL(mrp_layout_fill_kernel, dim3(g), dim3(256), 0, stream, plan_dev, hmms_dev, n_hmms, chunks_dev, xflags, out);
     return hipGetLastError();
 }
