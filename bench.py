@@ -82,7 +82,7 @@ def queue_child(args):
     from margin_amd import capi, sharding, synth
     params = capi.Params.from_reference_names(synth.shipped_phase_params())
     cpu_share = max(1, os.cpu_count() or 8)
-    capi.load().mrp_set_host_threads(max(1, min(16, cpu_share)))
+    capi.load().mrp_set_host_threads(max(1, min(int(os.environ.get("MRP_BENCH_HOST_THREADS", "32")), cpu_share)))
     n_threads = args.threads or min(16, cpu_share, args.chunks)
     seeds = sharding.chunk_seeds(0, args.chunks)
     with ThreadPoolExecutor(max_workers=n_threads) as ex:
@@ -285,9 +285,11 @@ def main():
     n_chunks = args.chunks * (n_gpus if single_process_multi else 1)
     cpu_share = max(1, (os.cpu_count() or 8) // max(1, world))
     n_threads = args.threads or min(16, cpu_share, n_chunks)
-    # the library's worker pool: this rank's share of the node's cores, at most 16 per device (a work queue gives every
-    # device its own pool of this size)
-    host_threads = max(1, min(16, cpu_share // (n_gpus if single_process_multi else 1)))
+    # the library's worker pool: this rank's share of the node's cores, at most 32 per device (a work queue gives every
+    # device its own pool of this size).  Round 5: 32 instead of 16 -- the GPU hosts of this pool have 256 hardware threads for eight
+    # devices, and the host-bound head of a call (the first merge levels' tiling paths) shrinks with the pool: 157 -> 153 ms per step
+    # at 32 threads, 152 at 48 (tools/step_probe.py); the pool's threads sleep outside their loops
+    host_threads = max(1, min(int(os.environ.get("MRP_BENCH_HOST_THREADS", "32")), cpu_share // (n_gpus if single_process_multi else 1)))
     capi.load().mrp_set_host_threads(host_threads)
     seeds = sharding.chunk_seeds(rank, n_chunks)
 

@@ -264,7 +264,7 @@ int mrp_chunk_create(mrp_context *ctx, int64_t n_sites, const uint32_t *allele_n
     if (e == hipSuccess) e = ch->d_same_until.upload(ch->same_until, s);
     if (e == hipSuccess) e = ch->d_sub.upload(ch->sub, s);
     if (e == hipSuccess) e = ch->d_prior.upload(ch->prior, s);
-    if (e == hipSuccess) e = ch->d_pool.alloc((size_t) pool_bytes);
+    if (e == hipSuccess) e = ch->d_pool.alloc((size_t) pool_bytes + 16); /* (the packing kernel reads a read's last bytes a dword at a time) */
     if (e == hipSuccess && pool_bytes > 0)
         e = hipMemcpyAsync(ch->d_pool.p, ch->pool.data(), (size_t) pool_bytes, hipMemcpyHostToDevice, s); /* (the chunk's own copy: the caller's may go) */
     if (e == hipSuccess) e = ctx->wait_stream(s);
@@ -1046,10 +1046,12 @@ int mrp_batch_launch(mrp_batch *b) {
     if (ps != s && ctx->last_emission) HIP_TRY(hipStreamWaitEvent(ps, ctx->last_emission, 0));
     HIP_TRY(hipEventRecord(ev[0], ps));
     HIP_TRY(mrp_launch_planes(d, ps));
+    if (b->resident && mrp_dup('p')) HIP_TRY(mrp_launch_planes(d, ps));
     HIP_TRY(hipEventRecord(ev[1], ps));
     if (ps != s) HIP_TRY(hipStreamWaitEvent(s, ev[1], 0));
     HIP_TRY(hipEventRecord(ev[4], s));
     if (b->pre_sweep) HIP_TRY(b->pre_sweep(s)); /* resident merge levels: cross product + emission in one pass */
+    if (b->pre_sweep && mrp_dup('x')) HIP_TRY(b->pre_sweep(s));
     HIP_TRY(mrp_launch_emission(d, b->d_tiles.p, b->n_fast_tiles, b->n_tiles_dev - b->n_fast_tiles, s));
     HIP_TRY(hipEventRecord(ev[3], s));
     ctx->last_emission = ev[3];
@@ -1082,6 +1084,11 @@ int mrp_batch_launch(mrp_batch *b) {
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_wide.p, (int64_t) b->order_wide.size(), t_wide, b->max_merge_wide, s));
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_mid.p, (int64_t) b->order_mid.size(), t_mid, b->max_merge_mid, a0));
     HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), t_narrow, b->max_merge_narrow, a1));
+    if (b->resident && mrp_dup('s')) {
+        HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_wide.p, (int64_t) b->order_wide.size(), t_wide, b->max_merge_wide, s));
+        HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_mid.p, (int64_t) b->order_mid.size(), t_mid, b->max_merge_mid, a0));
+        HIP_TRY(mrp_launch_sweep_i32(d, b->d_order_narrow.p, (int64_t) b->order_narrow.size(), t_narrow, b->max_merge_narrow, a1));
+    }
     HIP_TRY(mrp_launch_sweep_f64(d, b->d_order_f64.p, (int64_t) b->order_gen.size(), 256, s));
     HIP_TRY(mrp_launch_sweep_lse(d, b->d_order_lse.p, (int64_t) b->order_lse.size(), b->max_merge_lse, s));
     HIP_TRY(mrp_launch_sweep_lse(d, b->d_order_lse_big.p, (int64_t) b->order_lse_big.size(), std::max(b->max_merge_lse_big, MRP_LSE_CUR_LDS_MAX_MERGE + 2), s));

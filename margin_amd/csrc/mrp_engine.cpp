@@ -738,6 +738,9 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
     ENG_TRY(hipStreamWaitEvent(s, L->uploaded, 0));
     ENG_TRY(mrp_launch_layout(L->d_plan.p, L->d_phmm.p, n, total_cols, b->d_chunks.p, e->pp.S,
                               (e->params.include_inverted_partitions ? MRP_XF_INVERTED : 0u) | (L->units ? MRP_XF_UNITS : 0u), lo, s));
+    if (mrp_dup('l'))
+        ENG_TRY(mrp_launch_layout(L->d_plan.p, L->d_phmm.p, n, total_cols, b->d_chunks.p, e->pp.S,
+                                  (e->params.include_inverted_partitions ? MRP_XF_INVERTED : 0u) | (L->units ? MRP_XF_UNITS : 0u), lo, s));
     ENG_TRY(hipMemcpyAsync(L->totals, L->d_totals.p, 48, hipMemcpyDeviceToHost, s));
     /* the one host wait of a level: it also ends the level before (its error flags are in) */
     int rc = level_finish(e);
@@ -817,8 +820,10 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
         const int64_t n_reg = n - L->n_mini;
         ENG_TRY(mrp_launch_mini(b->dev, L->d_cc.p, L->d_ph.p + n_reg, L->n_mini, n_reg, L->pp, sc, s));
         ENG_TRY(mrp_launch_prune(b->dev, L->d_cc.p, L->d_ph.p, n_reg, L->pp, sc, s));
+        if (mrp_dup('r')) ENG_TRY(mrp_launch_prune(b->dev, L->d_cc.p, L->d_ph.p, n_reg, L->pp, sc, s));
         ENG_TRY(hipEventRecord(L->ev[4], s));
         ENG_TRY(mrp_launch_compact(b->dev, L->d_cc.p, L->d_ph.p, L->d_col_hmm.p, total_cols, n_reg, L->pp, sc, s));
+        if (mrp_dup('c')) ENG_TRY(mrp_launch_compact(b->dev, L->d_cc.p, L->d_ph.p, L->d_col_hmm.p, total_cols, n_reg, L->pp, sc, s));
     }
     ENG_TRY(hipEventRecord(L->ev[3], s));
     if (L->final_level) {

@@ -6,6 +6,8 @@
 #define MRP_INTERNAL_H_
 
 #include <hip/hip_runtime.h>
+#include <cstring>
+#include <cstdlib>
 
 #include <time.h>
 
@@ -518,4 +520,8 @@ static inline void mrp_parallel_for(int64_t n, int64_t grain, F f) {
     mrp_pool_run(n, grain, [](int64_t i, void *a) { (*static_cast<F *>(a))(i); }, &f);
 }
 
+
+/* development: MRP_DUP=<letters> launches the named kernel families of a resident level TWICE (they are idempotent) -- the slow-down of a
+ * step is that family's marginal cost in situ: p packing, x cross product + emission, s recursion, r prune, c compaction, l layout */
+static inline bool mrp_dup(char c) { const char *e = getenv("MRP_DUP"); return e && strchr(e, c) != nullptr; }
 #endif

@@ -138,7 +138,14 @@ __global__ void __launch_bounds__(256) mrp_planes_kernel(const PlaneCol *__restr
 }
 
 /* The packed bytes and byte sums alone (columns of the fast emission path): 16 lanes per column, lane = word
- * (4 reads); every load of a lane is independent of the other lanes, nothing is exchanged but the 16-lane sum. */
+ * (4 reads); every load of a lane is independent of the other lanes, nothing is exchanged but the 16-lane sum.
+ * Round 5: FOUR slots per step -- a read's profile bytes of consecutive slots are consecutive bytes of the pool, so one (unaligned)
+ * dword per read brings four slots, a 4 x 4 byte transpose (eight v_perm_b32) turns the four reads' dwords into the four slots'
+ * words, and the four byte sums travel through the 16-lane reduction two to a register.  A byte load per read and slot (round 1) made
+ * a column of the first merge levels -- two to four reads over sixty slots -- sixty dependent trips to memory per lane: the kernel
+ * waited 80 % of its cycles and a step paid 12 ms for it (marginal cost, MRP_DUP=p).  The last dword of a read's run may reach up to
+ * three bytes past it: into the next read's bytes or the padding behind the pool (mrp_chunk_create / mrp_chunk_block_create). */
+struct __attribute__((packed, aligned(1))) pack_u32 { uint32_t v; };
 __global__ void __launch_bounds__(256) mrp_pack_kernel(const PlaneCol *__restrict__ pcols, const int32_t *__restrict__ list,
                                                        int64_t n_list, const int64_t *__restrict__ read_byte_off,
                                                        uint32_t *__restrict__ slot_total, uint32_t *__restrict__ slot_bytes, int filter) {
@@ -153,18 +160,29 @@ __global__ void __launch_bounds__(256) mrp_pack_kernel(const PlaneCol *__restric
         const int read = 4 * w + r;
         off[r] = read < c.depth ? read_byte_off[c.read_off + read] : -1;
     }
-    for (int s = 0; s < c.n_slots; s++) {
-        uint32_t packed = 0;
+    for (int s = 0; s < c.n_slots; s += 4) {
+        uint32_t v[4];
 #pragma unroll
-        for (int r = 0; r < 4; r++)
-            if (off[r] >= 0) packed |= (uint32_t) c.pool[off[r] + s] << (8 * r);
-        slot_bytes[(c.slot_off + s) * 16 + w] = packed;
-        uint32_t total = __builtin_amdgcn_udot4(packed, 0x01010101u, 0u, false);
-        total += __shfl_xor(total, 1, WAVE);
-        total += __shfl_xor(total, 2, WAVE);
-        total += __shfl_xor(total, 4, WAVE);
-        total += __shfl_xor(total, 8, WAVE);
-        if (w == 0) slot_total[c.slot_off + s] = total;
+        for (int r = 0; r < 4; r++) /* (the pool is device memory: said to the compiler, which would otherwise use flat loads, counted twice) */
+            v[r] = off[r] >= 0 ? ((const __attribute__((address_space(1))) pack_u32 *) (c.pool + off[r] + s))->v : 0u;
+        /* v[r] = slots s .. s + 3 of read r  ->  o[j] = reads 0 .. 3 of slot s + j */
+        const uint32_t ta = __builtin_amdgcn_perm(v[1], v[0], 0x05010400u), tb = __builtin_amdgcn_perm(v[1], v[0], 0x07030602u);
+        const uint32_t tc = __builtin_amdgcn_perm(v[3], v[2], 0x05010400u), td = __builtin_amdgcn_perm(v[3], v[2], 0x07030602u);
+        const uint32_t o[4] = {__builtin_amdgcn_perm(tc, ta, 0x05040100u), __builtin_amdgcn_perm(tc, ta, 0x07060302u),
+                               __builtin_amdgcn_perm(td, tb, 0x05040100u), __builtin_amdgcn_perm(td, tb, 0x07060302u)};
+        const int left = c.n_slots - s; /* (the same for the column's 16 lanes) */
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+            if (j < left) slot_bytes[(c.slot_off + s + j) * 16 + w] = o[j];
+        /* byte sums of the four slots, two per register (a slot's sum over 64 reads is below 2^16) */
+        uint32_t t01 = __builtin_amdgcn_udot4(o[0], 0x01010101u, 0u, false) | (__builtin_amdgcn_udot4(o[1], 0x01010101u, 0u, false) << 16);
+        uint32_t t23 = __builtin_amdgcn_udot4(o[2], 0x01010101u, 0u, false) | (__builtin_amdgcn_udot4(o[3], 0x01010101u, 0u, false) << 16);
+        /* all-reduce over the column's 16 lanes (= one DPP row) by rotations: row_ror 8, 4, 2, 1 */
+        t01 += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t01, 0x128, 0xf, 0xf, false); t23 += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t23, 0x128, 0xf, 0xf, false);
+        t01 += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t01, 0x124, 0xf, 0xf, false); t23 += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t23, 0x124, 0xf, 0xf, false);
+        t01 += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t01, 0x122, 0xf, 0xf, false); t23 += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t23, 0x122, 0xf, 0xf, false);
+        t01 += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t01, 0x121, 0xf, 0xf, false); t23 += (uint32_t) __builtin_amdgcn_update_dpp(0, (int) t23, 0x121, 0xf, 0xf, false);
+        if (w < 4 && w < left) slot_total[c.slot_off + s + w] = w == 0 ? (t01 & 0xFFFFu) : (w == 1 ? (t01 >> 16) : (w == 2 ? (t23 & 0xFFFFu) : (t23 >> 16)));
     }
 }
 
