@@ -554,6 +554,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         si.plan = L->d_plan.p; si.cols = seg->cols.p; si.rbo = seg->rbo.p; si.col_hmm = L->d_col_hmm.p;
         si.err = L->d_err.p; si.err_hmm = L->d_err_hmm.p;
         ENG_TRY(mrp_launch_structure(si, cs));
+        if (mrp_dup('t')) ENG_TRY(mrp_launch_structure(si, cs));
     }
     L->frag = false;
     if (final_level && n > 0) { /* genome fragments on the device: every hmm of the stage brings its chunk's reads */
@@ -809,6 +810,7 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
     ENG_TRY(hipEventRecord(L->ev[2], s));
     if (L->final_level) {
         ENG_TRY(mrp_launch_traceback(b->dev, L->d_ph.p, n, L->d_err.p, L->d_err_hmm.p, s));
+        if (mrp_dup('b')) ENG_TRY(mrp_launch_traceback(b->dev, L->d_ph.p, n, L->d_err.p, L->d_err_hmm.p, s));
         if (L->frag) {
             FragArrays fa{};
             fa.hmms = L->d_frag_hmms.p; fa.reads = L->d_frag_reads.p; fa.by_pool = L->d_frag_by_pool.p; fa.discarded = L->d_frag_disc.p;
@@ -819,6 +821,7 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
     } else {
         const int64_t n_reg = n - L->n_mini;
         ENG_TRY(mrp_launch_mini(b->dev, L->d_cc.p, L->d_ph.p + n_reg, L->n_mini, n_reg, L->pp, sc, s));
+        if (mrp_dup('m')) ENG_TRY(mrp_launch_mini(b->dev, L->d_cc.p, L->d_ph.p + n_reg, L->n_mini, n_reg, L->pp, sc, s));
         ENG_TRY(mrp_launch_prune(b->dev, L->d_cc.p, L->d_ph.p, n_reg, L->pp, sc, s));
         if (mrp_dup('r')) ENG_TRY(mrp_launch_prune(b->dev, L->d_cc.p, L->d_ph.p, n_reg, L->pp, sc, s));
         ENG_TRY(hipEventRecord(L->ev[4], s));

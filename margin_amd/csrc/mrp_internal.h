@@ -522,6 +522,7 @@ static inline void mrp_parallel_for(int64_t n, int64_t grain, F f) {
 
 
 /* development: MRP_DUP=<letters> launches the named kernel families of a resident level TWICE (they are idempotent) -- the slow-down of a
- * step is that family's marginal cost in situ: p packing, x cross product + emission, s recursion, r prune, c compaction, l layout */
+ * step is that family's marginal cost in situ: p packing, x cross product + emission, s recursion, r prune, c compaction, l layout,
+ * m the one-wave kernel of the small hmms, t the structure kernel, b the trace back */
 static inline bool mrp_dup(char c) { const char *e = getenv("MRP_DUP"); return e && strchr(e, c) != nullptr; }
 #endif

@@ -274,12 +274,12 @@ void mrp_queue_destroy(mrp_queue *q) {
 
 /* Host threads a worker gets: every device its own pool (phase.c:276-279 uses every core of the machine; one pool of sixteen
  * threads shared by eight devices would starve them).  mrp_set_host_threads() is the number PER DEVICE; by default the
- * machine's hardware threads are split evenly, at most 16 and at least 2 each. */
+ * machine's hardware threads are split evenly, at most 32 (16 through round 4) and at least 2 each. */
 int mrp_queue_threads_per_device(int n_devices) {
     const int hw = (int) std::max(1u, std::thread::hardware_concurrency());
     const int asked = mrp_host_threads_setting();
     if (asked > 0) return asked;
-    return std::max(2, std::min(16, hw / std::max(1, n_devices)));
+    return std::max(2, std::min(32, hw / std::max(1, n_devices)));
 }
 
 /* The CPUs next to a device (Linux: /sys/bus/pci/devices/<bus id>/local_cpulist), for the worker of that device and every
