@@ -511,7 +511,9 @@ hipError_t mrp_launch_emission(const MrpBatchDev &d, const EmitTile *tiles_dev, 
  * computes the same integers, hmm.c:906-907), so col_total is a broadcast of the forward score.
  */
 #define SWEEP_R 8
+#ifndef SWEEP_WIN
 #define SWEEP_WIN 128
+#endif
 
 struct SweepShared {
     int32_t *cur;  /* merge column read by the column being processed */
