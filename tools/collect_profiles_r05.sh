@@ -7,7 +7,7 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/r05p; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 parts="${*:-bench trace traffic insitu levels host queue clocks}"
 has() { case " $parts " in *" $1 "*) return 0;; esac; return 1; }
-BENCH="python3 $R/bench.py --threads 2 --no-cpu-baseline --align-chunks 0 --queue-runs 0 --sum-chunks 0 --shape-runs 0 --genome-chunks 0"
+BENCH="python3 $R/bench.py --threads 8 --no-cpu-baseline --align-chunks 0 --queue-runs 0 --sum-chunks 0 --shape-runs 0 --genome-chunks 0"
 PROBE="python3 $R/tools/pipeline_probe.py --chunks 96 --repeat 2 --check-host 0"
 if has bench; then   # 1. the default bench line
   ( cd $R && timeout -k 10 1000 python bench.py > $O/bench_default.json 2> $O/bench_default.err ) || exit 1
@@ -20,12 +20,12 @@ fi
 if has traffic; then # 3. HBM traffic of the replay leg ALONE (--steps 0: no end-to-end step in the trace), separate passes per counter
   RS=20; NL=$((RS + 3)) # (bench.py launches the replay batch three times before it starts counting)
   for c in FETCH_SIZE WRITE_SIZE; do
-    timeout -k 10 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/t_$c -o t -- $BENCH --steps 0 --warmup 0 --roofline-steps $RS > $O/bench_$c.json 2> $O/bench_$c.err || exit 1
+    timeout -k 10 600 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/t_$c -o t -- $BENCH --chunks 96 --steps 0 --warmup 0 --roofline-steps $RS > $O/bench_$c.json 2> $O/bench_$c.err || exit 1
   done
   python3 $R/tools/r04_summary.py traffic $O/t_FETCH_SIZE $O/t_WRITE_SIZE 96 $NL $O/traffic.json profiles/r05 $R/margin_amd/csrc/mrp_kernels.hip > /dev/null
   python3 $R/tools/pmc_all.py $O/t_FETCH_SIZE 100000 > $O/pmc_FETCH_SIZE_replay.txt
   python3 $R/tools/pmc_all.py $O/t_WRITE_SIZE 100000 > $O/pmc_WRITE_SIZE_replay.txt
-  timeout -k 10 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU --output-format csv -d $O/t_sqr -o t -- $BENCH --steps 0 --warmup 0 --roofline-steps 4 > $O/bench_sq_replay.json 2> $O/bench_sq_replay.err || exit 1
+  timeout -k 10 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU --output-format csv -d $O/t_sqr -o t -- $BENCH --chunks 96 --steps 0 --warmup 0 --roofline-steps 4 > $O/bench_sq_replay.json 2> $O/bench_sq_replay.err || exit 1
   python3 $R/tools/pmc_all.py $O/t_sqr 100000 > $O/pmc_sq_replay.txt
   rm -rf $O/t_FETCH_SIZE $O/t_WRITE_SIZE $O/t_sqr
 fi
