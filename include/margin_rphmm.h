@@ -51,6 +51,12 @@ typedef struct mrp_batch mrp_batch;
 const char *mrp_last_error(void);
 /* "margin_rphmm <version> gfx950" */
 const char *mrp_version(void);
+/* The binary interface of this header: bumped whenever a function's parameters or a structure's layout change (round 4 changed
+ * mrp_queue_dry_run and mrp_phase_many_stats without one).  A caller built against another header finds out by comparing
+ * mrp_abi_version() with the MRP_ABI_VERSION it was compiled with, before it passes a structure in
+ * (integration/stRPHmm_forwardBackward_adaptor.c does so when it makes its first context). */
+#define MRP_ABI_VERSION 5
+int mrp_abi_version(void);
 /* Number of visible HIP devices (0 if none / runtime unavailable). */
 int mrp_device_count(void);
 

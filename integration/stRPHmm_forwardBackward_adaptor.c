@@ -99,6 +99,7 @@ static __thread int64_t adpChunkNo = 0, adpChunkCap = 0;
 static mrp_context *adp_context(void) {
     if (adpCtx == NULL) {
         if (mrp_device_count() <= 0) ADP_ABORT("margin_rphmm: no HIP device visible");
+        if (mrp_abi_version() != MRP_ABI_VERSION) ADP_ABORT("margin_rphmm: library speaks ABI %d, the adaptor was built against %d", mrp_abi_version(), MRP_ABI_VERSION);
         if (mrp_context_create(ADP_DEVICE_FOR_THIS_THREAD(), &adpCtx) != MRP_OK) ADP_ABORT("margin_rphmm: %s", mrp_last_error());
     }
     return adpCtx;

@@ -21,8 +21,10 @@ FLAG_MAX_NOT_SUM = 1
 FLAG_INCLUDE_ANCESTOR_SUB_PROB = 2
 
 #: every symbol include/margin_rphmm.h declares (checked by the CPU test-suite)
+ABI_VERSION = 5  # MRP_ABI_VERSION of include/margin_rphmm.h as transcribed here
+
 EXPORTED_SYMBOLS = [
-    "mrp_last_error", "mrp_version", "mrp_runtime_init", "mrp_device_count", "mrp_context_create", "mrp_context_destroy",
+    "mrp_last_error", "mrp_version", "mrp_abi_version", "mrp_runtime_init", "mrp_device_count", "mrp_context_create", "mrp_context_destroy",
     "mrp_context_synchronize", "mrp_context_trim", "mrp_hmm_split", "mrp_hmm_split_where_phasing_is_uncertain", "mrp_context_set_phase_groups", "mrp_context_set_test_hooks", "mrp_set_host_threads", "mrp_chunk_create", "mrp_chunk_destroy", "mrp_fb_run", "mrp_batch_create",
     "mrp_batch_add", "mrp_batch_upload", "mrp_batch_launch", "mrp_batch_download", "mrp_batch_destroy",
     "mrp_batch_stats", "mrp_count_bit_vectors", "mrp_emissions", "mrp_get_rp_hmms", "mrp_hmm_destroy", "mrp_free",
@@ -211,6 +213,9 @@ def load():
     P = C.POINTER
     L.mrp_last_error.restype = C.c_char_p
     L.mrp_version.restype = C.c_char_p
+    L.mrp_abi_version.restype = C.c_int
+    if L.mrp_abi_version() != ABI_VERSION:
+        raise MrpError(f"libmargin_rphmm.so speaks ABI {L.mrp_abi_version()}, this binding was transcribed from ABI {ABI_VERSION} of include/margin_rphmm.h")
     L.mrp_device_count.restype = C.c_int
     L.mrp_context_create.argtypes = [C.c_int, P(vp)]
     L.mrp_context_destroy.argtypes = [vp]

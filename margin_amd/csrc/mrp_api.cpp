@@ -109,7 +109,8 @@ int mrp_set_error(int code, const char *fmt, ...) {
 }
 
 const char *mrp_last_error(void) { return g_err; }
-const char *mrp_version(void) { return "margin_rphmm 0.2.0 gfx950"; }
+const char *mrp_version(void) { return "margin_rphmm 0.5.0 gfx950"; }
+int mrp_abi_version(void) { return MRP_ABI_VERSION; }
 
 /* Concurrent batches of mrp_phase_reads_many launch on 4 streams each; with the ROCm runtime's default of 4 hardware queues
  * their kernels would serialize (include/margin_rphmm.h).  An explicit call, to be made before the process's first HIP call:
