@@ -81,8 +81,11 @@ int64_t mrp_context_device_budget(mrp_context *ctx) { /* bytes the pools of the 
     const size_t b = DevPoolRegistry::get().budget_of(ctx->pool.device);
     return b > (size_t) 1 << 62 ? 0 : (int64_t) b;
 }
-uint64_t mrp_context_oom_events(mrp_context *ctx) { /* device allocations refused for good on the context's device so far */
-    return ctx->pool.device >= 0 ? DevPoolRegistry::get().oom_events[ctx->pool.device].load() : 0;
+uint64_t mrp_context_oom_events(mrp_context *ctx) { /* device allocations refused for good to this context and to its siblings (the concurrent batches of its calls) so far */
+    uint64_t n = ctx->pool.oom_local.load();
+    std::lock_guard<std::mutex> lock(ctx->sibling_mu);
+    for (mrp_context *s_ : ctx->siblings) n += s_->pool.oom_local.load();
+    return n;
 }
 void mrp_context_pool_bytes(mrp_context *ctx, int64_t *cached, int64_t *device_held) {
     { std::lock_guard<std::mutex> lock(ctx->pool.mu); *cached = (int64_t) ctx->pool.cached_bytes; }
@@ -181,6 +184,7 @@ int mrp_context_trim(mrp_context *ctx) {
     for (mrp_context *s_ : ctx->siblings) { s_->pool.reclaim(); s_->pool.trim(); }
     ctx->pool.reclaim();
     ctx->pool.trim();
+    DevPoolRegistry::get().forget_budget(ctx->pool.device); /* (asked for again at the next allocation: a budget shrunk under another tenant's pressure recovers) */
     return MRP_OK;
 }
 

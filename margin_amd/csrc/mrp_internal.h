@@ -100,6 +100,9 @@ struct DevPoolRegistry {
         }
         return b;
     }
+    /* the budget is asked for again at its next use (mrp_context_trim: the caches have just been given back, so what is free now
+     * is what another tenant's transient pressure -- the reason a budget was shrunk -- has left or given back) */
+    void forget_budget(int device) { if (device >= 0 && device < MAX_DEVICES) budget[device].store(0, std::memory_order_relaxed); }
     /* after the driver refused an allocation although nothing idles in any pool: what we hold now is what there is */
     void shrink_budget(int device) {
         const size_t ours = held[device].load(std::memory_order_relaxed);
@@ -120,6 +123,8 @@ struct DevPool {
                                               * held, 96 of them idle between calls); a limit of 24 GB per pool made every call
                                               * with more than ~100 chunks per batch give back and re-allocate (4x slower) */
     int device = -1;                         /* attach(): the device whose registry entry this pool is */
+    std::atomic<uint64_t> oom_local{0};      /* allocations the driver refused THIS pool for good: a call looks at the pools of its own contexts,
+                                              * not at the device-wide count (another lane's refusal is not this call's) */
     void attach(int dev) {
         device = dev >= 0 && dev < DevPoolRegistry::MAX_DEVICES ? dev : -1;
         if (device < 0) return;
@@ -172,6 +177,7 @@ struct DevPool {
         if (device >= 0 && cls >= ((size_t) 1 << 20) && DevPoolRegistry::get().inject_oom[device].load(std::memory_order_relaxed) > 0 &&
             DevPoolRegistry::get().inject_oom[device].exchange(0) > 0) { /* fault injection of the test suite */
             DevPoolRegistry::get().oom_events[device].fetch_add(1, std::memory_order_relaxed);
+            oom_local.fetch_add(1, std::memory_order_relaxed);
             return hipErrorOutOfMemory;
         }
         hipError_t e = hipMalloc(p, cls);
@@ -188,6 +194,7 @@ struct DevPool {
         if (e == hipSuccess) held_add(cls);
         else if (e == hipErrorOutOfMemory && device >= 0) { /* callers that can re-slice their work look at this count */
             DevPoolRegistry::get().oom_events[device].fetch_add(1, std::memory_order_relaxed);
+            oom_local.fetch_add(1, std::memory_order_relaxed);
             DevPoolRegistry::get().shrink_budget(device);
         }
         return e;
