@@ -97,11 +97,17 @@ struct mrp_engine_level_state {
     mrp_xhmm *x = nullptr;
     int64_t n = 0, total_cols = 0, n_slots = 0, n_reads = 0;
     PruneParams pp{};
-    double t_begin = 0, t_staged = 0, t_launch_ms = 0;
+    double t_begin = 0, t_staged = 0, t_launch_ms = 0, t_react_ms = 0, t_launched = 0; /* t_react_ms: from the totals' arrival to the last kernel queued */
+    hipEvent_t lay0 = nullptr; /* in front of the layout kernels (timing) */
     hipEvent_t uploaded = nullptr; /* end of the uploads on the copy stream */
+    hipEvent_t done = nullptr;     /* behind everything the level queued on the main stream (its results' copies included) */
+    bool deferred = false;         /* launched without waiting for its totals: arrays sized by the static bounds (level_launch_impl) */
+    int64_t bound_cells = 0, bound_merge = 0; /* sums of the hmms' static bounds (cells padded to a multiple of 4 per hmm) */
     hipEvent_t ev[5] = {nullptr, nullptr, nullptr, nullptr, nullptr}; /* before / after the cross product, after the sweeps, after the compaction, [4] after the prune */
     ~mrp_engine_level_state() {
         if (uploaded) (void) hipEventDestroy(uploaded);
+        if (done) (void) hipEventDestroy(done);
+        if (lay0) (void) hipEventDestroy(lay0);
         for (auto &e_ : ev)
             if (e_) (void) hipEventDestroy(e_);
         if (b) mrp_batch_destroy(b);
@@ -123,7 +129,16 @@ struct mrp_engine {
     DevBuf<SegDev> d_segs;
     mrp_engine_stats stats{};
     mrp_engine_level_state *staged = nullptr;  /* staged, not launched */
-    mrp_engine_level_state *running = nullptr; /* launched, not ended */
+    /* launched, not ended, oldest first.  A level is normally ended by the launch of the next one (the one host wait of a level: the
+     * exact sizes of the next level's arrays come back with it).  Small levels -- a call of a few chunks, the first merge levels --
+     * are launched WITHOUT that wait (deferred: arrays sized by the static bounds) and several of them are in flight at a time;
+     * they are ended, in order, as their events complete. */
+    std::vector<mrp_engine_level_state *> inflight;
+    double diag_layout_gap_ms = 0, diag_react_ms = 0;
+    std::vector<std::pair<long long, double>> timeline; /* MRP_TIMELINE: (hmms of the level, host time of its launch) */
+    double t_created = 0;
+    int64_t n_ended = 0;         /* levels ended so far (mrp_engine_levels_ended: the caller settles what it keeps per level) */
+    int64_t inflight_bytes = 0;  /* device bytes of the deferred levels in flight (by their bounds) */
     std::vector<mrp_batch *> spare;            /* emptied batch objects (host arrays keep their capacity) */
     std::vector<mrp_engine_level_state *> spare_levels; /* level states whose pinned buffers are reused */
 };
@@ -135,12 +150,15 @@ static double eng_now() {
 }
 
 /* back to the empty state; the batch object and the pinned buffers stay with the engine for the next level */
-static void level_retire(mrp_engine *e, mrp_engine_level_state *L) {
+static void level_retire(mrp_engine *e, mrp_engine_level_state *L, bool complete = false) {
     if (!L) return;
     mrp_context *ctx = e->ctx;
     (void) hipSetDevice(ctx->device);
-    (void) ctx->wait_stream(ctx->stream); /* before the buffers go back to the pool */
-    if (ctx->pre) (void) ctx->wait_stream(ctx->pre);
+    if (!complete) { /* (complete: the level's `done` event has been seen -- everything that touches its buffers is over, while later
+                      *  levels may still be queued on the stream) */
+        (void) ctx->wait_stream(ctx->stream); /* before the buffers go back to the pool */
+        if (ctx->pre) (void) ctx->wait_stream(ctx->pre);
+    }
     if (L->b) {
         L->b->recycle();
         e->spare.push_back(L->b);
@@ -155,6 +173,7 @@ static void level_retire(mrp_engine *e, mrp_engine_level_state *L) {
     L->d_err_hmm.release(); L->d_kept.release(); L->d_keptm.release(); L->d_kept_np.release();
     L->perm.clear();
     L->x = nullptr; L->n = 0;
+    if (L->deferred) { e->inflight_bytes -= 16 * L->bound_cells + 8 * L->bound_merge; L->deferred = false; }
     e->spare_levels.push_back(L);
     ctx->pool.reclaim();
 }
@@ -175,6 +194,7 @@ int mrp_engine_create(mrp_context *ctx, const mrp_params *params, mrp_engine **o
     if (!e) return mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
     e->ctx = ctx;
     e->params = *params;
+    e->t_created = eng_now();
     PruneParams &pp = e->pp;
     pp.S = (int32_t) ((lim + 3) & ~3ll);
     pp.min_p = (int32_t) params->min_partitions_in_a_column;
@@ -232,7 +252,13 @@ int mrp_engine_create(mrp_context *ctx, const mrp_params *params, mrp_engine **o
 void mrp_engine_destroy(mrp_engine *e) {
     if (!e) return;
     mrp_context *ctx = e->ctx;
+    if (getenv("MRP_TIMELINE") && !e->timeline.empty()) { /* one line per engine (= per concurrent batch of a call), times on the process clock */
+        char buf[4096]; int o = snprintf(buf, sizeof(buf), "timeline: engine made at %.1f, ends at %.1f; levels (hmms @ launch):", fmod(e->t_created, 1e5), fmod(eng_now(), 1e5));
+        for (auto &t : e->timeline) if (o < (int) sizeof(buf) - 40) o += snprintf(buf + o, sizeof(buf) - (size_t) o, " %lld@%.1f", t.first, fmod(t.second, 1e5));
+        fprintf(stderr, "%s\n", buf);
+    }
     if (getenv("MRP_TIMING")) {
+        fprintf(stderr, "  levels: %.1f ms of the stream between the start of the layout kernels and the first kernel of the level proper, %.1f ms of it the host reacting to the totals (allocations, launches)\n", e->diag_layout_gap_ms, e->diag_react_ms);
         fprintf(stderr, "  context waits so far: %.1f ms wall, %.1f ms of thread CPU inside them\n", ctx->wait_wall_ms, ctx->wait_cpu_ms);
         ctx->wait_wall_ms = ctx->wait_cpu_ms = 0;
     }
@@ -240,7 +266,8 @@ void mrp_engine_destroy(mrp_engine *e) {
     (void) hipStreamSynchronize(ctx->stream);
     if (ctx->pre) (void) hipStreamSynchronize(ctx->pre);
     if (e->staged) { level_retire(e, e->staged); e->staged = nullptr; }
-    if (e->running) { level_retire(e, e->running); e->running = nullptr; }
+    for (auto *L : e->inflight) level_retire(e, L);
+    e->inflight.clear();
     {   /* kept for the next engine of this context */
         std::lock_guard<std::mutex> lock(ctx->sibling_mu);
         for (auto *L : e->spare_levels) ctx->spare_levels.push_back(L);
@@ -314,6 +341,10 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     for (int64_t i = 0; i < n && L->fused; i++)
         if (x[i].flags & MRP_FLAG_INCLUDE_ANCESTOR_SUB_PROB) L->fused = false;
     const bool fused = L->fused;
+    if (!L->done) ENG_TRY(hipEventCreateWithFlags(&L->done, hipEventDisableTiming));
+    if (!L->lay0) ENG_TRY(hipEventCreate(&L->lay0));
+    L->deferred = false; L->bound_cells = 0; L->bound_merge = 0;
+    for (int64_t i = 0; i < n; i++) { L->bound_cells += (x[i].bound_cells + 3) & ~3ll; L->bound_merge += x[i].bound_merge; }
     if (!L->uploaded) {
         ENG_TRY(hipEventCreateWithFlags(&L->uploaded, hipEventDisableTiming));
         for (auto &ev : L->ev) ENG_TRY(hipEventCreate(&ev));
@@ -507,7 +538,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     }
     if (ctx->test_hooks & 8) pp.pairs = 0; /* test hook: the general prune chain, for A/B parity with the chain on complement pairs */
     if (L->units) pp.pairs = 2; /* (decided above: the level's arrays hold one entry per complement pair) */
-    pp.pad = (ctx->test_hooks & 1) && e->stats.levels + (e->running ? 1 : 0) == 1 ? 1 : 0; /* test hook, see mrp_context_set_test_hooks */
+    pp.pad = (ctx->test_hooks & 1) && e->stats.levels + (int64_t) e->inflight.size() == 1 ? 1 : 0; /* test hook, see mrp_context_set_test_hooks */
 
     tm[tmi++] = eng_now();
     /* device side of the description + the descriptor arrays the structure and layout kernels fill */
@@ -634,18 +665,12 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
 }
 
 /* ---- end: the per-hmm error flags of the running level (and the final level's results) ---- */
-static int level_finish(mrp_engine *e) {
-    if (!e->running) return MRP_OK;
-    mrp_engine_level_state *Lp = e->running;
-    e->running = nullptr;
-    mrp_context *ctx = e->ctx;
+/* one level whose `done` event is complete (or whose stream has been waited for) */
+static int level_finish_one(mrp_engine *e, mrp_engine_level_state *Lp, bool complete) {
     int rc = MRP_OK;
-    hipError_t se = hipSetDevice(ctx->device);
-    if (se == hipSuccess) se = ctx->wait_stream(ctx->stream);
-    if (se != hipSuccess) rc = mrp_set_error(MRP_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(se));
     if (rc == MRP_OK && getenv("MRP_TIMING")) {
-        fprintf(stderr, "  level: %lld hmms %lld cols %lld cells: staged in %.1f ms, launch (layout + totals + queue) %.1f ms\n", (long long) Lp->n,
-                (long long) Lp->total_cols, (long long) Lp->totals[0], Lp->t_staged - Lp->t_begin, Lp->t_launch_ms);
+        fprintf(stderr, "  level: %lld hmms %lld cols %lld cells: staged in %.1f ms, launch (layout + totals + queue) %.1f ms  [stage began at %.1f ms, launched at %.1f ms on the process clock]\n", (long long) Lp->n,
+                (long long) Lp->total_cols, (long long) Lp->totals[0], Lp->t_staged - Lp->t_begin, Lp->t_launch_ms, fmod(Lp->t_begin, 1e5), fmod(Lp->t_launched, 1e5));
 #if defined(PRUNE_EXP_CLOCK) || defined(PRUNE_EXP_CLOCK2) || defined(XE_CLOCK)
         fprintf(stderr, "  prune clocks (first hmm; shader cycles):");
         for (int i = 0; i < 12; i++) fprintf(stderr, " %llu", Lp->clk[i]);
@@ -661,7 +686,13 @@ static int level_finish(mrp_engine *e) {
             const int32_t bits = Lp->err_hmm[j];
             if (bits == 0) continue;
             Lp->x[(size_t) Lp->perm[(size_t) j]].err = bits;
-            if (bits & (MRP_ENGINE_ERR_STRUCTURE | MRP_ENGINE_ERR_MERGE)) continue;
+            if (bits & (MRP_ENGINE_ERR_STRUCTURE | MRP_ENGINE_ERR_MERGE)) {
+                /* the chunk leaves the resident path: said at once (the caller says the same when it settles the level), so that the
+                 * levels in flight behind this one -- they ran on this hmm's discarded arrays -- are not held to what they raise */
+                const mrp_xhmm &xq = Lp->x[(size_t) Lp->perm[(size_t) j]];
+                if (xq.discarded) *const_cast<int *>(xq.discarded) = 1;
+                continue;
+            }
             /* an hmm whose chunk already left the resident path at the level before (this level was staged before that was
              * known): it ran on a discarded parent's arrays, whatever it raised is that parent's */
             { const mrp_xhmm &xq = Lp->x[(size_t) Lp->perm[(size_t) j]]; if (xq.discarded && *xq.discarded) continue; }
@@ -708,6 +739,12 @@ static int level_finish(mrp_engine *e) {
         e->stats.sweep_ms += t_sweep;
         e->stats.prune_ms += t_prune;
         e->stats.device_ms += t_cross + t_sweep + t_prune;
+        {   /* (diagnostics, MRP_TIMING) the stream between the layout kernels' start and the level's first own kernel: layout kernels,
+             * totals back, the host's reaction (allocations, launches) */
+            float t_lay = 0;
+            (void) hipEventElapsedTime(&t_lay, Lp->lay0, Lp->ev[0]);
+            e->diag_layout_gap_ms += t_lay; e->diag_react_ms += Lp->t_react_ms > 0 ? Lp->t_react_ms : 0;
+        }
         {   /* by kernel family: packing, cross product + emission, recursion (the batch's own events), prune, compaction */
             float t_pack = 0, t_emit = 0, t_rec = 0, t_pr = 0;
             mrp_batch_last_launch_ms(Lp->b, &t_pack, &t_emit, &t_rec);
@@ -720,9 +757,40 @@ static int level_finish(mrp_engine *e) {
         }
         e->segments.push_back(std::move(Lp->seg));
     }
-    level_retire(e, Lp);
+    e->n_ended++;
+    level_retire(e, Lp, complete);
     return rc;
 }
+
+/* ends every level in flight, oldest first, after ONE wait for the stream they were queued on */
+static int level_finish(mrp_engine *e) {
+    if (e->inflight.empty()) return MRP_OK;
+    mrp_context *ctx = e->ctx;
+    int rc = MRP_OK;
+    hipError_t se = hipSetDevice(ctx->device);
+    if (se == hipSuccess) se = ctx->wait_stream(ctx->stream);
+    if (se != hipSuccess) rc = mrp_set_error(MRP_ERR_HIP, "hipStreamSynchronize failed: %s", hipGetErrorString(se));
+    std::vector<mrp_engine_level_state *> all;
+    all.swap(e->inflight);
+    for (auto *Lp : all) {
+        if (rc == MRP_OK) rc = level_finish_one(e, Lp, false);
+        else { e->n_ended++; level_retire(e, Lp); }
+    }
+    return rc;
+}
+
+/* ends the levels in flight whose work is over (oldest first, as far as their events say so); never waits */
+static int level_finish_ready(mrp_engine *e) {
+    int rc = MRP_OK;
+    while (rc == MRP_OK && !e->inflight.empty()) {
+        mrp_engine_level_state *Lp = e->inflight.front();
+        if (!Lp->done || hipEventQuery(Lp->done) != hipSuccess) { (void) hipGetLastError(); break; }
+        e->inflight.erase(e->inflight.begin());
+        rc = level_finish_one(e, Lp, true);
+    }
+    return rc;
+}
+
 
 /* ---- launch: layout on the device, four totals back, allocation, the level's kernels ---- */
 static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
@@ -737,18 +805,41 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
     lo.hmms = b->d_hmms.p; lo.cols = b->d_cols.p; lo.scols = b->d_scols.p; lo.pcols = b->d_pcols.p; lo.tilecols = b->d_tilecols.p;
     lo.ccols = L->d_cc.p;
     ENG_TRY(hipStreamWaitEvent(s, L->uploaded, 0));
+    ENG_TRY(hipEventRecord(L->lay0, s));
     ENG_TRY(mrp_launch_layout(L->d_plan.p, L->d_phmm.p, n, total_cols, b->d_chunks.p, e->pp.S,
                               (e->params.include_inverted_partitions ? MRP_XF_INVERTED : 0u) | (L->units ? MRP_XF_UNITS : 0u), lo, s));
     if (mrp_dup('l'))
         ENG_TRY(mrp_launch_layout(L->d_plan.p, L->d_phmm.p, n, total_cols, b->d_chunks.p, e->pp.S,
                                   (e->params.include_inverted_partitions ? MRP_XF_INVERTED : 0u) | (L->units ? MRP_XF_UNITS : 0u), lo, s));
     ENG_TRY(hipMemcpyAsync(L->totals, L->d_totals.p, 48, hipMemcpyDeviceToHost, s));
-    /* the one host wait of a level: it also ends the level before (its error flags are in) */
-    int rc = level_finish(e);
-    if (rc != MRP_OK) return rc;
-    ENG_TRY(ctx->wait_stream(s));
-    ctx->pool.reclaim(); /* the blocks of the level before can be reused */
-    const int64_t cells = L->totals[0], merge = L->totals[1], tiles_fast = L->totals[2], tiles = L->totals[2] + L->totals[3];
+    /* Deferred launch (round 5): a small merge level -- its arrays at most MRP_DEFER_MB (1 GB) by the hmms' STATIC bounds, 4 GB of
+     * such levels in flight -- does not wait for its totals: the arrays are sized by the bounds (the layout kernels' offsets stay
+     * inside them: every count is clamped to what the bounds assume), its kernels are queued behind the layout kernels at once and the
+     * level before is ended whenever its event has completed.  A call of one chunk walks eleven levels whose kernels take a
+     * millisecond or two each: the wait (totals back, the host awake again, two dozen allocations, a dozen launches) left the device
+     * idle for a third of a millisecond per level.  The large levels keep the wait: bounds are loose there (a pruned column of 100
+     * cells times another is the bound, a fifth of it the average) and their arrays are what the device's memory goes to. */
+    static const long defer_mb = getenv("MRP_DEFER_MB") ? atol(getenv("MRP_DEFER_MB")) : 1024;
+    const int64_t bound_bytes = 16 * L->bound_cells + 8 * L->bound_merge;
+    const bool defer = L->fused && !L->final_level && defer_mb > 0 && bound_bytes <= ((int64_t) defer_mb << 20) &&
+                       e->inflight_bytes + bound_bytes <= ((int64_t) 4 * defer_mb << 20) && e->inflight.size() < 12;
+    int rc;
+    int64_t cells, merge, tiles_fast = 0, tiles = 0;
+    if (defer) {
+        rc = level_finish_ready(e);
+        if (rc != MRP_OK) return rc;
+        cells = L->bound_cells; merge = L->bound_merge;
+        L->deferred = true;
+        e->inflight_bytes += bound_bytes;
+    } else {
+        /* the one host wait of a level: it also ends the levels before (their error flags are in) */
+        rc = level_finish(e);
+        if (rc != MRP_OK) return rc;
+        ENG_TRY(ctx->wait_stream(s));
+        L->t_react_ms = -eng_now();
+        ctx->pool.reclaim(); /* the blocks of the level before can be reused */
+        cells = L->totals[0]; merge = L->totals[1]; tiles_fast = L->totals[2]; tiles = L->totals[2] + L->totals[3];
+    }
     b->n_cells_total = cells; b->n_merge = merge; b->n_slots = L->n_slots; b->n_tiles_dev = tiles; b->n_fast_tiles = tiles_fast;
     b->stats.n_cells = cells; b->stats.n_merge_cells = merge;
     b->stats.algorithmic_bytes = 24 * cells + 32 * merge + 8 * total_cols;
@@ -844,17 +935,21 @@ static int level_launch_impl(mrp_engine *e, mrp_engine_level_state *L) {
 #if defined(PRUNE_EXP_CLOCK) || defined(PRUNE_EXP_CLOCK2) || defined(XE_CLOCK)
     ENG_TRY(hipMemcpyAsync(L->clk, L->d_err.p + 4, 96, hipMemcpyDeviceToHost, s));
 #endif
-    L->t_launch_ms = eng_now() - t0;
+    ENG_TRY(hipEventRecord(L->done, s));
+    if (L->t_react_ms < 0) L->t_react_ms += eng_now();
+    L->t_launched = eng_now();
+    if (getenv("MRP_TIMELINE")) e->timeline.emplace_back((long long) L->n, L->t_launched);
+    L->t_launch_ms = L->t_launched - t0;
     return MRP_OK;
 }
 
 static int level_launch(mrp_engine *e) {
-    if (!e->staged) return level_finish(e); /* an empty level still ends the one before */
+    if (!e->staged) return level_finish(e); /* an empty level still ends the ones before */
     mrp_engine_level_state *L = e->staged;
     e->staged = nullptr;
     int rc = level_launch_impl(e, L);
     if (rc != MRP_OK) { level_retire(e, L); return rc; }
-    e->running = L;
+    e->inflight.push_back(L);
     return MRP_OK;
 }
 
@@ -867,6 +962,7 @@ int mrp_engine_level_end(mrp_engine *e) {
     if (!e) return mrp_set_error(MRP_ERR_ARG, "mrp_engine_level_end: NULL engine");
     return level_finish(e);
 }
+int64_t mrp_engine_levels_ended(const mrp_engine *e) { return e ? e->n_ended : 0; }
 
 int mrp_engine_level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x) {
     int rc = level_stage(e, n, x, false);

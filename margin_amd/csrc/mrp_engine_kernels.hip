@@ -1140,11 +1140,16 @@ __global__ void __launch_bounds__(256) mrp_layout_count_kernel(const PlanCol *__
     const bool units = (xflags & MRP_XF_UNITS) != 0;
     for (int k = lane; k < h.n_cols; k += WAVE) {
         const PlanCol c = plan[h.col0 + k];
-        const int C1 = layout_count(c.a_ncells, S), C2 = layout_count(c.b_ncells, S);
+        /* Every count is kept within the bound the HOST assumes for the column (mrp_side_bound: a pruned column has at most S cells
+         * and never more than the bipartitions of its reads; rphmm_host.c r_cross_build sums exactly these products): a valid parent
+         * never exceeds it, a discarded one may hold anything -- and a level launched without waiting for its totals (mrp_engine.cpp,
+         * deferred launch) has arrays of the bounds' size. */
+        const int S1 = (int) mrp_side_bound(c.d1, S), S2 = (int) mrp_side_bound(c.d2, S);
+        const int C1 = layout_count(c.a_ncells, S1), C2 = layout_count(c.b_ncells, S2);
         int Ma = 0, Mb = 0;
         if (!c.last) {
-            Ma = c.out_a == MRP_CONN_REAL ? layout_count(c.a_nmerge, S) : (c.out_a == MRP_CONN_IDENT ? C1 : 1);
-            Mb = c.out_b == MRP_CONN_REAL ? layout_count(c.b_nmerge, S) : (c.out_b == MRP_CONN_IDENT ? C2 : 1);
+            Ma = c.out_a == MRP_CONN_REAL ? layout_count(c.a_nmerge, S1) : (c.out_a == MRP_CONN_IDENT ? C1 : 1);
+            Mb = c.out_b == MRP_CONN_REAL ? layout_count(c.b_nmerge, S2) : (c.out_b == MRP_CONN_IDENT ? C2 : 1);
         }
         uint16_t *dm = o.dims + 4 * (h.col0 + k);
         dm[0] = (uint16_t) C1; dm[1] = (uint16_t) C2; dm[2] = (uint16_t) Ma; dm[3] = (uint16_t) Mb;
@@ -3077,7 +3082,8 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, con
         return e;
     });
     if (configured != hipSuccess) return configured;
-    const size_t lds = prune_lds_bytes(p);
+    size_t lds = prune_lds_bytes(p);
+    if (const char *pad = getenv("MRP_PRUNE_LDS_PAD_KB")) lds += (size_t) atol(pad) << 10; /* (development: fewer workgroups per CU) */
     if (lds > (size_t) MRP_LDS_BUDGET) return hipErrorInvalidValue;
     const dim3 grid((unsigned) (n_hmms < 65536 ? n_hmms : 65536));
     const PruneIn in{d.scols, ccols_dev, d.cell_f32, d.cell_b32, d.merge_f32, d.merge_b32, d.hmm_fb};
@@ -3825,7 +3831,9 @@ hipError_t mrp_launch_traceback(const MrpBatchDev &d, const PruneHmm *hmms_dev, 
 hipError_t mrp_launch_compact(const MrpBatchDev &d, const CrossCol *ccols_dev, const PruneHmm *hmms_dev, const int32_t *col_hmm_dev, int64_t n_cols,
                               int64_t n_hmms_here, PruneParams p, PruneScratch s, hipStream_t stream) {
     if (n_cols <= 0 || n_hmms_here <= 0) return hipSuccess;
-    const int64_t wgs = (n_cols + 3) / 4;
+    int64_t wgs = (n_cols + 3) / 4;
+    static const long cg = getenv("MRP_COMPACT_GRID") ? atol(getenv("MRP_COMPACT_GRID")) : 0; /* (development) */
+    if (cg > 0 && wgs > cg) wgs = cg;
     hipLaunchKernelGGL(mrp_compact_kernel, dim3((unsigned) (wgs < 65536 ? wgs : 65536)), dim3(256), 0, stream, d, ccols_dev, hmms_dev,
                        col_hmm_dev, n_cols, (int32_t) n_hmms_here, p, s);
     return hipGetLastError();

@@ -1856,7 +1856,11 @@ typedef struct {
     level_item *items; int64_t n_items;
     mrp_xhmm *xh; xbuild *xb; int64_t n_x;
     int cls_items, cls_xh, cls_xb; /* the three lists are blocks of the shadow pool (megabytes per level: warm instead of mapped afresh) */
+    int64_t seq;                   /* the level is the seq-th the engine launched: over once mrp_engine_levels_ended() reaches seq */
 } level_run;
+/* the levels launched and not yet settled, oldest first (the engine ends small levels late: several are in flight at a time) */
+#define LEVEL_RUNS_MAX 72
+typedef struct { level_run r[LEVEL_RUNS_MAX]; int head, tail; int64_t launched; } level_runs;
 static void level_run_settle(level_run *r, int rc_ok) { /* the level has ended: its error flags are in */
     for (int64_t i = 0; i < r->n_x; i++)
         /* outside what the kernels handle (a parent not in complement-pair order, ...): the later levels leave this
@@ -1867,9 +1871,15 @@ static void level_run_settle(level_run *r, int rc_ok) { /* the level has ended: 
     if (r->items) shadow_release(r->items, r->cls_items);
     memset(r, 0, sizeof(*r));
 }
-/* pending: if not NULL the last level is left running (the caller stages what comes next beside it, then launches / ends and
- * settles *pending); otherwise the last level is ended here */
-static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, level_run *pending) {
+/* the levels the engine has ended (all of them: `all`, after mrp_engine_level_end or a launch that waited) */
+static void level_runs_settle(level_runs *q, mrp_engine *e, int rc_ok, int all) {
+    const int64_t ended = mrp_engine_levels_ended(e);
+    while (q->head < q->tail && (all || q->r[q->head].seq <= ended)) level_run_settle(&q->r[q->head++], rc_ok);
+    if (q->head == q->tail) q->head = q->tail = 0;
+}
+/* pending: if not NULL the levels still in flight are left there (the caller stages what comes next beside them, then launches / ends
+ * and settles them); otherwise they are ended here */
+static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, level_runs *pending) {
     int max_h = 0;
     for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > max_h) max_h = t->a[i].height;
     /* Level of a merge node = as late as its parent allows (every root at the last level), not its height: the merges
@@ -1888,7 +1898,7 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
     /* The host's part of level h -- which hmms are merged, their column boundaries -- needs nothing the device computes
      * (only WHERE level h - 1's results are, fixed when that level was staged): it is done while level h - 1 runs.  The one
      * wait per level is inside mrp_engine_level_launch. */
-    level_run prev = {0};
+    level_runs own = {0}, *runs = pending ? pending : &own;
     for (int h = 1; h <= max_h && rc == MRP_OK; h++) {
         const double t0 = now_ms();
         int64_t n_items = 0;
@@ -1925,10 +1935,11 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
         mrp_pool_set_tag(2); if (rc == MRP_OK) mrp_pool_run(n_items, n_items > 512 ? (n_items > 16384 ? 64 : n_items / 256) : 1, level_finish, items); mrp_pool_set_tag(0);
         for (int64_t i = 0; i < n_items; i++) t->a[items[i].node].path = items[i].res;
         const double t1 = now_ms();
-        /* the wait for level h - 1, then level h goes to the device */
-        if (rc == MRP_OK) rc = mrp_engine_level_launch(e);
+        /* level h goes to the device (a large level first waits for the levels before it, a small one does not) */
+        int launched = 0;
+        if (rc == MRP_OK) { rc = mrp_engine_level_launch(e); launched = rc == MRP_OK && n_x > 0; /* (an empty level is not staged: the launch only ends what runs) */ }
         else (void) mrp_engine_level_end(e);
-        level_run_settle(&prev, rc == MRP_OK);
+        level_runs_settle(runs, e, rc == MRP_OK, rc != MRP_OK);
         const double t2 = now_ms();
         for (int64_t i = 0; i < n_items; i++) level_drop_garbage(i, items);
         (void) t2;
@@ -1936,16 +1947,20 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
         if (getenv("MRP_TIMING"))
             fprintf(stderr, "    host level %d: prepare %.2f ms, gather %.2f, stage %.2f, sort %.2f | launch (waits for the level before) %.2f | settle+garbage %.2f\n",
                     h, ta - t0, tb - ta, tc - tb, t1 - tc, t2 - t1, now_ms() - t2);
-        prev.items = items; prev.n_items = n_items; prev.xh = xh; prev.xb = xb; prev.n_x = n_x;
-        prev.cls_items = cls_items; prev.cls_xh = cls_xh; prev.cls_xb = cls_xb;
+        {
+            level_run cur = {items, n_items, xh, xb, n_x, cls_items, cls_xh, cls_xb, 0};
+            if (launched && runs->tail < LEVEL_RUNS_MAX) { cur.seq = ++runs->launched; runs->r[runs->tail++] = cur; }
+            else { /* (not launched: the engine holds nothing of it; a queue that is full cannot happen -- the engine has 64 segments) */
+                if (launched) { (void) mrp_engine_level_end(e); level_runs_settle(runs, e, rc == MRP_OK, 1); }
+                level_run_settle(&cur, launched && rc == MRP_OK);
+            }
+        }
     }
-    if (pending && rc == MRP_OK) {
-        *pending = prev;
-    } else {
+    if (!(pending && rc == MRP_OK)) {
         const double t1 = now_ms();
         const int rc2 = mrp_engine_level_end(e);
         if (rc == MRP_OK) rc = rc2;
-        level_run_settle(&prev, rc == MRP_OK);
+        level_runs_settle(runs, e, rc == MRP_OK, 1);
         g_t_level += now_ms() - t1;
     }
     free(lvl);
@@ -2211,6 +2226,7 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
     pc.include_ancestor_sub_prob = 0; /* bubbleGraph.c:2733 */
     mrp_engine *e = NULL;
     const double t_enter = now_ms();
+    if (getenv("MRP_TIMING")) fprintf(stderr, "  batch of %lld chunks enters at %.1f ms on the process clock\n", (long long) n_chunks, fmod(t_enter, 1e5));
     int rc = mrp_engine_create(ctx, &pc, &e);
     if (rc != MRP_OK) return rc;
     many_state *st = xcalloc((size_t) n_chunks + 1, sizeof(*st));
@@ -2238,7 +2254,7 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
         m->tree.a = NULL; m->tree.n = m->tree.cap = 0;
     }
     tt[1] = now_ms();
-    level_run pending = {0}; /* the last merge level: still on the device while the final stage is described */
+    level_runs pending = {0}; /* the last merge levels: still on the device while the final stage is described */
     if (rc == MRP_OK) rc = r_run_tree(e, &tree, &pc, &pending);
     tt[2] = now_ms();
     tt[3] = now_ms();
@@ -2259,7 +2275,7 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
         /* the wait for the last merge level (its error flags mark the chunks to redo), then the final stage goes */
         if (rc == MRP_OK) rc = mrp_engine_level_launch(e);
         else (void) mrp_engine_level_end(e);
-        level_run_settle(&pending, rc == MRP_OK);
+        level_runs_settle(&pending, e, rc == MRP_OK, 1); /* (the final level's launch waits for everything before it) */
         if (rc == MRP_OK) rc = mrp_engine_level_end(e);
         for (int64_t c = 0; c < n_chunks; c++)
             if (st[c].hmm) {
@@ -2272,7 +2288,7 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
         free(ctl.xfinal);
     } else {
         (void) mrp_engine_level_end(e);
-        level_run_settle(&pending, 0);
+        level_runs_settle(&pending, e, 0, 1);
     }
     tt[4] = now_ms();
     if (rc == MRP_OK) {
@@ -2322,8 +2338,8 @@ static int phase_many_resident(mrp_context *ctx, int64_t n_chunks, const mrp_chu
     const double t_eng = now_ms();
     mrp_engine_destroy(e);
     if (timing)
-        fprintf(stderr, "  engine create %.1f ms, host clean-up %.1f, engine destroy %.1f, whole call %.1f\n", tt[0] - t_enter, t_eng - t_clean,
-                now_ms() - t_eng, now_ms() - t_enter);
+        fprintf(stderr, "  engine create %.1f ms, host clean-up %.1f, engine destroy %.1f, whole call %.1f (ends at %.1f ms on the process clock)\n", tt[0] - t_enter, t_eng - t_clean,
+                now_ms() - t_eng, now_ms() - t_enter, fmod(now_ms(), 1e5));
     return rc;
 }
 

@@ -114,6 +114,9 @@ typedef struct mrp_xhmm {
 
 /* static upper bound of the cells one side contributes to a cross product column: a pruned column has at most S cells,
  * and never more than the bipartitions of its reads */
+#ifdef __HIPCC__
+__host__ __device__
+#endif
 static inline int64_t mrp_side_bound(int depth, int S) { return depth >= 7 ? S : (((int64_t) 1 << depth) < S ? ((int64_t) 1 << depth) : S); }
 
 typedef struct mrp_engine_stats {
@@ -134,12 +137,17 @@ int mrp_engine_locate(const mrp_engine *e, int32_t seg, int64_t col0, const uint
 /* A level = cross product -> forward/backward -> prune for n independent hmms, in three steps:
  *   stage   host only (description built and uploaded, column structure derived on the copy stream; may run while the level
  *           before is still on the device); fills seg / col0 of every x[i];
- *   launch  waits for the level before (its x[i].err are set then), lays the level out on the device and queues its kernels;
+ *   launch  lays the level out on the device and queues its kernels; a large level first waits for the levels before it (their
+ *           x[i].err are set then: mrp_engine_levels_ended), a small one does not;
  *   end     waits for the level and sets its x[i].err.
  * x must stay valid until the level has ended. */
 int mrp_engine_level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x);
 int mrp_engine_level_launch(mrp_engine *e);
 int mrp_engine_level_end(mrp_engine *e);
+/* Round 5: a launch need not end the level before (small levels are launched without the wait and several are in flight at a time;
+ * they end in order, by a later launch or by mrp_engine_level_end, which ends them all).  The number of levels ended so far: the k-th
+ * level launched has ended -- its x[i].err are set, x may go -- once this is at least k. */
+int64_t mrp_engine_levels_ended(const mrp_engine *e);
 /* stage + launch */
 int mrp_engine_level_begin(mrp_engine *e, int64_t n, mrp_xhmm *x);
 /* stage + launch + end */
