@@ -2366,7 +2366,12 @@ static void *phase_group_main(void *p) {
     const double cpu0 = thread_cpu_ms();
     const long long pool0 = mrp_pool_task_cpu_ns(), mine0 = mrp_pool_task_cpu_ns_this_thread();
     mrp_pool_adopt(g->pool);
-    mrp_pool_set_priority(g->index); /* batch 0's host loops first: the batches reach their device-heavy levels one after the other */
+    {   /* batch 0's host loops first: the batches reach their device-heavy levels one after the other.  MRP_POOL_PRIORITY (development):
+         * 0 = no priorities (the oldest loop first), k > 1 = batches in groups of k share a priority */
+        const char *pe = getenv("MRP_POOL_PRIORITY");
+        const int pk = pe ? atoi(pe) : 1;
+        mrp_pool_set_priority(pk <= 0 ? 0 : g->index / pk);
+    }
     g->rc = phase_many_resident(g->ctx, g->n, g->chunks, g->reads, g->n_reads, g->params, g->out, &g->stats);
     mrp_pool_set_priority(0);
     if (getenv("MRP_TIMING")) {
@@ -2512,18 +2517,34 @@ static int phase_many_once(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *
         phase_group *grp = xcalloc((size_t) G, sizeof(*grp));
         pthread_t th[16];
         int started[16] = {0};
+        /* which batch a chunk goes to: interleaved (chunk i to batch i % G), or -- MRP_GROUP_WEIGHTS=w0,w1,... (development) -- by a
+         * repeating pattern that gives batch g the share w_g / sum w of the chunks */
+        uint8_t *group_of = xmalloc((size_t) n_chunks + 1);
+        {
+            int w[16], W = 0, pat[256], np = 0;
+            for (int g = 0; g < G; g++) w[g] = 1;
+            const char *we = getenv("MRP_GROUP_WEIGHTS");
+            if (we) { int g = 0; for (const char *c = we; *c && g < G; g++) { w[g] = atoi(c); if (w[g] < 1) w[g] = 1; if (w[g] > 8) w[g] = 8; while (*c >= '0' && *c <= '9') c++; if (*c) c++; /* (any separator) */ } }
+            for (int g = 0; g < G; g++) W += w[g];
+            /* the pattern: round by round, every batch that still has weight left takes one place */
+            for (int round = 0; np < W; round++) for (int g = 0; g < G && np < W; g++) if (w[g] > round) pat[np++] = g;
+            for (int64_t i = 0; i < n_chunks; i++) group_of[i] = (uint8_t) pat[i % W];
+        }
         for (int g = 0; g < G; g++) {
             phase_group *q = &grp[g];
             q->index = g;
             q->pool = mrp_pool_current();
             q->ctx = g == 0 ? ctx : mrp_context_sibling(ctx, g - 1);
             q->params = params;
-            q->n = (n_chunks - g + G - 1) / G;
-            q->chunks = xmalloc(sizeof(*q->chunks) * (size_t) q->n);
-            q->reads = xmalloc(sizeof(*q->reads) * (size_t) q->n);
-            q->n_reads = xmalloc(sizeof(*q->n_reads) * (size_t) q->n);
-            q->out = xcalloc((size_t) q->n, sizeof(*q->out));
-            for (int64_t i = 0; i < q->n; i++) { q->chunks[i] = chunks[g + i * G]; q->reads[i] = reads[g + i * G]; q->n_reads[i] = n_reads[g + i * G]; }
+            q->n = 0;
+            for (int64_t i = 0; i < n_chunks; i++) if (group_of[i] == g) q->n++;
+            q->chunks = xmalloc(sizeof(*q->chunks) * (size_t) (q->n + 1));
+            q->reads = xmalloc(sizeof(*q->reads) * (size_t) (q->n + 1));
+            q->n_reads = xmalloc(sizeof(*q->n_reads) * (size_t) (q->n + 1));
+            q->out = xcalloc((size_t) q->n + 1, sizeof(*q->out));
+            q->n = 0;
+            for (int64_t i = 0; i < n_chunks; i++)
+                if (group_of[i] == g) { q->chunks[q->n] = chunks[i]; q->reads[q->n] = reads[i]; q->n_reads[q->n] = n_reads[i]; q->n++; }
             if (!q->ctx) { q->rc = MRP_ERR_HIP; snprintf(q->err, sizeof(q->err), "%s", mrp_last_error()); }
         }
         const int was_grouped = mrp_context_set_grouped(ctx, 1); /* (the siblings always are) */
@@ -2541,7 +2562,7 @@ static int phase_many_once(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *
         for (int g = 0; g < G; g++) {
             phase_group *q = &grp[g];
             if (q->rc != MRP_OK && (rc == MRP_OK || rc == MRP_ERR_UNSUPPORTED)) rc = mrp_set_error(q->rc, "%s", q->err);
-            for (int64_t i = 0; i < q->n; i++) out[g + i * G] = q->out[i];
+            { int64_t k = 0; for (int64_t i = 0; i < n_chunks; i++) if (group_of[i] == g) out[i] = q->out[k++]; }
             if (stats && q->rc == MRP_OK) {
                 stats->resident = 1;
                 stats->fallback_chunks += q->stats.fallback_chunks;
@@ -2556,6 +2577,7 @@ static int phase_many_once(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *
             free(q->chunks); free(q->reads); free(q->n_reads); free(q->out);
         }
         free(grp);
+        free(group_of);
     }
     if (rc == MRP_ERR_UNSUPPORTED) {
         /* Parameters or hmm shapes outside the resident path: the hashing path (mrp_phase_reads), one chunk per host thread,
