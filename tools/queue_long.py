@@ -7,7 +7,7 @@ from concurrent.futures import ThreadPoolExecutor
 from margin_amd import capi, sharding, synth
 ap = argparse.ArgumentParser(); ap.add_argument("--chunks", type=int, default=1728); ap.add_argument("--runs", type=int, default=3); ap.add_argument("--batch", type=int, default=0); ap.add_argument("--sites", type=int, default=2000); ap.add_argument("--base", type=int, default=576); ap.add_argument("--skip-resident", type=int, default=0); a = ap.parse_args()
 params = capi.Params.from_reference_names(synth.shipped_phase_params())
-capi.load().mrp_set_host_threads(min(16, os.cpu_count() or 8))
+capi.load().mrp_set_host_threads(min(32, os.cpu_count() or 8))
 with ThreadPoolExecutor(max_workers=16) as ex:
     base = list(ex.map(lambda s: synth.make_ont_chunk(seed=s, region_bp=a.sites * 500, n_sites=a.sites, coverage=30), sharding.chunk_seeds(0, a.base)))
 for c in base:
