@@ -71,6 +71,7 @@ int mrp_engine_level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x) { return stage
 int mrp_engine_final_stage(mrp_engine *e, int64_t n, mrp_xhmm *x) { return stage(e, n, x, 1); }
 int mrp_engine_level_launch(mrp_engine *e) { (void) e; return MRP_OK; }
 int mrp_engine_level_end(mrp_engine *e) { (void) e; return MRP_OK; }
+int64_t mrp_engine_levels_ended(const mrp_engine *e) { return e->n_segs; } /* (the stub's levels end as they are launched) */
 int mrp_engine_fetch(mrp_engine *e, void *dst, const void *src, int64_t bytes) { (void) e; (void) dst; (void) src; (void) bytes; return MRP_OK; }
 int mrp_engine_sync(mrp_engine *e) { (void) e; return MRP_OK; }
 void mrp_engine_get_stats(const mrp_engine *e, mrp_engine_stats *out) { memset(out, 0, sizeof *out); out->columns = e->cols; out->levels = e->n_segs; }
