@@ -675,6 +675,7 @@ extern "C" long long mrp_pool_tag_cpu_ns(int tag) { return g_pool_tag_cpu_ns[tag
 namespace {
 thread_local int t_pool_priority = 0;
 thread_local int t_pool_tag = 0;
+thread_local int t_pool_weight_ns = 0; /* mrp_pool_set_weight: what one index of the calling thread's next loops costs, roughly; 0: unknown */
 /* The indices of a loop are dealt out from MRP_POOL_RANGES contiguous ranges, and a thread starts with the range of its own
  * number before it helps with the others: the loops of a batch's levels run over the same chunks in the same order, so the
  * thread that built a chunk's hmms at one level mostly meets them again at the next (their blocks are in its cache, or its
@@ -690,6 +691,7 @@ struct PoolJob {
     std::atomic<int64_t> done{0};
     std::atomic<int> exhausted{0}; /* ranges that have nothing left to hand out */
     int active = 0; /* workers currently holding the pointer (under Pool::mu) */
+    std::condition_variable cv; /* the posting thread waits here: woken by the last worker to let go of the job, not by every worker of every job */
     bool has_work() const { return exhausted.load(std::memory_order_relaxed) < MRP_POOL_RANGES; }
 };
 thread_local int t_pool_slot = -1; /* the calling thread's number in its pool: workers 0 .. threads - 2, a posting thread threads - 1 */
@@ -697,12 +699,16 @@ thread_local int t_pool_slot = -1; /* the calling thread's number in its pool: w
 /* One pool serves the process by default (mrp_set_host_threads); a work queue gives every device its own (mrp_queue.cpp:
  * the reference's axis is "every core works", phase.c:276-279 -- eight devices on one shared pool of sixteen threads would
  * starve each other), optionally bound to the CPUs next to the device.  A thread posts its loops to the pool it has adopted
- * (mrp_pool_adopt; the batch threads of mrp_phase_reads_many inherit their caller's). */
+ * (mrp_pool_adopt; the batch threads of mrp_phase_reads_many inherit their caller's).
+ * Wake-ups are counted: a loop wakes as many sleeping workers as it has grains to give away (a call posts some four hundred loops,
+ * half of them over a few hundred indices: waking every worker for each of them, and every posting thread whenever any worker
+ * finished, was a seventh of the call's host CPU time in futex calls and on the pool's mutex). */
 struct mrp_host_pool {
     std::mutex mu;
-    std::condition_variable cv_work, cv_done;
+    std::condition_variable cv_work;
     std::vector<PoolJob *> jobs;
     std::vector<std::thread> workers;
+    int idle = 0; /* workers asleep in cv_work (under mu) */
     bool stop = false;
     int fixed_threads = 0; /* 0: the process-wide pool, sized by mrp_host_threads() */
     static void run_chunks(PoolJob *j) {
@@ -714,6 +720,7 @@ struct mrp_host_pool {
                      g_pool_task_cpu_ns.fetch_add(d); g_pool_tag_cpu_ns[tag & 15].fetch_add(d); t_pool_task_cpu_ns += d; }
         } acc(j->tag);
         const int home = (t_pool_slot >= 0 ? t_pool_slot : 0) % MRP_POOL_RANGES;
+        int64_t mine = 0; /* booked once: the counter is one cache line shared by every thread of the loop */
         for (int k = 0; k < MRP_POOL_RANGES; k++) {
             PoolRange &r = j->range[(home + k) % MRP_POOL_RANGES];
             for (;;) {
@@ -723,9 +730,10 @@ struct mrp_host_pool {
                 const int64_t hi = std::min(r.end, lo + j->grain);
                 if (lo + j->grain >= r.end) j->exhausted.fetch_add(1); /* (took the range's last grain: exactly one thread does) */
                 for (int64_t i = lo; i < hi; i++) j->fn(i, j->arg);
-                j->done.fetch_add(hi - lo);
+                mine += hi - lo;
             }
         }
+        if (mine) j->done.fetch_add(mine);
     }
     void worker() {
         std::unique_lock<std::mutex> lk(mu);
@@ -735,15 +743,16 @@ struct mrp_host_pool {
                 if (q->has_work() && (!j || q->prio < j->prio)) j = q;
             if (!j) {
                 if (stop) return;
+                idle++;
                 cv_work.wait(lk);
+                idle--;
                 continue;
             }
             j->active++;
             lk.unlock();
             run_chunks(j);
             lk.lock();
-            j->active--;
-            cv_done.notify_all();
+            if (--j->active == 0 && j->done.load() >= j->n) j->cv.notify_one();
         }
     }
     void ensure(int n_workers) {
@@ -778,6 +787,13 @@ extern "C" void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void 
         for (int64_t i = 0; i < n; i++) fn(i, arg);
         return;
     }
+    /* a loop whose whole work is a few dozen microseconds is run here: posting it costs the poster and every woken worker a futex
+     * call and a turn on the pool's mutex each (the levels of a call of small chunks post hundreds of such loops) */
+    const int64_t est_ns = t_pool_weight_ns > 0 ? n * (int64_t) t_pool_weight_ns : -1;
+    if (est_ns >= 0 && est_ns < 60000) {
+        for (int64_t i = 0; i < n; i++) fn(i, arg);
+        return;
+    }
     P.ensure(threads - 1);
     PoolJob j;
     j.fn = fn; j.arg = arg; j.n = n; j.grain = grain; j.prio = t_pool_priority; j.tag = t_pool_tag;
@@ -792,14 +808,18 @@ extern "C" void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void 
         j.exhausted.store(empty);
     }
     if (t_pool_slot < 0) t_pool_slot = threads - 1;
+    int wake;
     {
         std::lock_guard<std::mutex> lk(P.mu);
         P.jobs.push_back(&j);
+        /* one sleeper per grain beyond the poster's own (a worker that is busy looks at the job list when it is done: nothing is lost) */
+        wake = (int) std::min<int64_t>(P.idle, std::min<int64_t>(threads - 1, (n + grain - 1) / grain - 1));
+        if (est_ns >= 0) wake = (int) std::min<int64_t>(wake, est_ns / 100000); /* ... that has some 100 us of work to find */
     }
-    P.cv_work.notify_all();
+    for (int k = 0; k < wake; k++) P.cv_work.notify_one();
     Pool::run_chunks(&j);
     std::unique_lock<std::mutex> lk(P.mu);
-    P.cv_done.wait(lk, [&] { return j.done.load() >= j.n && j.active == 0; });
+    j.cv.wait(lk, [&] { return j.done.load() >= j.n && j.active == 0; });
     P.jobs.erase(std::find(P.jobs.begin(), P.jobs.end(), &j));
 }
 
@@ -815,6 +835,7 @@ extern "C" void *mrp_pool_current(void) { return t_pool_current; }
 extern "C" void mrp_pool_adopt(void *p) { t_pool_current = static_cast<mrp_host_pool *>(p); }
 
 extern "C" void mrp_pool_set_priority(int p) { t_pool_priority = p; }
+extern "C" void mrp_pool_set_weight(int ns_per_index) { t_pool_weight_ns = ns_per_index; }
 extern "C" void mrp_pool_set_tag(int t) { t_pool_tag = t; } /* MRP_TIMING: which loop the CPU time of the pool tasks is booked to */
 
 static std::atomic<int> g_host_threads{0};

@@ -34,6 +34,7 @@
 
 #include "mrp_engine.h"
 extern "C" void mrp_pool_set_tag(int t);
+extern "C" void mrp_pool_set_weight(int ns_per_index);
 #include "mrp_internal.h"
 
 #define ENG_TRY(expr)                                                                                          \
@@ -330,7 +331,22 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
     const int S = e->pp.S;
     if (e->n_segs >= mrp_engine::MAX_SEGS) return mrp_set_error(MRP_ERR_UNSUPPORTED, "more than %d levels", mrp_engine::MAX_SEGS);
     std::unique_ptr<mrp_engine_level_state> L;
-    if (!e->spare_levels.empty()) { L.reset(e->spare_levels.back()); e->spare_levels.pop_back(); }
+    if (!e->spare_levels.empty()) {
+        /* the parked level object whose page-locked staging block fits best: the levels of a call differ a hundredfold in size, and a
+         * block that has to grow is freed and allocated again (milliseconds each, and both synchronize with the device) */
+        size_t want = 4096 + (size_t) n * (sizeof(XDesc) + sizeof(PlanHmm) + sizeof(PruneHmm) + 12 + 4 * 64);
+        for (int64_t i = 0; i < n; i++) want += 8 * (size_t) x[i].n_cols + sizeof(mrp_xpar) * (size_t) (x[i].n_a + x[i].n_b);
+        size_t best = 0;
+        long long best_score = -1;
+        for (size_t q = 0; q < e->spare_levels.size(); q++) {
+            const mrp_engine_level_state *c = e->spare_levels[q];
+            long long score = c->stage.bytes >= want ? (long long) (c->stage.bytes - want) : (1ll << 40) + (long long) (want - c->stage.bytes);
+            if (final_level != (c->frag_stage.bytes > 0)) score += 1ll << 36; /* (the final level alone stages the genome fragments' reads) */
+            if (best_score < 0 || score < best_score) { best_score = score; best = q; }
+        }
+        L.reset(e->spare_levels[best]);
+        e->spare_levels.erase(e->spare_levels.begin() + (long) best);
+    }
     else L.reset(new (std::nothrow) mrp_engine_level_state());
     if (!L) return mrp_set_error(MRP_ERR_NOMEM, "out of host memory");
     L->t_begin = eng_now();
@@ -473,7 +489,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         for (int64_t j = 0; j < n; j++) pos[(size_t) L->perm[(size_t) j]] = (int32_t) j;
     }
     /* per hmm records and the 8 bytes per column the host contributes (parallel) */
-    mrp_pool_set_tag(8); mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
+    mrp_pool_set_tag(8); mrp_pool_set_weight(400); mrp_parallel_for(n, std::max<int64_t>(1, n / 256), [&](int64_t i) {
         mrp_xhmm &h = x[i];
         if (i + 3 < n) { __builtin_prefetch(x[i + 3].col_start); __builtin_prefetch(x[i + 3].col_read_off); __builtin_prefetch(x[i + 3].par); }
         const int K = h.n_cols;
@@ -496,6 +512,7 @@ static int level_stage(mrp_engine *e, int64_t n, mrp_xhmm *x, bool final_level) 
         h.seg = seg_id; h.col0 = colbase;
         h.err = 0;
     });
+    mrp_pool_set_weight(0);
     cstart[total_cols] = 0;
     tm[tmi++] = eng_now();
     /* launch classes of the recursion kernel, from the static bounds; largest first inside a class */

@@ -1637,7 +1637,9 @@ static mrp_hmm *r_expand(const world *w, const rhmm *x, int with_masks) {
     return h;
 }
 
-typedef struct { rhmm *x; const world *w; } xbuild;
+/* a cross product of a level: its shadow, its chunk, and -- filled by the thread that built it, while the shadow is in its cache --
+ * what the engine is told about it (r_describe) */
+typedef struct { rhmm *x; const world *w; mrp_xhmm d; } xbuild;
 typedef VEC(xbuild) xbuild_vec;
 
 /* mergeTwoTilingPaths coordination.c:263-339, structure only: the overlap components that need a cross
@@ -1672,7 +1674,7 @@ static int r_prepare_merge(const world *w, int32_t stride, r_hmm_vec *tp1, r_hmm
             const r_hmm_vec va = {ma, 1, 1}, vb = {mb, 1, 1};
             const int32_t S = m0->ref_start < m1->ref_start ? m0->ref_start : m1->ref_start;
             const int32_t Ea = m0->ref_start + m0->ref_length, Eb = m1->ref_start + m1->ref_length;
-            xbuild xb = {NULL, w};
+            xbuild xb; xb.x = NULL; xb.w = w;
             tq = tcpu_ms();
             rc = r_cross_build(w, &va, &vb, S, Ea > Eb ? Ea : Eb, stride, &xb.x);
             T_ADD(2, tq);
@@ -1692,7 +1694,7 @@ static int r_prepare_merge(const world *w, int32_t stride, r_hmm_vec *tp1, r_hmm
                 int32_t Ea = a->a[a->n - 1]->ref_start + a->a[a->n - 1]->ref_length;
                 int32_t Eb = b->a[b->n - 1]->ref_start + b->a[b->n - 1]->ref_length;
                 int32_t E = Ea > Eb ? Ea : Eb;
-                xbuild xb = {NULL, w};
+                xbuild xb; xb.x = NULL; xb.w = w;
                 tq = tcpu_ms();
                 rc = r_cross_build(w, a, b, S, E, stride, &xb.x);
                 T_ADD(2, tq);
@@ -1785,6 +1787,7 @@ typedef struct {
     rnode_vec *t;
     int64_t node;
     int32_t stride;
+    uint32_t flags;    /* sweep_flags of the run: part of what the engine is told about every cross product */
     r_hmm_vec *res;
     xbuild_vec xs;
     int rc, res_class;
@@ -1792,6 +1795,7 @@ typedef struct {
     void *big_block;
     char err[256];
 } level_item;
+static void r_describe(const world *w, const rhmm *x, uint32_t flags, mrp_xhmm *d);
 static void level_prepare(int64_t i, void *arg) {
     level_item *it = &((level_item *) arg)[i];
     rnode *nd = &it->t->a[it->node];
@@ -1811,6 +1815,7 @@ static void level_prepare(int64_t i, void *arg) {
         it->res_class = cls;
     }
     it->rc = r_prepare_merge(nd->w, it->stride, l, r, it->res, &it->xs);
+    for (int64_t j = 0; j < it->xs.n && it->rc == MRP_OK; j++) r_describe(it->xs.a[j].w, it->xs.a[j].x, it->flags, &it->xs.a[j].d);
     if (it->res_class >= 0) it->res->cap = -(int64_t) it->res_class - 2;
     else { /* (a path beyond the pool's largest class: an ordinary vector again) */
         r_hmm_vec *v = xcalloc(1, sizeof(*v));
@@ -1841,20 +1846,20 @@ static void r_describe(const world *w, const rhmm *x, uint32_t flags, mrp_xhmm *
     d->n_col_reads = x->roff[x->n_cols];
     d->n_slots = (int64_t) w->ch.allele_offset[x->ref_start + x->ref_length] - (int64_t) w->ch.allele_offset[x->ref_start];
 }
-typedef struct { level_item *items; mrp_xhmm *xh; xbuild *xb; uint32_t flags; } level_gather_ctl;
-static void level_gather(int64_t i, void *arg) {
+typedef struct { rhmm *x; const world *w; } xowner; /* what the host keeps of a cross product while its level is on the device */
+typedef struct { level_item *items; mrp_xhmm *xh; xowner *xb; } level_gather_ctl;
+static void level_gather(int64_t i, void *arg) { /* (the descriptions were written by level_prepare, one item's side by side: a copy) */
     const level_gather_ctl *g = arg;
     const level_item *it = &g->items[i];
     for (int64_t j = 0; j < it->xs.n; j++) {
-        if (j + 4 < it->xs.n) { __builtin_prefetch(it->xs.a[j + 4].x); __builtin_prefetch((const char *) it->xs.a[j + 4].x + 64); }
-        g->xb[it->x0 + j] = it->xs.a[j];
-        r_describe(it->xs.a[j].w, it->xs.a[j].x, g->flags, &g->xh[it->x0 + j]);
+        g->xb[it->x0 + j].x = it->xs.a[j].x; g->xb[it->x0 + j].w = it->xs.a[j].w;
+        g->xh[it->x0 + j] = it->xs.a[j].d;
     }
 }
 /* what the host keeps of a level while it is on the device */
 typedef struct {
     level_item *items; int64_t n_items;
-    mrp_xhmm *xh; xbuild *xb; int64_t n_x;
+    mrp_xhmm *xh; xowner *xb; int64_t n_x;
     int cls_items, cls_xh, cls_xb; /* the three lists are blocks of the shadow pool (megabytes per level: warm instead of mapped afresh) */
     int64_t seq;                   /* the level is the seq-th the engine launched: over once mrp_engine_levels_ended() reaches seq */
 } level_run;
@@ -1908,9 +1913,9 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
         level_item *items = shadow_alloc(sizeof(*items) * ((size_t) n_items + 1), &cls_items);
         memset(items, 0, sizeof(*items) * ((size_t) n_items + 1));
         n_items = 0;
-        for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > 0 && lvl[i] == h && !t->a[i].w->failed) { items[n_items].t = t; items[n_items].node = i; items[n_items].stride = stride; n_items++; }
+        for (int64_t i = 0; i < t->n; i++) if (t->a[i].height > 0 && lvl[i] == h && !t->a[i].w->failed) { items[n_items].t = t; items[n_items].node = i; items[n_items].stride = stride; items[n_items].flags = flags; n_items++; }
         /* the merges of a level touch disjoint nodes: structure in parallel, device work as one batch */
-        mrp_pool_set_tag(1); mrp_pool_run(n_items, n_items > 512 ? (n_items > 16384 ? 64 : n_items / 256) : 1, level_prepare, items); mrp_pool_set_tag(0);
+        mrp_pool_set_tag(1); mrp_pool_set_weight(8000); mrp_pool_run(n_items, n_items > 512 ? (n_items > 16384 ? 64 : n_items / 256) : 1, level_prepare, items); mrp_pool_set_weight(0); mrp_pool_set_tag(0);
         const double ta = now_ms();
         int64_t n_x = 0;
         for (int64_t i = 0; i < n_items; i++) {
@@ -1918,12 +1923,12 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
             if (items[i].rc != MRP_OK && rc == MRP_OK) rc = mrp_set_error(items[i].rc, "%s", items[i].err);
         }
         mrp_xhmm *xh = shadow_alloc(sizeof(*xh) * ((size_t) n_x + 1), &cls_xh);
-        xbuild *xb = shadow_alloc(sizeof(*xb) * ((size_t) n_x + 1), &cls_xb);
+        xowner *xb = shadow_alloc(sizeof(*xb) * ((size_t) n_x + 1), &cls_xb);
         n_x = 0;
         for (int64_t i = 0; i < n_items; i++) { items[i].x0 = n_x; n_x += items[i].xs.n; }
         {   /* the level as the engine is told about it, in node order (worker threads: the shadows are in their caches) */
-            level_gather_ctl gc = {items, xh, xb, flags};
-            mrp_pool_set_tag(3); mrp_pool_run(n_items, n_items > 512 ? n_items / 256 : 1, level_gather, &gc); mrp_pool_set_tag(0);
+            level_gather_ctl gc = {items, xh, xb};
+            mrp_pool_set_tag(3); mrp_pool_set_weight(400); mrp_pool_run(n_items, n_items > 512 ? n_items / 256 : 1, level_gather, &gc); mrp_pool_set_weight(0); mrp_pool_set_tag(0);
         }
         for (int64_t i = 0; i < n_items; i++) /* coordination.c:312: one forward/backward per overlap component */
             ((world *) t->a[items[i].node].w)->n_sweeps += (int) items[i].xs.n, items[i].xs.a = NULL; /* (the list is part of the path's block) */
@@ -1932,7 +1937,7 @@ static int r_run_tree(mrp_engine *e, rnode_vec *t, const mrp_params *params, lev
         const double tc = now_ms();
         /* where the level's results will be is known from here on: the next level can be described against them */
         for (int64_t i = 0; i < n_x && rc == MRP_OK; i++) { xb[i].x->seg = xh[i].seg; xb[i].x->col0 = xh[i].col0; }
-        mrp_pool_set_tag(2); if (rc == MRP_OK) mrp_pool_run(n_items, n_items > 512 ? (n_items > 16384 ? 64 : n_items / 256) : 1, level_finish, items); mrp_pool_set_tag(0);
+        mrp_pool_set_tag(2); mrp_pool_set_weight(300); if (rc == MRP_OK) mrp_pool_run(n_items, n_items > 512 ? (n_items > 16384 ? 64 : n_items / 256) : 1, level_finish, items); mrp_pool_set_weight(0); mrp_pool_set_tag(0);
         for (int64_t i = 0; i < n_items; i++) t->a[items[i].node].path = items[i].res;
         const double t1 = now_ms();
         /* level h goes to the device (a large level first waits for the levels before it, a small one does not) */

@@ -54,6 +54,9 @@ void mrp_pool_adopt(void *pool);
 long long mrp_pool_tag_cpu_ns(int tag);
 /* fn(i, arg) for every i in [0, n), grain indices at a time, on the caller and the persistent worker pool (mrp_api.cpp) */
 void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void *), void *arg);
+/* rough cost of one index of the calling thread's next loops, nanoseconds (0: unknown): short loops run on the caller, longer ones wake only
+ * as many workers as they can keep busy */
+void mrp_pool_set_weight(int ns_per_index);
 
 /* ---- device-resident merge levels (mrp_engine.cpp), driven by the structural code of rphmm_host.c ---- */
 typedef struct mrp_engine mrp_engine;

@@ -30,6 +30,7 @@ int mrp_host_threads(void) { return g_threads; }
 int mrp_context_phase_groups(const mrp_context *ctx) { (void) ctx; return 1; }
 void mrp_pool_set_priority(int p) { (void) p; }
 void mrp_pool_set_tag(int t) { (void) t; }
+void mrp_pool_set_weight(int ns) { (void) ns; }
 long long mrp_pool_tag_cpu_ns(int tag) { (void) tag; return 0; }
 long long mrp_pool_task_cpu_ns(void) { return 0; }
 long long mrp_pool_task_cpu_ns_this_thread(void) { return 0; }

@@ -75,7 +75,7 @@ def main():
         if args.sample and r == 1:
             import ctypes
             sampler = ctypes.CDLL(os.path.join(os.path.dirname(os.path.abspath(__file__)), "sampler", "libcpusampler.so"))
-            sampler.cpusampler_start(250)
+            sampler.cpusampler_start(int(os.environ.get("MRP_SAMPLE_HZ", "250")))
         t0, c0 = time.perf_counter(), time.process_time()
         got, st = capi.phase_reads_many(ctx, dchunks, chunks, params, convert=last)
         dt, cpu = time.perf_counter() - t0, time.process_time() - c0
