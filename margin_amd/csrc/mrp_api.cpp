@@ -680,7 +680,8 @@ thread_local int t_pool_weight_ns = 0; /* mrp_pool_set_weight: what one index of
  * number before it helps with the others: the loops of a batch's levels run over the same chunks in the same order, so the
  * thread that built a chunk's hmms at one level mostly meets them again at the next (their blocks are in its cache, or its
  * neighbours') instead of wherever a single shared counter sends it. */
-#define MRP_POOL_RANGES 16
+#define MRP_POOL_RANGES 64 /* at most; in use: pool_ranges() */
+static inline int pool_ranges() { const char *e = getenv("MRP_POOL_RANGES"); const int v = e ? atoi(e) : 16; return v < 1 ? 1 : (v > MRP_POOL_RANGES ? MRP_POOL_RANGES : v); } /* development knob */
 struct alignas(64) PoolRange { std::atomic<int64_t> next{0}; int64_t end = 0; };
 struct PoolJob {
     void (*fn)(int64_t, void *);
@@ -690,9 +691,10 @@ struct PoolJob {
     PoolRange range[MRP_POOL_RANGES];
     std::atomic<int64_t> done{0};
     std::atomic<int> exhausted{0}; /* ranges that have nothing left to hand out */
+    int n_ranges = 16;
     int active = 0; /* workers currently holding the pointer (under Pool::mu) */
     std::condition_variable cv; /* the posting thread waits here: woken by the last worker to let go of the job, not by every worker of every job */
-    bool has_work() const { return exhausted.load(std::memory_order_relaxed) < MRP_POOL_RANGES; }
+    bool has_work() const { return exhausted.load(std::memory_order_relaxed) < n_ranges; }
 };
 thread_local int t_pool_slot = -1; /* the calling thread's number in its pool: workers 0 .. threads - 2, a posting thread threads - 1 */
 }  // namespace
@@ -719,10 +721,10 @@ struct mrp_host_pool {
             ~Acc() { timespec b; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &b); const long long d = (b.tv_sec - a.tv_sec) * 1000000000ll + (b.tv_nsec - a.tv_nsec);
                      g_pool_task_cpu_ns.fetch_add(d); g_pool_tag_cpu_ns[tag & 15].fetch_add(d); t_pool_task_cpu_ns += d; }
         } acc(j->tag);
-        const int home = (t_pool_slot >= 0 ? t_pool_slot : 0) % MRP_POOL_RANGES;
+        const int nr = j->n_ranges, home = (t_pool_slot >= 0 ? t_pool_slot : 0) % nr;
         int64_t mine = 0; /* booked once: the counter is one cache line shared by every thread of the loop */
-        for (int k = 0; k < MRP_POOL_RANGES; k++) {
-            PoolRange &r = j->range[(home + k) % MRP_POOL_RANGES];
+        for (int k = 0; k < nr; k++) {
+            PoolRange &r = j->range[(home + k) % nr];
             for (;;) {
                 if (r.next.load(std::memory_order_relaxed) >= r.end) break;
                 const int64_t lo = r.next.fetch_add(j->grain);
@@ -800,8 +802,9 @@ extern "C" void mrp_pool_run(int64_t n, int64_t grain, void (*fn)(int64_t, void 
     {   /* ranges of whole grains; the empty ones (a short loop) count as exhausted from the start */
         const int64_t grains = (n + grain - 1) / grain;
         int empty = 0;
-        for (int r = 0; r < MRP_POOL_RANGES; r++) {
-            const int64_t lo = std::min(n, grains * r / MRP_POOL_RANGES * grain), hi = std::min(n, grains * (r + 1) / MRP_POOL_RANGES * grain);
+        const int nr = j.n_ranges = pool_ranges();
+        for (int r = 0; r < nr; r++) {
+            const int64_t lo = std::min(n, grains * r / nr * grain), hi = std::min(n, grains * (r + 1) / nr * grain);
             j.range[r].next.store(lo); j.range[r].end = hi;
             if (lo >= hi) empty++;
         }

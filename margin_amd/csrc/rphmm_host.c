@@ -2522,12 +2522,15 @@ static int phase_many_once(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *
         phase_group *grp = xcalloc((size_t) G, sizeof(*grp));
         pthread_t th[16];
         int started[16] = {0};
-        /* which batch a chunk goes to: interleaved (chunk i to batch i % G), or -- MRP_GROUP_WEIGHTS=w0,w1,... (development) -- by a
-         * repeating pattern that gives batch g the share w_g / sum w of the chunks */
+        /* which batch a chunk goes to: by a repeating pattern that gives batch g the share w_g / sum w of the chunks.  The first batches
+         * are the smaller ones (shares 2 : 3 : 4 : 5 : 5 ...): every batch starts with merge levels that cost the host more than the device,
+         * the batches leave them one after the other (the pool serves batch 0 first), and the device waits for the first batch to
+         * reach its large levels -- a small first batch gets there sooner, the later ones are prepared beside its kernels (-2 % per call of
+         * 1 152 chunks, A/B on one box; equal shares below 16 chunks per batch).  MRP_GROUP_WEIGHTS=w0:w1:... (development) sets the shares. */
         uint8_t *group_of = xmalloc((size_t) n_chunks + 1);
         {
             int w[16], W = 0, pat[256], np = 0;
-            for (int g = 0; g < G; g++) w[g] = 1;
+            for (int g = 0; g < G; g++) w[g] = (G >= 4 && n_chunks >= 16 * (int64_t) G) ? (g + 2 < 5 ? g + 2 : 5) : 1;
             const char *we = getenv("MRP_GROUP_WEIGHTS");
             if (we) { int g = 0; for (const char *c = we; *c && g < G; g++) { w[g] = atoi(c); if (w[g] < 1) w[g] = 1; if (w[g] > 8) w[g] = 8; while (*c >= '0' && *c <= '9') c++; if (*c) c++; /* (any separator) */ } }
             for (int g = 0; g < G; g++) W += w[g];

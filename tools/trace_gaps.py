@@ -58,3 +58,16 @@ if len(sys.argv) > 4:  # every kernel that starts before <until_ms>, in start or
         if s > until:
             break
         print(f"  {s:8.2f} .. {(int(r['End_Timestamp']) - t0) / 1e6:8.2f}  q{r[key]:>3s}  {fam(r):18s} grid {r.get('Grid_Size', r.get('Grid_Size_X', '?'))}")
+if len(sys.argv) > 5:  # every kernel of the main queue that finishes <rank>-th (0: first to finish), as trace_levels.py lists a call
+    rank = int(sys.argv[5])
+    mains = sorted(((max(int(r["End_Timestamp"]) for r in rs), q) for q, rs in by.items() if len(rs) >= 20))
+    q = mains[min(rank, len(mains) - 1)][1]
+    rs = sorted(by[q], key=lambda r: int(r["Start_Timestamp"]))
+    print(f"queue {q} (finishes {rank}-th of {len(mains)}):")
+    prev_end, tot = int(rs[0]["Start_Timestamp"]), {}
+    for r in rs:
+        s, e = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
+        print(f"  {(s - t0) / 1e6:9.3f} ms  {fam(r):18s} grid {int(r.get('Grid_Size', r.get('Grid_Size_X', 0))):>9d}  {(e - s) / 1e3:9.1f} us  gap {(s - prev_end) / 1e3:8.1f} us")
+        prev_end = max(prev_end, e)
+        tot[fam(r)] = tot.get(fam(r), 0.0) + (e - s) / 1e6
+    print("  totals (ms):", {k: round(v, 2) for k, v in sorted(tot.items(), key=lambda kv: -kv[1])}, f"busy {sum(tot.values()):.1f}")
