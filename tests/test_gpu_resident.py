@@ -707,3 +707,40 @@ def test_results_do_not_depend_on_the_host_threads(gpu_ctx, orc):
         assert results[0][i]["reads1"] == ref["reads1"] and results[0][i]["reads2"] == ref["reads2"]
     for d in dchunks:
         d.close()
+
+
+def test_results_do_not_depend_on_the_batches_shares(gpu_ctx, orc, monkeypatch):
+    """A call of many chunks deals them to its concurrent batches in graded shares (2 : 3 : 4 : 5 : 5 ..., the first batch the
+    smallest, rphmm_host.c); MRP_GROUP_WEIGHTS sets other shares.  Size-independent property: 160 small chunks in eight batches give
+    the same results, chunk for chunk, with the graded shares, with equal shares and with reversed ones; a sample against the oracle."""
+    chunks = [synth.make_ont_chunk(seed=9100 + s, region_bp=40_000, n_sites=80, coverage=30.0) for s in range(160)]
+    pd = _params()
+    params = capi.Params.from_reference_names(pd)
+    dchunks = [capi.DeviceChunk.from_chunk(gpu_ctx, c) for c in chunks]
+    gpu_ctx.set_phase_groups(8)
+    results = []
+    try:
+        for shares in (None, "1:1:1:1:1:1:1:1", "5:5:5:5:4:3:2:1"):
+            if shares is None:
+                monkeypatch.delenv("MRP_GROUP_WEIGHTS", raising=False)
+            else:
+                monkeypatch.setenv("MRP_GROUP_WEIGHTS", shares)
+            got, st = capi.phase_reads_many(gpu_ctx, dchunks, chunks, params)
+            assert st.resident == 1 and st.fallback_chunks == 0
+            results.append(got)
+    finally:
+        gpu_ctx.set_phase_groups(0)
+    for other in results[1:]:
+        for a, b in zip(results[0], other):
+            for k in PHASE_KEYS:
+                assert (np.asarray(a[k]) == np.asarray(b[k])).all(), k
+            assert a["reads1"] == b["reads1"] and a["reads2"] == b["reads2"] and a["n_sweeps"] == b["n_sweeps"]
+    for i in (0, 1, 79, 158, 159):
+        oc = orc.OracleChunk(chunks[i])
+        ref = oc.phase(pd)
+        oc.close()
+        for k in PHASE_KEYS:
+            assert (np.asarray(results[0][i][k]) == np.asarray(ref[k])).all(), k
+        assert results[0][i]["reads1"] == ref["reads1"] and results[0][i]["reads2"] == ref["reads2"]
+    for d in dchunks:
+        d.close()
