@@ -1106,7 +1106,8 @@ int mrp_batch_launch(mrp_batch *b) {
      * 1 152-chunk call: 2 304 on 512 slots), 256 threads -- four to a CU -- get them through sooner: -3 % per call, A/B on one box;
      * a single batch, whose hmms all find a slot, stays at 512 (+4 % with 256). */
     const int64_t chains = 2 * (int64_t) (b->order_wide.size() + b->order_mid.size()) * (int64_t) ctx->concurrent_batches;
-    const int t_chain = ctx->concurrent_batches > 1 && chains > 2 * 256 ? 256 : 512; /* (a batch on its own -- the kernel replay of bench.py too: 512, as measured in rounds 1-3) */
+    int t_chain = ctx->concurrent_batches > 1 && chains > 2 * 256 ? 256 : 512; /* (a batch on its own -- the kernel replay of bench.py too: 512, as measured in rounds 1-3) */
+    if (const char *ts = getenv("MRP_SWEEP_T")) { const int v = atoi(ts); if (v == 64 || v == 128 || v == 256 || v == 512) t_chain = v; } /* development */
     const int t_wide = t_chain, t_mid = t_chain, t_narrow = 64;
     /* workgroup sizes of the recursion kernel's classes (measured; in the
                                                          * concurrent batches of a call 64 to 512 threads for the mid class make no difference) */

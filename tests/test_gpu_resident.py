@@ -710,9 +710,10 @@ def test_results_do_not_depend_on_the_host_threads(gpu_ctx, orc):
 
 
 def test_results_do_not_depend_on_the_batches_shares(gpu_ctx, orc, monkeypatch):
-    """A call of many chunks deals them to its concurrent batches in graded shares (2 : 3 : 4 : 5 : 5 ..., the first batch the
-    smallest, rphmm_host.c); MRP_GROUP_WEIGHTS sets other shares.  Size-independent property: 160 small chunks in eight batches give
-    the same results, chunk for chunk, with the graded shares, with equal shares and with reversed ones; a sample against the oracle."""
+    """A call of many large chunks deals them to its concurrent batches in graded shares (2 : 3 : 4 : 5 : 5 ..., the first batch the
+    smallest, rphmm_host.c), small chunks in equal shares; MRP_GROUP_WEIGHTS sets the shares.  Size-independent property: 160 small
+    chunks in eight batches give the same results, chunk for chunk, with equal shares, with the graded ones and with reversed ones;
+    a sample against the oracle."""
     chunks = [synth.make_ont_chunk(seed=9100 + s, region_bp=40_000, n_sites=80, coverage=30.0) for s in range(160)]
     pd = _params()
     params = capi.Params.from_reference_names(pd)
@@ -720,7 +721,7 @@ def test_results_do_not_depend_on_the_batches_shares(gpu_ctx, orc, monkeypatch):
     gpu_ctx.set_phase_groups(8)
     results = []
     try:
-        for shares in (None, "1:1:1:1:1:1:1:1", "5:5:5:5:4:3:2:1"):
+        for shares in (None, "2:3:4:5:5:5:5:5", "5:5:5:5:4:3:2:1"):
             if shares is None:
                 monkeypatch.delenv("MRP_GROUP_WEIGHTS", raising=False)
             else:
