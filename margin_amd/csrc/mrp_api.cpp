@@ -311,10 +311,18 @@ int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *co
         if (rcs[(size_t) i] != MRP_OK) rc = fail(rcs[(size_t) i], "%s", msgs[(size_t) i].c_str());
     auto al = [](size_t v) { return (v + 255) & ~(size_t) 255; };
     if (groups < 1 || n < 4 * (int64_t) groups) groups = 1;
-    /* the order of the chunks in the block: group 0's (chunks 0, groups, 2 groups, ...), then group 1's, ... */
+    if (groups > 16) groups = 16;
+    /* the order of the chunks in the block: group 0's, then group 1's, ... -- the groups are the concurrent batches mrp_phase_reads_many
+     * will deal the chunks to (mrp_phase_group_assign: not always i % groups) */
+    std::vector<uint8_t> group_of((size_t) n + 1, 0);
+    {
+        int64_t sites = 0;
+        for (int64_t i = 0; i < n; i++) sites += descs[i]->n_sites;
+        mrp_phase_group_assign(n, groups, sites, group_of.data());
+    }
     std::vector<int64_t> order; order.reserve((size_t) n);
     std::vector<int64_t> group_first((size_t) groups + 1, 0);
-    for (int g = 0; g < groups; g++) { group_first[(size_t) g] = (int64_t) order.size(); for (int64_t i = g; i < n; i += groups) order.push_back(i); }
+    for (int g = 0; g < groups; g++) { group_first[(size_t) g] = (int64_t) order.size(); for (int64_t i = 0; i < n; i++) if (group_of[(size_t) i] == g) order.push_back(i); }
     group_first[(size_t) groups] = n;
     std::vector<size_t> off((size_t) n + 1, 0), at_of((size_t) n, 0); /* off: by position in the block; at_of: by chunk */
     for (int64_t k = 0; k < n && rc == MRP_OK; k++) {
@@ -366,7 +374,7 @@ int mrp_chunk_block_create(mrp_context *ctx, int64_t n, const mrp_chunk_desc *co
                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
         }
         if (e == hipSuccess)
-            for (int64_t i = 0; i < n; i++) { out[i]->ready = blk->group_ready[(size_t) (i % groups)]; out[i]->owns_ready = false; out[i]->ready_pending.store(true); }
+            for (int64_t i = 0; i < n; i++) { out[i]->ready = blk->group_ready[(size_t) group_of[(size_t) i]]; out[i]->owns_ready = false; out[i]->ready_pending.store(true); }
     }
     if (rc == MRP_OK && e != hipSuccess) rc = fail(MRP_ERR_HIP, "chunk block upload failed: %s", hipGetErrorString(e));
     if (rc != MRP_OK)

@@ -2366,6 +2366,28 @@ typedef struct {
 long long mrp_pool_task_cpu_ns(void);
 long long mrp_pool_task_cpu_ns_this_thread(void);
 static double thread_cpu_ms(void) { struct timespec t; clock_gettime(CLOCK_THREAD_CPUTIME_ID, &t); return 1e3 * t.tv_sec + 1e-6 * t.tv_nsec; }
+/* The batch (0 .. G - 1) every chunk of a call goes to: a repeating pattern that gives batch g the share w_g / sum w of the chunks.
+ * For calls of large chunks the first batches are the smaller ones (shares 2 : 3 : 4 : 5 : 5 ...): every batch starts with merge levels
+ * that cost the host more than the device, the batches leave them one after the other (the pool serves batch 0 first), and the device
+ * waits for the first batch to reach its large levels -- a small first batch gets there sooner, the later ones are prepared beside its
+ * kernels (-1 to -2 % per call of 1 152 configs[1] chunks, A/B on three boxes).  Chunks of a few hundred sites keep equal shares: their
+ * calls are the host's time throughout, and a larger last batch only lengthens them (640 chunks of 130 sites: 16.2 ms with equal shares,
+ * 17.6 with graded ones).  MRP_GROUP_WEIGHTS=w0:w1:... (development) sets the shares.  A work queue's chunk block is uploaded in the
+ * same groups (mrp_chunk_block_create): a batch waits for its own group's copy only. */
+void mrp_phase_group_assign(int64_t n_chunks, int G, int64_t total_sites, uint8_t *group_of) {
+    int w[16], W = 0, pat[256], np = 0;
+    if (G < 1) G = 1;
+    if (G > 16) G = 16;
+    const int graded = G >= 4 && n_chunks >= 16 * (int64_t) G && total_sites >= 500 * n_chunks;
+    for (int g = 0; g < G; g++) w[g] = graded ? (g + 2 < 5 ? g + 2 : 5) : 1;
+    const char *we = getenv("MRP_GROUP_WEIGHTS");
+    if (we) { int g = 0; for (const char *c = we; *c && g < G; g++) { w[g] = atoi(c); if (w[g] < 1) w[g] = 1; if (w[g] > 8) w[g] = 8; while (*c >= '0' && *c <= '9') c++; if (*c) c++; /* (any separator) */ } }
+    for (int g = 0; g < G; g++) W += w[g];
+    /* the pattern: round by round, every batch that still has weight left takes one place */
+    for (int round = 0; np < W; round++) for (int g = 0; g < G && np < W; g++) if (w[g] > round) pat[np++] = g;
+    for (int64_t i = 0; i < n_chunks; i++) group_of[i] = (uint8_t) pat[i % W];
+}
+
 static void *phase_group_main(void *p) {
     phase_group *g = p;
     const double cpu0 = thread_cpu_ms();
@@ -2522,26 +2544,12 @@ static int phase_many_once(mrp_context *ctx, int64_t n_chunks, const mrp_chunk *
         phase_group *grp = xcalloc((size_t) G, sizeof(*grp));
         pthread_t th[16];
         int started[16] = {0};
-        /* which batch a chunk goes to: by a repeating pattern that gives batch g the share w_g / sum w of the chunks.  The first batches
-         * are the smaller ones (shares 2 : 3 : 4 : 5 : 5 ...): every batch starts with merge levels that cost the host more than the device,
-         * the batches leave them one after the other (the pool serves batch 0 first), and the device waits for the first batch to
-         * reach its large levels -- a small first batch gets there sooner, the later ones are prepared beside its kernels (-2 % per call of
-         * 1 152 chunks, A/B on one box; equal shares below 16 chunks per batch).  MRP_GROUP_WEIGHTS=w0:w1:... (development) sets the shares. */
+        /* which batch a chunk goes to (mrp_phase_group_assign: graded shares for calls of large chunks) */
         uint8_t *group_of = xmalloc((size_t) n_chunks + 1);
         {
-            int w[16], W = 0, pat[256], np = 0;
-            /* (chunks of a few hundred sites keep equal shares: their calls are the host's time throughout, and a larger last batch only
-             * lengthens them -- 640 chunks of 130 sites: 16.2 ms with equal shares, 17.6 with graded ones) */
             int64_t sites = 0;
             for (int64_t i = 0; i < n_chunks; i++) { mrp_chunk_host hv; mrp_chunk_host_view(chunks[i], &hv); sites += hv.n_sites; }
-            const int graded = G >= 4 && n_chunks >= 16 * (int64_t) G && sites >= 500 * n_chunks;
-            for (int g = 0; g < G; g++) w[g] = graded ? (g + 2 < 5 ? g + 2 : 5) : 1;
-            const char *we = getenv("MRP_GROUP_WEIGHTS");
-            if (we) { int g = 0; for (const char *c = we; *c && g < G; g++) { w[g] = atoi(c); if (w[g] < 1) w[g] = 1; if (w[g] > 8) w[g] = 8; while (*c >= '0' && *c <= '9') c++; if (*c) c++; /* (any separator) */ } }
-            for (int g = 0; g < G; g++) W += w[g];
-            /* the pattern: round by round, every batch that still has weight left takes one place */
-            for (int round = 0; np < W; round++) for (int g = 0; g < G && np < W; g++) if (w[g] > round) pat[np++] = g;
-            for (int64_t i = 0; i < n_chunks; i++) group_of[i] = (uint8_t) pat[i % W];
+            mrp_phase_group_assign(n_chunks, G, sites, group_of);
         }
         for (int g = 0; g < G; g++) {
             phase_group *q = &grp[g];

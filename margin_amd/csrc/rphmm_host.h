@@ -27,6 +27,8 @@ typedef struct mrp_chunk_host {
 
 void mrp_chunk_host_view(const mrp_chunk *chunk, mrp_chunk_host *out);
 mrp_context *mrp_chunk_context(const mrp_chunk *chunk);
+/* the concurrent batch (0 .. G - 1) of every chunk of an mrp_phase_reads_many call (rphmm_host.c) */
+void mrp_phase_group_assign(int64_t n_chunks, int G, int64_t total_sites, uint8_t *group_of);
 int mrp_context_device(const mrp_context *ctx);
 /* the context is one of several concurrent batches of its device: no side streams (mrp_internal.h) */
 int mrp_context_set_grouped(mrp_context *ctx, int grouped); /* returns the previous setting */
