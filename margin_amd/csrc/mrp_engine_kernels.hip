@@ -2906,9 +2906,39 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
         }
         __syncthreads(); /* also makes the lists above visible in global memory */
 
+        /* (stRPHmm_pruneBackwards runs as a kernel of its own, mrp_prune_back_kernel: one wave per hmm instead of one wave of eight for a
+         * quarter of this workgroup's life) */
+        if (errbits) { atomicOr(sc.err, errbits); atomicOr(sc.err_hmm + hi_, errbits); }
+        __syncthreads();
+    }
+}
+
+/*
+ * stRPHmm_pruneBackwards (hmm.c:1111-1158) of a level, one WAVE per hmm.  It used to be the tail of mrp_prune_kernel, run by the chain
+ * wave while the workgroup's other seven waves -- and their registers, half a CU's -- waited: 1.3-1.9 M of a top-level workgroup's 7 M
+ * cycles (`-DPRUNE_EXP_CLOCK`), a quarter of the slot-time of the kernel that holds most of it.  Here it holds 64 lanes and a few hundred
+ * bytes of LDS per hmm (the kept flag per merge cell).  The forward pass's lists (sc.kept, kept_np, keptm, their counts) are complete when
+ * this kernel starts: same stream, behind mrp_prune_kernel.
+ */
+template <bool PAIRS>
+__global__ void __launch_bounds__(256) mrp_prune_back_kernel(const PruneHmm *__restrict__ hmms, int64_t n_hmms, PruneParams p, PruneScratch sc) {
+    extern __shared__ uint32_t lds[];
+    const int lane = threadIdx.x & (WAVE - 1);
+    const int wave = __builtin_amdgcn_readfirstlane((int) (threadIdx.x / WAVE));
+    const int S = p.S;
+    const int n_flagw = ((p.max_merge + 127) >> 7) << 2; /* words, a multiple of four */
+    uint32_t *flagw = lds + wave * n_flagw;              /* [max_merge bits] kept flag per merge cell, this wave's */
+    auto flag_get = [&](uint32_t i) -> bool { return (flagw[i >> 5] >> (i & 31u)) & 1u; };
+    auto flag_set = [&](uint32_t i) { atomicOr(&flagw[i >> 5], 1u << (i & 31u)); };
+    auto flag_clr = [&](uint32_t i) { atomicAnd(&flagw[i >> 5], ~(1u << (i & 31u))); };
+    for (int i = lane; i < n_flagw; i += WAVE) flagw[i] = 0u;
+    wave_lds_fence();
+    for (int64_t hi_ = (int64_t) blockIdx.x * 4 + wave; hi_ < n_hmms; hi_ += (int64_t) gridDim.x * 4) {
+        const PruneHmm h = k_load(hmms + hi_);
+        const int K = h.n_cols;
         /* ---- stRPHmm_pruneBackwards hmm.c:1111-1158: lists of at most S entries, one wave; the lists of
          * column k - 1 are requested before column k is worked on ---- */
-        if (PAIRS && wave == 0) {
+        if constexpr (PAIRS) {
             /* The lists in UNITS: entry i = cells 2 i, 2 i + 1 of the kept list (the list stages wrote a unit's cells next to each
              * other; a column or merge column of one cell has a list of one -- an odd count), one entry per lane, the flags one
              * per merge unit.  The merge cells the surviving cells come from are all in the forward pass's kept merge list (it
@@ -2967,7 +2997,7 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
                 nx1 = nx2;
             }
             if (pmk) flag_clr(pm);
-        } else if (wave == 0) {
+        } else {
             uint32_t pm[2] = {0u, 0u}; /* kept merge cells of the merge column after column k: they own the flags */
             bool pmk[2] = {false, false};
             /* the lists of a column are requested two columns before they are used */
@@ -3052,8 +3082,7 @@ __global__ void __launch_bounds__(T, T <= 512 ? 4 : 1) mrp_prune_kernel(PruneIn 
             if (pmk[0]) flag_clr(pm[0]);
             if (pmk[1]) flag_clr(pm[1]);
         }
-        if (errbits) { atomicOr(sc.err, errbits); atomicOr(sc.err_hmm + hi_, errbits); }
-        __syncthreads();
+        wave_lds_fence(); /* (the flags are left clean for the wave's next hmm) */
     }
 }
 
@@ -3107,6 +3136,17 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, con
     else if (held <= MRP_PRUNE_MID_CELLS && !(force && force[0] == 'b')) PRUNE_LAUNCH(512, 10, 1, 4);
     else PRUNE_LAUNCH(1024, 36, 2, 1);
 #undef PRUNE_LAUNCH
+    {
+        const hipError_t fe = hipGetLastError();
+        if (fe != hipSuccess) return fe;
+    }
+    {   /* the backward pass: one wave per hmm, four to a workgroup */
+        const size_t back_lds = (size_t) 4 * ((size_t) (((p.max_merge + 127) >> 7) << 2)) * sizeof(uint32_t);
+        const int64_t wgs = (n_hmms + 3) / 4;
+        const dim3 bgrid((unsigned) (wgs < 65536 ? wgs : 65536));
+        if (pairs) hipLaunchKernelGGL((mrp_prune_back_kernel<true>), bgrid, dim3(256), back_lds, stream, hmms_dev, n_hmms, p, s);
+        else hipLaunchKernelGGL((mrp_prune_back_kernel<false>), bgrid, dim3(256), back_lds, stream, hmms_dev, n_hmms, p, s);
+    }
     return hipGetLastError();
 }
 
