@@ -3107,6 +3107,7 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, con
         big_lds((const void *) mrp_prune_kernel<512, 32, 2, 1, false>); big_lds((const void *) mrp_prune_kernel<512, 32, 2, 1, true>);
         big_lds((const void *) mrp_prune_kernel<256, 4, 1, 1, false>); big_lds((const void *) mrp_prune_kernel<256, 4, 1, 1, true>);
         big_lds((const void *) mrp_prune_kernel<512, 10, 1, 4, false>); big_lds((const void *) mrp_prune_kernel<512, 10, 1, 4, true>);
+        big_lds((const void *) mrp_prune_kernel<512, 10, 2, 4, false>); big_lds((const void *) mrp_prune_kernel<512, 10, 2, 4, true>);
         big_lds((const void *) mrp_prune_kernel<1024, 36, 2, 1, false>); big_lds((const void *) mrp_prune_kernel<1024, 36, 2, 1, true>);
         return e;
     });
@@ -3133,6 +3134,9 @@ hipError_t mrp_launch_prune(const MrpBatchDev &d, const CrossCol *ccols_dev, con
     /* columns of at most 256 entries (the first merge levels: a few reads per hmm): four waves, the table wave writes the bins */
     if (held <= 4 * WAVE && !(force && force[0] == 's')) PRUNE_LAUNCH(256, 4, 1, 1);
     else if (held <= 2 * WAVE * 32) PRUNE_LAUNCH(512, 32, 2, 1);
+    /* up to 5 120 entries -- the unit levels of the shipped parameters (100 x 100 cells = 5 000 units): the same four streaming waves as
+     * two groups that alternate over the columns, so that a column's f and b have TWO column times to arrive (MRP_PRUNE_VARIANT=1: one group) */
+    else if (held <= 2 * WAVE * 10 * 4 && !(force && (force[0] == 'b' || force[0] == '1'))) PRUNE_LAUNCH(512, 10, 2, 4);
     else if (held <= MRP_PRUNE_MID_CELLS && !(force && force[0] == 'b')) PRUNE_LAUNCH(512, 10, 1, 4);
     else PRUNE_LAUNCH(1024, 36, 2, 1);
 #undef PRUNE_LAUNCH
