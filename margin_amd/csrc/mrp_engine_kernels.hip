@@ -2961,41 +2961,85 @@ __global__ void __launch_bounds__(256) mrp_prune_back_kernel(const PruneHmm *__r
             };
             uint32_t pm = 0u; /* merge unit of the merge column after column k this lane has flagged */
             bool pmk = false;
-            ListsU cur = fetch(K - 1), nx1 = fetch(K - 2);
-            for (int k = K - 1; k >= 0; k--) {
-                const int64_t lcol = h.col0 + k;
-                const ListsU nx2 = fetch(k - 2);
-                const int sk = (cur.nk & 1) ? 0 : 1, so = (cur.nm & 1) ? 0 : 1; /* cells / merge cells after the column in pairs */
-                const int nku = cur.nk >> sk;
-                const bool keep = lane < nku && (k + 1 == K || flag_get((cur.cn.x & 0xFFFFu) >> so));
-                const uint64_t m0 = __ballot(keep);
-                const int ns = __popcll(m0);
-                if (pmk) flag_clr(pm);
-                if (ns != nku) {
-                    if (keep) {
-                        const int pos = mbcnt64(m0);
-                        *reinterpret_cast<uint32_t *>(sc.kept + lcol * S + 2 * pos) = cur.cc;
-                        *reinterpret_cast<uint2 *>(sc.kept_np + lcol * S + 2 * pos) = cur.cn;
-                    }
-                    if (lane == 0) sc.n_kept[lcol] = ns << sk;
-                }
-                if (k == 0) break;
-                /* merge column k - 1 keeps the merge cells some surviving cell comes from (:1141-1155) */
-                const int si = (nx1.nm & 1) ? 0 : 1;
-                if (keep) flag_set((cur.cn.x >> 16) >> si);
-                const int nmu = nx1.nm >> si;
-                const uint32_t mu_ = (nx1.mm & 0xFFFFu) >> si;
-                const bool mk = lane < nmu && flag_get(mu_);
-                const uint64_t q0 = __ballot(mk);
-                const int nms = __popcll(q0);
-                if (nms != nmu) {
-                    if (mk) *reinterpret_cast<uint32_t *>(sc.keptm + (lcol - 1) * S + 2 * mbcnt64(q0)) = nx1.mm;
-                    if (lane == 0) sc.n_keptm[lcol - 1] = nms << si;
-                }
-                pm = mu_; pmk = mk;
-                cur = nx1;
-                nx1 = nx2;
+            (void) fetch;
+            /* The lists of four columns are in flight at a time, in a ring of registers loaded by inline asm and waited for by count (as the
+             * recursion kernel's ring, mrp_kernels.hip): through the compiler's own waits -- the lists are loop-carried registers, so it
+             * waits with vmcnt(0) at the loop head -- every column paid the whole trip to HBM / L2 of the lists asked for a column earlier
+             * (1 450 cycles per column for some 500 of LDS flag operations and ballots).  Memory operations retire in issue order and
+             * stores share the counter: a step issues exactly FIVE ring loads (unconditionally: beyond column 0 they read column 0 and
+             * are ignored) plus stores that can only make a wait stricter; when a step starts, the two entries it needs are followed
+             * by the loads of two younger entries: vmcnt(10). */
+            typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+            int32_t bnk0 = 0, bnk1 = 0, bnk2 = 0, bnk3 = 0, bnm0 = 0, bnm1 = 0, bnm2 = 0, bnm3 = 0;
+            uint32_t bcc0 = 0u, bcc1 = 0u, bcc2 = 0u, bcc3 = 0u, bmm0 = 0u, bmm1 = 0u, bmm2 = 0u, bmm3 = 0u;
+            u32x2 bcn0 = {0u, 0u}, bcn1 = {0u, 0u}, bcn2 = {0u, 0u}, bcn3 = {0u, 0u};
+            const int lane2 = 2 * lane < S ? 2 * lane : 0; /* (lanes beyond the lists read entry 0 and never use it: lane < nku <= S / 2) */
+#define BK_LOAD(i, k_)                                                                                                                  \
+            {                                                                                                                           \
+                const int kk_ = (k_) < 0 ? 0 : (k_);                                                                                    \
+                const int64_t lc_ = h.col0 + kk_;                                                                                       \
+                asm volatile("global_load_dword %0, %5, off\n\tglobal_load_dword %1, %6, off\n\tglobal_load_dword %2, %7, off\n\t"       \
+                             "global_load_dwordx2 %3, %8, off\n\tglobal_load_dword %4, %9, off"                                        \
+                             : "=&v"(bnk##i), "=&v"(bnm##i), "=&v"(bcc##i), "=&v"(bcn##i), "=&v"(bmm##i)                                \
+                             : "v"(sc.n_kept + lc_), "v"(sc.n_keptm + lc_), "v"(sc.kept + lc_ * S + lane2), "v"(sc.kept_np + lc_ * S + lane2), \
+                               "v"(sc.keptm + lc_ * S + lane2)                                                                          \
+                             : "memory");                                                                                               \
             }
+#ifdef MRP_SAFE_WAIT /* debugging aid: drain everything */
+#define BK_WAIT(i, j) asm volatile("s_waitcnt vmcnt(0)" : "+v"(bnk##i), "+v"(bnm##i), "+v"(bcc##i), "+v"(bcn##i), "+v"(bmm##i), "+v"(bnk##j), "+v"(bnm##j), "+v"(bcc##j), "+v"(bcn##j), "+v"(bmm##j)::"memory");
+#else
+#define BK_WAIT(i, j) asm volatile("s_waitcnt vmcnt(10)" : "+v"(bnk##i), "+v"(bnm##i), "+v"(bcc##i), "+v"(bcn##i), "+v"(bmm##i), "+v"(bnk##j), "+v"(bnm##j), "+v"(bcc##j), "+v"(bcn##j), "+v"(bmm##j)::"memory");
+#endif
+            /* one column: entry i holds its lists, entry j those of the column before it; entry i is then asked for column k_ - 4 */
+#define BK_STEP(i, j, k_)                                                                                                               \
+            {                                                                                                                           \
+                const int k = (k_);                                                                                                     \
+                BK_WAIT(i, j)                                                                                                           \
+                const int64_t lcol = h.col0 + k;                                                                                        \
+                const int c_nk = bnk##i, c_nm = bnm##i, n_nm = k > 0 ? bnm##j : 0;                                                      \
+                const uint32_t c_cc = bcc##i, c_cnx = bcn##i.x, c_cny = bcn##i.y, n_mm = bmm##j;                                        \
+                const int sk = (c_nk & 1) ? 0 : 1, so = (c_nm & 1) ? 0 : 1; /* cells / merge cells after the column in pairs */          \
+                const int nku = c_nk >> sk;                                                                                             \
+                const bool keep = lane < nku && (k + 1 == K || flag_get((c_cnx & 0xFFFFu) >> so));                                      \
+                const uint64_t m0 = __ballot(keep);                                                                                     \
+                const int ns = __popcll(m0);                                                                                            \
+                if (pmk) flag_clr(pm);                                                                                                  \
+                pmk = false;                                                                                                            \
+                if (ns != nku) {                                                                                                        \
+                    if (keep) {                                                                                                         \
+                        const int pos = mbcnt64(m0);                                                                                    \
+                        *reinterpret_cast<uint32_t *>(sc.kept + lcol * S + 2 * pos) = c_cc;                                             \
+                        *reinterpret_cast<uint2 *>(sc.kept_np + lcol * S + 2 * pos) = make_uint2(c_cnx, c_cny);                         \
+                    }                                                                                                                   \
+                    if (lane == 0) sc.n_kept[lcol] = ns << sk;                                                                          \
+                }                                                                                                                       \
+                if (k > 0) { /* merge column k - 1 keeps the merge cells some surviving cell comes from (:1141-1155) */                  \
+                    const int si = (n_nm & 1) ? 0 : 1;                                                                                  \
+                    if (keep) flag_set((c_cnx >> 16) >> si);                                                                            \
+                    const int nmu = n_nm >> si;                                                                                         \
+                    const uint32_t mu_ = (n_mm & 0xFFFFu) >> si;                                                                        \
+                    const bool mk = lane < nmu && flag_get(mu_);                                                                        \
+                    const uint64_t q0 = __ballot(mk);                                                                                   \
+                    const int nms = __popcll(q0);                                                                                       \
+                    if (nms != nmu) {                                                                                                   \
+                        if (mk) *reinterpret_cast<uint32_t *>(sc.keptm + (lcol - 1) * S + 2 * mbcnt64(q0)) = n_mm;                      \
+                        if (lane == 0) sc.n_keptm[lcol - 1] = nms << si;                                                                \
+                    }                                                                                                                   \
+                    pm = mu_; pmk = mk;                                                                                                 \
+                }                                                                                                                       \
+                BK_LOAD(i, k - 4)                                                                                                       \
+            }
+            BK_LOAD(0, K - 1) BK_LOAD(1, K - 2) BK_LOAD(2, K - 3) BK_LOAD(3, K - 4)
+            for (int kq = K - 1; kq >= 0; kq -= 4) {
+                BK_STEP(0, 1, kq)
+                if (kq - 1 >= 0) BK_STEP(1, 2, kq - 1)
+                if (kq - 2 >= 0) BK_STEP(2, 3, kq - 2)
+                if (kq - 3 >= 0) BK_STEP(3, 0, kq - 3)
+            }
+            asm volatile("s_waitcnt vmcnt(0)" : "+v"(bnk0), "+v"(bnk1), "+v"(bnk2), "+v"(bnk3), "+v"(bmm0), "+v"(bmm1), "+v"(bmm2), "+v"(bmm3)::"memory"); /* the ring drains before its registers are used again */
+#undef BK_STEP
+#undef BK_WAIT
+#undef BK_LOAD
             if (pmk) flag_clr(pm);
         } else {
             uint32_t pm[2] = {0u, 0u}; /* kept merge cells of the merge column after column k: they own the flags */
