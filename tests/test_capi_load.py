@@ -103,3 +103,34 @@ def test_host_worker_pool_runs_every_index_once():
     for t in threads:
         t.join()
     assert not errors
+
+
+def test_batch_shares_of_a_call(monkeypatch):
+    """mrp_phase_group_assign (rphmm_host.c): which concurrent batch every chunk of an mrp_phase_reads_many call goes to -- and, the
+    same function, in which group a work queue uploads it.  Equal shares for small calls and small chunks, graded ones
+    (2 : 3 : 4 : 5 : 5 ...) for many large chunks, MRP_GROUP_WEIGHTS on request; every chunk gets a batch below G."""
+    lib = capi.load()
+    lib.mrp_phase_group_assign.argtypes = [C.c_int64, C.c_int, C.c_int64, C.POINTER(C.c_uint8)]
+    lib.mrp_phase_group_assign.restype = None
+    monkeypatch.delenv("MRP_GROUP_WEIGHTS", raising=False)
+
+    def shares(n, g, sites):
+        buf = (C.c_uint8 * (n + 1))()
+        lib.mrp_phase_group_assign(n, g, sites, buf)
+        got = list(buf)[:n]
+        assert all(0 <= x < g for x in got)
+        return [got.count(q) for q in range(g)], got
+
+    cnt, got = shares(1152, 8, 1152 * 2000)          # the headline call: graded
+    assert cnt[0] < cnt[1] < cnt[2] < cnt[3] and max(cnt[3:]) - min(cnt[3:]) <= 1 and cnt[0] * 2 < cnt[-1] and sum(cnt) == 1152
+    assert abs(cnt[0] / 1152 - 2 / 34) < 0.01 and abs(cnt[-1] / 1152 - 5 / 34) < 0.01
+    assert got[:8] == list(range(8))                 # (every batch has a chunk among the first G: the pattern goes round by round)
+    cnt, _ = shares(640, 8, 640 * 130)               # chunks of a few hundred sites: equal
+    assert max(cnt) - min(cnt) <= 1
+    cnt, _ = shares(64, 8, 64 * 2000)                # fewer than 16 chunks per batch: equal
+    assert max(cnt) - min(cnt) <= 1
+    cnt, _ = shares(300, 2, 300 * 2000)              # fewer than four batches: equal
+    assert max(cnt) - min(cnt) <= 1
+    monkeypatch.setenv("MRP_GROUP_WEIGHTS", "1:3")
+    cnt, _ = shares(400, 2, 400 * 130)
+    assert cnt == [100, 300]
